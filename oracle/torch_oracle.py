@@ -1,0 +1,345 @@
+"""Pure-PyTorch (CPU, fp32) restatement of the reference hot path.
+
+TEST INFRASTRUCTURE -- see oracle/__init__.py.  Every function cites the
+reference file:line it follows (paths relative to the upstream repository).
+
+The two networks are described by small tables and assembled from stock
+torch.nn layers, keeping the reference's module *names* (so state_dicts
+interchange) and its construction *order* (so that seeding the global torch
+RNG yields the same initial weights).
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+from typing import List, Sequence, Tuple
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+# --------------------------------------------------------------------------
+# MTnnUNet   (src/models/multitask/MTnnUNet.py:19-183)
+# --------------------------------------------------------------------------
+
+NNUNET_WIDTHS = (32, 64, 128, 256, 320)      # MTnnUNet.py:72
+
+
+def _cell(cin: int, cout: int) -> nn.Sequential:
+    """conv3x3(pad 1, no bias) -> InstanceNorm2d(eps 1e-5, no affine) -> LeakyReLU(0.01).
+    MTnnUNet.py:12-16 (conv factory), :30-38 (cell)."""
+    return nn.Sequential(OrderedDict(
+        Conv=nn.Conv2d(cin, cout, kernel_size=3, padding=1, bias=False),
+        InNorm=nn.InstanceNorm2d(cout),
+        LeReLU=nn.LeakyReLU(inplace=True),
+    ))
+
+
+def _level(cin: int, cmid: int, cout: int) -> nn.Sequential:
+    """Two stacked cells.  MTnnUNet.py:42-61."""
+    return nn.Sequential(OrderedDict(
+        ConvInNormLRelu1=_cell(cin, cmid),
+        ConvInNormLRelu2=_cell(cmid, cout),
+    ))
+
+
+class OracleMTnnUNet(nn.Module):
+    """nnU-Net style 5-level encoder/decoder + pooled classification head."""
+
+    def __init__(self, sequences: int = 1, regions: int = 1, n_classes: int = 3):
+        super().__init__()
+        w = NNUNET_WIDTHS
+        self.n_classes = 1 if n_classes == 2 else n_classes           # :74-76
+        # creation order == MTnnUNet.py:79-118
+        enc_io = [(sequences, w[0]), (w[0], w[1]), (w[1], w[2]), (w[2], w[3]), (w[3], w[4])]
+        for i, (a, b) in enumerate(enc_io, start=1):
+            setattr(self, f"encoder{i}", _level(a, b, b))
+        self.bottleneck = _level(w[4], w[4], w[4])
+        dec_io = {5: (2 * w[4], w[3], w[3]), 4: (2 * w[3], w[2], w[2]), 3: (2 * w[2], w[1], w[1]),
+                  2: (2 * w[1], w[0], w[0]), 1: (2 * w[0], w[0], w[0] // 2)}
+        for i in (5, 4, 3, 2, 1):
+            setattr(self, f"decoder{i}", _level(*dec_io[i]))
+        for i in (5, 4, 3, 2, 1):
+            c = w[i - 1]
+            setattr(self, f"upsample{i}", nn.ConvTranspose2d(c, c, kernel_size=2, stride=2))
+        self.downsample = nn.MaxPool2d(2, 2)
+        self.output4 = nn.Sequential(nn.ConvTranspose2d(w[2], w[2], kernel_size=8, stride=8),
+                                     nn.Conv2d(w[2], regions, kernel_size=1))
+        self.output3 = nn.Sequential(nn.ConvTranspose2d(w[1], w[1], kernel_size=4, stride=4),
+                                     nn.Conv2d(w[1], regions, kernel_size=1))
+        self.output2 = nn.Sequential(nn.ConvTranspose2d(w[0], w[0], kernel_size=2, stride=2),
+                                     nn.Conv2d(w[0], regions, kernel_size=1))
+        self.output1 = nn.Conv2d(w[0] // 2, regions, kernel_size=1)
+
+        # MTnnUNet.py:120 + :134-140 -- kaiming-normal over every Conv2d that
+        # exists *so far*; the classification head built below keeps torch's
+        # default init.
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, nonlinearity="leaky_relu")
+                if m.bias is not None:
+                    nn.init.constant_(m.bias, 0)
+
+        # MTnnUNet.py:123-132
+        self.process_encoder_5 = _cell(w[4], w[4])
+        self.process_decoder_5 = _cell(w[3], w[4])
+        self.classifier = nn.Sequential(
+            _cell(3 * w[4], 512), nn.AdaptiveAvgPool2d(1), nn.Flatten(),
+            nn.Linear(512, 256), nn.ReLU(), nn.Linear(256, self.n_classes))
+
+    def forward(self, x):                                            # :142-183
+        skips = []
+        t = x
+        for i in range(1, 6):
+            e = getattr(self, f"encoder{i}")(t)
+            skips.append(e)
+            t = self.downsample(e)
+        bott = self.bottleneck(t)
+        d = bott
+        dec = {}
+        for i in (5, 4, 3, 2, 1):
+            up = getattr(self, f"upsample{i}")(d)
+            d = getattr(self, f"decoder{i}")(torch.cat([skips[i - 1], up], dim=1))
+            dec[i] = d
+        feats = torch.cat([self.process_encoder_5(skips[4]),
+                           self.upsample5(bott),                    # second use, F10
+                           self.process_decoder_5(dec[5])], dim=1)
+        logits = self.classifier(feats)
+        outs = [self.output4(dec[4]), self.output3(dec[3]), self.output2(dec[2]), self.output1(dec[1])]
+        return [logits], outs
+
+
+# --------------------------------------------------------------------------
+# MTUNetPlusPlus (src/models/multitask/MTUNetPlusPlus.py:12-136) on MONAI 1.3.0
+# blocks (monai/networks/nets/basic_unet.py TwoConv/Down/UpCat,
+# monai/networks/blocks/convolutions.py Convolution + ADN "NDA",
+# monai/networks/blocks/upsample.py UpSample mode "deconv").  PARITY UNPINNED.
+# --------------------------------------------------------------------------
+
+UNETPP_FEATURES = (24, 48, 96, 192, 384, 24)   # MTUNetPlusPlus.py:18
+UNETPP_SLOPE = 0.1                             # MTUNetPlusPlus.py:20
+
+
+def _monai_convolution(cin: int, cout: int) -> nn.Sequential:
+    """MONAI Convolution(k3, s1, pad1, bias) + ADN ordering N-D-A:
+    InstanceNorm(affine) -> Dropout(p=0) -> LeakyReLU(0.1)."""
+    adn = nn.Sequential(OrderedDict(
+        N=nn.InstanceNorm2d(cout, affine=True),
+        D=nn.Dropout(0.0),
+        A=nn.LeakyReLU(negative_slope=UNETPP_SLOPE, inplace=True),
+    ))
+    return nn.Sequential(OrderedDict(
+        conv=nn.Conv2d(cin, cout, kernel_size=3, stride=1, padding=1, bias=True),
+        adn=adn,
+    ))
+
+
+def _two_conv(cin: int, cout: int) -> nn.Sequential:
+    return nn.Sequential(OrderedDict(conv_0=_monai_convolution(cin, cout),
+                                     conv_1=_monai_convolution(cout, cout)))
+
+
+def _down(cin: int, cout: int) -> nn.Sequential:
+    return nn.Sequential(OrderedDict(max_pooling=nn.MaxPool2d(kernel_size=2),
+                                     convs=_two_conv(cin, cout)))
+
+
+class _UpCat(nn.Module):
+    """MONAI UpCat with upsample='deconv': ConvTranspose(k2,s2,bias) then
+    cat([skip, up]) then TwoConv.  Channel order: skip first."""
+
+    def __init__(self, in_chns: int, cat_chns: int, out_chns: int, halves: bool = True):
+        super().__init__()
+        up_chns = in_chns // 2 if halves else in_chns
+        self.upsample = nn.Sequential(OrderedDict(
+            deconv=nn.ConvTranspose2d(in_chns, up_chns, kernel_size=2, stride=2, bias=True)))
+        self.convs = _two_conv(cat_chns + up_chns, out_chns)
+
+    def forward(self, x, x_e):
+        x_0 = self.upsample(x)
+        # MONAI replicate-pads odd sizes; all hot-path sizes are even so the
+        # branch never fires -- guarded here so misuse is loud, not silent.
+        if x_e.shape[-2:] != x_0.shape[-2:]:
+            raise ValueError("oracle UpCat: spatial sizes must match (H, W % 16 == 0)")
+        return self.convs(torch.cat([x_e, x_0], dim=1))
+
+
+class OracleMTUNetPlusPlus(nn.Module):
+    def __init__(self, in_channels: int = 1, out_channels: int = 1, n_classes: int = 3,
+                 deep_supervision: bool = False, features: Sequence[int] = UNETPP_FEATURES):
+        super().__init__()
+        self.deep_supervision = deep_supervision
+        self.n_classes = 1 if n_classes == 2 else n_classes
+        f = tuple(features)
+        # creation order == MTUNetPlusPlus.py:47-87
+        self.conv_0_0 = _two_conv(in_channels, f[0])
+        self.conv_1_0 = _down(f[0], f[1])
+        self.conv_2_0 = _down(f[1], f[2])
+        self.conv_3_0 = _down(f[2], f[3])
+        self.conv_4_0 = _down(f[3], f[4])
+        self.upcat_0_1 = _UpCat(f[1], f[0], f[0], halves=False)
+        self.upcat_1_1 = _UpCat(f[2], f[1], f[1])
+        self.upcat_2_1 = _UpCat(f[3], f[2], f[2])
+        self.upcat_3_1 = _UpCat(f[4], f[3], f[3])
+        self.upcat_0_2 = _UpCat(f[1], f[0] * 2, f[0], halves=False)
+        self.upcat_1_2 = _UpCat(f[2], f[1] * 2, f[1])
+        self.upcat_2_2 = _UpCat(f[3], f[2] * 2, f[2])
+        self.upcat_0_3 = _UpCat(f[1], f[0] * 3, f[0], halves=False)
+        self.upcat_1_3 = _UpCat(f[2], f[1] * 3, f[1])
+        self.upcat_0_4 = _UpCat(f[1], f[0] * 4, f[5], halves=False)
+        self.final_conv_0_1 = nn.Conv2d(f[0], out_channels, kernel_size=1)
+        self.final_conv_0_2 = nn.Conv2d(f[0], out_channels, kernel_size=1)
+        self.final_conv_0_3 = nn.Conv2d(f[0], out_channels, kernel_size=1)
+        self.final_conv_0_4 = nn.Conv2d(f[5], out_channels, kernel_size=1)
+        self.process_level_3 = _down(f[3], f[4])
+        self.classifier = nn.Sequential(
+            _two_conv(f[4] * 3, 512), nn.AdaptiveAvgPool2d(1), nn.Flatten(),
+            nn.Linear(512, 256), nn.ReLU(), nn.Linear(256, self.n_classes))
+
+    def forward(self, x):                                            # :101-136
+        cat = lambda *ts: torch.cat(ts, dim=1)
+        x00 = self.conv_0_0(x)
+        x10 = self.conv_1_0(x00)
+        x01 = self.upcat_0_1(x10, x00)
+        x20 = self.conv_2_0(x10)
+        x11 = self.upcat_1_1(x20, x10)
+        x02 = self.upcat_0_2(x11, cat(x00, x01))
+        x30 = self.conv_3_0(x20)
+        x21 = self.upcat_2_1(x30, x20)
+        x12 = self.upcat_1_2(x21, cat(x10, x11))
+        x03 = self.upcat_0_3(x12, cat(x00, x01, x02))
+        x40 = self.conv_4_0(x30)
+        x31 = self.upcat_3_1(x40, x30)
+        x22 = self.upcat_2_2(x31, cat(x20, x21))
+        x13 = self.upcat_1_3(x22, cat(x10, x11, x12))
+        x04 = self.upcat_0_4(x13, cat(x00, x01, x02, x03))
+        o1, o2, o3, o4 = (self.final_conv_0_1(x01), self.final_conv_0_2(x02),
+                          self.final_conv_0_3(x03), self.final_conv_0_4(x04))
+        feats = cat(self.process_level_3(x30), x40, self.process_level_3(x31))   # shared weights, F10
+        logits = self.classifier(feats)
+        if self.deep_supervision:
+            return [logits], [o1, o2, o3, o4]
+        return logits, o4
+
+
+def build_oracle_model(architecture: str, sequences: int = 1, regions: int = 1, n_classes: int = 3,
+                       deep_supervision: bool = True) -> nn.Module:
+    """src/utils/experiment_init.py:154-159."""
+    if architecture == "MTnnUNet":
+        return OracleMTnnUNet(sequences, regions, n_classes)
+    if architecture == "MTUNetPlusPlus":
+        return OracleMTUNetPlusPlus(sequences, regions, n_classes, deep_supervision)
+    raise ValueError(f"unknown architecture {architecture!r}")
+
+
+# --------------------------------------------------------------------------
+# Losses
+# --------------------------------------------------------------------------
+
+def dice_loss_sigmoid_sq(logits: torch.Tensor, target: torch.Tensor,
+                         smooth_nr: float = 1.0, smooth_dr: float = 1.0) -> torch.Tensor:
+    """MONAI 1.3.0 DiceLoss(include_background=True, sigmoid=True, squared_pred=True,
+    smooth_nr=1, smooth_dr=1, reduction='mean', batch=False) as built at
+    src/utils/experiment_init.py:210-211.  PARITY UNPINNED (monai absent).
+
+    p = sigmoid(x);  per (n, c):  I = sum_hw p*t,  D = sum_hw p^2 + sum_hw t^2
+    f = 1 - (2 I + nr) / (D + dr);  loss = mean_{n,c} f
+    """
+    p = torch.sigmoid(logits)
+    dims = tuple(range(2, logits.dim()))
+    inter = torch.sum(p * target, dim=dims)
+    denom = torch.sum(p * p, dim=dims) + torch.sum(target * target, dim=dims)
+    f = 1.0 - (2.0 * inter + smooth_nr) / (denom + smooth_dr)
+    return torch.mean(f)
+
+
+def focal_loss_soft(logits: torch.Tensor, targets: torch.Tensor, alpha: float = 1.0,
+                    gamma: float = 2.0, weight: torch.Tensor | None = None) -> torch.Tensor:
+    """src/utils/criterions.py:14-20 with reduction='mean':
+    ce_i = -sum_c w_c t_ic log_softmax(x_i)_c ; pt = exp(-ce) ; mean(alpha (1-pt)^gamma ce)."""
+    logp = F.log_softmax(logits, dim=1)
+    if weight is not None:
+        logp = logp * weight.view(1, -1)
+    ce = -(targets * logp).sum(dim=1)
+    pt = torch.exp(-ce)
+    return torch.mean(alpha * (1.0 - pt) ** gamma * ce)
+
+
+def multitask_losses(seg_outputs, mask, cls_outputs, onehot, inversely_weighted: bool = True):
+    """src/utils/criterions.py:52-76 (list branch and tensor branch); NaN -> SystemExit(1)."""
+    if isinstance(seg_outputs, (list, tuple)):
+        seg_terms = []
+        for j, s in enumerate(reversed(list(seg_outputs))):
+            d = dice_loss_sigmoid_sq(s, mask)
+            seg_terms.append(d / (j + 1) if inversely_weighted else d)
+        seg = torch.sum(torch.stack(seg_terms))
+        cls = torch.sum(torch.stack([focal_loss_soft(c, onehot) for c in reversed(list(cls_outputs))]))
+    else:
+        seg = dice_loss_sigmoid_sq(seg_outputs, mask)
+        cls = focal_loss_soft(cls_outputs, onehot)
+    if torch.isnan(seg) or torch.isnan(cls):
+        raise SystemExit(1)
+    return seg, cls
+
+
+def dice_score_from_tensor(gt: torch.Tensor, seg: torch.Tensor):
+    """src/utils/metrics.py:255-267 (whole-batch TP/FP/FN in float64)."""
+    gt = gt.double()
+    seg = seg.double()
+    tp = torch.sum(torch.logical_and(seg, gt)).double()
+    fp = torch.sum(torch.logical_and(seg, torch.logical_not(gt))).double()
+    fn = torch.sum(torch.logical_and(torch.logical_not(seg), gt)).double()
+    if torch.sum(gt) == 0:
+        return 1 if torch.sum(seg) == 0 else 0
+    return 2 * tp / (2 * tp + fp + fn)
+
+
+# --------------------------------------------------------------------------
+# One optimisation step  (src/training_multitask.py:82-103)
+# --------------------------------------------------------------------------
+
+def make_adam(model: nn.Module, lr: float = 1e-4) -> torch.optim.Optimizer:
+    """src/utils/experiment_init.py:186-187 -- note eps=1e-4."""
+    return torch.optim.Adam(model.parameters(), lr=lr, eps=1e-4)
+
+
+def train_step(model: nn.Module, optimizer, image: torch.Tensor, mask: torch.Tensor,
+               label: torch.Tensor, alpha: float, inversely_weighted: bool = True, n_classes: int = 3):
+    """Returns (total, seg, cls) python floats plus the raw outputs of the forward pass."""
+    onehot = F.one_hot(label.flatten().to(torch.int64), num_classes=n_classes).to(torch.float)
+    optimizer.zero_grad(set_to_none=True)
+    logits, outputs = model(image)
+    seg, cls = multitask_losses(outputs, mask, logits, onehot, inversely_weighted)
+    total = alpha * seg + (1.0 - alpha) * cls
+    total.backward()
+    optimizer.step()
+    return total.detach(), seg.detach(), cls.detach(), logits, outputs
+
+
+def seed_everything(seed: int) -> None:
+    """src/utils/miscellany.py:78-96 (the parts that matter on CPU)."""
+    import os
+    import random
+    import numpy as np
+    os.environ["PYTHONHASHSEED"] = str(seed)
+    random.seed(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+
+
+def synthetic_batch(n: int, h: int, w: int, seed: int = 0) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """Curated-BUSI-shaped synthetic batch: image U[0,255) smooth speckle,
+    one filled ellipse per non-normal sample, labels 0/1/2.  Deterministic in `seed`."""
+    g = torch.Generator().manual_seed(seed)
+    base = torch.randn(n, 1, h // 8 + 1, w // 8 + 1, generator=g)
+    low = F.interpolate(base, size=(h, w), mode="bilinear", align_corners=True)
+    img = torch.clamp(128.0 + 48.0 * low + 32.0 * torch.randn(n, 1, h, w, generator=g), 0.0, 255.0)
+    label = torch.randint(0, 3, (n, 1), generator=g).to(torch.float)
+    yy = torch.arange(h).view(1, h, 1).float()
+    xx = torch.arange(w).view(1, 1, w).float()
+    cy = (0.25 + 0.5 * torch.rand(n, 1, 1, generator=g)) * h
+    cx = (0.25 + 0.5 * torch.rand(n, 1, 1, generator=g)) * w
+    ry = (0.08 + 0.17 * torch.rand(n, 1, 1, generator=g)) * h
+    rx = (0.08 + 0.17 * torch.rand(n, 1, 1, generator=g)) * w
+    ell = (((yy - cy) / ry) ** 2 + ((xx - cx) / rx) ** 2 <= 1.0).float()
+    mask = (ell * (label.view(n, 1, 1) != 2).float()).view(n, 1, h, w)
+    return img.contiguous(), mask.contiguous(), label

@@ -1,0 +1,175 @@
+"""Pin the CPU oracle against fixtures generated from the reference's own modules
+(oracle/make_goldens.py).  CPU only."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import torch_oracle as O
+from oracle.oversampling_oracle import deterministic_oversampling_positions, scaling_factors
+
+
+def _sha(sd):
+    h = hashlib.sha256()
+    for k, v in sd.items():
+        h.update(k.encode())
+        h.update(v.detach().cpu().contiguous().numpy().tobytes())
+    return h.hexdigest()
+
+
+@pytest.fixture(scope="module")
+def seeded_nnunet():
+    O.seed_everything(1993)
+    return O.OracleMTnnUNet(1, 1, 3)
+
+
+def test_nnunet_seeded_state_dict_matches_reference(golden_dir, seeded_nnunet):
+    g = np.load(os.path.join(golden_dir, "mtnnunet_seed1993_forward.npz"))
+    sd = seeded_nnunet.state_dict()
+    assert list(sd.keys()) == [str(n) for n in g["names"]]
+    assert [str(tuple(v.shape)) for v in sd.values()] == [str(s) for s in g["shapes"]]
+    assert _sha(sd) == str(g["sha256"])          # bit-exact initial weights
+    assert sum(p.numel() for p in seeded_nnunet.parameters()) == 15_819_799
+
+
+def test_nnunet_forward_matches_reference(golden_dir, seeded_nnunet):
+    g = np.load(os.path.join(golden_dir, "mtnnunet_seed1993_forward.npz"))
+    seeded_nnunet.train(True)
+    with torch.no_grad():
+        logits, segs = seeded_nnunet(torch.from_numpy(g["x"]))
+    np.testing.assert_allclose(logits[0].numpy(), g["logits"], rtol=0, atol=1e-6)
+    for i, s in enumerate(segs):
+        np.testing.assert_allclose(s.numpy(), g[f"seg{i}"], rtol=0, atol=2e-6)
+
+
+def test_nnunet_full_step_matches_reference(golden_dir):
+    g = np.load(os.path.join(golden_dir, "mtnnunet_step.npz"))
+    f = np.load(os.path.join(golden_dir, "mtnnunet_seed1993_forward.npz"))
+    O.seed_everything(1993)
+    model = O.OracleMTnnUNet(1, 1, 3)
+    opt = O.make_adam(model, lr=1e-4)
+    total, seg, cls, _, _ = O.train_step(model, opt, torch.from_numpy(f["x"]), torch.from_numpy(g["mask"]),
+                                         torch.from_numpy(g["label"]), float(g["alpha"]), True, 3)
+    assert abs(total.item() - float(g["total"])) < 1e-6
+    assert abs(seg.item() - float(g["seg"])) < 1e-6
+    assert abs(cls.item() - float(g["cls"])) < 1e-6
+    params = dict(model.named_parameters())
+    for k in [str(p) for p in g["probe"]]:
+        np.testing.assert_allclose(params[k].grad.flatten()[:16].numpy(), g[f"grad::{k}"], rtol=1e-4, atol=1e-7)
+        np.testing.assert_allclose(params[k].detach().flatten()[:16].numpy(), g[f"after::{k}"], rtol=0, atol=1e-7)
+
+
+def test_focal_known_answers(golden_dir):
+    g = np.load(os.path.join(golden_dir, "focal.npz"))
+    t = torch.from_numpy
+    assert abs(O.focal_loss_soft(t(g["x1"]), t(g["t1"])).item() - 0.20617523789405823) < 1e-7   # SURVEY A8 KAT
+    assert abs(O.focal_loss_soft(t(g["x1"]), t(g["t1"])).item() - float(g["y1"])) < 1e-7
+    assert abs(O.focal_loss_soft(t(g["x2"]), t(g["t2"])).item() - float(g["y2"])) < 1e-6
+    assert abs(O.focal_loss_soft(t(g["x2"]), t(g["t3"])).item() - float(g["y3"])) < 1e-6
+    assert abs(O.focal_loss_soft(t(g["x2"]), t(g["t2"]), weight=t(g["w"])).item() - float(g["y4"])) < 1e-6
+
+
+def test_loss_aggregation_matches_reference(golden_dir):
+    g = np.load(os.path.join(golden_dir, "criterion_aggregation.npz"))
+    t = torch.from_numpy
+    segs = [t(g[f"seg{i}"]) for i in range(4)]
+    for iw in (True, False):
+        s, c = O.multitask_losses(segs, t(g["gt"]), [t(g["cls0"])], t(g["onehot"]), iw)
+        assert abs(s.item() - float(g[f"seg_iw{int(iw)}"])) < 1e-6
+        assert abs(c.item() - float(g[f"cls_iw{int(iw)}"])) < 1e-6
+    s, c = O.multitask_losses(segs[3], t(g["gt"]), t(g["cls0"]), t(g["onehot"]), True)
+    assert abs(s.item() - float(g["seg_tensor"])) < 1e-6
+    assert abs(c.item() - float(g["cls_tensor"])) < 1e-6
+
+
+def test_loss_nan_exits():
+    bad = [torch.full((1, 1, 4, 4), float("nan"))] * 4
+    with pytest.raises(SystemExit):
+        O.multitask_losses(bad, torch.zeros(1, 1, 4, 4), [torch.zeros(1, 3)], torch.tensor([[1., 0., 0.]]), True)
+
+
+def test_dice_score_known_answers(golden_dir):
+    g = np.load(os.path.join(golden_dir, "dice_score.npz"))
+    assert float(O.dice_score_from_tensor(torch.tensor([[1., 1.], [0., 0.]]),
+                                          torch.tensor([[True, False], [True, False]]))) == float(g["k1"]) == 0.5
+    assert float(O.dice_score_from_tensor(torch.zeros(2, 2), torch.zeros(2, 2).bool())) == float(g["k_empty"]) == 1.0
+    assert float(O.dice_score_from_tensor(torch.zeros(2, 2), torch.ones(2, 2).bool())) == float(g["k_fp_only"]) == 0.0
+    v = float(O.dice_score_from_tensor(torch.from_numpy(g["gt"]).float(), torch.from_numpy(g["seg"])))
+    assert abs(v - float(g["k_rand"])) < 1e-12
+
+
+def test_dice_loss_closed_form():
+    # all-zero logits & zero target: p=.5, I=0, D=.25*HW -> f = 1 - 1/(.25 HW + 1)   
+    for hw in (4, 16, 64):
+        x = torch.zeros(2, 1, hw, hw)
+        want = 1.0 - 1.0 / (0.25 * hw * hw + 1.0)
+        assert abs(O.dice_loss_sigmoid_sq(x, torch.zeros_like(x)).item() - want) < 1e-6
+    # saturated perfect prediction: p->1 on target, 0 elsewhere -> f = 1 - (2A+1)/(2A+1) = 0
+    tgt = torch.zeros(1, 1, 8, 8)
+    tgt[..., 2:6, 2:6] = 1
+    x = (tgt * 2 - 1) * 40.0
+    assert abs(O.dice_loss_sigmoid_sq(x, tgt).item()) < 1e-6
+
+
+def test_levelblock_cell_matches_reference(golden_dir):
+    g = np.load(os.path.join(golden_dir, "levelblock.npz"))
+    blk = O._level(3, 8, 8)
+    with torch.no_grad():
+        blk.ConvInNormLRelu1.Conv.weight.copy_(torch.from_numpy(g["w1"]))
+        blk.ConvInNormLRelu2.Conv.weight.copy_(torch.from_numpy(g["w2"]))
+        y = blk(torch.from_numpy(g["x"]))
+    np.testing.assert_allclose(y.numpy(), g["y"], rtol=0, atol=1e-6)
+
+
+def test_unetpp_restatement_shape_and_param_count():
+    O.seed_everything(1993)
+    m = O.OracleMTUNetPlusPlus(1, 1, 3, deep_supervision=True)
+    assert sum(p.numel() for p in m.parameters()) == 14_927_455        # SURVEY §6 / BASELINE.md
+    sd = m.state_dict()
+    for k in ("conv_0_0.conv_0.conv.weight", "conv_0_0.conv_0.adn.N.weight", "conv_1_0.convs.conv_1.conv.bias",
+              "upcat_0_4.upsample.deconv.weight", "upcat_2_2.convs.conv_0.adn.N.bias", "final_conv_0_4.bias",
+              "process_level_3.convs.conv_0.conv.weight", "classifier.0.conv_1.conv.weight", "classifier.5.weight"):
+        assert k in sd, k
+    assert tuple(sd["upcat_0_1.upsample.deconv.weight"].shape) == (48, 48, 2, 2)      # halves=False
+    assert tuple(sd["upcat_1_1.upsample.deconv.weight"].shape) == (96, 48, 2, 2)      # halves=True
+    assert tuple(sd["upcat_0_4.convs.conv_0.conv.weight"].shape) == (24, 144, 3, 3)
+    with torch.no_grad():
+        logits, segs = m(torch.rand(1, 1, 32, 32) * 255)
+    assert logits[0].shape == (1, 3) and all(s.shape == (1, 1, 32, 32) for s in segs)
+    m2 = O.OracleMTUNetPlusPlus(1, 1, 3, deep_supervision=False)
+    with torch.no_grad():
+        lg, sg = m2(torch.rand(1, 1, 32, 32))
+    assert lg.shape == (1, 3) and sg.shape == (1, 1, 32, 32)
+
+
+def test_oversampling_curated_busi(golden_dir):
+    classes = [str(c) for c in np.load(os.path.join(golden_dir, "curated_busi_classes.npz"))["classes"]]
+    assert len(classes) == 450
+    assert scaling_factors(classes) == {"benign": 2, "malignant": 3, "normal": 7}
+    pos = deterministic_oversampling_positions(classes)
+    assert len(pos) == 1384                                  # 444 / 492 / 448  
+    out = [classes[i] for i in pos]
+    assert (out.count("benign"), out.count("malignant"), out.count("normal")) == (444, 492, 448)
+    assert pos[:450] == list(range(450))
+    ben = [i for i, c in enumerate(classes) if c == "benign"]
+    mal = [i for i, c in enumerate(classes) if c == "malignant"]
+    nor = [i for i, c in enumerate(classes) if c == "normal"]
+    assert pos[450:] == ben + mal * 2 + nor * 6
+
+
+def test_oversampling_edge_cases():
+    # proportion 0.4 -> 2.5 -> half-to-even -> 2 ; proportion 0.6 -> 1.67 -> 2
+    cl = ["a"] * 6 + ["b"] * 4
+    assert scaling_factors(cl) == {"a": 2, "b": 2}
+    # dominant class (> 2/3): factor 1 -> still duplicated once (reference quirk :334-336)
+    cl = ["a"] * 8 + ["b"] * 2
+    assert scaling_factors(cl) == {"a": 1, "b": 5}
+    pos = deterministic_oversampling_positions(cl)
+    assert pos == list(range(10)) + list(range(8)) + [8, 9] * 4
+    # ties keep first-seen order
+    cl = ["x", "y", "y", "x"]
+    assert list(scaling_factors(cl).keys()) == ["x", "y"]
+    assert deterministic_oversampling_positions(cl) == [0, 1, 2, 3, 0, 3, 1, 2]
+    assert deterministic_oversampling_positions([]) == []
