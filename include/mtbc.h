@@ -1,0 +1,301 @@
+/*
+ * mtbc.h -- C-ABI of libmtbc_hip.so: the MI355X (gfx950) hot path of the multi-task
+ * conv encoder-decoder training step of caumente/multi_task_breast_cancer.
+ *
+ * The reference has no FFI of its own (it is pure Python on torch.nn); each
+ * entry point below names the reference call it replaces (file:line, relative to the
+ * upstream repository).  All tensors are fp32, NCHW, plane-contiguous (channel stride =
+ * H*W) device pointers BORROWED from the caller until the stream operation completes.
+ *
+ * Conventions: return 0 (MTBC_OK) or a negative MTBC_E_* code; never throws, never
+ * allocates, never synchronises the device; deterministic (no float atomics); thread-safe
+ * for distinct streams.  `stream` is a hipStream_t passed as void*.
+ */
+#ifndef MTBC_H
+#define MTBC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MTBC_VERSION 100            /* 0.1.0 */
+#define MTBC_MAX_SEGS 6
+
+enum {
+    MTBC_OK = 0,
+    MTBC_E_BADSHAPE = -1,
+    MTBC_E_BADARG = -2,
+    MTBC_E_WORKSPACE = -3,
+    MTBC_E_LAUNCH = -4,
+    MTBC_E_UNSUPPORTED = -5
+};
+
+int mtbc_version(void);
+const char* mtbc_strerror(int code);
+/* name of the GPU architecture the device code was built for ("gfx950") */
+const char* mtbc_arch(void);
+
+/* A channel segment of a virtually concatenated NCHW tensor (replaces torch.cat(dim=1),
+ * MTnnUNet.py:161-169,174; MTUNetPlusPlus.py:107-118,128).  Element (n, c, y, x) of the
+ * segment lives at ptr[n*batch_stride + c*H*W + y*W + x].  `accumulate` is honoured when
+ * the segment is an OUTPUT (gradient fan-in): 0 = overwrite, 1 = add to what is there. */
+typedef struct {
+    float* ptr;
+    int64_t batch_stride;   /* elements */
+    int32_t channels;
+    int32_t accumulate;
+} mtbc_seg;
+
+/* ---------------------------------------------------------------- conv 3x3, stride 1, pad 1
+ * replaces nn.Conv2d(k=3, padding=1): MTnnUNet.py:12-16 ; MONAI Convolution in
+ * MTUNetPlusPlus.py:47-81.  Weight layout = torch (Cout, Cin, 3, 3).                       */
+typedef struct {
+    int32_t N, H, W, Cin, Cout;
+    int32_t n_in;                    /* fwd/wgrad: input segments (sum channels == Cin)      */
+    mtbc_seg in[MTBC_MAX_SEGS];      /* dgrad: OUTPUT dx segments (accumulate honoured)      */
+    const float* w;                  /* (Cout,Cin,3,3)                                       */
+    const float* w_packed;           /* fwd: mtbc_conv3x3_pack_fwd image, dgrad: _pack_dgrad;
+                                        NULL selects the direct (non-MFMA) kernel           */
+    const float* bias;               /* (Cout) or NULL                                       */
+    float* out;                      /* fwd: z (N,Cout,H,W) ; dgrad: unused                  */
+    const float* dout;               /* dgrad/wgrad: dz (N,Cout,H,W)                         */
+    float* dw;                       /* wgrad: (Cout,Cin,3,3), overwritten or accumulated    */
+    float* dbias;                    /* wgrad: (Cout) or NULL                                */
+    int32_t accumulate_dw;           /* wgrad: 1 = add into dw/dbias (shared modules, F10)   */
+    int32_t force_direct;            /* 1 = never use the MFMA kernels (debug / tests)       */
+    /* optional fused InstanceNorm statistics of the output (fwd only): per-(n,co) partial
+       (count, mean, M2) triples are written to stats_partial; NULL = off                    */
+    float* stats_partial;
+    void* workspace;                 /* wgrad split-K partials                               */
+    size_t workspace_bytes;
+} mtbc_conv3x3_args;
+
+size_t mtbc_conv3x3_packed_elems(int32_t Cin, int32_t Cout);          /* fwd image size      */
+size_t mtbc_conv3x3_packed_dgrad_elems(int32_t Cin, int32_t Cout);    /* dgrad image size    */
+int mtbc_conv3x3_pack_fwd(const float* w, float* packed, int32_t Cin, int32_t Cout, void* stream);
+int mtbc_conv3x3_pack_dgrad(const float* w, float* packed, int32_t Cin, int32_t Cout, void* stream);
+size_t mtbc_conv3x3_wgrad_workspace(const mtbc_conv3x3_args* a);
+int mtbc_conv3x3_fwd(const mtbc_conv3x3_args* a, void* stream);
+int mtbc_conv3x3_dgrad(const mtbc_conv3x3_args* a, void* stream);
+int mtbc_conv3x3_wgrad(const mtbc_conv3x3_args* a, void* stream);
+
+/* ------------------------------------------------- InstanceNorm2d(eps, affine?) + LeakyReLU
+ * replaces nn.InstanceNorm2d + nn.LeakyReLU: MTnnUNet.py:35-36 (no affine, slope 0.01);
+ * MONAI ADN "NDA" in MTUNetPlusPlus.py:20-22 (affine, slope 0.1).
+ *   y = lrelu(gamma * (z - mean) * rstd + beta), biased variance over H*W per (n, c).
+ * The output may be a channel slice of a wider buffer (out_batch_stride).                   */
+typedef struct {
+    int32_t N, C, H, W;
+    float eps, slope;
+    const float* z;          /* (N,C,H,W) conv output                                        */
+    const float* gamma;      /* (C) or NULL                                                  */
+    const float* beta;       /* (C) or NULL                                                  */
+    float* y;                /* activation, element (n,c,p) at y[n*y_batch_stride + c*HW + p] */
+    int64_t y_batch_stride;
+    float* mean;             /* (N*C) saved for backward                                     */
+    float* rstd;             /* (N*C)                                                        */
+    /* backward */
+    const float* dy;         /* grad wrt y, same addressing as y (dy_batch_stride)           */
+    int64_t dy_batch_stride;
+    float* dz;               /* (N,C,H,W) grad wrt z                                         */
+    float* dgamma;           /* (C) or NULL */
+    float* dbeta;            /* (C) or NULL */
+    int32_t accumulate_dparams;
+    void* workspace;         /* bwd with affine: N*C*2 floats                                */
+    size_t workspace_bytes;
+} mtbc_instnorm_args;
+
+int mtbc_instnorm_lrelu_fwd(const mtbc_instnorm_args* a, void* stream);
+int mtbc_instnorm_lrelu_bwd(const mtbc_instnorm_args* a, void* stream);
+
+/* --------------------------------------------------------------------- MaxPool2d(2, 2)
+ * replaces nn.MaxPool2d(2,2): MTnnUNet.py:103 ; MONAI Down in MTUNetPlusPlus.py:48-51.
+ * bwd routes dy to the first maximal element in (0,0),(0,1),(1,0),(1,1) order, like ATen.  */
+typedef struct {
+    int32_t N, C, H, W;              /* INPUT spatial size; output is H/2 x W/2              */
+    const float* x;  int64_t x_batch_stride;
+    float* y;        int64_t y_batch_stride;
+    const float* dy; int64_t dy_batch_stride;
+    float* dx;       int64_t dx_batch_stride;
+    int32_t accumulate_dx;
+} mtbc_maxpool_args;
+
+int mtbc_maxpool2_fwd(const mtbc_maxpool_args* a, void* stream);
+int mtbc_maxpool2_bwd(const mtbc_maxpool_args* a, void* stream);
+
+/* --------------------------------------------- ConvTranspose2d, kernel == stride == k
+ * replaces nn.ConvTranspose2d(k, stride=k): MTnnUNet.py:96-100,106-116 (k = 2, 4, 8);
+ * MONAI UpSample("deconv") in UpCat.  Weight layout = torch (Cin, Cout, k, k).
+ *   y[n,co,k*i+a,k*j+b] = bias[co] + sum_ci x[n,ci,i,j] * W[ci,co,a,b]                      */
+typedef struct {
+    int32_t N, H, W, Cin, Cout, k;   /* INPUT spatial size H x W; output kH x kW             */
+    const float* x;  int64_t x_batch_stride;
+    const float* w;
+    const float* bias;               /* (Cout) or NULL */
+    float* y;        int64_t y_batch_stride;
+    const float* dy; int64_t dy_batch_stride;
+    float* dx;       int64_t dx_batch_stride;
+    int32_t accumulate_dx;
+    float* dw;       float* dbias;
+    int32_t accumulate_dw;
+    void* workspace; size_t workspace_bytes;
+} mtbc_convT_args;
+
+size_t mtbc_convT_wgrad_workspace(const mtbc_convT_args* a);
+int mtbc_convT_fwd(const mtbc_convT_args* a, void* stream);
+int mtbc_convT_dgrad(const mtbc_convT_args* a, void* stream);
+int mtbc_convT_wgrad(const mtbc_convT_args* a, void* stream);
+
+/* -------------------------------------------------------------------------- conv 1x1 + bias
+ * replaces nn.Conv2d(k=1): MTnnUNet.py:6-9,106-118 ; MTUNetPlusPlus.py:73-76 (Cout = regions) */
+typedef struct {
+    int32_t N, H, W, Cin, Cout;
+    const float* x;  int64_t x_batch_stride;
+    const float* w;                  /* (Cout,Cin,1,1) */
+    const float* bias;
+    float* y;                        /* (N,Cout,H,W) */
+    const float* dy;
+    float* dx;       int64_t dx_batch_stride;
+    int32_t accumulate_dx;
+    float* dw;       float* dbias;
+    int32_t accumulate_dw;
+    void* workspace; size_t workspace_bytes;
+} mtbc_conv1x1_args;
+
+size_t mtbc_conv1x1_wgrad_workspace(const mtbc_conv1x1_args* a);
+int mtbc_conv1x1_fwd(const mtbc_conv1x1_args* a, void* stream);
+int mtbc_conv1x1_dgrad(const mtbc_conv1x1_args* a, void* stream);
+int mtbc_conv1x1_wgrad(const mtbc_conv1x1_args* a, void* stream);
+
+/* ----------------------------------------------- AdaptiveAvgPool2d(1) + Flatten
+ * replaces MTnnUNet.py:126-127 ; MTUNetPlusPlus.py:81-82                                    */
+typedef struct {
+    int32_t N, C, H, W;
+    const float* x;  float* y;       /* y: (N,C) */
+    const float* dy; float* dx;      /* dx: (N,C,H,W) overwritten */
+} mtbc_gap_args;
+int mtbc_gap_fwd(const mtbc_gap_args* a, void* stream);
+int mtbc_gap_bwd(const mtbc_gap_args* a, void* stream);
+
+/* ----------------------------------------------------------- Linear (+ optional ReLU)
+ * replaces nn.Linear/nn.ReLU: MTnnUNet.py:128-131 ; MTUNetPlusPlus.py:83-86.
+ * y = relu?(x W^T + b), W: (Out, In).  bwd needs y when relu != 0.                          */
+typedef struct {
+    int32_t N, In, Out, relu;
+    const float* x; const float* w; const float* bias; float* y;
+    const float* dy; float* dx;      /* dx (N,In) overwritten; may be NULL */
+    float* dw; float* dbias; int32_t accumulate_dw;
+    void* workspace; size_t workspace_bytes;   /* bwd with relu: N*Out floats */
+} mtbc_linear_args;
+int mtbc_linear_fwd(const mtbc_linear_args* a, void* stream);
+int mtbc_linear_bwd(const mtbc_linear_args* a, void* stream);
+
+/* ------------------------------------------------------------------------------ Dice loss
+ * replaces monai.losses.DiceLoss(include_background=True, sigmoid=True, squared_pred=True,
+ * smooth_nr=1, smooth_dr=1) built at experiment_init.py:210-211, fused over up to 4 deep
+ * supervision heads with the 1/(j+1) weights of criterions.py:62.
+ *   loss_h = mean_{n,c}( 1 - (2 I + nr) / (D + dr) ),  I = sum p t, D = sum p^2 + sum t^2
+ * fwd : stats[h][n*C+c] = {I, P2, T2};  loss[h] = loss_h (unweighted);
+ *       loss[n_heads] = sum_h head_weight[h] * loss_h
+ * bwd : dx_h = gscale * head_weight[h] / (N*C) * d f / d x   (gscale: host scalar times an
+ *       optional device scalar *gscale_dev, e.g. the upstream autograd gradient)            */
+typedef struct {
+    int32_t n_heads, N, C, H, W;
+    float smooth_nr, smooth_dr;
+    const float* x[4];               /* logits per head (N,C,H,W) */
+    const float* target;             /* (N,C,H,W) */
+    float head_weight[4];
+    float* stats;                    /* n_heads * N*C * 3 floats */
+    float* loss;                     /* n_heads + 1 floats */
+    float* dx[4];
+    float gscale;
+    const float* gscale_dev;         /* may be NULL */
+} mtbc_dice_args;
+int mtbc_dice_fwd(const mtbc_dice_args* a, void* stream);
+int mtbc_dice_bwd(const mtbc_dice_args* a, void* stream);
+
+/* ----------------------------------------------------------------------------- Focal loss
+ * replaces FocalLoss.forward (criterions.py:14-24, reduction='mean', soft/one-hot float
+ * targets, optional class weight).  One launch computes the loss and d loss / d logits.
+ *   ce_i = -sum_c w_c t_ic log_softmax(x_i)_c ; pt = exp(-ce_i) ;
+ *   loss = mean_i alpha (1 - pt)^gamma ce_i ;  dx = gscale * (*gscale_dev) * d loss / d x    */
+typedef struct {
+    int32_t N, C;
+    float alpha, gamma;
+    const float* x; const float* target; const float* weight;   /* weight may be NULL */
+    float* loss;                     /* 1 float */
+    float* dx;                       /* (N,C) or NULL */
+    float gscale;
+    const float* gscale_dev;
+} mtbc_focal_args;
+int mtbc_focal_fwd_bwd(const mtbc_focal_args* a, void* stream);
+
+/* -------------------------------------------------------------- loss mix + NaN guard
+ * replaces training_multitask.py:98 (alpha-mix) and the isnan guard of criterions.py:72-76:
+ *   out[0] = alpha*seg + (1-alpha)*cls, out[1] = seg, out[2] = cls, out[3] = nan flag (0/1)  */
+int mtbc_loss_mix(const float* seg, const float* cls, float alpha, float* out4, void* stream);
+
+/* ------------------------------------------------------------------------------------ Adam
+ * replaces torch.optim.Adam(lr, betas=(.9,.999), eps=1e-4).step(): experiment_init.py:187,
+ * training_multitask.py:103 -- one fused launch over the flat parameter buffer.
+ *   g' = grad_scale * g ; m = m + (1-b1)(g'-m) ; v = b2 v + (1-b2) g'^2
+ *   p -= (lr / (1-b1^t)) * m / (sqrt(v)/sqrt(1-b2^t) + eps)                                 */
+typedef struct {
+    int64_t n;
+    float* p; const float* g; float* m; float* v;
+    float lr, beta1, beta2, eps, grad_scale;
+    int32_t step;                    /* t >= 1 */
+    int32_t zero_grad;               /* 1 = also clear g (optimizer.zero_grad) */
+} mtbc_adam_args;
+int mtbc_adam_step(const mtbc_adam_args* a, void* stream);
+
+/* Whole-batch TP/FP/FN of (sigmoid(x) > .5) vs target, the train-loop Dice metric of
+ * metrics.py:255-267 (training_multitask.py:66-71).  out3 = {tp, fp, fn} as float64.        */
+int mtbc_dice_counts(const float* logits, const float* target, int64_t n, double* out3, void* stream);
+
+/* ---------------------------------------------------------------------------- step program
+ * A training step is a static list of the ops above with every pointer resolved at plan
+ * time; mtbc_program_run issues them back-to-back on one stream (no host work in between). */
+enum {
+    MTBC_OP_CONV3_FWD = 1, MTBC_OP_CONV3_DGRAD, MTBC_OP_CONV3_WGRAD,
+    MTBC_OP_CONV3_PACK_FWD, MTBC_OP_CONV3_PACK_DGRAD,
+    MTBC_OP_IN_FWD, MTBC_OP_IN_BWD, MTBC_OP_POOL_FWD, MTBC_OP_POOL_BWD,
+    MTBC_OP_CONVT_FWD, MTBC_OP_CONVT_DGRAD, MTBC_OP_CONVT_WGRAD,
+    MTBC_OP_CONV1_FWD, MTBC_OP_CONV1_DGRAD, MTBC_OP_CONV1_WGRAD,
+    MTBC_OP_GAP_FWD, MTBC_OP_GAP_BWD, MTBC_OP_LINEAR_FWD, MTBC_OP_LINEAR_BWD,
+    MTBC_OP_DICE_FWD, MTBC_OP_DICE_BWD, MTBC_OP_FOCAL, MTBC_OP_LOSS_MIX, MTBC_OP_ADAM,
+    MTBC_OP_MEMSET, MTBC_OP_DICE_COUNTS
+};
+
+typedef struct {
+    int32_t kind;
+    int32_t tag;                     /* free for the caller (layer id) */
+    union {
+        mtbc_conv3x3_args conv3;
+        mtbc_instnorm_args inorm;
+        mtbc_maxpool_args pool;
+        mtbc_convT_args convT;
+        mtbc_conv1x1_args conv1;
+        mtbc_gap_args gap;
+        mtbc_linear_args linear;
+        mtbc_dice_args dice;
+        mtbc_focal_args focal;
+        mtbc_adam_args adam;
+        struct { const float* w; float* packed; int32_t Cin, Cout; } pack;
+        struct { const float* seg; const float* cls; float alpha; float* out4; } mix;
+        struct { void* ptr; size_t bytes; } memset0;
+        struct { const float* logits; const float* target; int64_t n; double* out3; } counts;
+    } u;
+} mtbc_op;
+
+/* run ops[first .. first+count) on `stream`; returns 0 or the first failing op's error code,
+ * with *failed_index (may be NULL) set to its index. */
+int mtbc_program_run(const mtbc_op* ops, int32_t first, int32_t count, void* stream, int32_t* failed_index);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MTBC_H */

@@ -1,0 +1,226 @@
+"""ctypes binding of libmtbc_hip.so (the C-ABI declared in include/mtbc.h).
+
+The product path has NO CPU fallback: if the shared library is missing or a call
+returns an error code this module raises, loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmtbc_hip.so")
+
+MAX_SEGS = 6
+c_float_p = C.POINTER(C.c_float)
+
+
+class MtbcError(RuntimeError):
+    pass
+
+
+class Seg(C.Structure):
+    _fields_ = [("ptr", C.c_void_p), ("batch_stride", C.c_int64), ("channels", C.c_int32), ("accumulate", C.c_int32)]
+
+
+class Conv3x3Args(C.Structure):
+    _fields_ = [("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Cin", C.c_int32), ("Cout", C.c_int32),
+                ("n_in", C.c_int32), ("in_", Seg * MAX_SEGS),
+                ("w", C.c_void_p), ("w_packed", C.c_void_p), ("bias", C.c_void_p),
+                ("out", C.c_void_p), ("dout", C.c_void_p), ("dw", C.c_void_p), ("dbias", C.c_void_p),
+                ("accumulate_dw", C.c_int32), ("force_direct", C.c_int32),
+                ("stats_partial", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]
+
+
+class InstNormArgs(C.Structure):
+    _fields_ = [("N", C.c_int32), ("C", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
+                ("eps", C.c_float), ("slope", C.c_float),
+                ("z", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p),
+                ("y", C.c_void_p), ("y_batch_stride", C.c_int64),
+                ("mean", C.c_void_p), ("rstd", C.c_void_p),
+                ("dy", C.c_void_p), ("dy_batch_stride", C.c_int64),
+                ("dz", C.c_void_p), ("dgamma", C.c_void_p), ("dbeta", C.c_void_p),
+                ("accumulate_dparams", C.c_int32),
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]
+
+
+class MaxPoolArgs(C.Structure):
+    _fields_ = [("N", C.c_int32), ("C", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
+                ("x", C.c_void_p), ("x_batch_stride", C.c_int64),
+                ("y", C.c_void_p), ("y_batch_stride", C.c_int64),
+                ("dy", C.c_void_p), ("dy_batch_stride", C.c_int64),
+                ("dx", C.c_void_p), ("dx_batch_stride", C.c_int64),
+                ("accumulate_dx", C.c_int32)]
+
+
+class ConvTArgs(C.Structure):
+    _fields_ = [("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Cin", C.c_int32), ("Cout", C.c_int32),
+                ("k", C.c_int32),
+                ("x", C.c_void_p), ("x_batch_stride", C.c_int64),
+                ("w", C.c_void_p), ("bias", C.c_void_p),
+                ("y", C.c_void_p), ("y_batch_stride", C.c_int64),
+                ("dy", C.c_void_p), ("dy_batch_stride", C.c_int64),
+                ("dx", C.c_void_p), ("dx_batch_stride", C.c_int64),
+                ("accumulate_dx", C.c_int32),
+                ("dw", C.c_void_p), ("dbias", C.c_void_p), ("accumulate_dw", C.c_int32),
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]
+
+
+class Conv1x1Args(C.Structure):
+    _fields_ = [("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Cin", C.c_int32), ("Cout", C.c_int32),
+                ("x", C.c_void_p), ("x_batch_stride", C.c_int64),
+                ("w", C.c_void_p), ("bias", C.c_void_p), ("y", C.c_void_p), ("dy", C.c_void_p),
+                ("dx", C.c_void_p), ("dx_batch_stride", C.c_int64), ("accumulate_dx", C.c_int32),
+                ("dw", C.c_void_p), ("dbias", C.c_void_p), ("accumulate_dw", C.c_int32),
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]
+
+
+class GapArgs(C.Structure):
+    _fields_ = [("N", C.c_int32), ("C", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
+                ("x", C.c_void_p), ("y", C.c_void_p), ("dy", C.c_void_p), ("dx", C.c_void_p)]
+
+
+class LinearArgs(C.Structure):
+    _fields_ = [("N", C.c_int32), ("In", C.c_int32), ("Out", C.c_int32), ("relu", C.c_int32),
+                ("x", C.c_void_p), ("w", C.c_void_p), ("bias", C.c_void_p), ("y", C.c_void_p),
+                ("dy", C.c_void_p), ("dx", C.c_void_p), ("dw", C.c_void_p), ("dbias", C.c_void_p),
+                ("accumulate_dw", C.c_int32), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]
+
+
+class DiceArgs(C.Structure):
+    _fields_ = [("n_heads", C.c_int32), ("N", C.c_int32), ("C", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
+                ("smooth_nr", C.c_float), ("smooth_dr", C.c_float),
+                ("x", C.c_void_p * 4), ("target", C.c_void_p), ("head_weight", C.c_float * 4),
+                ("stats", C.c_void_p), ("loss", C.c_void_p), ("dx", C.c_void_p * 4),
+                ("gscale", C.c_float), ("gscale_dev", C.c_void_p)]
+
+
+class FocalArgs(C.Structure):
+    _fields_ = [("N", C.c_int32), ("C", C.c_int32), ("alpha", C.c_float), ("gamma", C.c_float),
+                ("x", C.c_void_p), ("target", C.c_void_p), ("weight", C.c_void_p),
+                ("loss", C.c_void_p), ("dx", C.c_void_p), ("gscale", C.c_float), ("gscale_dev", C.c_void_p)]
+
+
+class AdamArgs(C.Structure):
+    _fields_ = [("n", C.c_int64), ("p", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p),
+                ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
+                ("grad_scale", C.c_float), ("step", C.c_int32), ("zero_grad", C.c_int32)]
+
+
+class _PackArgs(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("packed", C.c_void_p), ("Cin", C.c_int32), ("Cout", C.c_int32)]
+
+
+class _MixArgs(C.Structure):
+    _fields_ = [("seg", C.c_void_p), ("cls", C.c_void_p), ("alpha", C.c_float), ("out4", C.c_void_p)]
+
+
+class _MemsetArgs(C.Structure):
+    _fields_ = [("ptr", C.c_void_p), ("bytes", C.c_size_t)]
+
+
+class _CountsArgs(C.Structure):
+    _fields_ = [("logits", C.c_void_p), ("target", C.c_void_p), ("n", C.c_int64), ("out3", C.c_void_p)]
+
+
+class _OpUnion(C.Union):
+    _fields_ = [("conv3", Conv3x3Args), ("inorm", InstNormArgs), ("pool", MaxPoolArgs), ("convT", ConvTArgs),
+                ("conv1", Conv1x1Args), ("gap", GapArgs), ("linear", LinearArgs), ("dice", DiceArgs),
+                ("focal", FocalArgs), ("adam", AdamArgs), ("pack", _PackArgs), ("mix", _MixArgs),
+                ("memset0", _MemsetArgs), ("counts", _CountsArgs)]
+
+
+class Op(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("tag", C.c_int32), ("u", _OpUnion)]
+
+
+# op kinds -- keep in sync with the enum in include/mtbc.h
+(OP_CONV3_FWD, OP_CONV3_DGRAD, OP_CONV3_WGRAD, OP_CONV3_PACK_FWD, OP_CONV3_PACK_DGRAD,
+ OP_IN_FWD, OP_IN_BWD, OP_POOL_FWD, OP_POOL_BWD, OP_CONVT_FWD, OP_CONVT_DGRAD, OP_CONVT_WGRAD,
+ OP_CONV1_FWD, OP_CONV1_DGRAD, OP_CONV1_WGRAD, OP_GAP_FWD, OP_GAP_BWD, OP_LINEAR_FWD, OP_LINEAR_BWD,
+ OP_DICE_FWD, OP_DICE_BWD, OP_FOCAL, OP_LOSS_MIX, OP_ADAM, OP_MEMSET, OP_DICE_COUNTS) = range(1, 27)
+
+OP_UNION_FIELD = {
+    OP_CONV3_FWD: "conv3", OP_CONV3_DGRAD: "conv3", OP_CONV3_WGRAD: "conv3",
+    OP_CONV3_PACK_FWD: "pack", OP_CONV3_PACK_DGRAD: "pack",
+    OP_IN_FWD: "inorm", OP_IN_BWD: "inorm", OP_POOL_FWD: "pool", OP_POOL_BWD: "pool",
+    OP_CONVT_FWD: "convT", OP_CONVT_DGRAD: "convT", OP_CONVT_WGRAD: "convT",
+    OP_CONV1_FWD: "conv1", OP_CONV1_DGRAD: "conv1", OP_CONV1_WGRAD: "conv1",
+    OP_GAP_FWD: "gap", OP_GAP_BWD: "gap", OP_LINEAR_FWD: "linear", OP_LINEAR_BWD: "linear",
+    OP_DICE_FWD: "dice", OP_DICE_BWD: "dice", OP_FOCAL: "focal", OP_LOSS_MIX: "mix", OP_ADAM: "adam",
+    OP_MEMSET: "memset0", OP_DICE_COUNTS: "counts",
+}
+
+# every symbol include/mtbc.h declares (tests check the library exports all of them)
+EXPORTS = [
+    "mtbc_version", "mtbc_strerror", "mtbc_arch",
+    "mtbc_conv3x3_packed_elems", "mtbc_conv3x3_packed_dgrad_elems", "mtbc_conv3x3_pack_fwd",
+    "mtbc_conv3x3_pack_dgrad", "mtbc_conv3x3_wgrad_workspace", "mtbc_conv3x3_fwd", "mtbc_conv3x3_dgrad",
+    "mtbc_conv3x3_wgrad", "mtbc_instnorm_lrelu_fwd", "mtbc_instnorm_lrelu_bwd", "mtbc_maxpool2_fwd",
+    "mtbc_maxpool2_bwd", "mtbc_convT_wgrad_workspace", "mtbc_convT_fwd", "mtbc_convT_dgrad", "mtbc_convT_wgrad",
+    "mtbc_conv1x1_wgrad_workspace", "mtbc_conv1x1_fwd", "mtbc_conv1x1_dgrad", "mtbc_conv1x1_wgrad",
+    "mtbc_gap_fwd", "mtbc_gap_bwd", "mtbc_linear_fwd", "mtbc_linear_bwd", "mtbc_dice_fwd", "mtbc_dice_bwd",
+    "mtbc_focal_fwd_bwd", "mtbc_loss_mix", "mtbc_adam_step", "mtbc_dice_counts", "mtbc_program_run",
+]
+
+_lib: Optional[C.CDLL] = None
+
+
+def load() -> C.CDLL:
+    """Load libmtbc_hip.so; raise MtbcError (never fall back) when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MtbcError(
+            f"{LIB_PATH} not found: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; "
+            f"g.build()'` (or `make -C multi_task_breast_cancer_amd/csrc`). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    lib.mtbc_version.restype = C.c_int
+    lib.mtbc_strerror.restype = C.c_char_p
+    lib.mtbc_strerror.argtypes = [C.c_int]
+    lib.mtbc_arch.restype = C.c_char_p
+    for name in ("mtbc_conv3x3_packed_elems", "mtbc_conv3x3_packed_dgrad_elems"):
+        getattr(lib, name).restype = C.c_size_t
+        getattr(lib, name).argtypes = [C.c_int32, C.c_int32]
+    for name in ("mtbc_conv3x3_pack_fwd", "mtbc_conv3x3_pack_dgrad"):
+        getattr(lib, name).restype = C.c_int
+        getattr(lib, name).argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
+    for name, typ in (("mtbc_conv3x3_wgrad_workspace", Conv3x3Args), ("mtbc_convT_wgrad_workspace", ConvTArgs),
+                      ("mtbc_conv1x1_wgrad_workspace", Conv1x1Args)):
+        getattr(lib, name).restype = C.c_size_t
+        getattr(lib, name).argtypes = [C.POINTER(typ)]
+    for name, typ in (("mtbc_conv3x3_fwd", Conv3x3Args), ("mtbc_conv3x3_dgrad", Conv3x3Args),
+                      ("mtbc_conv3x3_wgrad", Conv3x3Args), ("mtbc_instnorm_lrelu_fwd", InstNormArgs),
+                      ("mtbc_instnorm_lrelu_bwd", InstNormArgs), ("mtbc_maxpool2_fwd", MaxPoolArgs),
+                      ("mtbc_maxpool2_bwd", MaxPoolArgs), ("mtbc_convT_fwd", ConvTArgs),
+                      ("mtbc_convT_dgrad", ConvTArgs), ("mtbc_convT_wgrad", ConvTArgs),
+                      ("mtbc_conv1x1_fwd", Conv1x1Args), ("mtbc_conv1x1_dgrad", Conv1x1Args),
+                      ("mtbc_conv1x1_wgrad", Conv1x1Args), ("mtbc_gap_fwd", GapArgs), ("mtbc_gap_bwd", GapArgs),
+                      ("mtbc_linear_fwd", LinearArgs), ("mtbc_linear_bwd", LinearArgs),
+                      ("mtbc_dice_fwd", DiceArgs), ("mtbc_dice_bwd", DiceArgs), ("mtbc_focal_fwd_bwd", FocalArgs),
+                      ("mtbc_adam_step", AdamArgs)):
+        getattr(lib, name).restype = C.c_int
+        getattr(lib, name).argtypes = [C.POINTER(typ), C.c_void_p]
+    lib.mtbc_loss_mix.restype = C.c_int
+    lib.mtbc_loss_mix.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]
+    lib.mtbc_dice_counts.restype = C.c_int
+    lib.mtbc_dice_counts.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+    lib.mtbc_program_run.restype = C.c_int
+    lib.mtbc_program_run.argtypes = [C.POINTER(Op), C.c_int32, C.c_int32, C.c_void_p, C.POINTER(C.c_int32)]
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load().mtbc_strerror(rc).decode()
+        raise MtbcError(f"libmtbc_hip: {what or 'call'} failed: {msg} ({rc})")
+
+
+def require_gpu() -> None:
+    import torch
+    if not torch.cuda.is_available():
+        raise MtbcError("no HIP device visible: the multi-task training path runs on MI355X only "
+                        "(there is no CPU fallback in the product path)")

@@ -1,0 +1,87 @@
+// Shared device/host helpers for the gfx950 kernels.  wave = 64 lanes everywhere.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/mtbc.h"
+
+#define MTBC_WAVE 64
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define MTBC_CHECK_LAUNCH()                                   \
+    do {                                                      \
+        hipError_t e__ = hipGetLastError();                   \
+        if (e__ != hipSuccess) return MTBC_E_LAUNCH;          \
+    } while (0)
+
+static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// Segment table passed by value to kernels (virtual channel concat).
+struct SegTable {
+    float* ptr[MTBC_MAX_SEGS];
+    long long bstride[MTBC_MAX_SEGS];
+    int cbegin[MTBC_MAX_SEGS + 1];   // prefix sums of channels; cbegin[n] = total
+    int accumulate[MTBC_MAX_SEGS];
+    int n;
+};
+
+static inline int make_segtable(const mtbc_seg* segs, int n, int expect_channels, SegTable* t) {
+    if (n < 1 || n > MTBC_MAX_SEGS) return MTBC_E_BADARG;
+    int c = 0;
+    for (int i = 0; i < MTBC_MAX_SEGS; ++i) {
+        t->ptr[i] = nullptr; t->bstride[i] = 0; t->accumulate[i] = 0; t->cbegin[i] = c;
+        if (i < n) {
+            if (!segs[i].ptr || segs[i].channels <= 0) return MTBC_E_BADARG;
+            t->ptr[i] = segs[i].ptr; t->bstride[i] = segs[i].batch_stride;
+            t->accumulate[i] = segs[i].accumulate;
+            c += segs[i].channels;
+        }
+    }
+    t->cbegin[MTBC_MAX_SEGS] = c;
+    for (int i = n; i <= MTBC_MAX_SEGS; ++i) t->cbegin[i] = c;
+    t->n = n;
+    return c == expect_channels ? MTBC_OK : MTBC_E_BADSHAPE;
+}
+
+// channel c -> its segment (select chain over constant indices: no dynamic kernarg indexing)
+struct SegRef { float* ptr; long long bs; int cb; int acc; };
+__device__ __forceinline__ SegRef seg_ref(const SegTable& t, int c) {
+    SegRef r{t.ptr[0], t.bstride[0], 0, t.accumulate[0]};
+#pragma unroll
+    for (int i = 1; i < MTBC_MAX_SEGS; ++i) {
+        const bool hit = i < t.n && c >= t.cbegin[i];
+        r.ptr = hit ? t.ptr[i] : r.ptr;
+        r.bs = hit ? t.bstride[i] : r.bs;
+        r.cb = hit ? t.cbegin[i] : r.cb;
+        r.acc = hit ? t.accumulate[i] : r.acc;
+    }
+    return r;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// Block-wide sum; every thread gets the result.  `red` = shared float[17+].  Deterministic.
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    v = wave_sum(v);
+    __syncthreads();                       // protect `red` from a previous use
+    if (lane == 0) red[wid] = v;
+    __syncthreads();
+    float s = 0.f;
+    for (int i = 0; i < nw; ++i) s += red[i];
+    return s;
+}
+
+// internal (C++) helpers implemented in reduce.hip
+int mtbc_i_splitk_reduce(const float* partial, float* out, int nsplit, size_t elems, int accumulate, hipStream_t st);
+int mtbc_i_channel_sums(const float* x, float* planes_ws, float* out, int N, int C, int HW, int accumulate, hipStream_t st);

@@ -1,0 +1,586 @@
+// conv3x3 (stride 1, pad 1) forward / dgrad / wgrad for gfx950.
+//
+// Hot path: implicit GEMM on the fp32 MFMA v_mfma_f32_16x16x4_f32 (exact fp32 == fmaf chain).
+//   fwd  : Z[co][pix] = sum_{ci,tap} Wp[co][ci,tap] * X[ci][pix+tap]   M=Cout, N=pixels, K=9*Cin
+//   dgrad: the same kernel on dZ with the flipped/transposed packed image
+//   wgrad: dW[co][ci][tap] = sum_pix dZ[co][pix] * X[ci][pix+tap]      M=Cout, N=Cin, K=pixels (split-K)
+// NCHW planes are staged through LDS as halo tiles with 16-byte coalesced global reads; the
+// packed weight image is already the LDS image ([mtile][ci][tap][16]) so its staging is a copy.
+// Replaces nn.Conv2d(k=3,padding=1) of MTnnUNet.py:12-16 and MONAI Convolution (MTUNetPlusPlus.py:47-81).
+#include "common.h"
+
+namespace {
+
+// ------------------------------------------------------------------ packing
+__global__ void pack_fwd_kernel(const float* __restrict__ w, float* __restrict__ p, int Cin, int Cout, int total) {
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    int i = idx & 15, tap = (idx >> 4) % 9, ci = (idx / 144) % Cin, mt = idx / (144 * Cin);
+    int co = mt * 16 + i;
+    p[idx] = co < Cout ? w[((size_t)co * Cin + ci) * 9 + tap] : 0.f;
+}
+// dgrad image: rows = input channels of the forward conv, K = (co, flipped tap)
+__global__ void pack_dgrad_kernel(const float* __restrict__ w, float* __restrict__ p, int Cin, int Cout, int total) {
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    int i = idx & 15, tap = (idx >> 4) % 9, co = (idx / 144) % Cout, mt = idx / (144 * Cout);
+    int ci = mt * 16 + i;
+    p[idx] = ci < Cin ? w[((size_t)co * Cin + ci) * 9 + (8 - tap)] : 0.f;
+}
+
+// ------------------------------------------------------------------ geometry
+// 256 output pixels per block = 16 groups of 16 pixels; wave w owns groups 4w..4w+3.
+template <int GEO> struct Geo;
+template <> struct Geo<0> {   // wide maps: 8 rows x 32 cols
+    static constexpr int TH = 8, TW = 32, ROWS = 10, LW = 40, IMG = 1, IMGS = 400, PS = 400;
+};
+template <> struct Geo<1> {   // 16-wide maps: 16 rows x 16 cols
+    static constexpr int TH = 16, TW = 16, ROWS = 18, LW = 24, IMG = 1, IMGS = 432, PS = 432;
+};
+template <> struct Geo<2> {   // 8x8 maps: 4 images per block
+    static constexpr int TH = 8, TW = 8, ROWS = 10, LW = 16, IMG = 4, IMGS = 160, PS = 648;
+};
+
+struct ConvP {
+    int N, H, W, Cin, Cout;     // Cout = rows of this GEMM (dgrad: the forward conv's Cin)
+    SegTable in, out;
+    const float* wp;
+    const float* bias;
+    int tiles_x, tiles_y;
+    int mtiles;
+};
+
+constexpr int KC = 8;           // input channels per LDS chunk
+
+template <int MT, int GEO>
+__global__ __launch_bounds__(256, 2) void conv3x3_igemm_kernel(const ConvP p) {
+    using G = Geo<GEO>;
+    constexpr int XS = KC * G::PS;                 // floats
+    constexpr int WS = MT * KC * 144;
+    constexpr int BUF = XS + WS;
+    constexpr int XF4_PER_CH = G::IMG * G::ROWS * G::LW / 4;
+    constexpr int XF4 = KC * XF4_PER_CH;
+    constexpr int XSLOTS = (XF4 + 255) / 256;
+    constexpr int WF4 = MT * KC * 36;
+    constexpr int WSLOTS = (WF4 + 255) / 256;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int HW = p.H * p.W;
+    int t = blockIdx.x;
+    const int tx = t % p.tiles_x; t /= p.tiles_x;
+    const int ty = t % p.tiles_y; t /= p.tiles_y;
+    const int n0 = t * G::IMG;
+    const int x0 = tx * G::TW, y0 = ty * G::TH;
+    const int mt0 = blockIdx.y * MT;
+
+    // ---- per-thread staging descriptors (same for every chunk)
+    int x_lds[XSLOTS], x_goff[XSLOTS], x_ci[XSLOTS];   // x_ci: c | img<<8 | valid<<16
+#pragma unroll
+    for (int s = 0; s < XSLOTS; ++s) {
+        int idx = tid + s * 256;
+        int c = idx / XF4_PER_CH, rem = idx % XF4_PER_CH;
+        int img = rem / (G::ROWS * G::LW / 4); rem %= (G::ROWS * G::LW / 4);
+        int row = rem / (G::LW / 4), c4 = rem % (G::LW / 4);
+        int y = y0 + row - 1, x = x0 - 4 + c4 * 4;
+        bool ok = idx < XF4 && (n0 + img) < p.N && y >= 0 && y < p.H && x >= 0 && x < p.W;
+        x_lds[s] = idx < XF4 ? c * G::PS + img * G::IMGS + row * G::LW + c4 * 4 : -1;
+        x_goff[s] = y * p.W + x;
+        x_ci[s] = c | (img << 8) | ((ok ? 1 : 0) << 16);
+    }
+    float4 xr[XSLOTS], wr[WSLOTS];
+
+    auto load_chunk = [&](int chunk) {
+        const int ci0 = chunk * KC;
+        const SegRef sr = seg_ref(p.in, ci0);
+        const float* base = sr.ptr + (size_t)(ci0 - sr.cb) * HW;
+        const long long bs = sr.bs;
+#pragma unroll
+        for (int s = 0; s < XSLOTS; ++s) {
+            const int c = x_ci[s] & 255, img = (x_ci[s] >> 8) & 255;
+            xr[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (x_ci[s] >> 16)
+                xr[s] = *reinterpret_cast<const float4*>(base + (size_t)(n0 + img) * bs + (size_t)c * HW + x_goff[s]);
+        }
+#pragma unroll
+        for (int s = 0; s < WSLOTS; ++s) {
+            int idx = tid + s * 256;
+            int mt = idx / (KC * 36), r = idx % (KC * 36);
+            wr[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx < WF4 && (mt0 + mt) < p.mtiles)
+                wr[s] = *reinterpret_cast<const float4*>(p.wp + ((size_t)(mt0 + mt) * p.Cin + ci0) * 144 + r * 4);
+        }
+    };
+    auto store_chunk = [&](float* buf) {
+#pragma unroll
+        for (int s = 0; s < XSLOTS; ++s)
+            if (x_lds[s] >= 0) *reinterpret_cast<float4*>(buf + x_lds[s]) = xr[s];
+#pragma unroll
+        for (int s = 0; s < WSLOTS; ++s) {
+            int idx = tid + s * 256;
+            if (idx < WF4) *reinterpret_cast<float4*>(buf + XS + idx * 4) = wr[s];
+        }
+    };
+
+    // ---- per-lane fragment bases
+    const int j = lane & 15, kk = lane >> 4;
+    int laneB, gbase;
+    if (GEO == 0) { laneB = kk * G::PS + j; gbase = (2 * wv) * G::LW; }
+    else if (GEO == 1) { laneB = kk * G::PS + j; gbase = (4 * wv) * G::LW; }
+    else { laneB = kk * G::PS + (j >> 3) * G::LW + (j & 7); gbase = wv * G::IMGS; }
+    const int bBase = laneB + gbase + 3;
+    const int aBase = XS + kk * 144 + j;
+
+    f32x4 acc[MT][4];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc[m][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nchunks = p.Cin / KC;
+    load_chunk(0);
+    store_chunk(smem);
+    __syncthreads();
+    for (int ch = 0; ch < nchunks; ++ch) {
+        float* cur = smem + (ch & 1) * BUF;
+        if (ch + 1 < nchunks) load_chunk(ch + 1);
+#pragma unroll
+        for (int cs = 0; cs < KC / 4; ++cs) {
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int r = tap / 3, s = tap % 3;
+                float a[MT], b[4];
+#pragma unroll
+                for (int m = 0; m < MT; ++m) a[m] = cur[aBase + m * (KC * 144) + cs * 576 + tap * 16];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    int toff;
+                    if (GEO == 0) toff = (g >> 1) * G::LW + 16 * (g & 1);
+                    else if (GEO == 1) toff = g * G::LW;
+                    else toff = 2 * g * G::LW;
+                    b[g] = cur[bBase + toff + cs * 4 * G::PS + r * G::LW + s];
+                }
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        acc[m][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], b[g], acc[m][g], 0, 0, 0);
+            }
+        }
+        if (ch + 1 < nchunks) store_chunk(smem + ((ch + 1) & 1) * BUF);
+        __syncthreads();
+    }
+
+    // ---- epilogue: D row = (lane>>4)*4 + reg (channel), col = lane&15 (pixel)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        int n, y, x;
+        if (GEO == 0) { n = n0; y = y0 + 2 * wv + (g >> 1); x = x0 + 16 * (g & 1) + j; }
+        else if (GEO == 1) { n = n0; y = y0 + 4 * wv + g; x = x0 + j; }
+        else { n = n0 + wv; y = y0 + 2 * g + (j >> 3); x = x0 + (j & 7); }
+        if (n >= p.N || y >= p.H || x >= p.W) continue;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = (mt0 + m) * 16 + kk * 4 + r;
+                if (co >= p.Cout) continue;
+                const SegRef sr = seg_ref(p.out, co);
+                float* dst = sr.ptr + (size_t)n * sr.bs + (size_t)(co - sr.cb) * HW + y * p.W + x;
+                float v = acc[m][g][r];
+                if (p.bias) v += p.bias[co];
+                if (sr.acc) v += *dst;
+                *dst = v;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ wgrad (MFMA, split-K)
+template <int GEO> struct WGeo;
+template <> struct WGeo<0> { static constexpr int TH = 4, TW = 32, ROWS = 6, LW = 40, IMG = 1, IMGS = 240, PSX = 258; };
+template <> struct WGeo<1> { static constexpr int TH = 8, TW = 16, ROWS = 10, LW = 24, IMG = 1, IMGS = 240, PSX = 258; };
+template <> struct WGeo<2> { static constexpr int TH = 8, TW = 8, ROWS = 10, LW = 16, IMG = 2, IMGS = 160, PSX = 322; };
+constexpr int PSZ = 130;
+
+struct WgP {
+    int N, H, W, Cin, Cout;
+    SegTable in;
+    const float* dz;
+    float* partial;            // [nsplit][Cout][Cin][9]
+    int tiles_x, tiles_y, total_tiles, tiles_per_split;
+    int ciblocks;
+};
+
+template <int GEO>
+__global__ __launch_bounds__(256, 2) void conv3x3_wgrad_mfma_kernel(const WgP p) {
+    using G = WGeo<GEO>;
+    constexpr int XS = 32 * G::PSX;
+    constexpr int XF4_PER_CH = G::IMG * G::ROWS * G::LW / 4;
+    constexpr int XF4 = 32 * XF4_PER_CH;
+    constexpr int ZF4 = 32 * 32;            // 32 channels x 128 pixels / 4
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Xs = smem;
+    float* Zs = smem + XS;
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int HW = p.H * p.W;
+    const int co0 = (blockIdx.y / p.ciblocks) * 32, ci0 = (blockIdx.y % p.ciblocks) * 32;
+    const int split = blockIdx.x;
+    const int t_begin = split * p.tiles_per_split;
+    const int t_end = min(p.total_tiles, t_begin + p.tiles_per_split);
+
+    const int j = lane & 15, kk = lane >> 4;
+    const int aBase = ((wv >> 1) * 16 + j) * PSZ + kk;
+    const int bBase = ((wv & 1) * 16 + j) * G::PSX + kk + 3;
+
+    f32x4 acc[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    for (int tile = t_begin; tile < t_end; ++tile) {
+        int t = tile;
+        const int tx = t % p.tiles_x; t /= p.tiles_x;
+        const int ty = t % p.tiles_y; t /= p.tiles_y;
+        const int n0 = t * G::IMG, x0 = tx * G::TW, y0 = ty * G::TH;
+        __syncthreads();
+        // stage X halo tile: [32 ci][IMG][ROWS][LW]
+        for (int idx = tid; idx < XF4; idx += 256) {
+            int c = idx / XF4_PER_CH, rem = idx % XF4_PER_CH;
+            int img = rem / (G::ROWS * G::LW / 4); rem %= (G::ROWS * G::LW / 4);
+            int row = rem / (G::LW / 4), c4 = rem % (G::LW / 4);
+            int y = y0 + row - 1, x = x0 - 4 + c4 * 4, n = n0 + img, ci = ci0 + c;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ci < p.Cin && n < p.N && y >= 0 && y < p.H && x >= 0 && x < p.W) {
+                const SegRef sr = seg_ref(p.in, ci);
+                v = *reinterpret_cast<const float4*>(sr.ptr + (size_t)n * sr.bs + (size_t)(ci - sr.cb) * HW + y * p.W + x);
+            }
+            float* d = Xs + c * G::PSX + img * G::IMGS + row * G::LW + c4 * 4;   // 8-byte aligned only
+            *reinterpret_cast<float2*>(d) = make_float2(v.x, v.y);
+            *reinterpret_cast<float2*>(d + 2) = make_float2(v.z, v.w);
+        }
+        // stage dZ tile: [32 co][128 px]
+        for (int idx = tid; idx < ZF4; idx += 256) {
+            int c = idx >> 5, p4 = idx & 31, px = p4 * 4;
+            int n, y, x;
+            if (GEO == 0) { n = n0; y = y0 + px / 32; x = x0 + px % 32; }
+            else if (GEO == 1) { n = n0; y = y0 + px / 16; x = x0 + px % 16; }
+            else { n = n0 + px / 64; y = y0 + (px % 64) / 8; x = x0 + px % 8; }
+            const int co = co0 + c;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (co < p.Cout && n < p.N && y < p.H && x < p.W)
+                v = *reinterpret_cast<const float4*>(p.dz + ((size_t)n * p.Cout + co) * HW + y * p.W + x);
+            float* d = Zs + c * PSZ + px;
+            *reinterpret_cast<float2*>(d) = make_float2(v.x, v.y);
+            *reinterpret_cast<float2*>(d + 2) = make_float2(v.z, v.w);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int p4 = 0; p4 < 32; ++p4) {
+            const int px = p4 * 4;
+            int xoff;
+            if (GEO == 0) xoff = (px / 32) * G::LW + px % 32;
+            else if (GEO == 1) xoff = (px / 16) * G::LW + px % 16;
+            else xoff = (px / 64) * G::IMGS + ((px % 64) / 8) * G::LW + px % 8;
+            const float a = Zs[aBase + px];
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const float b = Xs[bBase + xoff + (tap / 3) * G::LW + tap % 3];
+                acc[tap] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[tap], 0, 0, 0);
+            }
+        }
+    }
+    // partial[split][co][ci][tap]; D row = co (kk*4+r), col = ci (j)
+    const int ci = ci0 + (wv & 1) * 16 + j;
+    if (ci < p.Cin) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int co = co0 + (wv >> 1) * 16 + kk * 4 + r;
+            if (co >= p.Cout) continue;
+            float* d = p.partial + (((size_t)split * p.Cout + co) * p.Cin + ci) * 9;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) d[tap] = acc[tap][r];
+        }
+    }
+}
+
+// ------------------------------------------------------------------ direct (VALU) fallbacks
+// One thread = one pixel x 8 output channels.  mode 0: fwd  (w[co][ci][tap])
+//                                              mode 1: dgrad (w[ci_in][co_out][8-tap], in = dz)
+struct DirP {
+    int N, H, W, Cin, Cout;    // Cin = channels of the tensor being read, Cout = channels written
+    SegTable in, out;
+    const float* w;
+    const float* bias;
+    int mode, wCin;            // wCin = Cin of the torch weight tensor (forward sense)
+};
+__global__ void conv3x3_direct_kernel(const DirP p) {
+    const int HW = p.H * p.W;
+    const int pix = blockIdx.x * blockDim.x + threadIdx.x;
+    const int cog = blockIdx.y * 8, n = blockIdx.z;
+    if (pix >= HW) return;
+    const int y = pix / p.W, x = pix % p.W;
+    float acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+    for (int ci = 0; ci < p.Cin; ++ci) {
+        const SegRef si = seg_ref(p.in, ci);
+        const float* src = si.ptr + (size_t)n * si.bs + (size_t)(ci - si.cb) * HW;
+        float v[9];
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+            v[tap] = (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W) ? src[yy * p.W + xx] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int co = cog + i;
+            if (co >= p.Cout) break;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const float wv = p.mode == 0 ? p.w[((size_t)co * p.wCin + ci) * 9 + tap]
+                                             : p.w[((size_t)ci * p.wCin + co) * 9 + (8 - tap)];
+                acc[i] = fmaf(wv, v[tap], acc[i]);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int co = cog + i;
+        if (co >= p.Cout) break;
+        const SegRef so = seg_ref(p.out, co);
+        float* dst = so.ptr + (size_t)n * so.bs + (size_t)(co - so.cb) * HW + pix;
+        float v = acc[i] + (p.bias ? p.bias[co] : 0.f);
+        if (so.acc) v += *dst;
+        *dst = v;
+    }
+}
+
+// wgrad direct: block = (co, ci, split over n); 9 sums per thread, block-reduced.  partial[split][co][ci][9]
+struct DirWgP {
+    int N, H, W, Cin, Cout, nsplit;
+    SegTable in;
+    const float* dz;
+    float* partial;
+};
+__global__ void conv3x3_wgrad_direct_kernel(const DirWgP p) {
+    __shared__ float red[32];
+    const int co = blockIdx.x / p.Cin, ci = blockIdx.x % p.Cin, split = blockIdx.y;
+    const int HW = p.H * p.W;
+    const SegRef si = seg_ref(p.in, ci);
+    float acc[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) acc[i] = 0.f;
+    for (int n = split; n < p.N; n += p.nsplit) {
+        const float* src = si.ptr + (size_t)n * si.bs + (size_t)(ci - si.cb) * HW;
+        const float* g = p.dz + ((size_t)n * p.Cout + co) * HW;
+        for (int pix = threadIdx.x; pix < HW; pix += blockDim.x) {
+            const int y = pix / p.W, x = pix % p.W;
+            const float gv = g[pix];
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+                if (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W) acc[tap] = fmaf(gv, src[yy * p.W + xx], acc[tap]);
+            }
+        }
+    }
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        float s = block_sum(acc[tap], red);
+        if (threadIdx.x == 0) p.partial[(((size_t)split * p.Cout + co) * p.Cin + ci) * 9 + tap] = s;
+    }
+}
+
+// ------------------------------------------------------------------ host helpers
+bool mfma_ok(const mtbc_seg* segs, int nseg, int H, int W) {
+    if (W % 4 != 0 || W < 8 || H < 8) return false;
+    for (int i = 0; i < nseg; ++i) {
+        if (segs[i].channels % KC) return false;
+        if (segs[i].batch_stride % 4) return false;
+        if ((reinterpret_cast<uintptr_t>(segs[i].ptr) & 15) != 0) return false;
+    }
+    return true;
+}
+int pick_geo(int H, int W) { return (W == 8 && H == 8) ? 2 : (W <= 16 ? 1 : 0); }
+
+template <int MT, int GEO>
+int launch_igemm(const ConvP& p, int tiles, int mblocks, hipStream_t st) {
+    using G = Geo<GEO>;
+    const size_t lds = 2ull * (KC * G::PS + MT * KC * 144) * sizeof(float);
+    static bool attr_set = false;   // >64 KiB dynamic LDS needs the opt-in once per kernel
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_igemm_kernel<MT, GEO>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((conv3x3_igemm_kernel<MT, GEO>), dim3(tiles, mblocks), dim3(256), lds, st, p);
+    MTBC_CHECK_LAUNCH();
+    return MTBC_OK;
+}
+template <int GEO>
+int launch_igemm_mt(int MT, const ConvP& p, int tiles, int mblocks, hipStream_t st) {
+    switch (MT) {
+        case 1: return launch_igemm<1, GEO>(p, tiles, mblocks, st);
+        case 2: return launch_igemm<2, GEO>(p, tiles, mblocks, st);
+        case 3: return launch_igemm<3, GEO>(p, tiles, mblocks, st);
+        default: return launch_igemm<4, GEO>(p, tiles, mblocks, st);
+    }
+}
+
+// shared by fwd and dgrad: `rows` = channels written, `red` = channels read
+int run_igemm(int N, int H, int W, int red, int rows, const SegTable& in, const SegTable& out, const float* wp,
+              const float* bias, hipStream_t st) {
+    ConvP p;
+    p.N = N; p.H = H; p.W = W; p.Cin = red; p.Cout = rows; p.in = in; p.out = out; p.wp = wp; p.bias = bias;
+    const int geo = pick_geo(H, W);
+    p.mtiles = cdiv(rows, 16);
+    const int mblocks = cdiv(p.mtiles, 4);
+    const int MT = cdiv(p.mtiles, mblocks);
+    int tiles;
+    if (geo == 0) { p.tiles_x = cdiv(W, 32); p.tiles_y = cdiv(H, 8); tiles = p.tiles_x * p.tiles_y * N; return launch_igemm_mt<0>(MT, p, tiles, mblocks, st); }
+    if (geo == 1) { p.tiles_x = cdiv(W, 16); p.tiles_y = cdiv(H, 16); tiles = p.tiles_x * p.tiles_y * N; return launch_igemm_mt<1>(MT, p, tiles, mblocks, st); }
+    p.tiles_x = 1; p.tiles_y = 1; tiles = cdiv(N, 4);
+    return launch_igemm_mt<2>(MT, p, tiles, mblocks, st);
+}
+
+struct WgPlan { bool mfma; int geo, tiles_x, tiles_y, total_tiles, nsplit, tiles_per_split, coblocks, ciblocks; size_t partial_elems, dbias_elems; };
+WgPlan plan_wgrad(const mtbc_conv3x3_args* a) {
+    WgPlan w{};
+    w.mfma = !a->force_direct && mfma_ok(a->in, a->n_in, a->H, a->W) && a->Cin >= 8 &&
+             (reinterpret_cast<uintptr_t>(a->dout) & 15) == 0;
+    const size_t wel = (size_t)a->Cout * a->Cin * 9;
+    if (w.mfma) {
+        w.geo = pick_geo(a->H, a->W);
+        int tn;
+        if (w.geo == 0) { w.tiles_x = cdiv(a->W, 32); w.tiles_y = cdiv(a->H, 4); tn = a->N; }
+        else if (w.geo == 1) { w.tiles_x = cdiv(a->W, 16); w.tiles_y = cdiv(a->H, 8); tn = a->N; }
+        else { w.tiles_x = 1; w.tiles_y = 1; tn = cdiv(a->N, 2); }
+        w.total_tiles = w.tiles_x * w.tiles_y * tn;
+        w.coblocks = cdiv(a->Cout, 32); w.ciblocks = cdiv(a->Cin, 32);
+        const int pairs = w.coblocks * w.ciblocks;
+        int ns = cdiv(1024, pairs);
+        if (ns > w.total_tiles) ns = w.total_tiles;
+        if (ns < 1) ns = 1;
+        w.tiles_per_split = cdiv(w.total_tiles, ns);
+        w.nsplit = cdiv(w.total_tiles, w.tiles_per_split);
+    } else {
+        w.nsplit = a->N < 16 ? a->N : 16;
+    }
+    w.partial_elems = (size_t)w.nsplit * wel;
+    w.dbias_elems = a->dbias ? (size_t)a->N * a->Cout : 0;
+    return w;
+}
+
+}  // namespace
+
+// ====================================================================== C ABI
+extern "C" {
+
+size_t mtbc_conv3x3_packed_elems(int32_t Cin, int32_t Cout) { return (size_t)cdiv(Cout, 16) * Cin * 144; }
+size_t mtbc_conv3x3_packed_dgrad_elems(int32_t Cin, int32_t Cout) { return (size_t)cdiv(Cin, 16) * Cout * 144; }
+
+int mtbc_conv3x3_pack_fwd(const float* w, float* packed, int32_t Cin, int32_t Cout, void* stream) {
+    if (!w || !packed || Cin <= 0 || Cout <= 0) return MTBC_E_BADARG;
+    const int total = (int)mtbc_conv3x3_packed_elems(Cin, Cout);
+    hipLaunchKernelGGL(pack_fwd_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, w, packed, Cin, Cout, total);
+    MTBC_CHECK_LAUNCH();
+    return MTBC_OK;
+}
+int mtbc_conv3x3_pack_dgrad(const float* w, float* packed, int32_t Cin, int32_t Cout, void* stream) {
+    if (!w || !packed || Cin <= 0 || Cout <= 0) return MTBC_E_BADARG;
+    const int total = (int)mtbc_conv3x3_packed_dgrad_elems(Cin, Cout);
+    hipLaunchKernelGGL(pack_dgrad_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, w, packed, Cin, Cout, total);
+    MTBC_CHECK_LAUNCH();
+    return MTBC_OK;
+}
+
+static int check_conv(const mtbc_conv3x3_args* a) {
+    if (!a) return MTBC_E_BADARG;
+    if (a->N <= 0 || a->H <= 0 || a->W <= 0 || a->Cin <= 0 || a->Cout <= 0) return MTBC_E_BADSHAPE;
+    return MTBC_OK;
+}
+
+int mtbc_conv3x3_fwd(const mtbc_conv3x3_args* a, void* stream) {
+    int rc = check_conv(a); if (rc) return rc;
+    if (!a->out || (!a->w && !a->w_packed)) return MTBC_E_BADARG;
+    SegTable in, out;
+    rc = make_segtable(a->in, a->n_in, a->Cin, &in); if (rc) return rc;
+    mtbc_seg o{a->out, (int64_t)a->Cout * a->H * a->W, a->Cout, 0};
+    rc = make_segtable(&o, 1, a->Cout, &out); if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    if (a->w_packed && !a->force_direct && mfma_ok(a->in, a->n_in, a->H, a->W))
+        return run_igemm(a->N, a->H, a->W, a->Cin, a->Cout, in, out, a->w_packed, a->bias, st);
+    if (!a->w) return MTBC_E_BADARG;
+    DirP p; p.N = a->N; p.H = a->H; p.W = a->W; p.Cin = a->Cin; p.Cout = a->Cout; p.in = in; p.out = out;
+    p.w = a->w; p.bias = a->bias; p.mode = 0; p.wCin = a->Cin;
+    hipLaunchKernelGGL(conv3x3_direct_kernel, dim3(cdiv(a->H * a->W, 128), cdiv(a->Cout, 8), a->N), dim3(128), 0, st, p);
+    MTBC_CHECK_LAUNCH();
+    return MTBC_OK;
+}
+
+int mtbc_conv3x3_dgrad(const mtbc_conv3x3_args* a, void* stream) {
+    int rc = check_conv(a); if (rc) return rc;
+    if (!a->dout || (!a->w && !a->w_packed)) return MTBC_E_BADARG;
+    SegTable in, out;
+    mtbc_seg g{const_cast<float*>(a->dout), (int64_t)a->Cout * a->H * a->W, a->Cout, 0};
+    rc = make_segtable(&g, 1, a->Cout, &in); if (rc) return rc;
+    rc = make_segtable(a->in, a->n_in, a->Cin, &out); if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    bool ok = a->w_packed && !a->force_direct && mfma_ok(&g, 1, a->H, a->W) && a->Cout % KC == 0;
+    for (int i = 0; ok && i < a->n_in; ++i) ok = a->in[i].ptr != nullptr;
+    if (ok) return run_igemm(a->N, a->H, a->W, a->Cout, a->Cin, in, out, a->w_packed, nullptr, st);
+    if (!a->w) return MTBC_E_BADARG;
+    DirP p; p.N = a->N; p.H = a->H; p.W = a->W; p.Cin = a->Cout; p.Cout = a->Cin; p.in = in; p.out = out;
+    p.w = a->w; p.bias = nullptr; p.mode = 1; p.wCin = a->Cin;
+    hipLaunchKernelGGL(conv3x3_direct_kernel, dim3(cdiv(a->H * a->W, 128), cdiv(a->Cin, 8), a->N), dim3(128), 0, st, p);
+    MTBC_CHECK_LAUNCH();
+    return MTBC_OK;
+}
+
+size_t mtbc_conv3x3_wgrad_workspace(const mtbc_conv3x3_args* a) {
+    if (check_conv(a)) return 0;
+    WgPlan w = plan_wgrad(a);
+    return (w.partial_elems + w.dbias_elems) * sizeof(float);
+}
+
+int mtbc_conv3x3_wgrad(const mtbc_conv3x3_args* a, void* stream) {
+    int rc = check_conv(a); if (rc) return rc;
+    if (!a->dout || !a->dw) return MTBC_E_BADARG;
+    SegTable in;
+    rc = make_segtable(a->in, a->n_in, a->Cin, &in); if (rc) return rc;
+    WgPlan w = plan_wgrad(a);
+    if (!a->workspace || a->workspace_bytes < (w.partial_elems + w.dbias_elems) * sizeof(float)) return MTBC_E_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    float* partial = reinterpret_cast<float*>(a->workspace);
+    const size_t wel = (size_t)a->Cout * a->Cin * 9;
+    if (w.mfma) {
+        WgP p; p.N = a->N; p.H = a->H; p.W = a->W; p.Cin = a->Cin; p.Cout = a->Cout; p.in = in; p.dz = a->dout;
+        p.partial = partial; p.tiles_x = w.tiles_x; p.tiles_y = w.tiles_y; p.total_tiles = w.total_tiles;
+        p.tiles_per_split = w.tiles_per_split; p.ciblocks = w.ciblocks;
+        dim3 grid(w.nsplit, w.coblocks * w.ciblocks);
+        if (w.geo == 0) {
+            const size_t lds = (32 * WGeo<0>::PSX + 32 * PSZ) * sizeof(float);
+            hipLaunchKernelGGL(conv3x3_wgrad_mfma_kernel<0>, grid, dim3(256), lds, st, p);
+        } else if (w.geo == 1) {
+            const size_t lds = (32 * WGeo<1>::PSX + 32 * PSZ) * sizeof(float);
+            hipLaunchKernelGGL(conv3x3_wgrad_mfma_kernel<1>, grid, dim3(256), lds, st, p);
+        } else {
+            const size_t lds = (32 * WGeo<2>::PSX + 32 * PSZ) * sizeof(float);
+            hipLaunchKernelGGL(conv3x3_wgrad_mfma_kernel<2>, grid, dim3(256), lds, st, p);
+        }
+        MTBC_CHECK_LAUNCH();
+    } else {
+        DirWgP p; p.N = a->N; p.H = a->H; p.W = a->W; p.Cin = a->Cin; p.Cout = a->Cout; p.nsplit = w.nsplit;
+        p.in = in; p.dz = a->dout; p.partial = partial;
+        hipLaunchKernelGGL(conv3x3_wgrad_direct_kernel, dim3(a->Cout * a->Cin, w.nsplit), dim3(256), 0, st, p);
+        MTBC_CHECK_LAUNCH();
+    }
+    rc = mtbc_i_splitk_reduce(partial, a->dw, w.nsplit, wel, a->accumulate_dw, st); if (rc) return rc;
+    if (a->dbias) {
+        rc = mtbc_i_channel_sums(a->dout, partial + w.partial_elems, a->dbias, a->N, a->Cout, a->H * a->W, a->accumulate_dw, st);
+        if (rc) return rc;
+    }
+    return MTBC_OK;
+}
+
+}  // extern "C"

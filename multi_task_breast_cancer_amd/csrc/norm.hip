@@ -1,0 +1,210 @@
+// InstanceNorm2d(eps, optional affine) + LeakyReLU, forward and backward, HBM-bound.
+// One workgroup per (n, c) plane; the plane is held in registers between the statistics and the
+// normalisation so HBM sees one read + one write (forward).  Per-image statistics are reduced with
+// wavefront shuffles (64 lanes) then across the waves through LDS -- deterministic.
+// Replaces nn.InstanceNorm2d + nn.LeakyReLU (MTnnUNet.py:35-36) and MONAI ADN "NDA" (MTUNetPlusPlus.py:20-22).
+#include "common.h"
+
+namespace {
+
+struct InP {
+    int N, C, HW;
+    float eps, slope;
+    const float* z; const float* gamma; const float* beta;
+    float* y; long long ybs;
+    float* mean; float* rstd;
+    const float* dy; long long dybs;
+    float* dz;
+    float* part;       // bwd: [N*C][2] = {sum g, sum g*xh}
+};
+
+// ---- forward, register-resident plane: HW % 4 == 0 and HW/4 <= VPT * blockDim
+template <int VPT>
+__global__ void in_fwd_reg_kernel(const InP p) {
+    __shared__ float red[32];
+    const int plane = blockIdx.x, n = plane / p.C, c = plane % p.C;
+    const float4* src = reinterpret_cast<const float4*>(p.z + (size_t)plane * p.HW);
+    const int n4 = p.HW >> 2;
+    float4 v[VPT];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+        const int idx = threadIdx.x + i * blockDim.x;
+        v[i] = idx < n4 ? src[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
+        s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+    const float mean = block_sum(s, red) / (float)p.HW;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+        const int idx = threadIdx.x + i * blockDim.x;
+        if (idx < n4) {
+            const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
+            q += (a * a + b * b) + (cc * cc + d * d);
+        }
+    }
+    const float var = block_sum(q, red) / (float)p.HW;
+    const float rstd = 1.0f / sqrtf(var + p.eps);
+    if (threadIdx.x == 0) { p.mean[plane] = mean; p.rstd[plane] = rstd; }
+    const float g = p.gamma ? p.gamma[c] : 1.f, b = p.beta ? p.beta[c] : 0.f;
+    float4* dst = reinterpret_cast<float4*>(p.y + (size_t)n * p.ybs + (size_t)c * p.HW);
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+        const int idx = threadIdx.x + i * blockDim.x;
+        if (idx < n4) {
+            float4 o;
+            float t;
+            t = (v[i].x - mean) * rstd * g + b; o.x = t > 0.f ? t : t * p.slope;
+            t = (v[i].y - mean) * rstd * g + b; o.y = t > 0.f ? t : t * p.slope;
+            t = (v[i].z - mean) * rstd * g + b; o.z = t > 0.f ? t : t * p.slope;
+            t = (v[i].w - mean) * rstd * g + b; o.w = t > 0.f ? t : t * p.slope;
+            dst[idx] = o;
+        }
+    }
+}
+
+// ---- forward, streaming (any HW): three passes, the last two hit L2
+__global__ void in_fwd_stream_kernel(const InP p) {
+    __shared__ float red[32];
+    const int plane = blockIdx.x, n = plane / p.C, c = plane % p.C;
+    const float* src = p.z + (size_t)plane * p.HW;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < p.HW; i += blockDim.x) s += src[i];
+    const float mean = block_sum(s, red) / (float)p.HW;
+    float q = 0.f;
+    for (int i = threadIdx.x; i < p.HW; i += blockDim.x) { const float d = src[i] - mean; q += d * d; }
+    const float var = block_sum(q, red) / (float)p.HW;
+    const float rstd = 1.0f / sqrtf(var + p.eps);
+    if (threadIdx.x == 0) { p.mean[plane] = mean; p.rstd[plane] = rstd; }
+    const float g = p.gamma ? p.gamma[c] : 1.f, b = p.beta ? p.beta[c] : 0.f;
+    float* dst = p.y + (size_t)n * p.ybs + (size_t)c * p.HW;
+    for (int i = threadIdx.x; i < p.HW; i += blockDim.x) {
+        const float t = (src[i] - mean) * rstd * g + b;
+        dst[i] = t > 0.f ? t : t * p.slope;
+    }
+}
+
+// ---- backward.  xh = (z-mean)*rstd ; yh = g*xh + b ; gy = dy * (yh > 0 ? 1 : slope)
+//      dz = rstd * g * (gy - mean(gy) - xh * mean(gy*xh))
+template <bool VEC>
+__global__ void in_bwd_kernel(const InP p) {
+    __shared__ float red[32];
+    const int plane = blockIdx.x, n = plane / p.C, c = plane % p.C;
+    const float* zs = p.z + (size_t)plane * p.HW;
+    const float* gs = p.dy + (size_t)n * p.dybs + (size_t)c * p.HW;
+    float* ds = p.dz + (size_t)plane * p.HW;
+    const float mean = p.mean[plane], rstd = p.rstd[plane];
+    const float g = p.gamma ? p.gamma[c] : 1.f, b = p.beta ? p.beta[c] : 0.f;
+    float s1 = 0.f, s2 = 0.f;
+    if (VEC) {
+        const int n4 = p.HW >> 2;
+        const float4* z4 = reinterpret_cast<const float4*>(zs);
+        const float4* g4 = reinterpret_cast<const float4*>(gs);
+        for (int i = threadIdx.x; i < n4; i += blockDim.x) {
+            const float4 zv = z4[i], gv = g4[i];
+            float xh, gy;
+            xh = (zv.x - mean) * rstd; gy = gv.x * ((xh * g + b) > 0.f ? 1.f : p.slope); s1 += gy; s2 += gy * xh;
+            xh = (zv.y - mean) * rstd; gy = gv.y * ((xh * g + b) > 0.f ? 1.f : p.slope); s1 += gy; s2 += gy * xh;
+            xh = (zv.z - mean) * rstd; gy = gv.z * ((xh * g + b) > 0.f ? 1.f : p.slope); s1 += gy; s2 += gy * xh;
+            xh = (zv.w - mean) * rstd; gy = gv.w * ((xh * g + b) > 0.f ? 1.f : p.slope); s1 += gy; s2 += gy * xh;
+        }
+    } else {
+        for (int i = threadIdx.x; i < p.HW; i += blockDim.x) {
+            const float xh = (zs[i] - mean) * rstd;
+            const float gy = gs[i] * ((xh * g + b) > 0.f ? 1.f : p.slope);
+            s1 += gy; s2 += gy * xh;
+        }
+    }
+    s1 = block_sum(s1, red);
+    s2 = block_sum(s2, red);
+    if (threadIdx.x == 0 && p.part) { p.part[2 * plane] = s1; p.part[2 * plane + 1] = s2; }
+    const float m1 = s1 / (float)p.HW, m2 = s2 / (float)p.HW, k = rstd * g;
+    if (VEC) {
+        const int n4 = p.HW >> 2;
+        const float4* z4 = reinterpret_cast<const float4*>(zs);
+        const float4* g4 = reinterpret_cast<const float4*>(gs);
+        float4* d4 = reinterpret_cast<float4*>(ds);
+        for (int i = threadIdx.x; i < n4; i += blockDim.x) {
+            const float4 zv = z4[i], gv = g4[i];
+            float4 o; float xh, gy;
+            xh = (zv.x - mean) * rstd; gy = gv.x * ((xh * g + b) > 0.f ? 1.f : p.slope); o.x = k * (gy - m1 - xh * m2);
+            xh = (zv.y - mean) * rstd; gy = gv.y * ((xh * g + b) > 0.f ? 1.f : p.slope); o.y = k * (gy - m1 - xh * m2);
+            xh = (zv.z - mean) * rstd; gy = gv.z * ((xh * g + b) > 0.f ? 1.f : p.slope); o.z = k * (gy - m1 - xh * m2);
+            xh = (zv.w - mean) * rstd; gy = gv.w * ((xh * g + b) > 0.f ? 1.f : p.slope); o.w = k * (gy - m1 - xh * m2);
+            d4[i] = o;
+        }
+    } else {
+        for (int i = threadIdx.x; i < p.HW; i += blockDim.x) {
+            const float xh = (zs[i] - mean) * rstd;
+            const float gy = gs[i] * ((xh * g + b) > 0.f ? 1.f : p.slope);
+            ds[i] = k * (gy - m1 - xh * m2);
+        }
+    }
+}
+
+// dgamma[c] = sum_n part[n,c,1] ; dbeta[c] = sum_n part[n,c,0]
+__global__ void in_dparam_kernel(const float* __restrict__ part, float* dgamma, float* dbeta, int N, int C, int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float sb = 0.f, sg = 0.f;
+    for (int n = 0; n < N; ++n) { sb += part[2 * ((size_t)n * C + c)]; sg += part[2 * ((size_t)n * C + c) + 1]; }
+    if (dgamma) dgamma[c] = accumulate ? dgamma[c] + sg : sg;
+    if (dbeta) dbeta[c] = accumulate ? dbeta[c] + sb : sb;
+}
+
+int fill(const mtbc_instnorm_args* a, InP* p) {
+    if (!a || a->N <= 0 || a->C <= 0 || a->H <= 0 || a->W <= 0) return MTBC_E_BADSHAPE;
+    p->N = a->N; p->C = a->C; p->HW = a->H * a->W; p->eps = a->eps; p->slope = a->slope;
+    p->z = a->z; p->gamma = a->gamma; p->beta = a->beta; p->y = a->y; p->ybs = a->y_batch_stride;
+    p->mean = a->mean; p->rstd = a->rstd; p->dy = a->dy; p->dybs = a->dy_batch_stride; p->dz = a->dz; p->part = nullptr;
+    return MTBC_OK;
+}
+bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
+
+}  // namespace
+
+extern "C" {
+
+int mtbc_instnorm_lrelu_fwd(const mtbc_instnorm_args* a, void* stream) {
+    InP p; int rc = fill(a, &p); if (rc) return rc;
+    if (!p.z || !p.y || !p.mean || !p.rstd) return MTBC_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    const int planes = a->N * a->C, HW = p.HW, n4 = HW / 4;
+    const bool vec = HW % 4 == 0 && al16(p.z) && al16(p.y) && p.ybs % 4 == 0;
+    if (vec && n4 <= 16 * 1024) {
+        if (n4 <= 64) hipLaunchKernelGGL(in_fwd_reg_kernel<1>, dim3(planes), dim3(64), 0, st, p);
+        else if (n4 <= 4 * 64) hipLaunchKernelGGL(in_fwd_reg_kernel<4>, dim3(planes), dim3(64), 0, st, p);
+        else if (n4 <= 4 * 256) hipLaunchKernelGGL(in_fwd_reg_kernel<4>, dim3(planes), dim3(256), 0, st, p);
+        else if (n4 <= 16 * 256) hipLaunchKernelGGL(in_fwd_reg_kernel<16>, dim3(planes), dim3(256), 0, st, p);
+        else hipLaunchKernelGGL(in_fwd_reg_kernel<16>, dim3(planes), dim3(1024), 0, st, p);
+    } else {
+        hipLaunchKernelGGL(in_fwd_stream_kernel, dim3(planes), dim3(HW >= 4096 ? 1024 : 256), 0, st, p);
+    }
+    MTBC_CHECK_LAUNCH();
+    return MTBC_OK;
+}
+
+int mtbc_instnorm_lrelu_bwd(const mtbc_instnorm_args* a, void* stream) {
+    InP p; int rc = fill(a, &p); if (rc) return rc;
+    if (!p.z || !p.dy || !p.dz || !p.mean || !p.rstd) return MTBC_E_BADARG;
+    const bool want = a->dgamma || a->dbeta;
+    const int planes = a->N * a->C;
+    if (want) {
+        if (!a->workspace || a->workspace_bytes < (size_t)planes * 2 * sizeof(float)) return MTBC_E_WORKSPACE;
+        p.part = reinterpret_cast<float*>(a->workspace);
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const bool vec = p.HW % 4 == 0 && al16(p.z) && al16(p.dy) && al16(p.dz) && p.dybs % 4 == 0;
+    const int threads = p.HW >= 16384 ? 1024 : (p.HW >= 1024 ? 256 : 64);
+    if (vec) hipLaunchKernelGGL(in_bwd_kernel<true>, dim3(planes), dim3(threads), 0, st, p);
+    else hipLaunchKernelGGL(in_bwd_kernel<false>, dim3(planes), dim3(threads), 0, st, p);
+    MTBC_CHECK_LAUNCH();
+    if (want) {
+        hipLaunchKernelGGL(in_dparam_kernel, dim3(cdiv(a->C, 128)), dim3(128), 0, st, p.part, a->dgamma, a->dbeta, a->N,
+                           a->C, a->accumulate_dparams);
+        MTBC_CHECK_LAUNCH();
+    }
+    return MTBC_OK;
+}
+
+}  // extern "C"

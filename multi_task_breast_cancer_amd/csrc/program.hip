@@ -1,0 +1,67 @@
+// Step-program executor: issues a pre-resolved list of ops back-to-back on one stream, so the host does no
+// per-op work inside a training step (the reference drives the same sequence op-by-op from Python autograd,
+// training_multitask.py:87-103).  Also hosts version / error-string entry points.
+#include "common.h"
+
+extern "C" {
+
+int mtbc_version(void) { return MTBC_VERSION; }
+const char* mtbc_arch(void) { return "gfx950"; }
+
+const char* mtbc_strerror(int code) {
+    switch (code) {
+        case MTBC_OK: return "ok";
+        case MTBC_E_BADSHAPE: return "bad shape";
+        case MTBC_E_BADARG: return "bad argument (null or misaligned pointer)";
+        case MTBC_E_WORKSPACE: return "workspace missing or too small";
+        case MTBC_E_LAUNCH: return "kernel launch failed";
+        case MTBC_E_UNSUPPORTED: return "unsupported configuration";
+        default: return "unknown error";
+    }
+}
+
+int mtbc_program_run(const mtbc_op* ops, int32_t first, int32_t count, void* stream, int32_t* failed_index) {
+    if (!ops || first < 0 || count < 0) return MTBC_E_BADARG;
+    for (int32_t i = first; i < first + count; ++i) {
+        const mtbc_op* o = &ops[i];
+        int rc;
+        switch (o->kind) {
+            case MTBC_OP_CONV3_FWD: rc = mtbc_conv3x3_fwd(&o->u.conv3, stream); break;
+            case MTBC_OP_CONV3_DGRAD: rc = mtbc_conv3x3_dgrad(&o->u.conv3, stream); break;
+            case MTBC_OP_CONV3_WGRAD: rc = mtbc_conv3x3_wgrad(&o->u.conv3, stream); break;
+            case MTBC_OP_CONV3_PACK_FWD: rc = mtbc_conv3x3_pack_fwd(o->u.pack.w, o->u.pack.packed, o->u.pack.Cin, o->u.pack.Cout, stream); break;
+            case MTBC_OP_CONV3_PACK_DGRAD: rc = mtbc_conv3x3_pack_dgrad(o->u.pack.w, o->u.pack.packed, o->u.pack.Cin, o->u.pack.Cout, stream); break;
+            case MTBC_OP_IN_FWD: rc = mtbc_instnorm_lrelu_fwd(&o->u.inorm, stream); break;
+            case MTBC_OP_IN_BWD: rc = mtbc_instnorm_lrelu_bwd(&o->u.inorm, stream); break;
+            case MTBC_OP_POOL_FWD: rc = mtbc_maxpool2_fwd(&o->u.pool, stream); break;
+            case MTBC_OP_POOL_BWD: rc = mtbc_maxpool2_bwd(&o->u.pool, stream); break;
+            case MTBC_OP_CONVT_FWD: rc = mtbc_convT_fwd(&o->u.convT, stream); break;
+            case MTBC_OP_CONVT_DGRAD: rc = mtbc_convT_dgrad(&o->u.convT, stream); break;
+            case MTBC_OP_CONVT_WGRAD: rc = mtbc_convT_wgrad(&o->u.convT, stream); break;
+            case MTBC_OP_CONV1_FWD: rc = mtbc_conv1x1_fwd(&o->u.conv1, stream); break;
+            case MTBC_OP_CONV1_DGRAD: rc = mtbc_conv1x1_dgrad(&o->u.conv1, stream); break;
+            case MTBC_OP_CONV1_WGRAD: rc = mtbc_conv1x1_wgrad(&o->u.conv1, stream); break;
+            case MTBC_OP_GAP_FWD: rc = mtbc_gap_fwd(&o->u.gap, stream); break;
+            case MTBC_OP_GAP_BWD: rc = mtbc_gap_bwd(&o->u.gap, stream); break;
+            case MTBC_OP_LINEAR_FWD: rc = mtbc_linear_fwd(&o->u.linear, stream); break;
+            case MTBC_OP_LINEAR_BWD: rc = mtbc_linear_bwd(&o->u.linear, stream); break;
+            case MTBC_OP_DICE_FWD: rc = mtbc_dice_fwd(&o->u.dice, stream); break;
+            case MTBC_OP_DICE_BWD: rc = mtbc_dice_bwd(&o->u.dice, stream); break;
+            case MTBC_OP_FOCAL: rc = mtbc_focal_fwd_bwd(&o->u.focal, stream); break;
+            case MTBC_OP_LOSS_MIX: rc = mtbc_loss_mix(o->u.mix.seg, o->u.mix.cls, o->u.mix.alpha, o->u.mix.out4, stream); break;
+            case MTBC_OP_ADAM: rc = mtbc_adam_step(&o->u.adam, stream); break;
+            case MTBC_OP_MEMSET:
+                rc = hipMemsetAsync(o->u.memset0.ptr, 0, o->u.memset0.bytes, (hipStream_t)stream) == hipSuccess ? MTBC_OK : MTBC_E_LAUNCH;
+                break;
+            case MTBC_OP_DICE_COUNTS: rc = mtbc_dice_counts(o->u.counts.logits, o->u.counts.target, o->u.counts.n, o->u.counts.out3, stream); break;
+            default: rc = MTBC_E_BADARG;
+        }
+        if (rc != MTBC_OK) {
+            if (failed_index) *failed_index = i;
+            return rc;
+        }
+    }
+    return MTBC_OK;
+}
+
+}  // extern "C"

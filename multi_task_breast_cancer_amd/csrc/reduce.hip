@@ -1,0 +1,47 @@
+// Small deterministic reductions shared by the wgrad paths (split-K partial sums, per-channel bias grads).
+#include "common.h"
+
+namespace {
+__global__ void splitk_reduce_k(const float* __restrict__ partial, float* __restrict__ out, int nsplit, size_t elems,
+                                int accumulate) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= elems) return;
+    float s = 0.f;
+    for (int k = 0; k < nsplit; ++k) s += partial[(size_t)k * elems + i];
+    out[i] = accumulate ? out[i] + s : s;
+}
+__global__ void plane_sum_k(const float* __restrict__ x, float* __restrict__ out, int HW) {
+    __shared__ float red[32];
+    const float* src = x + (size_t)blockIdx.x * HW;
+    float s = 0.f;
+    if ((HW & 3) == 0 && ((reinterpret_cast<uintptr_t>(src) & 15) == 0)) {
+        const float4* s4 = reinterpret_cast<const float4*>(src);
+        for (int i = threadIdx.x; i < (HW >> 2); i += blockDim.x) { const float4 v = s4[i]; s += (v.x + v.y) + (v.z + v.w); }
+    } else {
+        for (int i = threadIdx.x; i < HW; i += blockDim.x) s += src[i];
+    }
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) out[blockIdx.x] = s;
+}
+__global__ void sum_over_n_k(const float* __restrict__ planes, float* __restrict__ out, int N, int C, int accumulate) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f;
+    for (int n = 0; n < N; ++n) s += planes[(size_t)n * C + c];
+    out[c] = accumulate ? out[c] + s : s;
+}
+}  // namespace
+
+int mtbc_i_splitk_reduce(const float* partial, float* out, int nsplit, size_t elems, int accumulate, hipStream_t st) {
+    hipLaunchKernelGGL(splitk_reduce_k, dim3((unsigned)cdiv64(elems, 256)), dim3(256), 0, st, partial, out, nsplit, elems, accumulate);
+    MTBC_CHECK_LAUNCH();
+    return MTBC_OK;
+}
+// out[c] (+)= sum over n and the HW plane of x[n][c][:]; planes_ws holds N*C floats
+int mtbc_i_channel_sums(const float* x, float* planes_ws, float* out, int N, int C, int HW, int accumulate, hipStream_t st) {
+    hipLaunchKernelGGL(plane_sum_k, dim3(N * C), dim3(HW >= 4096 ? 256 : 64), 0, st, x, planes_ws, HW);
+    MTBC_CHECK_LAUNCH();
+    hipLaunchKernelGGL(sum_over_n_k, dim3(cdiv(C, 128)), dim3(128), 0, st, planes_ws, out, N, C, accumulate);
+    MTBC_CHECK_LAUNCH();
+    return MTBC_OK;
+}

@@ -1,0 +1,504 @@
+"""Static step programs: the forward / loss / backward / optimiser sequence of one training step as a
+list of C-ABI op descriptors with every device pointer resolved at plan time.
+
+The reference builds the same sequence dynamically each step through torch autograd
+(src/training_multitask.py:87-103); here the graph is static, so the backward program is emitted once by
+walking the forward tape in reverse, and `mtbc_program_run` issues it with no host work between kernels.
+torch is used for device memory (arena tensors) and streams only.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib as L
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+@dataclass
+class Act:
+    """An NCHW activation living in its own contiguous arena tensor (virtual concat = list of Acts)."""
+    name: str
+    data: torch.Tensor                 # (N, C, H, W)
+    needs_grad: bool = True
+    grad: Optional[torch.Tensor] = None
+    grad_written: bool = False         # has any backward op produced (part of) this grad yet?
+
+    @property
+    def N(self): return self.data.shape[0]
+    @property
+    def C(self): return self.data.shape[1]
+    @property
+    def H(self): return self.data.shape[2]
+    @property
+    def W(self): return self.data.shape[3]
+    @property
+    def bstride(self): return self.data.shape[1] * self.data.shape[2] * self.data.shape[3]
+
+
+@dataclass
+class ParamSlot:
+    name: str
+    shape: Tuple[int, ...]
+    offset: int = 0                    # element offset in the flat buffers
+    grad_written: bool = False
+    ready_at: int = -1                 # index of the last backward op that writes this grad
+
+    @property
+    def numel(self) -> int:
+        n = 1
+        for s in self.shape:
+            n *= s
+        return n
+
+
+class Program:
+    """A contiguous ctypes array of ops + the stream-ordered runner."""
+
+    def __init__(self, ops: List[L.Op], keep: list):
+        self.n = len(ops)
+        self.array = (L.Op * max(1, self.n))(*ops)
+        self.keep = keep                 # tensors referenced by raw pointer
+        self._failed = C.c_int32(-1)
+
+    def run(self, first: int = 0, count: Optional[int] = None, stream: Optional[torch.cuda.Stream] = None) -> None:
+        if count is None:
+            count = self.n - first
+        if count <= 0:
+            return
+        s = (stream or torch.cuda.current_stream()).cuda_stream
+        rc = L.load().mtbc_program_run(self.array, first, count, C.c_void_p(s), C.byref(self._failed))
+        if rc != 0:
+            i = self._failed.value
+            L.check(rc, f"program op #{i} (kind {self.array[i].kind}, tag {self.array[i].tag})")
+
+
+def _mk(kind: int, tag: int = 0) -> L.Op:
+    op = L.Op()
+    op.kind = kind
+    op.tag = tag
+    return op
+
+
+class StepPlan:
+    """Builds the forward tape of a network for a fixed (N, H, W) and derives loss/backward/Adam programs.
+
+    params: flat fp32 buffers (values p, grads g) with one ParamSlot per named tensor.
+    """
+
+    def __init__(self, device: torch.device, N: int, param_view: Callable[[str], torch.Tensor],
+                 grad_view: Callable[[str], torch.Tensor], slots: Dict[str, ParamSlot], force_direct: bool = False):
+        self.dev = device
+        self.N = N
+        self.pv, self.gv, self.slots = param_view, grad_view, slots
+        self.force_direct = 1 if force_direct else 0
+        self.keep: list = []
+        self.fwd_ops: List[L.Op] = []
+        self.pack_ops: List[L.Op] = []
+        self.bwd_emitters: List[Callable[[], None]] = []
+        self.bwd_ops: List[L.Op] = []
+        self.loss_ops: List[L.Op] = []
+        self.ws_bytes = 0
+        self.ws_users: List[Tuple[L.Op, str]] = []
+        self.arena_bytes = 0
+        self._tag = 0
+        self.lib = L.load()
+        for s in slots.values():
+            s.grad_written = False
+            s.ready_at = -1
+
+    # ------------------------------------------------------------------ memory
+    def alloc(self, *shape, dtype=torch.float32) -> torch.Tensor:
+        t = torch.empty(*shape, dtype=dtype, device=self.dev)
+        self.arena_bytes += t.numel() * t.element_size()
+        self.keep.append(t)
+        return t
+
+    def new_act(self, name: str, C_: int, H: int, W: int, needs_grad: bool = True) -> Act:
+        return Act(name, self.alloc(self.N, C_, H, W), needs_grad)
+
+    def grad_of(self, a: Act) -> torch.Tensor:
+        if a.grad is None:
+            a.grad = self.alloc(*a.data.shape)
+        return a.grad
+
+    def _need_ws(self, op: L.Op, fieldname: str, nbytes: int) -> None:
+        self.ws_bytes = max(self.ws_bytes, int(nbytes))
+        self.ws_users.append((op, fieldname))
+
+    def _mark_param(self, name: str) -> int:
+        """returns accumulate flag for a grad write to `name` and records readiness."""
+        s = self.slots[name]
+        acc = 1 if s.grad_written else 0
+        s.grad_written = True
+        s.ready_at = len(self.bwd_ops)      # index of the op about to be appended
+        return acc
+
+    def _segs(self, arr, acts: Sequence[Act], grads: bool = False) -> None:
+        for i, a in enumerate(acts):
+            if grads:
+                g = self.grad_of(a)
+                arr[i].ptr = g.data_ptr()
+                arr[i].accumulate = 1 if a.grad_written else 0
+            else:
+                arr[i].ptr = a.data.data_ptr()
+                arr[i].accumulate = 0
+            arr[i].batch_stride = a.bstride
+            arr[i].channels = a.C
+
+    # ------------------------------------------------------------------ layers
+    def conv_cell(self, inputs: Sequence[Act], cout: int, wname: str, bname: Optional[str],
+                  gname: Optional[str], betaname: Optional[str], slope: float, out_name: str) -> Act:
+        """conv3x3(pad 1) -> InstanceNorm(eps 1e-5, affine optional) -> LeakyReLU(slope)."""
+        inputs = list(inputs)
+        N, H, W = self.N, inputs[0].H, inputs[0].W
+        cin = sum(a.C for a in inputs)
+        w = self.pv(wname)
+        assert tuple(w.shape) == (cout, cin, 3, 3), (wname, tuple(w.shape), cout, cin)
+        use_packed = cin % 8 == 0 and all(a.C % 8 == 0 for a in inputs)
+        wp_f = wp_d = None
+        if use_packed:
+            wp_f = self.alloc(self.lib.mtbc_conv3x3_packed_elems(cin, cout))
+            op = _mk(L.OP_CONV3_PACK_FWD)
+            op.u.pack.w, op.u.pack.packed, op.u.pack.Cin, op.u.pack.Cout = w.data_ptr(), wp_f.data_ptr(), cin, cout
+            self.pack_ops.append(op)
+            if any(a.needs_grad for a in inputs) and cout % 8 == 0:
+                wp_d = self.alloc(self.lib.mtbc_conv3x3_packed_dgrad_elems(cin, cout))
+                op = _mk(L.OP_CONV3_PACK_DGRAD)
+                op.u.pack.w, op.u.pack.packed, op.u.pack.Cin, op.u.pack.Cout = w.data_ptr(), wp_d.data_ptr(), cin, cout
+                self.pack_ops.append(op)
+        z = self.alloc(N, cout, H, W)
+        y = self.new_act(out_name, cout, H, W)
+        mean, rstd = self.alloc(N * cout), self.alloc(N * cout)
+        self._tag += 1
+        tag = self._tag
+
+        def base_conv() -> L.Op:
+            op = _mk(0, tag)
+            a = op.u.conv3
+            a.N, a.H, a.W, a.Cin, a.Cout, a.n_in = N, H, W, cin, cout, len(inputs)
+            a.w = w.data_ptr()
+            a.force_direct = self.force_direct
+            return op
+
+        op = base_conv()
+        op.kind = L.OP_CONV3_FWD
+        self._segs(op.u.conv3.in_, inputs)
+        op.u.conv3.w_packed = _ptr(wp_f)
+        op.u.conv3.bias = _ptr(self.pv(bname)) if bname else None
+        op.u.conv3.out = z.data_ptr()
+        self.fwd_ops.append(op)
+
+        def base_in() -> L.Op:
+            op = _mk(0, tag)
+            a = op.u.inorm
+            a.N, a.C, a.H, a.W, a.eps, a.slope = N, cout, H, W, 1e-5, slope
+            a.z = z.data_ptr()
+            a.gamma = _ptr(self.pv(gname)) if gname else None
+            a.beta = _ptr(self.pv(betaname)) if betaname else None
+            a.mean, a.rstd = mean.data_ptr(), rstd.data_ptr()
+            return op
+
+        op = base_in()
+        op.kind = L.OP_IN_FWD
+        op.u.inorm.y, op.u.inorm.y_batch_stride = y.data.data_ptr(), y.bstride
+        self.fwd_ops.append(op)
+
+        def emit_bwd() -> None:
+            if not y.grad_written:
+                return
+            dy = self.grad_of(y)
+            # IN+LReLU backward, dz written in place over dy (each element is read before it is written)
+            op = base_in()
+            op.kind = L.OP_IN_BWD
+            a = op.u.inorm
+            a.dy, a.dy_batch_stride, a.dz = dy.data_ptr(), y.bstride, dy.data_ptr()
+            if gname:
+                acc = self._mark_param(gname)
+                self._mark_param(betaname)
+                a.dgamma, a.dbeta, a.accumulate_dparams = self.gv(gname).data_ptr(), self.gv(betaname).data_ptr(), acc
+                self._need_ws(op, "inorm", N * cout * 2 * 4)
+            self.bwd_ops.append(op)
+            # wgrad
+            op = base_conv()
+            op.kind = L.OP_CONV3_WGRAD
+            a = op.u.conv3
+            self._segs(a.in_, inputs)
+            a.dout = dy.data_ptr()
+            a.accumulate_dw = self._mark_param(wname)
+            a.dw = self.gv(wname).data_ptr()
+            if bname:
+                self._mark_param(bname)
+                a.dbias = self.gv(bname).data_ptr()
+            self._need_ws(op, "conv3", self.lib.mtbc_conv3x3_wgrad_workspace(C.byref(a)))
+            self.bwd_ops.append(op)
+            # dgrad into every input that needs one
+            need = [a_ for a_ in inputs if a_.needs_grad]
+            if need:
+                if len(need) != len(inputs):
+                    raise NotImplementedError("mixed grad / no-grad concat inputs")
+                op = base_conv()
+                op.kind = L.OP_CONV3_DGRAD
+                a = op.u.conv3
+                self._segs(a.in_, inputs, grads=True)
+                a.dout = dy.data_ptr()
+                a.w_packed = _ptr(wp_d)
+                self.bwd_ops.append(op)
+                for a_ in inputs:
+                    a_.grad_written = True
+
+        self.bwd_emitters.append(emit_bwd)
+        return y
+
+    def maxpool(self, x: Act, out_name: str) -> Act:
+        y = self.new_act(out_name, x.C, x.H // 2, x.W // 2)
+
+        def base() -> L.Op:
+            op = _mk(0)
+            a = op.u.pool
+            a.N, a.C, a.H, a.W = self.N, x.C, x.H, x.W
+            a.x, a.x_batch_stride = x.data.data_ptr(), x.bstride
+            a.y, a.y_batch_stride = y.data.data_ptr(), y.bstride
+            return op
+
+        op = base()
+        op.kind = L.OP_POOL_FWD
+        self.fwd_ops.append(op)
+
+        def emit_bwd() -> None:
+            if not y.grad_written or not x.needs_grad:
+                return
+            op = base()
+            op.kind = L.OP_POOL_BWD
+            a = op.u.pool
+            a.dy, a.dy_batch_stride = self.grad_of(y).data_ptr(), y.bstride
+            a.dx, a.dx_batch_stride = self.grad_of(x).data_ptr(), x.bstride
+            a.accumulate_dx = 1 if x.grad_written else 0
+            x.grad_written = True
+            self.bwd_ops.append(op)
+
+        self.bwd_emitters.append(emit_bwd)
+        return y
+
+    def convT(self, x: Act, cout: int, k: int, wname: str, bname: Optional[str], out_name: str) -> Act:
+        w = self.pv(wname)
+        assert tuple(w.shape) == (x.C, cout, k, k), (wname, tuple(w.shape))
+        y = self.new_act(out_name, cout, x.H * k, x.W * k)
+
+        def base() -> L.Op:
+            op = _mk(0)
+            a = op.u.convT
+            a.N, a.H, a.W, a.Cin, a.Cout, a.k = self.N, x.H, x.W, x.C, cout, k
+            a.x, a.x_batch_stride = x.data.data_ptr(), x.bstride
+            a.w = w.data_ptr()
+            a.bias = _ptr(self.pv(bname)) if bname else None
+            a.y, a.y_batch_stride = y.data.data_ptr(), y.bstride
+            return op
+
+        op = base()
+        op.kind = L.OP_CONVT_FWD
+        self.fwd_ops.append(op)
+
+        def emit_bwd() -> None:
+            if not y.grad_written:
+                return
+            dy = self.grad_of(y)
+            op = base()
+            op.kind = L.OP_CONVT_WGRAD
+            a = op.u.convT
+            a.dy, a.dy_batch_stride = dy.data_ptr(), y.bstride
+            a.accumulate_dw = self._mark_param(wname)
+            a.dw = self.gv(wname).data_ptr()
+            if bname:
+                self._mark_param(bname)
+                a.dbias = self.gv(bname).data_ptr()
+            self._need_ws(op, "convT", self.lib.mtbc_convT_wgrad_workspace(C.byref(a)))
+            self.bwd_ops.append(op)
+            if x.needs_grad:
+                op = base()
+                op.kind = L.OP_CONVT_DGRAD
+                a = op.u.convT
+                a.dy, a.dy_batch_stride = dy.data_ptr(), y.bstride
+                a.dx, a.dx_batch_stride = self.grad_of(x).data_ptr(), x.bstride
+                a.accumulate_dx = 1 if x.grad_written else 0
+                x.grad_written = True
+                self.bwd_ops.append(op)
+
+        self.bwd_emitters.append(emit_bwd)
+        return y
+
+    def conv1x1(self, x: Act, cout: int, wname: str, bname: str, out_name: str) -> Act:
+        w = self.pv(wname)
+        assert tuple(w.shape) == (cout, x.C, 1, 1), (wname, tuple(w.shape))
+        y = self.new_act(out_name, cout, x.H, x.W)
+
+        def base() -> L.Op:
+            op = _mk(0)
+            a = op.u.conv1
+            a.N, a.H, a.W, a.Cin, a.Cout = self.N, x.H, x.W, x.C, cout
+            a.x, a.x_batch_stride = x.data.data_ptr(), x.bstride
+            a.w, a.bias, a.y = w.data_ptr(), _ptr(self.pv(bname)), y.data.data_ptr()
+            return op
+
+        op = base()
+        op.kind = L.OP_CONV1_FWD
+        self.fwd_ops.append(op)
+
+        def emit_bwd() -> None:
+            if not y.grad_written:
+                return
+            dy = self.grad_of(y)
+            op = base()
+            op.kind = L.OP_CONV1_WGRAD
+            a = op.u.conv1
+            a.dy = dy.data_ptr()
+            a.accumulate_dw = self._mark_param(wname)
+            self._mark_param(bname)
+            a.dw, a.dbias = self.gv(wname).data_ptr(), self.gv(bname).data_ptr()
+            self._need_ws(op, "conv1", self.lib.mtbc_conv1x1_wgrad_workspace(C.byref(a)))
+            self.bwd_ops.append(op)
+            if x.needs_grad:
+                op = base()
+                op.kind = L.OP_CONV1_DGRAD
+                a = op.u.conv1
+                a.dy = dy.data_ptr()
+                a.dx, a.dx_batch_stride = self.grad_of(x).data_ptr(), x.bstride
+                a.accumulate_dx = 1 if x.grad_written else 0
+                x.grad_written = True
+                self.bwd_ops.append(op)
+
+        self.bwd_emitters.append(emit_bwd)
+        return y
+
+    def gap(self, x: Act, out_name: str) -> Act:
+        y = Act(out_name, self.alloc(self.N, x.C, 1, 1))
+
+        def base() -> L.Op:
+            op = _mk(0)
+            a = op.u.gap
+            a.N, a.C, a.H, a.W = self.N, x.C, x.H, x.W
+            a.x, a.y = x.data.data_ptr(), y.data.data_ptr()
+            return op
+
+        op = base()
+        op.kind = L.OP_GAP_FWD
+        self.fwd_ops.append(op)
+
+        def emit_bwd() -> None:
+            if not y.grad_written:
+                return
+            if x.grad_written:
+                raise NotImplementedError("gap backward overwrites dx")
+            op = base()
+            op.kind = L.OP_GAP_BWD
+            op.u.gap.dy, op.u.gap.dx = self.grad_of(y).data_ptr(), self.grad_of(x).data_ptr()
+            x.grad_written = True
+            self.bwd_ops.append(op)
+
+        self.bwd_emitters.append(emit_bwd)
+        return y
+
+    def linear(self, x: Act, out_f: int, wname: str, bname: str, relu: bool, out_name: str) -> Act:
+        in_f = x.C * x.H * x.W
+        w = self.pv(wname)
+        assert tuple(w.shape) == (out_f, in_f), (wname, tuple(w.shape))
+        y = Act(out_name, self.alloc(self.N, out_f, 1, 1))
+
+        def base() -> L.Op:
+            op = _mk(0)
+            a = op.u.linear
+            a.N, a.In, a.Out, a.relu = self.N, in_f, out_f, 1 if relu else 0
+            a.x, a.w, a.bias, a.y = x.data.data_ptr(), w.data_ptr(), _ptr(self.pv(bname)), y.data.data_ptr()
+            return op
+
+        op = base()
+        op.kind = L.OP_LINEAR_FWD
+        self.fwd_ops.append(op)
+
+        def emit_bwd() -> None:
+            if not y.grad_written:
+                return
+            if x.grad_written:
+                raise NotImplementedError("linear backward overwrites dx")
+            op = base()
+            op.kind = L.OP_LINEAR_BWD
+            a = op.u.linear
+            a.dy = self.grad_of(y).data_ptr()
+            a.dx = self.grad_of(x).data_ptr() if x.needs_grad else None
+            a.accumulate_dw = self._mark_param(wname)
+            self._mark_param(bname)
+            a.dw, a.dbias = self.gv(wname).data_ptr(), self.gv(bname).data_ptr()
+            if relu:
+                self._need_ws(op, "linear", self.N * out_f * 4)
+            x.grad_written = True
+            self.bwd_ops.append(op)
+
+        self.bwd_emitters.append(emit_bwd)
+        return y
+
+    # ------------------------------------------------------------------ losses (fused-step path)
+    def fused_losses(self, seg_heads: Sequence[Act], logits: Act, mask: torch.Tensor, onehot: torch.Tensor,
+                     alpha: float, inversely_weighted: bool, focal_weight: Optional[torch.Tensor] = None):
+        """criterions.py:52-76 + training_multitask.py:98 on device: Dice over the heads (weights 1/(j+1) from the
+        LAST head backwards), Focal on the logits, alpha-mix, NaN flag.  Gradients land in the heads' grad buffers."""
+        nh = len(seg_heads)
+        assert 1 <= nh <= 4
+        N, C_, H, W = seg_heads[0].data.shape
+        self.dice_stats = self.alloc(nh * N * C_ * 3)
+        self.dice_loss = self.alloc(nh + 1)
+        self.focal_loss = self.alloc(1)
+        self.loss_out = self.alloc(4)
+        weights = [(1.0 / (nh - i)) if inversely_weighted else 1.0 for i in range(nh)]   # head i is reversed index nh-1-i
+
+        def dice_base(kind: int) -> L.Op:
+            op = _mk(kind)
+            a = op.u.dice
+            a.n_heads, a.N, a.C, a.H, a.W, a.smooth_nr, a.smooth_dr = nh, N, C_, H, W, 1.0, 1.0
+            for i, h in enumerate(seg_heads):
+                a.x[i] = h.data.data_ptr()
+                a.head_weight[i] = weights[i]
+            a.target, a.stats, a.loss = mask.data_ptr(), self.dice_stats.data_ptr(), self.dice_loss.data_ptr()
+            return op
+
+        self.loss_ops.append(dice_base(L.OP_DICE_FWD))
+        op = dice_base(L.OP_DICE_BWD)
+        for i, h in enumerate(seg_heads):
+            op.u.dice.dx[i] = self.grad_of(h).data_ptr()
+            h.grad_written = True
+        op.u.dice.gscale = alpha
+        self.loss_ops.append(op)
+        op = _mk(L.OP_FOCAL)
+        a = op.u.focal
+        a.N, a.C, a.alpha, a.gamma = N, logits.C, 1.0, 2.0
+        a.x, a.target, a.weight = logits.data.data_ptr(), onehot.data_ptr(), _ptr(focal_weight)
+        a.loss, a.dx, a.gscale = self.focal_loss.data_ptr(), self.grad_of(logits).data_ptr(), 1.0 - alpha
+        logits.grad_written = True
+        self.loss_ops.append(op)
+        op = _mk(L.OP_LOSS_MIX)
+        op.u.mix.seg = self.dice_loss.data_ptr() + 4 * nh
+        op.u.mix.cls, op.u.mix.alpha, op.u.mix.out4 = self.focal_loss.data_ptr(), alpha, self.loss_out.data_ptr()
+        self.loss_ops.append(op)
+        self.keep += [mask, onehot]
+
+    # ------------------------------------------------------------------ finalisation
+    def emit_backward(self) -> None:
+        for em in reversed(self.bwd_emitters):
+            em()
+
+    def finalize(self) -> Dict[str, Program]:
+        ws = self.alloc(max(16, (self.ws_bytes + 15) // 16 * 4)) if self.ws_bytes else None
+        for op, fieldname in self.ws_users:
+            a = getattr(op.u, fieldname)
+            a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+        return {
+            "pack": Program(self.pack_ops, self.keep),
+            "fwd": Program(self.fwd_ops, self.keep),
+            "loss": Program(self.loss_ops, self.keep),
+            "bwd": Program(self.bwd_ops, self.keep),
+        }

@@ -1,0 +1,102 @@
+"""String -> object factory with the reference's names and signatures (src/utils/experiment_init.py:130-318),
+restricted to the multi-task training path.  Unknown names raise ValueError (the reference silently builds an
+empty nn.Module, experiment_init.py:160-163 -- stricter here)."""
+from __future__ import annotations
+
+import logging
+import sys
+from pathlib import Path
+
+import torch
+from torch.optim.lr_scheduler import CosineAnnealingLR, ReduceLROnPlateau
+
+from .criterions import DiceLoss, FocalLoss
+from .nets import MTnnUNet, MTUNetPlusPlus
+from .optim import FusedAdam
+
+
+def count_parameters(model: torch.nn.Module) -> int:
+    return sum(p.numel() for p in model.parameters() if p.requires_grad)
+
+
+def init_multitask_model(architecture: str, sequences: int = 1, regions: int = 1, n_classes: int = 2, width: int = 48,
+                         save_folder: Path = None, deep_supervision: bool = False) -> torch.nn.Module:
+    logging.info(f"Creating {architecture} model")
+    logging.info(f"The model will be fed with {sequences} sequences")
+    if architecture == "MTUNetPlusPlus":
+        model = MTUNetPlusPlus(in_channels=sequences, out_channels=regions, n_classes=n_classes,
+                               deep_supervision=deep_supervision)
+    elif architecture == "MTnnUNet":
+        model = MTnnUNet(sequences=sequences, regions=regions, n_classes=n_classes)
+    else:
+        raise ValueError(f"The model selected ({architecture!r}) is not on the MI355X hot path. Choose "
+                         "'MTnnUNet' or 'MTUNetPlusPlus'.")
+    if save_folder is not None:
+        save_folder = Path(save_folder)
+        save_folder.mkdir(parents=True, exist_ok=True)
+        with (save_folder / "model.txt").open("w") as f:
+            print(model, file=f)
+    logging.info(f"Total number of trainable parameters: {count_parameters(model)}")
+    return model
+
+
+def init_optimizer(model: torch.nn.Module, optimizer: str, learning_rate: float = 0.001):
+    if optimizer == "Adam":
+        return FusedAdam(model, lr=learning_rate, eps=1e-4)          # experiment_init.py:187: eps=1e-4
+    raise ValueError(f"optimizer {optimizer!r}: only 'Adam' is on the MI355X hot path")
+
+
+def init_criterion_segmentation(loss_function: str = "dice") -> torch.nn.Module:
+    if loss_function == "DICE":
+        return DiceLoss(include_background=True, sigmoid=True, smooth_dr=1, smooth_nr=1, squared_pred=True)
+    logging.info("Select a loss function allowed on the MI355X hot path: ['DICE']")
+    sys.exit()
+
+
+def init_criterion_classification(n_classes: int = 2, classes_weighted=None, classification_criterion="CE"):
+    if n_classes == 2 or classification_criterion != "Focal":
+        raise ValueError("only the 3-class Focal criterion (config.yaml:19) is on the MI355X hot path")
+    weight = None
+    if classes_weighted:
+        freq = torch.tensor(classes_weighted, dtype=torch.float)
+        cw = 1.0 / freq
+        weight = (cw / cw.sum()).to("cuda")
+    return FocalLoss(alpha=1, gamma=2, reduction="mean", weight=weight)
+
+
+def init_lr_scheduler(optimizer, scheduler: str = "cosine", t_max: int = 20, factor: float = 0.5,
+                      min_lr: float = 1e-6, patience: int = 20):
+    if scheduler == "plateau":
+        return ReduceLROnPlateau(optimizer, mode="min", factor=factor, patience=patience, min_lr=min_lr)
+    if scheduler == "cosine":
+        return CosineAnnealingLR(optimizer, T_max=t_max, eta_min=min_lr)
+    print("Select a scheduler allowed: ['plateau', 'cosine']")
+    sys.exit()
+
+
+def load_multitask_experiment_artefacts(config_data, config_model, config_opt, config_loss, n_augments, run_path):
+    """experiment_init.py:301-318 -> (model, optimizer, segmentation_criterion, classification_criterion, scheduler)"""
+    model = init_multitask_model(architecture=config_model["architecture"],
+                                 sequences=config_model["sequences"] + n_augments,
+                                 width=config_model["width"],
+                                 n_classes=len(config_data["classes"]),
+                                 deep_supervision=config_model["deep_supervision"],
+                                 save_folder=Path(f"{run_path}/") if run_path is not None else None)
+    optimizer = init_optimizer(model=model, optimizer=config_opt["opt"], learning_rate=config_opt["lr"])
+    segmentation_criterion = init_criterion_segmentation(loss_function=config_loss["function"])
+    classification_criterion = init_criterion_classification(
+        n_classes=len(config_data["classes"]), classes_weighted=config_data["classes_weighted"],
+        classification_criterion=config_loss["classification_criterion"])
+    scheduler = init_lr_scheduler(optimizer=optimizer, scheduler=config_opt["scheduler"],
+                                  t_max=int(config_opt["t_max"]), patience=int(config_opt["patience"]),
+                                  min_lr=float(config_opt["min_lr"]), factor=float(config_opt["decrease_factor"]))
+    return model, optimizer, segmentation_criterion, classification_criterion, scheduler
+
+
+def device_setup() -> str:
+    """experiment_init.py:339-347"""
+    if torch.cuda.is_available():
+        logging.info("GPU will be used to train the model")
+        return "cuda:0"
+    logging.info("CPU will be used to train the model")
+    return "cpu"

@@ -1,0 +1,320 @@
+"""Tensor-level wrappers over the per-op C-ABI (one call = one mtbc_* entry point).
+
+Used by the parity tests and as the reference-side binding example of INTEGRATION.md; the training path itself
+goes through step programs (engine.py).  Device fp32 tensors only; every wrapper raises on CPU input.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib as L
+
+
+def _s() -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _chk(*ts):
+    for t in ts:
+        if t is None:
+            continue
+        if t.device.type != "cuda":
+            L.require_gpu()
+            raise L.MtbcError("device tensors required")
+        if t.dtype != torch.float32 or not t.is_contiguous():
+            raise ValueError("fp32 contiguous tensors required")
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _fill_segs(arr, tensors: Sequence[torch.Tensor], accumulate: Sequence[int] = ()):
+    for i, t in enumerate(tensors):
+        arr[i].ptr = t.data_ptr()
+        arr[i].batch_stride = t.shape[1] * t.shape[2] * t.shape[3]
+        arr[i].channels = t.shape[1]
+        arr[i].accumulate = accumulate[i] if i < len(accumulate) else 0
+
+
+def _ws(nbytes: int, dev) -> torch.Tensor:
+    return torch.empty(max(4, (nbytes + 3) // 4), dtype=torch.float32, device=dev)
+
+
+# ------------------------------------------------------------------ conv3x3
+def conv3x3_pack(w: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    _chk(w)
+    lib = L.load()
+    cout, cin = w.shape[0], w.shape[1]
+    pf = torch.empty(lib.mtbc_conv3x3_packed_elems(cin, cout), dtype=torch.float32, device=w.device)
+    pd = torch.empty(lib.mtbc_conv3x3_packed_dgrad_elems(cin, cout), dtype=torch.float32, device=w.device)
+    L.check(lib.mtbc_conv3x3_pack_fwd(w.data_ptr(), pf.data_ptr(), cin, cout, _s()), "pack_fwd")
+    L.check(lib.mtbc_conv3x3_pack_dgrad(w.data_ptr(), pd.data_ptr(), cin, cout, _s()), "pack_dgrad")
+    return pf, pd
+
+
+def _conv_args(xs, w, N, H, W):
+    a = L.Conv3x3Args()
+    cin = sum(x.shape[1] for x in xs)
+    a.N, a.H, a.W, a.Cin, a.Cout, a.n_in = N, H, W, cin, w.shape[0], len(xs)
+    a.w = w.data_ptr()
+    return a
+
+
+def conv3x3_fwd(xs: Sequence[torch.Tensor], w: torch.Tensor, bias: Optional[torch.Tensor] = None,
+                packed: Optional[torch.Tensor] = None, force_direct: bool = False) -> torch.Tensor:
+    _chk(*xs, w, bias, packed)
+    N, _, H, W = xs[0].shape
+    a = _conv_args(xs, w, N, H, W)
+    _fill_segs(a.in_, xs)
+    out = torch.empty(N, w.shape[0], H, W, dtype=torch.float32, device=w.device)
+    a.w_packed, a.bias, a.out, a.force_direct = _p(packed), _p(bias), out.data_ptr(), int(force_direct)
+    L.check(L.load().mtbc_conv3x3_fwd(C.byref(a), _s()), "conv3x3_fwd")
+    return out
+
+
+def conv3x3_dgrad(dz: torch.Tensor, w: torch.Tensor, dxs: Sequence[torch.Tensor], accumulate: Sequence[int] = (),
+                  packed: Optional[torch.Tensor] = None, force_direct: bool = False) -> None:
+    _chk(dz, w, packed, *dxs)
+    N, _, H, W = dz.shape
+    a = _conv_args(dxs, w, N, H, W)
+    _fill_segs(a.in_, dxs, accumulate)
+    a.w_packed, a.dout, a.force_direct = _p(packed), dz.data_ptr(), int(force_direct)
+    L.check(L.load().mtbc_conv3x3_dgrad(C.byref(a), _s()), "conv3x3_dgrad")
+
+
+def conv3x3_wgrad(xs: Sequence[torch.Tensor], dz: torch.Tensor, w_shape, want_bias: bool = False,
+                  force_direct: bool = False, dw: Optional[torch.Tensor] = None, accumulate: bool = False):
+    _chk(*xs, dz)
+    N, _, H, W = dz.shape
+    dev = dz.device
+    if dw is None:
+        dw = torch.empty(*w_shape, dtype=torch.float32, device=dev)
+    db = torch.empty(w_shape[0], dtype=torch.float32, device=dev) if want_bias else None
+    a = L.Conv3x3Args()
+    a.N, a.H, a.W, a.Cin, a.Cout, a.n_in = N, H, W, w_shape[1], w_shape[0], len(xs)
+    _fill_segs(a.in_, xs)
+    a.dout, a.dw, a.dbias, a.force_direct, a.accumulate_dw = dz.data_ptr(), dw.data_ptr(), _p(db), int(force_direct), int(accumulate)
+    nb = L.load().mtbc_conv3x3_wgrad_workspace(C.byref(a))
+    ws = _ws(nb, dev)
+    a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+    L.check(L.load().mtbc_conv3x3_wgrad(C.byref(a), _s()), "conv3x3_wgrad")
+    return dw, db
+
+
+# ------------------------------------------------------------------ instance norm + leaky relu
+def instnorm_lrelu_fwd(z, gamma=None, beta=None, eps=1e-5, slope=0.01):
+    _chk(z, gamma, beta)
+    N, Cc, H, W = z.shape
+    y = torch.empty_like(z)
+    mean = torch.empty(N * Cc, dtype=torch.float32, device=z.device)
+    rstd = torch.empty_like(mean)
+    a = L.InstNormArgs()
+    a.N, a.C, a.H, a.W, a.eps, a.slope = N, Cc, H, W, eps, slope
+    a.z, a.gamma, a.beta, a.y, a.y_batch_stride = z.data_ptr(), _p(gamma), _p(beta), y.data_ptr(), Cc * H * W
+    a.mean, a.rstd = mean.data_ptr(), rstd.data_ptr()
+    L.check(L.load().mtbc_instnorm_lrelu_fwd(C.byref(a), _s()), "instnorm_fwd")
+    return y, mean, rstd
+
+
+def instnorm_lrelu_bwd(z, dy, mean, rstd, gamma=None, beta=None, eps=1e-5, slope=0.01, inplace=False):
+    _chk(z, dy, mean, rstd, gamma, beta)
+    N, Cc, H, W = z.shape
+    dz = dy if inplace else torch.empty_like(z)
+    dg = torch.empty(Cc, dtype=torch.float32, device=z.device) if gamma is not None else None
+    db = torch.empty(Cc, dtype=torch.float32, device=z.device) if gamma is not None else None
+    ws = _ws(N * Cc * 8, z.device)
+    a = L.InstNormArgs()
+    a.N, a.C, a.H, a.W, a.eps, a.slope = N, Cc, H, W, eps, slope
+    a.z, a.gamma, a.beta, a.mean, a.rstd = z.data_ptr(), _p(gamma), _p(beta), mean.data_ptr(), rstd.data_ptr()
+    a.dy, a.dy_batch_stride, a.dz, a.dgamma, a.dbeta = dy.data_ptr(), Cc * H * W, dz.data_ptr(), _p(dg), _p(db)
+    a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+    L.check(L.load().mtbc_instnorm_lrelu_bwd(C.byref(a), _s()), "instnorm_bwd")
+    return dz, dg, db
+
+
+# ------------------------------------------------------------------ maxpool
+def maxpool2_fwd(x):
+    _chk(x)
+    N, Cc, H, W = x.shape
+    y = torch.empty(N, Cc, H // 2, W // 2, dtype=torch.float32, device=x.device)
+    a = L.MaxPoolArgs()
+    a.N, a.C, a.H, a.W = N, Cc, H, W
+    a.x, a.x_batch_stride, a.y, a.y_batch_stride = x.data_ptr(), Cc * H * W, y.data_ptr(), Cc * H * W // 4
+    L.check(L.load().mtbc_maxpool2_fwd(C.byref(a), _s()), "maxpool_fwd")
+    return y
+
+
+def maxpool2_bwd(x, dy, dx=None, accumulate=False):
+    _chk(x, dy, dx)
+    N, Cc, H, W = x.shape
+    if dx is None:
+        dx = torch.empty_like(x)
+    a = L.MaxPoolArgs()
+    a.N, a.C, a.H, a.W = N, Cc, H, W
+    a.x, a.x_batch_stride = x.data_ptr(), Cc * H * W
+    a.dy, a.dy_batch_stride, a.dx, a.dx_batch_stride = dy.data_ptr(), Cc * H * W // 4, dx.data_ptr(), Cc * H * W
+    a.accumulate_dx = int(accumulate)
+    L.check(L.load().mtbc_maxpool2_bwd(C.byref(a), _s()), "maxpool_bwd")
+    return dx
+
+
+# ------------------------------------------------------------------ conv transpose (k == stride)
+def _ct_args(x, w, k):
+    a = L.ConvTArgs()
+    N, Cin, H, W = x.shape
+    a.N, a.H, a.W, a.Cin, a.Cout, a.k = N, H, W, Cin, w.shape[1], k
+    a.x, a.x_batch_stride, a.w = x.data_ptr(), Cin * H * W, w.data_ptr()
+    return a
+
+
+def convT_fwd(x, w, bias, k):
+    _chk(x, w, bias)
+    N, Cin, H, W = x.shape
+    y = torch.empty(N, w.shape[1], H * k, W * k, dtype=torch.float32, device=x.device)
+    a = _ct_args(x, w, k)
+    a.bias, a.y, a.y_batch_stride = _p(bias), y.data_ptr(), y[0].numel()
+    L.check(L.load().mtbc_convT_fwd(C.byref(a), _s()), "convT_fwd")
+    return y
+
+
+def convT_dgrad(x, w, dy, k, dx=None, accumulate=False):
+    _chk(x, w, dy, dx)
+    if dx is None:
+        dx = torch.empty_like(x)
+    a = _ct_args(x, w, k)
+    a.dy, a.dy_batch_stride, a.dx, a.dx_batch_stride, a.accumulate_dx = dy.data_ptr(), dy[0].numel(), dx.data_ptr(), x[0].numel(), int(accumulate)
+    L.check(L.load().mtbc_convT_dgrad(C.byref(a), _s()), "convT_dgrad")
+    return dx
+
+
+def convT_wgrad(x, w, dy, k, want_bias=True):
+    _chk(x, w, dy)
+    dw = torch.empty_like(w)
+    db = torch.empty(w.shape[1], dtype=torch.float32, device=x.device) if want_bias else None
+    a = _ct_args(x, w, k)
+    a.dy, a.dy_batch_stride, a.dw, a.dbias = dy.data_ptr(), dy[0].numel(), dw.data_ptr(), _p(db)
+    ws = _ws(L.load().mtbc_convT_wgrad_workspace(C.byref(a)), x.device)
+    a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+    L.check(L.load().mtbc_convT_wgrad(C.byref(a), _s()), "convT_wgrad")
+    return dw, db
+
+
+# ------------------------------------------------------------------ conv1x1
+def _c1_args(x, w):
+    a = L.Conv1x1Args()
+    N, Cin, H, W = x.shape
+    a.N, a.H, a.W, a.Cin, a.Cout = N, H, W, Cin, w.shape[0]
+    a.x, a.x_batch_stride, a.w = x.data_ptr(), Cin * H * W, w.data_ptr()
+    return a
+
+
+def conv1x1_fwd(x, w, bias):
+    _chk(x, w, bias)
+    N, _, H, W = x.shape
+    y = torch.empty(N, w.shape[0], H, W, dtype=torch.float32, device=x.device)
+    a = _c1_args(x, w)
+    a.bias, a.y = _p(bias), y.data_ptr()
+    L.check(L.load().mtbc_conv1x1_fwd(C.byref(a), _s()), "conv1x1_fwd")
+    return y
+
+
+def conv1x1_bwd(x, w, dy):
+    _chk(x, w, dy)
+    dx, dw = torch.empty_like(x), torch.empty_like(w)
+    db = torch.empty(w.shape[0], dtype=torch.float32, device=x.device)
+    a = _c1_args(x, w)
+    a.dy, a.dx, a.dx_batch_stride = dy.data_ptr(), dx.data_ptr(), x[0].numel()
+    L.check(L.load().mtbc_conv1x1_dgrad(C.byref(a), _s()), "conv1x1_dgrad")
+    a.dw, a.dbias = dw.data_ptr(), db.data_ptr()
+    ws = _ws(L.load().mtbc_conv1x1_wgrad_workspace(C.byref(a)), x.device)
+    a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+    L.check(L.load().mtbc_conv1x1_wgrad(C.byref(a), _s()), "conv1x1_wgrad")
+    return dx, dw, db
+
+
+# ------------------------------------------------------------------ head
+def gap_fwd(x):
+    _chk(x)
+    N, Cc, H, W = x.shape
+    y = torch.empty(N, Cc, dtype=torch.float32, device=x.device)
+    a = L.GapArgs()
+    a.N, a.C, a.H, a.W, a.x, a.y = N, Cc, H, W, x.data_ptr(), y.data_ptr()
+    L.check(L.load().mtbc_gap_fwd(C.byref(a), _s()), "gap_fwd")
+    return y
+
+
+def gap_bwd(dy, H, W):
+    _chk(dy)
+    N, Cc = dy.shape
+    dx = torch.empty(N, Cc, H, W, dtype=torch.float32, device=dy.device)
+    a = L.GapArgs()
+    a.N, a.C, a.H, a.W, a.dy, a.dx = N, Cc, H, W, dy.data_ptr(), dx.data_ptr()
+    L.check(L.load().mtbc_gap_bwd(C.byref(a), _s()), "gap_bwd")
+    return dx
+
+
+def linear_fwd(x, w, b, relu=False):
+    _chk(x, w, b)
+    y = torch.empty(x.shape[0], w.shape[0], dtype=torch.float32, device=x.device)
+    a = L.LinearArgs()
+    a.N, a.In, a.Out, a.relu = x.shape[0], x.shape[1], w.shape[0], int(relu)
+    a.x, a.w, a.bias, a.y = x.data_ptr(), w.data_ptr(), _p(b), y.data_ptr()
+    L.check(L.load().mtbc_linear_fwd(C.byref(a), _s()), "linear_fwd")
+    return y
+
+
+def linear_bwd(x, w, y, dy, relu=False):
+    _chk(x, w, y, dy)
+    dx, dw = torch.empty_like(x), torch.empty_like(w)
+    db = torch.empty(w.shape[0], dtype=torch.float32, device=x.device)
+    ws = _ws(x.shape[0] * w.shape[0] * 4, x.device)
+    a = L.LinearArgs()
+    a.N, a.In, a.Out, a.relu = x.shape[0], x.shape[1], w.shape[0], int(relu)
+    a.x, a.w, a.y, a.dy = x.data_ptr(), w.data_ptr(), y.data_ptr(), dy.data_ptr()
+    a.dx, a.dw, a.dbias = dx.data_ptr(), dw.data_ptr(), db.data_ptr()
+    a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+    L.check(L.load().mtbc_linear_bwd(C.byref(a), _s()), "linear_bwd")
+    return dx, dw, db
+
+
+# ------------------------------------------------------------------ losses / optimiser
+def dice_multihead(xs: Sequence[torch.Tensor], target, weights: Sequence[float], gscale: float = 1.0):
+    """returns (loss[n_heads+1], [dx per head])"""
+    _chk(*xs, target)
+    nh = len(xs)
+    N, Cc, H, W = xs[0].shape
+    dev = target.device
+    stats = torch.empty(nh * N * Cc * 3, dtype=torch.float32, device=dev)
+    loss = torch.empty(nh + 1, dtype=torch.float32, device=dev)
+    dxs = [torch.empty_like(x) for x in xs]
+    a = L.DiceArgs()
+    a.n_heads, a.N, a.C, a.H, a.W, a.smooth_nr, a.smooth_dr = nh, N, Cc, H, W, 1.0, 1.0
+    for i in range(nh):
+        a.x[i], a.dx[i], a.head_weight[i] = xs[i].data_ptr(), dxs[i].data_ptr(), weights[i]
+    a.target, a.stats, a.loss, a.gscale = target.data_ptr(), stats.data_ptr(), loss.data_ptr(), gscale
+    L.check(L.load().mtbc_dice_fwd(C.byref(a), _s()), "dice_fwd")
+    L.check(L.load().mtbc_dice_bwd(C.byref(a), _s()), "dice_bwd")
+    return loss, dxs
+
+
+def focal(x, t, alpha=1.0, gamma=2.0, weight=None, gscale=1.0):
+    _chk(x, t, weight)
+    loss = torch.empty(1, dtype=torch.float32, device=x.device)
+    dx = torch.empty_like(x)
+    a = L.FocalArgs()
+    a.N, a.C, a.alpha, a.gamma = x.shape[0], x.shape[1], alpha, gamma
+    a.x, a.target, a.weight, a.loss, a.dx, a.gscale = x.data_ptr(), t.data_ptr(), _p(weight), loss.data_ptr(), dx.data_ptr(), gscale
+    L.check(L.load().mtbc_focal_fwd_bwd(C.byref(a), _s()), "focal")
+    return loss, dx
+
+
+def adam_step(p, g, m, v, lr, step, beta1=0.9, beta2=0.999, eps=1e-4, grad_scale=1.0, zero_grad=False):
+    _chk(p, g, m, v)
+    a = L.AdamArgs()
+    a.n, a.p, a.g, a.m, a.v = p.numel(), p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr()
+    a.lr, a.beta1, a.beta2, a.eps, a.grad_scale, a.step, a.zero_grad = lr, beta1, beta2, eps, grad_scale, step, int(zero_grad)
+    L.check(L.load().mtbc_adam_step(C.byref(a), _s()), "adam")

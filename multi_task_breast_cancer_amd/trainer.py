@@ -1,0 +1,182 @@
+"""The optimisation step of src/training_multitask.py:87-103 as ONE stream-ordered program, plus the
+data-parallel layer the reference does not have: one process per GPU, equal contiguous shards of a
+single seeded global permutation, bucketed gradient all-reduce (RCCL over xGMI) overlapped with backward,
+1/world folded into the fused Adam.
+
+    zero_grad -> fwd -> Dice(4 heads, 1/(j+1)) + Focal -> alpha-mix -> bwd -> [all-reduce] -> Adam
+
+No host synchronisation happens inside a step: the loss scalars and the NaN flag stay on the device
+(`FusedTrainStep.losses`), to be read every k steps (the reference syncs 3+N times per step).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib as L
+
+
+# ------------------------------------------------------------------------------------------------
+# pure host logic (CPU-testable with gloo)
+# ------------------------------------------------------------------------------------------------
+@dataclass
+class Bucket:
+    start: int          # element range [start, end) of the flat gradient buffer
+    end: int
+    ready_op: int       # backward ops [0, ready_op] must have been issued before this bucket is reduced
+
+
+def plan_buckets(slots: Sequence[Tuple[int, int, int]], flat_numel: int, n_buckets: int) -> List[Bucket]:
+    """slots: (offset, numel, ready_at) per parameter in layout order.  Splits the flat buffer into
+    `n_buckets` contiguous ranges of roughly equal size on parameter boundaries and returns them sorted by
+    readiness (earliest first).  Ranges tile [0, flat_numel) exactly."""
+    if not slots:
+        return []
+    n_buckets = max(1, min(n_buckets, len(slots)))
+    target = flat_numel / n_buckets
+    cuts, acc = [0], 0
+    for i, (off, numel, _) in enumerate(slots):
+        nxt = slots[i + 1][0] if i + 1 < len(slots) else flat_numel
+        acc = nxt
+        if len(cuts) < n_buckets and acc >= target * len(cuts):
+            cuts.append(nxt)
+    if cuts[-1] != flat_numel:
+        cuts.append(flat_numel)
+    out = []
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        if b <= a:
+            continue
+        ready = max((r for off, numel, r in slots if a <= off < b), default=0)
+        out.append(Bucket(a, b, ready))
+    out.sort(key=lambda bk: bk.ready_op)
+    return out
+
+
+def shard_positions(positions: np.ndarray, rank: int, world: int, global_batch: int, step: int) -> np.ndarray:
+    """Batch `step` of a global index list, cut into `world` equal contiguous shards: rank r takes
+    rows [r*G/world, (r+1)*G/world) of the global batch, so the union over ranks IS the single-GPU batch."""
+    if global_batch % world:
+        raise ValueError("global batch must divide evenly across ranks")
+    per = global_batch // world
+    lo = step * global_batch + rank * per
+    return positions[lo:lo + per]
+
+
+def global_permutation(n: int, seed: int, epoch: int) -> np.ndarray:
+    """One seeded permutation of the (oversampled) index list per epoch, identical on every rank."""
+    return np.random.Generator(np.random.PCG64(seed * 1_000_003 + epoch)).permutation(n)
+
+
+def allreduce_buckets(flat_g: torch.Tensor, buckets: Sequence[Bucket], group=None, async_op: bool = False):
+    """Sum-all-reduce every bucket of the flat gradient buffer (averaging = grad_scale 1/world in Adam)."""
+    import torch.distributed as dist
+    works = []
+    for b in buckets:
+        w = dist.all_reduce(flat_g[b.start:b.end], op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+        if async_op:
+            works.append(w)
+    return works
+
+
+# ------------------------------------------------------------------------------------------------
+# the fused step (HIP)
+# ------------------------------------------------------------------------------------------------
+class FusedTrainStep:
+    def __init__(self, model, optimizer, alpha: float, inversely_weighted: bool = True, n_classes: int = 3,
+                 distributed: bool = False, n_buckets: int = 4, focal_weight: Optional[torch.Tensor] = None):
+        self.model, self.opt = model, optimizer
+        self.alpha, self.iw, self.n_classes = float(alpha), bool(inversely_weighted), n_classes
+        self.focal_weight = focal_weight
+        self.distributed = distributed
+        self.n_buckets = n_buckets
+        self.world = 1
+        self.comm_stream = None
+        if distributed:
+            import torch.distributed as dist
+            self.world = dist.get_world_size()
+            self.comm_stream = torch.cuda.Stream()
+            optimizer.grad_scale = 1.0 / self.world
+        self._st = None
+        self._buckets: List[Bucket] = []
+        self.losses: Optional[torch.Tensor] = None      # device: [total, seg, cls, nan_flag]
+
+    def _compiled(self, N: int, H: int, W: int):
+        st = self.model.compiled(N, H, W, fused_loss={"alpha": self.alpha, "inversely_weighted": self.iw,
+                                                      "focal_weight": self.focal_weight})
+        if st is not self._st:
+            self._st = st
+            m = self.model
+            slots = [(m.slots[n].offset, m.slots[n].numel, m.slots[n].ready_at) for n in m._order]
+            self._buckets = plan_buckets(slots, m.flat_numel, self.n_buckets)
+            m.grads_as_views()
+        return st
+
+    def load_batch(self, image: torch.Tensor, mask: torch.Tensor, label: torch.Tensor):
+        """H2D / D2D of training_multitask.py:82-84 into the plan's static buffers (one-hot on the device)."""
+        N, _, H, W = image.shape
+        st = self._compiled(N, H, W)
+        st.x.data.copy_(image, non_blocking=True)
+        st.mask.copy_(mask, non_blocking=True)
+        lab = label.to(st.onehot.device, non_blocking=True).flatten().to(torch.int64)
+        st.onehot.zero_()
+        st.onehot.scatter_(1, lab.view(-1, 1), 1.0)
+        return st
+
+    def run(self, st) -> torch.Tensor:
+        """One optimisation step on the batch already resident in the plan's buffers."""
+        P = st.programs
+        P["pack"].run()
+        P["fwd"].run()
+        P["loss"].run()
+        if not self.distributed:
+            P["bwd"].run()
+        else:
+            cur = torch.cuda.current_stream()
+            done = 0
+            for b in self._buckets:
+                upto = min(P["bwd"].n, b.ready_op + 1)
+                if upto > done:
+                    P["bwd"].run(done, upto - done)
+                    done = upto
+                ev = torch.cuda.Event()
+                ev.record(cur)
+                with torch.cuda.stream(self.comm_stream):
+                    self.comm_stream.wait_event(ev)
+                    allreduce_buckets(self.model.flat_g, [b])
+            if done < P["bwd"].n:
+                P["bwd"].run(done, P["bwd"].n - done)
+            cur.wait_stream(self.comm_stream)
+        self.opt.step(grads_in_flat=True)
+        self.losses = st.plan.loss_out
+        return self.losses
+
+    def __call__(self, image, mask, label) -> torch.Tensor:
+        return self.run(self.load_batch(image, mask, label))
+
+    def check_nan(self) -> None:
+        """The reference's NaN guard (criterions.py:72-76), one device->host read when the caller chooses."""
+        if self.losses is not None and float(self.losses[3].item()) != 0.0:
+            import logging
+            import sys
+            logging.info("NaN in model loss!!")
+            sys.exit(1)
+
+
+def dice_score_from_counts(counts: torch.Tensor) -> float:
+    """metrics.py:255-267 from {tp, fp, fn} float64 counts (mtbc_dice_counts)."""
+    tp, fp, fn = (float(v) for v in counts.tolist())
+    if tp + fn == 0:
+        return 1.0 if tp + fp == 0 else 0.0
+    return 2 * tp / (2 * tp + fp + fn)
+
+
+def dice_counts(logits: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
+    import ctypes as C
+    out = torch.empty(3, dtype=torch.float64, device=logits.device)
+    x, t = logits.contiguous().float(), target.contiguous().float()
+    L.check(L.load().mtbc_dice_counts(x.data_ptr(), t.data_ptr(), x.numel(), out.data_ptr(),
+                                      C.c_void_p(torch.cuda.current_stream().cuda_stream)), "dice_counts")
+    return out

@@ -1,0 +1,91 @@
+"""C-ABI checks that need no GPU: the library loads, exports every symbol include/mtbc.h declares, and the
+ctypes mirrors in _lib.py have exactly the C layout (sizes + a few offsets) of the header's structs."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "mtbc.h")
+
+from multi_task_breast_cancer_amd import _lib as L   # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not os.path.exists(L.LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
+    return L.load()
+
+
+def test_library_exports_every_declared_symbol(lib):
+    src = open(HEADER).read()
+    declared = set(re.findall(r"\b(mtbc_[A-Za-z0-9_]+)\s*\(", src))
+    assert declared == set(L.EXPORTS), declared ^ set(L.EXPORTS)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.mtbc_version() == 100
+    assert lib.mtbc_arch() == b"gfx950"
+    assert lib.mtbc_strerror(0) == b"ok" and b"workspace" in lib.mtbc_strerror(-3)
+
+
+def test_ctypes_layout_matches_header(tmp_path):
+    structs = {"mtbc_seg": L.Seg, "mtbc_conv3x3_args": L.Conv3x3Args, "mtbc_instnorm_args": L.InstNormArgs,
+               "mtbc_maxpool_args": L.MaxPoolArgs, "mtbc_convT_args": L.ConvTArgs, "mtbc_conv1x1_args": L.Conv1x1Args,
+               "mtbc_gap_args": L.GapArgs, "mtbc_linear_args": L.LinearArgs, "mtbc_dice_args": L.DiceArgs,
+               "mtbc_focal_args": L.FocalArgs, "mtbc_adam_args": L.AdamArgs, "mtbc_op": L.Op}
+    offs = [("mtbc_conv3x3_args", "workspace_bytes", L.Conv3x3Args.workspace_bytes.offset),
+            ("mtbc_conv3x3_args", "w_packed", L.Conv3x3Args.w_packed.offset),
+            ("mtbc_instnorm_args", "dgamma", L.InstNormArgs.dgamma.offset),
+            ("mtbc_convT_args", "accumulate_dw", L.ConvTArgs.accumulate_dw.offset),
+            ("mtbc_dice_args", "gscale_dev", L.DiceArgs.gscale_dev.offset),
+            ("mtbc_adam_args", "zero_grad", L.AdamArgs.zero_grad.offset),
+            ("mtbc_op", "u", L.Op.u.offset)]
+    lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{HEADER}"', "int main(void){"]
+    for name in structs:
+        lines.append(f'printf("{name} %zu\\n", sizeof({name}));')
+    for s, f, _ in offs:
+        lines.append(f'printf("{s}.{f} %zu\\n", offsetof({s}, {f}));')
+    lines.append("return 0;}")
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-std=c11", "-o", str(exe), str(src)])
+    got = dict(l.split() for l in subprocess.check_output([str(exe)]).decode().splitlines())
+    for name, typ in structs.items():
+        assert int(got[name]) == C.sizeof(typ), (name, got[name], C.sizeof(typ))
+    for s, f, off in offs:
+        assert int(got[f"{s}.{f}"]) == off, (s, f)
+
+
+def test_op_kind_enum_in_sync():
+    src = open(HEADER).read()
+    body = src[src.index("MTBC_OP_CONV3_FWD = 1"):]
+    body = body[:body.index("};")]
+    names = [n.strip().split("=")[0].strip() for n in body.replace("\n", " ").split(",") if n.strip()]
+    want = ["CONV3_FWD", "CONV3_DGRAD", "CONV3_WGRAD", "CONV3_PACK_FWD", "CONV3_PACK_DGRAD", "IN_FWD", "IN_BWD",
+            "POOL_FWD", "POOL_BWD", "CONVT_FWD", "CONVT_DGRAD", "CONVT_WGRAD", "CONV1_FWD", "CONV1_DGRAD", "CONV1_WGRAD",
+            "GAP_FWD", "GAP_BWD", "LINEAR_FWD", "LINEAR_BWD", "DICE_FWD", "DICE_BWD", "FOCAL", "LOSS_MIX", "ADAM",
+            "MEMSET", "DICE_COUNTS"]
+    assert names == ["MTBC_OP_" + w for w in want]
+    for i, w in enumerate(want, start=1):
+        assert getattr(L, "OP_" + w) == i
+
+
+def test_product_path_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from multi_task_breast_cancer_amd.nets import MTnnUNet
+    from multi_task_breast_cancer_amd.criterions import DiceLoss, FocalLoss
+    m = MTnnUNet(1, 1, 3)
+    with pytest.raises(L.MtbcError):
+        m(torch.rand(1, 1, 64, 64))
+    with pytest.raises(L.MtbcError):
+        DiceLoss()(torch.zeros(1, 1, 8, 8), torch.zeros(1, 1, 8, 8))
+    with pytest.raises(L.MtbcError):
+        FocalLoss()(torch.zeros(2, 3), torch.zeros(2, 3))
