@@ -108,6 +108,7 @@ class StepPlan:
         self.ws_users: List[Tuple[L.Op, str]] = []
         self.arena_bytes = 0
         self._tag = 0
+        self.acts: Dict[str, Act] = {}     # every activation by (reference module path) name, for parity probes
         self.lib = L.load()
         for s in slots.values():
             s.grad_written = False
@@ -121,7 +122,9 @@ class StepPlan:
         return t
 
     def new_act(self, name: str, C_: int, H: int, W: int, needs_grad: bool = True) -> Act:
-        return Act(name, self.alloc(self.N, C_, H, W), needs_grad)
+        a = Act(name, self.alloc(self.N, C_, H, W), needs_grad)
+        self.acts[name] = a
+        return a
 
     def grad_of(self, a: Act) -> torch.Tensor:
         if a.grad is None:

@@ -36,15 +36,16 @@ def plan_buckets(slots: Sequence[Tuple[int, int, int]], flat_numel: int, n_bucke
     if not slots:
         return []
     n_buckets = max(1, min(n_buckets, len(slots)))
-    target = flat_numel / n_buckets
-    cuts, acc = [0], 0
+    cuts = [0]
     for i, (off, numel, _) in enumerate(slots):
         nxt = slots[i + 1][0] if i + 1 < len(slots) else flat_numel
-        acc = nxt
-        if len(cuts) < n_buckets and acc >= target * len(cuts):
+        left = n_buckets - len(cuts)            # cuts still allowed after this bucket closes
+        if left <= 0:
+            break
+        target = cuts[-1] + (flat_numel - cuts[-1]) / (left + 1)
+        if nxt >= target and nxt < flat_numel:
             cuts.append(nxt)
-    if cuts[-1] != flat_numel:
-        cuts.append(flat_numel)
+    cuts.append(flat_numel)
     out = []
     for a, b in zip(cuts[:-1], cuts[1:]):
         if b <= a:

@@ -1,0 +1,293 @@
+"""Per-op parity of the HIP kernels (through the C-ABI) against the same torch op on the CPU in fp32.
+Tolerances are written per test; integer results are bit-exact."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from multi_task_breast_cancer_amd import ops  # noqa: E402
+from oracle import torch_oracle as O  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def _g(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+def _close(got, want, rtol, atol, what=""):
+    got = got.detach().cpu()
+    err = (got - want).abs()
+    tol = atol + rtol * want.abs()
+    assert bool((err <= tol).all()), f"{what}: max err {err.max().item():.3e}, max |want| {want.abs().max().item():.3e}"
+
+
+# (N, segs, Cout, H, W): geometry wide / 16-wide / 8x8, multi-segment virtual concat, ragged channel tiles
+CONV_CASES = [
+    (2, [8], 16, 32, 32),
+    (1, [24, 48], 24, 40, 64),          # UNet++ level-0 style node, H not a multiple of 8
+    (2, [24, 24, 24, 48], 24, 16, 32),
+    (3, [16], 40, 16, 16),              # 16-wide geometry, Cout not a multiple of 16
+    (2, [96, 96], 96, 16, 16),          # MT=3 x 2 blocks
+    (5, [32], 80, 8, 8),                # 8x8 geometry: 4 images / block, ragged batch
+    (6, [64, 64], 320, 8, 8),
+    (1, [8], 8, 24, 48),                # width not a multiple of 32
+    (2, [128], 64, 32, 32),
+    (2, [320, 320, 320], 512, 16, 16),  # MTnnUNet classifier conv at 256^2 input
+    (2, [320], 320, 8, 8),              # bottleneck, fewer images than a block holds
+    (2, [320, 320], 256, 16, 16),
+    (1, [384, 384, 384], 512, 16, 16),  # UNet++ classifier conv
+]
+
+
+@pytest.mark.parametrize("N,segs,Cout,H,W", CONV_CASES)
+def test_conv3x3_mfma_fwd_dgrad_wgrad(N, segs, Cout, H, W):
+    g = _g(N * 1000 + Cout + H)
+    Cin = sum(segs)
+    xs = [torch.randn(N, c, H, W, generator=g) for c in segs]
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (9 * Cin)) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    dz = torch.randn(N, Cout, H, W, generator=g)
+    xcat = torch.cat(xs, 1).requires_grad_(True)
+    wr, br = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    z = F.conv2d(xcat, wr, br, padding=1)
+    z.backward(dz)
+    dxs_ref = torch.split(xcat.grad, segs, dim=1)
+
+    xd = [x.to(DEV) for x in xs]
+    wd, bd, dzd = w.to(DEV), b.to(DEV), dz.to(DEV)
+    pf, pd = ops.conv3x3_pack(wd)
+    zg = ops.conv3x3_fwd(xd, wd, bd, packed=pf)
+    _close(zg, z.detach(), 2e-5, 2e-5, "fwd")
+    # dgrad: first segment overwritten, the others accumulate onto a preset value
+    pre = [torch.randn(N, c, H, W, generator=g) for c in segs]
+    dxd = [p.to(DEV).clone() for p in pre]
+    acc = [0] + [1] * (len(segs) - 1)
+    ops.conv3x3_dgrad(dzd, wd, dxd, acc, packed=pd)
+    for i, (got, want) in enumerate(zip(dxd, dxs_ref)):
+        _close(got, want + (pre[i] if acc[i] else 0), 2e-5, 5e-5, f"dgrad seg {i}")
+    dw, db = ops.conv3x3_wgrad(xd, dzd, tuple(w.shape), want_bias=True)
+    scale = max(1.0, wr.grad.abs().max().item())
+    _close(dw, wr.grad, 1e-4, 2e-5 * scale, "wgrad")
+    _close(db, br.grad, 1e-4, 1e-4 * max(1.0, br.grad.abs().max().item()), "dbias")
+    # shared-module accumulation (F10)
+    dw2, _ = ops.conv3x3_wgrad(xd, dzd, tuple(w.shape), dw=dw.clone(), accumulate=True)
+    _close(dw2, 2 * wr.grad, 1e-4, 4e-5 * scale, "wgrad accumulate")
+
+
+@pytest.mark.parametrize("N,Cin,Cout,H,W", [(2, 1, 32, 64, 64), (1, 3, 5, 7, 9), (2, 12, 8, 4, 4), (1, 8, 8, 2, 2)])
+def test_conv3x3_direct_path(N, Cin, Cout, H, W):
+    g = _g(Cin * 7 + H)
+    x = (torch.rand(N, Cin, H, W, generator=g) * 255.0)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * 0.1
+    dz = torch.randn(N, Cout, H, W, generator=g)
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    z = F.conv2d(xr, wr, None, padding=1)
+    z.backward(dz)
+    xd, wd, dzd = x.to(DEV), w.to(DEV), dz.to(DEV)
+    zg = ops.conv3x3_fwd([xd], wd, None, packed=None)
+    _close(zg, z.detach(), 1e-5, 1e-3, "direct fwd")
+    dx = torch.zeros_like(xd)
+    ops.conv3x3_dgrad(dzd, wd, [dx], [0], packed=None)
+    _close(dx, xr.grad, 1e-5, 1e-5, "direct dgrad")
+    dw, _ = ops.conv3x3_wgrad([xd], dzd, tuple(w.shape))
+    _close(dw, wr.grad, 1e-4, 1e-4 * max(1.0, wr.grad.abs().max().item()), "direct wgrad")
+
+
+def test_conv3x3_mfma_equals_direct_kernel():
+    g = _g(11)
+    x = torch.randn(2, 16, 32, 32, generator=g).to(DEV)
+    w = (torch.randn(24, 16, 3, 3, generator=g) * 0.1).to(DEV)
+    pf, _ = ops.conv3x3_pack(w)
+    a = ops.conv3x3_fwd([x], w, None, packed=pf)
+    b = ops.conv3x3_fwd([x], w, None, packed=pf, force_direct=True)
+    _close(a, b.cpu(), 1e-5, 1e-5, "mfma vs direct")
+
+
+@pytest.mark.parametrize("N,C,H,W,affine,slope", [(2, 24, 256, 256, True, 0.1), (3, 5, 64, 64, False, 0.01),
+                                                   (2, 7, 32, 32, True, 0.1), (4, 320, 8, 8, False, 0.01),
+                                                   (2, 3, 16, 16, True, 0.1), (1, 2, 6, 5, True, 0.1),
+                                                   (1, 2, 2, 2, False, 0.01)])
+def test_instnorm_lrelu_fwd_bwd(N, C, H, W, affine, slope):
+    g = _g(C + H)
+    z = torch.randn(N, C, H, W, generator=g) * 3.0 + 1.5
+    gamma = (torch.rand(C, generator=g) + 0.5) if affine else None
+    beta = (torch.randn(C, generator=g) * 0.3) if affine else None
+    dy = torch.randn(N, C, H, W, generator=g)
+    zr = z.clone().requires_grad_(True)
+    gr = gamma.clone().requires_grad_(True) if affine else None
+    br = beta.clone().requires_grad_(True) if affine else None
+    y = F.leaky_relu(F.instance_norm(zr, weight=gr, bias=br, eps=1e-5), slope)
+    y.backward(dy)
+    zd, dyd = z.to(DEV), dy.to(DEV)
+    gd, bd = (gamma.to(DEV), beta.to(DEV)) if affine else (None, None)
+    yg, mean, rstd = ops.instnorm_lrelu_fwd(zd, gd, bd, 1e-5, slope)
+    _close(yg, y.detach(), 1e-5, 2e-5, "in fwd")
+    _close(mean.view(N, C), z.mean(dim=(2, 3)), 1e-5, 1e-5, "mean")
+    dz, dg, db = ops.instnorm_lrelu_bwd(zd, dyd, mean, rstd, gd, bd, 1e-5, slope)
+    _close(dz, zr.grad, 1e-4, 2e-5, "in bwd")
+    if affine:
+        _close(dg, gr.grad, 1e-4, 1e-3, "dgamma")
+        _close(db, br.grad, 1e-4, 1e-3, "dbeta")
+    dz2, _, _ = ops.instnorm_lrelu_bwd(zd, dyd.clone(), mean, rstd, gd, bd, 1e-5, slope, inplace=True)
+    assert torch.equal(dz2, dz)                       # in-place form is bit-identical
+
+
+@pytest.mark.parametrize("N,C,H,W", [(2, 3, 8, 8), (1, 5, 6, 10), (2, 24, 64, 64)])
+def test_maxpool_fwd_bwd(N, C, H, W):
+    g = _g(H * W)
+    x = torch.randn(N, C, H, W, generator=g)
+    x[0, 0, :2, :2] = 1.0                               # tie: gradient must go to the first element
+    dy = torch.randn(N, C, H // 2, W // 2, generator=g)
+    xr = x.clone().requires_grad_(True)
+    y = F.max_pool2d(xr, 2, 2)
+    y.backward(dy)
+    xd = x.to(DEV)
+    assert torch.equal(ops.maxpool2_fwd(xd).cpu(), y.detach())
+    assert torch.equal(ops.maxpool2_bwd(xd, dy.to(DEV)).cpu(), xr.grad)
+    pre = torch.randn(N, C, H, W, generator=g)
+    got = ops.maxpool2_bwd(xd, dy.to(DEV), dx=pre.to(DEV).clone(), accumulate=True)
+    _close(got, xr.grad + pre, 0, 1e-6, "pool bwd accumulate")
+
+
+@pytest.mark.parametrize("N,Cin,Cout,H,W,k", [(2, 48, 48, 16, 16, 2), (1, 96, 48, 8, 8, 2), (2, 20, 12, 6, 10, 2),
+                                               (2, 64, 64, 8, 8, 4), (1, 128, 128, 4, 4, 8), (3, 32, 32, 5, 3, 4)])
+def test_convT_fwd_dgrad_wgrad(N, Cin, Cout, H, W, k):
+    g = _g(Cin + k)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cin, Cout, k, k, generator=g) * 0.1
+    b = torch.randn(Cout, generator=g)
+    dy = torch.randn(N, Cout, H * k, W * k, generator=g)
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    y = F.conv_transpose2d(xr, wr, br, stride=k)
+    y.backward(dy)
+    xd, wd, bd, dyd = x.to(DEV), w.to(DEV), b.to(DEV), dy.to(DEV)
+    _close(ops.convT_fwd(xd, wd, bd, k), y.detach(), 2e-5, 2e-5, "convT fwd")
+    _close(ops.convT_dgrad(xd, wd, dyd, k), xr.grad, 2e-5, 5e-5, "convT dgrad")
+    pre = torch.randn(N, Cin, H, W, generator=g)
+    _close(ops.convT_dgrad(xd, wd, dyd, k, dx=pre.to(DEV).clone(), accumulate=True), xr.grad + pre, 2e-5, 5e-5, "convT dgrad acc")
+    dw, db = ops.convT_wgrad(xd, wd, dyd, k)
+    _close(dw, wr.grad, 1e-4, 2e-5 * max(1.0, wr.grad.abs().max().item()), "convT wgrad")
+    _close(db, br.grad, 1e-4, 1e-4 * max(1.0, br.grad.abs().max().item()), "convT dbias")
+
+
+@pytest.mark.parametrize("N,Cin,Cout,H,W", [(2, 16, 1, 32, 32), (1, 24, 1, 64, 64), (2, 12, 3, 8, 8), (1, 20, 10, 4, 4)])
+def test_conv1x1(N, Cin, Cout, H, W):
+    g = _g(Cin)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 1, 1, generator=g) * 0.2
+    b = torch.randn(Cout, generator=g)
+    dy = torch.randn(N, Cout, H, W, generator=g)
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    y = F.conv2d(xr, wr, br)
+    y.backward(dy)
+    xd, wd = x.to(DEV), w.to(DEV)
+    _close(ops.conv1x1_fwd(xd, wd, b.to(DEV)), y.detach(), 1e-5, 1e-5, "1x1 fwd")
+    dx, dw, db = ops.conv1x1_bwd(xd, wd, dy.to(DEV))
+    _close(dx, xr.grad, 1e-5, 1e-5, "1x1 dgrad")
+    _close(dw, wr.grad, 1e-4, 1e-4 * max(1.0, wr.grad.abs().max().item()), "1x1 wgrad")
+    _close(db, br.grad, 1e-4, 1e-4 * max(1.0, br.grad.abs().max().item()), "1x1 dbias")
+
+
+def test_gap_linear_head():
+    g = _g(5)
+    x = torch.randn(4, 512, 16, 16, generator=g)
+    w1, b1 = torch.randn(256, 512, generator=g) * 0.05, torch.randn(256, generator=g) * 0.1
+    w2, b2 = torch.randn(3, 256, generator=g) * 0.05, torch.randn(3, generator=g) * 0.1
+    dlog = torch.randn(4, 3, generator=g)
+    xr = x.clone().requires_grad_(True)
+    ws = [t.clone().requires_grad_(True) for t in (w1, b1, w2, b2)]
+    pooled = F.adaptive_avg_pool2d(xr, 1).flatten(1)
+    h = F.relu(F.linear(pooled, ws[0], ws[1]))
+    out = F.linear(h, ws[2], ws[3])
+    out.backward(dlog)
+    xd = x.to(DEV)
+    pg = ops.gap_fwd(xd)
+    _close(pg, pooled.detach(), 1e-5, 1e-6, "gap")
+    hg = ops.linear_fwd(pg, w1.to(DEV), b1.to(DEV), relu=True)
+    og = ops.linear_fwd(hg, w2.to(DEV), b2.to(DEV), relu=False)
+    _close(og, out.detach(), 1e-5, 1e-5, "linear fwd")
+    dh, dw2, db2 = ops.linear_bwd(hg, w2.to(DEV), og, dlog.to(DEV), relu=False)
+    dp, dw1, db1 = ops.linear_bwd(pg, w1.to(DEV), hg, dh, relu=True)
+    _close(dw2, ws[2].grad, 1e-4, 1e-5, "dw2"); _close(db2, ws[3].grad, 1e-4, 1e-5, "db2")
+    _close(dw1, ws[0].grad, 1e-4, 1e-5, "dw1"); _close(db1, ws[1].grad, 1e-4, 1e-5, "db1")
+    _close(ops.gap_bwd(dp, 16, 16), xr.grad, 1e-4, 1e-7, "gap bwd")
+
+
+def test_dice_multihead_matches_oracle():
+    g = _g(9)
+    N, H, W = 3, 64, 64
+    xs = [torch.randn(N, 1, H, W, generator=g) * 2 for _ in range(4)]
+    t = (torch.rand(N, 1, H, W, generator=g) > 0.7).float()
+    t[1] = 0                                              # empty mask (class "normal")
+    weights = [1 / 4, 1 / 3, 1 / 2, 1.0]
+    xr = [x.clone().requires_grad_(True) for x in xs]
+    each = [O.dice_loss_sigmoid_sq(x, t) for x in xr]
+    total = sum(wi * e for wi, e in zip(weights, each))
+    (0.35 * total).backward()
+    loss, dxs = ops.dice_multihead([x.to(DEV) for x in xs], t.to(DEV), weights, gscale=0.35)
+    loss = loss.cpu()
+    for i in range(4):
+        assert abs(loss[i].item() - each[i].item()) < 2e-6
+        _close(dxs[i], xr[i].grad, 1e-4, 1e-9, f"dice dx head {i}")
+    assert abs(loss[4].item() - total.item()) < 5e-6
+    # closed form: zero logits, zero target -> 1 - 1/(.25 HW + 1)
+    z = torch.zeros(2, 1, 16, 16, device=DEV)
+    l0, _ = ops.dice_multihead([z], z.clone(), [1.0])
+    assert abs(l0[0].item() - (1 - 1 / (0.25 * 256 + 1))) < 1e-6
+
+
+def test_focal_matches_reference_goldens(golden_dir):
+    import os
+    gold = np.load(os.path.join(golden_dir, "focal.npz"))
+    t = lambda k: torch.from_numpy(gold[k]).to(DEV)
+    l, _ = ops.focal(t("x1"), t("t1"))
+    assert abs(l.item() - 0.20617523789405823) < 1e-6          # SURVEY A8 known answer
+    l, _ = ops.focal(t("x2"), t("t2"))
+    assert abs(l.item() - float(gold["y2"])) < 1e-6
+    l, _ = ops.focal(t("x2"), t("t3"))
+    assert abs(l.item() - float(gold["y3"])) < 1e-6
+    l, _ = ops.focal(t("x2"), t("t2"), weight=t("w"))
+    assert abs(l.item() - float(gold["y4"])) < 1e-6
+    for tk in ("t2", "t3"):
+        x = torch.from_numpy(gold["x2"]).clone().requires_grad_(True)
+        (0.65 * O.focal_loss_soft(x, torch.from_numpy(gold[tk]))).backward()
+        _, dx = ops.focal(t("x2"), t(tk), gscale=0.65)
+        _close(dx, x.grad, 1e-4, 1e-7, "focal dx")
+
+
+def test_adam_matches_torch():
+    g = _g(21)
+    n = 10_003 // 4 * 4
+    p0, grads = torch.randn(n, generator=g), [torch.randn(n, generator=g) * 10 ** float(e) for e in (-6, -3, 0, -2)]
+    pr = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([pr], lr=1e-4, eps=1e-4)
+    pd, m, v = p0.to(DEV), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    for step, gr in enumerate(grads, start=1):
+        pr.grad = gr.clone()
+        opt.step()
+        ops.adam_step(pd, gr.to(DEV), m, v, lr=1e-4, step=step, eps=1e-4)
+        _close(pd, pr.detach(), 0, 2e-7, f"adam step {step}")
+    # grad_scale (data-parallel averaging) and zero_grad
+    gd = (grads[0] * 8).to(DEV)
+    p1, p2 = p0.to(DEV), p0.to(DEV)
+    ops.adam_step(p1, gd, torch.zeros(n, device=DEV), torch.zeros(n, device=DEV), 1e-4, 1, grad_scale=0.125, zero_grad=True)
+    ops.adam_step(p2, grads[0].to(DEV), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV), 1e-4, 1)
+    assert torch.allclose(p1, p2, atol=1e-8) and float(gd.abs().max()) == 0.0
+
+
+def test_dice_counts_exact(golden_dir):
+    import os
+    from multi_task_breast_cancer_amd.trainer import dice_counts, dice_score_from_counts
+    gold = np.load(os.path.join(golden_dir, "dice_score.npz"))
+    gt = torch.from_numpy(gold["gt"]).float()
+    seg = torch.from_numpy(gold["seg"])
+    logits = torch.where(seg, torch.tensor(3.0), torch.tensor(-3.0))
+    c = dice_counts(logits.to(DEV), gt.to(DEV))
+    assert abs(dice_score_from_counts(c) - float(gold["k_rand"])) < 1e-12
+    tp = float((seg & (gt > 0)).sum()); fp = float((seg & (gt == 0)).sum()); fn = float((~seg & (gt > 0)).sum())
+    assert c.tolist() == [tp, fp, fn]                                # integer counts: bit-exact
+    z = torch.zeros(1, 1, 8, 8, device=DEV)
+    assert dice_score_from_counts(dice_counts(z - 1, z)) == 1.0       # empty / empty -> 1 (metrics.py:262-263)
