@@ -198,3 +198,29 @@ def test_nan_guard_exits():
     step(img.to(DEV), mask.to(DEV), label.to(DEV))
     with pytest.raises(SystemExit):
         step.check_nan()                                                          # criterions.py:72-76
+
+
+def test_distributed_step_single_rank_rccl_equals_local_step():
+    """The data-parallel code path (bucketed RCCL all-reduce on a side stream, split backward program,
+    1/world in Adam) with world_size 1 must reproduce the local step bit for bit."""
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=DEV)
+    try:
+        res = []
+        for distributed in (False, True):
+            seed_everything(1993)
+            m = MTnnUNet(1, 1, 3).to(DEV)
+            step = FusedTrainStep(m, FusedAdam(m, lr=1e-4, eps=1e-4), alpha=0.35, distributed=distributed, n_buckets=4)
+            img, mask, label = O.synthetic_batch(2, 64, 64, seed=4)
+            for _ in range(2):
+                l = step(img.to(DEV), mask.to(DEV), label.to(DEV))
+            torch.cuda.synchronize()
+            if distributed:
+                assert len(step._buckets) >= 2
+                assert sorted(b.ready_op for b in step._buckets) == [b.ready_op for b in step._buckets]
+            res.append((m.flat_p.clone(), l.clone()))
+        assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    finally:
+        dist.destroy_process_group()
