@@ -103,8 +103,11 @@ typedef struct {
     float* dz;               /* (N,C,H,W) grad wrt z                                         */
     float* dgamma;           /* (C) or NULL */
     float* dbeta;            /* (C) or NULL */
+    float* dbias_pre;        /* (C) or NULL: gradient of a per-channel bias added in front of the
+                                norm (the conv bias) = sum over n,h,w of dz, fused here so the
+                                conv wgrad does not re-read dz                                 */
     int32_t accumulate_dparams;
-    void* workspace;         /* bwd with affine: N*C*2 floats                                */
+    void* workspace;         /* bwd with any of the three: N*C*3 floats                      */
     size_t workspace_bytes;
 } mtbc_instnorm_args;
 

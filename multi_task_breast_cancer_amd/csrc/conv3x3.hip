@@ -46,14 +46,43 @@ struct ConvP {
     SegTable in, out;
     const float* wp;
     const float* bias;
-    int tiles_x, tiles_y;
+    int tiles_x, tiles_y, ntiles;
     int mtiles;
 };
 
 constexpr int KC = 8;           // input channels per LDS chunk
 
+// Segment tables copied from the kernel arguments into LDS once per block: looking a channel up from LDS keeps
+// ~66 SGPRs (two by-value tables) from staying live across the MFMA loop, where they spilled.
+struct SegL { float* ptr; long long bs; int cb; int acc; };
+constexpr int SEGL_FLOATS = 2 * MTBC_MAX_SEGS * (int)(sizeof(SegL) / sizeof(float));
+__device__ __forceinline__ void segl_fill(SegL* dst, const SegTable& t) {
+    if (threadIdx.x < MTBC_MAX_SEGS) {
+        const int i = threadIdx.x;
+        SegL e;
+        // entries past t.n get cb = INT_MAX so that the scan below never selects them
+        e.ptr = t.ptr[0]; e.bs = t.bstride[0]; e.cb = 0; e.acc = t.accumulate[0];
+#pragma unroll
+        for (int k = 1; k < MTBC_MAX_SEGS; ++k)
+            if (i == k) { e.ptr = t.ptr[k]; e.bs = t.bstride[k]; e.cb = k < t.n ? t.cbegin[k] : 0x7fffffff; e.acc = t.accumulate[k]; }
+        dst[i] = e;
+    }
+}
+__device__ __forceinline__ SegL segl_ref(const SegL* t, int c) {
+    SegL r = t[0];
+#pragma unroll
+    for (int i = 1; i < MTBC_MAX_SEGS; ++i) {
+        const SegL e = t[i];
+        if (c >= e.cb) r = e;
+    }
+    return r;
+}
+
+// Persistent: block (bx, by) walks pixel tiles bx, bx+gridDim.x, ... for its channel block by.  The work list is the
+// flattened sequence of (tile, chunk) items; item i+1 is prefetched into registers while item i feeds the MFMAs, so a
+// tile's prologue and epilogue overlap the neighbouring tiles' matrix work (one barrier per item).
 template <int MT, int GEO>
-__global__ __launch_bounds__(256, 2) void conv3x3_igemm_kernel(const ConvP p) {
+__global__ __launch_bounds__(256, MT >= 3 ? 2 : 3) void conv3x3_igemm_kernel(const ConvP p) {
     using G = Geo<GEO>;
     constexpr int XS = KC * G::PS;                 // floats
     constexpr int WS = MT * KC * 144;
@@ -64,60 +93,73 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm_kernel(const ConvP p) {
     constexpr int WF4 = MT * KC * 36;
     constexpr int WSLOTS = (WF4 + 255) / 256;
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    SegL* seg_in = reinterpret_cast<SegL*>(smem + 2 * BUF);
+    SegL* seg_out = seg_in + MTBC_MAX_SEGS;
+    segl_fill(seg_in, p.in);
+    segl_fill(seg_out, p.out);
+    __syncthreads();
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int HW = p.H * p.W;
-    int t = blockIdx.x;
-    const int tx = t % p.tiles_x; t /= p.tiles_x;
-    const int ty = t % p.tiles_y; t /= p.tiles_y;
-    const int n0 = t * G::IMG;
-    const int x0 = tx * G::TW, y0 = ty * G::TH;
     const int mt0 = blockIdx.y * MT;
+    const int nchunks = p.Cin / KC;
+    const int my_tiles = (p.ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int total = my_tiles * nchunks;
+    if (total <= 0) return;
 
-    // ---- per-thread staging descriptors (same for every chunk)
-    int x_lds[XSLOTS], x_goff[XSLOTS], x_ci[XSLOTS];   // x_ci: c | img<<8 | valid<<16
-#pragma unroll
-    for (int s = 0; s < XSLOTS; ++s) {
-        int idx = tid + s * 256;
-        int c = idx / XF4_PER_CH, rem = idx % XF4_PER_CH;
-        int img = rem / (G::ROWS * G::LW / 4); rem %= (G::ROWS * G::LW / 4);
-        int row = rem / (G::LW / 4), c4 = rem % (G::LW / 4);
-        int y = y0 + row - 1, x = x0 - 4 + c4 * 4;
-        bool ok = idx < XF4 && (n0 + img) < p.N && y >= 0 && y < p.H && x >= 0 && x < p.W;
-        x_lds[s] = idx < XF4 ? c * G::PS + img * G::IMGS + row * G::LW + c4 * 4 : -1;
-        x_goff[s] = y * p.W + x;
-        x_ci[s] = c | (img << 8) | ((ok ? 1 : 0) << 16);
-    }
+    // ---- staging: per-slot indices are recomputed from the tile origin (cheap integer math) instead of being kept
+    //      live across the MFMA loop, which would cost ~15 VGPRs
+    int pn0 = 0, py0 = 0, px0 = 0;                     // origin of the tile being prefetched
+    auto set_tile = [&](int tile) {
+        int t = tile;
+        const int tx = t % p.tiles_x; t /= p.tiles_x;
+        const int ty = t % p.tiles_y; t /= p.tiles_y;
+        pn0 = t * G::IMG; px0 = tx * G::TW; py0 = ty * G::TH;
+    };
     float4 xr[XSLOTS], wr[WSLOTS];
-
     auto load_chunk = [&](int chunk) {
         const int ci0 = chunk * KC;
-        const SegRef sr = seg_ref(p.in, ci0);
+        const SegL sr = segl_ref(seg_in, ci0);
         const float* base = sr.ptr + (size_t)(ci0 - sr.cb) * HW;
         const long long bs = sr.bs;
 #pragma unroll
         for (int s = 0; s < XSLOTS; ++s) {
-            const int c = x_ci[s] & 255, img = (x_ci[s] >> 8) & 255;
-            xr[s] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (x_ci[s] >> 16)
-                xr[s] = *reinterpret_cast<const float4*>(base + (size_t)(n0 + img) * bs + (size_t)c * HW + x_goff[s]);
+            const int idx = tid + s * 256;
+            const int c = idx / XF4_PER_CH;
+            int rem = idx % XF4_PER_CH;
+            const int img = rem / (G::ROWS * G::LW / 4); rem %= (G::ROWS * G::LW / 4);
+            const int row = rem / (G::LW / 4), c4 = rem % (G::LW / 4);
+            const int y = py0 + row - 1, x = px0 - 4 + c4 * 4;
+            const bool ok = idx < XF4 && (pn0 + img) < p.N && y >= 0 && y < p.H && x >= 0 && x < p.W;
+            // branch-free: an out-of-image slot reads the (always valid) first pixels of the segment and is zeroed
+            const size_t off = ok ? (size_t)(pn0 + img) * bs + (size_t)c * HW + y * p.W + x : 0;
+            const float4 v = *reinterpret_cast<const float4*>(base + off);
+            xr[s] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
         for (int s = 0; s < WSLOTS; ++s) {
-            int idx = tid + s * 256;
-            int mt = idx / (KC * 36), r = idx % (KC * 36);
-            wr[s] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (idx < WF4 && (mt0 + mt) < p.mtiles)
-                wr[s] = *reinterpret_cast<const float4*>(p.wp + ((size_t)(mt0 + mt) * p.Cin + ci0) * 144 + r * 4);
+            const int idx = tid + s * 256;
+            const int mt = idx / (KC * 36), r = idx % (KC * 36);
+            const bool ok = idx < WF4 && (mt0 + mt) < p.mtiles;
+            const float4 v = *reinterpret_cast<const float4*>(p.wp + (ok ? ((size_t)(mt0 + mt) * p.Cin + ci0) * 144 + r * 4 : 0));
+            wr[s] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
     auto store_chunk = [&](float* buf) {
 #pragma unroll
-        for (int s = 0; s < XSLOTS; ++s)
-            if (x_lds[s] >= 0) *reinterpret_cast<float4*>(buf + x_lds[s]) = xr[s];
+        for (int s = 0; s < XSLOTS; ++s) {
+            const int idx = tid + s * 256;
+            if (idx < XF4) {
+                const int c = idx / XF4_PER_CH;
+                int rem = idx % XF4_PER_CH;
+                const int img = rem / (G::ROWS * G::LW / 4); rem %= (G::ROWS * G::LW / 4);
+                const int row = rem / (G::LW / 4), c4 = rem % (G::LW / 4);
+                *reinterpret_cast<float4*>(buf + c * G::PS + img * G::IMGS + row * G::LW + c4 * 4) = xr[s];
+            }
+        }
 #pragma unroll
         for (int s = 0; s < WSLOTS; ++s) {
-            int idx = tid + s * 256;
+            const int idx = tid + s * 256;
             if (idx < WF4) *reinterpret_cast<float4*>(buf + XS + idx * 4) = wr[s];
         }
     };
@@ -137,62 +179,105 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm_kernel(const ConvP p) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) acc[m][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int nchunks = p.Cin / KC;
+    set_tile(blockIdx.x);
     load_chunk(0);
     store_chunk(smem);
     __syncthreads();
-    for (int ch = 0; ch < nchunks; ++ch) {
-        float* cur = smem + (ch & 1) * BUF;
-        if (ch + 1 < nchunks) load_chunk(ch + 1);
+    int chunk = 0, tile = blockIdx.x;
+    for (int it = 0; it < total; ++it) {
+        float* cur = smem + (it & 1) * BUF;
+        const bool more = it + 1 < total;
+        const bool last = chunk + 1 == nchunks;
+        if (more) {
+            if (last) set_tile(tile + gridDim.x);
+            load_chunk(last ? 0 : chunk + 1);
+        }
+        // 6 groups of 3 taps (fixed cs, kernel row r); the fragments of group q+1 are read from LDS before the MFMAs
+        // of group q issue.  sched_barriers keep hipcc from hoisting every read of the chunk to the top (~90 VGPRs).
+        float fa[2][3][MT], fb[2][3][4];
+        auto read_group = [&](int q, int slot) {
+            const int cs = q / 3, r = q % 3;
 #pragma unroll
-        for (int cs = 0; cs < KC / 4; ++cs) {
+            for (int s3 = 0; s3 < 3; ++s3) {
+                const int tap = r * 3 + s3;
 #pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                const int r = tap / 3, s = tap % 3;
-                float a[MT], b[4];
-#pragma unroll
-                for (int m = 0; m < MT; ++m) a[m] = cur[aBase + m * (KC * 144) + cs * 576 + tap * 16];
+                for (int m = 0; m < MT; ++m) fa[slot][s3][m] = cur[aBase + m * (KC * 144) + cs * 576 + tap * 16];
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     int toff;
                     if (GEO == 0) toff = (g >> 1) * G::LW + 16 * (g & 1);
                     else if (GEO == 1) toff = g * G::LW;
                     else toff = 2 * g * G::LW;
-                    b[g] = cur[bBase + toff + cs * 4 * G::PS + r * G::LW + s];
+                    fb[slot][s3][g] = cur[bBase + toff + cs * 4 * G::PS + r * G::LW + s3];
                 }
+            }
+        };
+        read_group(0, 0);
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            if (q + 1 < 6) read_group(q + 1, (q + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s3 = 0; s3 < 3; ++s3)
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
 #pragma unroll
                     for (int g = 0; g < 4; ++g)
-                        acc[m][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], b[g], acc[m][g], 0, 0, 0);
-            }
+                        acc[m][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[q & 1][s3][m], fb[q & 1][s3][g], acc[m][g], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        if (ch + 1 < nchunks) store_chunk(smem + ((ch + 1) & 1) * BUF);
+        if (more) store_chunk(smem + ((it + 1) & 1) * BUF);     // prefetch registers die here, before the epilogue
+        if (last) {
+            // ---- epilogue of `tile`: D row = (lane>>4)*4 + reg (channel), col = lane&15 (pixel)
+            int t = tile;
+            const int tx = t % p.tiles_x; t /= p.tiles_x;
+            const int ty = t % p.tiles_y; t /= p.tiles_y;
+            const int n0 = t * G::IMG, x0 = tx * G::TW, y0 = ty * G::TH;
+            int poff[4];
+            const int n = GEO == 2 ? n0 + wv : n0;
+            bool all_px = n < p.N;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                int y, x;
+                if (GEO == 0) { y = y0 + 2 * wv + (g >> 1); x = x0 + 16 * (g & 1) + j; }
+                else if (GEO == 1) { y = y0 + 4 * wv + g; x = x0 + j; }
+                else { y = y0 + 2 * g + (j >> 3); x = x0 + (j & 7); }
+                const bool ok = n < p.N && y < p.H && x < p.W;
+                all_px = all_px && ok;
+                poff[g] = ok ? y * p.W + x : -1;
+            }
+            // wave-uniform fast path: every pixel and every channel row of this wave's fragment is in range
+            const bool fast = __all(all_px) && (mt0 + MT) * 16 <= p.Cout;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int co = (mt0 + m) * 16 + kk * 4 + r;
+                    const bool row_ok = fast || co < p.Cout;
+                    const SegL so = segl_ref(seg_out, row_ok ? co : 0);
+                    float* cb = so.ptr + (size_t)n * so.bs + (size_t)((row_ok ? co : 0) - so.cb) * HW;
+                    const float bv = (p.bias && row_ok) ? p.bias[co] : 0.f;
+                    if (fast) {
+                        float old[4];
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) old[g] = so.acc ? cb[poff[g]] : 0.f;
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) cb[poff[g]] = acc[m][g][r] + bv + old[g];
+                    } else if (row_ok) {
+#pragma unroll
+                        for (int g = 0; g < 4; ++g)
+                            if (poff[g] >= 0) cb[poff[g]] = acc[m][g][r] + bv + (so.acc ? cb[poff[g]] : 0.f);
+                    }
+                }
+#pragma unroll
+                for (int g = 0; g < 4; ++g) acc[m][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+            tile += gridDim.x;
+            chunk = 0;
+        } else {
+            ++chunk;
+        }
         __syncthreads();
-    }
-
-    // ---- epilogue: D row = (lane>>4)*4 + reg (channel), col = lane&15 (pixel)
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        int n, y, x;
-        if (GEO == 0) { n = n0; y = y0 + 2 * wv + (g >> 1); x = x0 + 16 * (g & 1) + j; }
-        else if (GEO == 1) { n = n0; y = y0 + 4 * wv + g; x = x0 + j; }
-        else { n = n0 + wv; y = y0 + 2 * g + (j >> 3); x = x0 + (j & 7); }
-        if (n >= p.N || y >= p.H || x >= p.W) continue;
-#pragma unroll
-        for (int m = 0; m < MT; ++m) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int co = (mt0 + m) * 16 + kk * 4 + r;
-                if (co >= p.Cout) continue;
-                const SegRef sr = seg_ref(p.out, co);
-                float* dst = sr.ptr + (size_t)n * sr.bs + (size_t)(co - sr.cb) * HW + y * p.W + x;
-                float v = acc[m][g][r];
-                if (p.bias) v += p.bias[co];
-                if (sr.acc) v += *dst;
-                *dst = v;
-            }
-        }
     }
 }
 
@@ -216,9 +301,8 @@ template <int GEO>
 __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_mfma_kernel(const WgP p) {
     using G = WGeo<GEO>;
     constexpr int XS = 32 * G::PSX;
-    constexpr int XF4_PER_CH = G::IMG * G::ROWS * G::LW / 4;
-    constexpr int XF4 = 32 * XF4_PER_CH;
-    constexpr int ZF4 = 32 * 32;            // 32 channels x 128 pixels / 4
+    constexpr int XF4_PER_CH = G::IMG * G::ROWS * G::LW / 4;      // float4 per channel of the halo tile
+    constexpr int XSLOTS = (XF4_PER_CH + 7) / 8;                   // 8 threads share one channel
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Xs = smem;
     float* Zs = smem + XS;
@@ -230,6 +314,63 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_mfma_kernel(const WgP p)
     const int t_begin = split * p.tiles_per_split;
     const int t_end = min(p.total_tiles, t_begin + p.tiles_per_split);
 
+    // ---- staging role: thread -> (channel ch = tid/8, lane-in-channel q = tid%8), fixed for the block
+    const int ch = tid >> 3, q = tid & 7;
+    const int my_ci = ci0 + ch, my_co = co0 + ch;
+    const bool ci_ok = my_ci < p.Cin, co_ok = my_co < p.Cout;
+    const SegRef sr = seg_ref(p.in, ci_ok ? my_ci : 0);
+    const float* xplane = sr.ptr + (size_t)((ci_ok ? my_ci : 0) - sr.cb) * HW;       // + n*bs + y*W + x
+    const long long xbs = sr.bs;
+    const float* zplane = p.dz + (size_t)(co_ok ? my_co : 0) * HW;                    // + n*Cout*HW + y*W + x
+    float4 xr[XSLOTS], zr[4];
+
+    auto prefetch = [&](int tile) {
+        int t = tile;
+        const int tx = t % p.tiles_x; t /= p.tiles_x;
+        const int ty = t % p.tiles_y; t /= p.tiles_y;
+        const int n0 = t * G::IMG, x0 = tx * G::TW, y0 = ty * G::TH;
+#pragma unroll
+        for (int s = 0; s < XSLOTS; ++s) {
+            const int f = q + 8 * s;
+            const int img = f / (G::ROWS * G::LW / 4), rem = f % (G::ROWS * G::LW / 4);
+            const int row = rem / (G::LW / 4), c4 = rem % (G::LW / 4);
+            const int y = y0 + row - 1, x = x0 - 4 + c4 * 4, n = n0 + img;
+            const bool ok = f < XF4_PER_CH && ci_ok && n < p.N && y >= 0 && y < p.H && x >= 0 && x < p.W;
+            const float4 v = *reinterpret_cast<const float4*>(xplane + (ok ? (size_t)n * xbs + y * p.W + x : 0));
+            xr[s] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int px = (q + 8 * s) * 4;
+            int n, y, x;
+            if (GEO == 0) { n = n0; y = y0 + px / 32; x = x0 + px % 32; }
+            else if (GEO == 1) { n = n0; y = y0 + px / 16; x = x0 + px % 16; }
+            else { n = n0 + px / 64; y = y0 + (px % 64) / 8; x = x0 + px % 8; }
+            const bool ok = co_ok && n < p.N && y < p.H && x < p.W;
+            const float4 v = *reinterpret_cast<const float4*>(zplane + (ok ? (size_t)n * p.Cout * HW + y * p.W + x : 0));
+            zr[s] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto commit = [&]() {       // registers -> LDS (8-byte aligned rows: stride PSX/PSZ == 2 mod 32)
+#pragma unroll
+        for (int s = 0; s < XSLOTS; ++s) {
+            const int f = q + 8 * s;
+            if (f < XF4_PER_CH) {
+                const int img = f / (G::ROWS * G::LW / 4), rem = f % (G::ROWS * G::LW / 4);
+                const int row = rem / (G::LW / 4), c4 = rem % (G::LW / 4);
+                float* d = Xs + ch * G::PSX + img * G::IMGS + row * G::LW + c4 * 4;
+                *reinterpret_cast<float2*>(d) = make_float2(xr[s].x, xr[s].y);
+                *reinterpret_cast<float2*>(d + 2) = make_float2(xr[s].z, xr[s].w);
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            float* d = Zs + ch * PSZ + (q + 8 * s) * 4;
+            *reinterpret_cast<float2*>(d) = make_float2(zr[s].x, zr[s].y);
+            *reinterpret_cast<float2*>(d + 2) = make_float2(zr[s].z, zr[s].w);
+        }
+    };
+
     const int j = lane & 15, kk = lane >> 4;
     const int aBase = ((wv >> 1) * 16 + j) * PSZ + kk;
     const int bBase = ((wv & 1) * 16 + j) * G::PSX + kk + 3;
@@ -238,43 +379,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_mfma_kernel(const WgP p)
 #pragma unroll
     for (int i = 0; i < 9; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    if (t_begin < t_end) prefetch(t_begin);
     for (int tile = t_begin; tile < t_end; ++tile) {
-        int t = tile;
-        const int tx = t % p.tiles_x; t /= p.tiles_x;
-        const int ty = t % p.tiles_y; t /= p.tiles_y;
-        const int n0 = t * G::IMG, x0 = tx * G::TW, y0 = ty * G::TH;
+        __syncthreads();                       // everyone is done reading the previous tile
+        commit();
         __syncthreads();
-        // stage X halo tile: [32 ci][IMG][ROWS][LW]
-        for (int idx = tid; idx < XF4; idx += 256) {
-            int c = idx / XF4_PER_CH, rem = idx % XF4_PER_CH;
-            int img = rem / (G::ROWS * G::LW / 4); rem %= (G::ROWS * G::LW / 4);
-            int row = rem / (G::LW / 4), c4 = rem % (G::LW / 4);
-            int y = y0 + row - 1, x = x0 - 4 + c4 * 4, n = n0 + img, ci = ci0 + c;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ci < p.Cin && n < p.N && y >= 0 && y < p.H && x >= 0 && x < p.W) {
-                const SegRef sr = seg_ref(p.in, ci);
-                v = *reinterpret_cast<const float4*>(sr.ptr + (size_t)n * sr.bs + (size_t)(ci - sr.cb) * HW + y * p.W + x);
-            }
-            float* d = Xs + c * G::PSX + img * G::IMGS + row * G::LW + c4 * 4;   // 8-byte aligned only
-            *reinterpret_cast<float2*>(d) = make_float2(v.x, v.y);
-            *reinterpret_cast<float2*>(d + 2) = make_float2(v.z, v.w);
-        }
-        // stage dZ tile: [32 co][128 px]
-        for (int idx = tid; idx < ZF4; idx += 256) {
-            int c = idx >> 5, p4 = idx & 31, px = p4 * 4;
-            int n, y, x;
-            if (GEO == 0) { n = n0; y = y0 + px / 32; x = x0 + px % 32; }
-            else if (GEO == 1) { n = n0; y = y0 + px / 16; x = x0 + px % 16; }
-            else { n = n0 + px / 64; y = y0 + (px % 64) / 8; x = x0 + px % 8; }
-            const int co = co0 + c;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (co < p.Cout && n < p.N && y < p.H && x < p.W)
-                v = *reinterpret_cast<const float4*>(p.dz + ((size_t)n * p.Cout + co) * HW + y * p.W + x);
-            float* d = Zs + c * PSZ + px;
-            *reinterpret_cast<float2*>(d) = make_float2(v.x, v.y);
-            *reinterpret_cast<float2*>(d + 2) = make_float2(v.z, v.w);
-        }
-        __syncthreads();
+        if (tile + 1 < t_end) prefetch(tile + 1);   // in flight under the MFMAs below
 #pragma unroll
         for (int p4 = 0; p4 < 32; ++p4) {
             const int px = p4 * 4;
@@ -404,26 +514,30 @@ bool mfma_ok(const mtbc_seg* segs, int nseg, int H, int W) {
 int pick_geo(int H, int W) { return (W == 8 && H == 8) ? 2 : (W <= 16 ? 1 : 0); }
 
 template <int MT, int GEO>
-int launch_igemm(const ConvP& p, int tiles, int mblocks, hipStream_t st) {
+int launch_igemm(const ConvP& p, int mblocks, hipStream_t st) {
     using G = Geo<GEO>;
-    const size_t lds = 2ull * (KC * G::PS + MT * KC * 144) * sizeof(float);
+    const size_t lds = (2ull * (KC * G::PS + MT * KC * 144) + SEGL_FLOATS) * sizeof(float);
     static bool attr_set = false;   // >64 KiB dynamic LDS needs the opt-in once per kernel
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_igemm_kernel<MT, GEO>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv3x3_igemm_kernel<MT, GEO>), dim3(tiles, mblocks), dim3(256), lds, st, p);
+    // persistent grid: ~3 resident blocks per CU in total, gridDim.x a multiple of 8 so that the channel blocks of one
+    // pixel tile (same blockIdx.x) land on one XCD and share its L2
+    int gx = (768 / mblocks + 7) / 8 * 8;
+    if (gx < 8) gx = 8;
+    if (gx > p.ntiles) gx = p.ntiles;
+    hipLaunchKernelGGL((conv3x3_igemm_kernel<MT, GEO>), dim3(gx, mblocks), dim3(256), lds, st, p);
     MTBC_CHECK_LAUNCH();
     return MTBC_OK;
 }
 template <int GEO>
-int launch_igemm_mt(int MT, const ConvP& p, int tiles, int mblocks, hipStream_t st) {
+int launch_igemm_mt(int MT, const ConvP& p, int mblocks, hipStream_t st) {
     switch (MT) {
-        case 1: return launch_igemm<1, GEO>(p, tiles, mblocks, st);
-        case 2: return launch_igemm<2, GEO>(p, tiles, mblocks, st);
-        case 3: return launch_igemm<3, GEO>(p, tiles, mblocks, st);
-        default: return launch_igemm<4, GEO>(p, tiles, mblocks, st);
+        case 1: return launch_igemm<1, GEO>(p, mblocks, st);
+        case 2: return launch_igemm<2, GEO>(p, mblocks, st);
+        default: return launch_igemm<3, GEO>(p, mblocks, st);
     }
 }
 
@@ -434,13 +548,20 @@ int run_igemm(int N, int H, int W, int red, int rows, const SegTable& in, const 
     p.N = N; p.H = H; p.W = W; p.Cin = red; p.Cout = rows; p.in = in; p.out = out; p.wp = wp; p.bias = bias;
     const int geo = pick_geo(H, W);
     p.mtiles = cdiv(rows, 16);
-    const int mblocks = cdiv(p.mtiles, 4);
-    const int MT = cdiv(p.mtiles, mblocks);
-    int tiles;
-    if (geo == 0) { p.tiles_x = cdiv(W, 32); p.tiles_y = cdiv(H, 8); tiles = p.tiles_x * p.tiles_y * N; return launch_igemm_mt<0>(MT, p, tiles, mblocks, st); }
-    if (geo == 1) { p.tiles_x = cdiv(W, 16); p.tiles_y = cdiv(H, 16); tiles = p.tiles_x * p.tiles_y * N; return launch_igemm_mt<1>(MT, p, tiles, mblocks, st); }
-    p.tiles_x = 1; p.tiles_y = 1; tiles = cdiv(N, 4);
-    return launch_igemm_mt<2>(MT, p, tiles, mblocks, st);
+    if (geo == 0) { p.tiles_x = cdiv(W, 32); p.tiles_y = cdiv(H, 8); p.ntiles = p.tiles_x * p.tiles_y * N; }
+    else if (geo == 1) { p.tiles_x = cdiv(W, 16); p.tiles_y = cdiv(H, 16); p.ntiles = p.tiles_x * p.tiles_y * N; }
+    else { p.tiles_x = 1; p.tiles_y = 1; p.ntiles = cdiv(N, 4); }
+    // channel tiles per block: up to 3 (4 spills past 256 VGPRs), fewer when the launch would not fill 256 CUs twice over
+    int mblocks = cdiv(p.mtiles, 3);
+    int MT = cdiv(p.mtiles, mblocks);
+    while (MT > 1 && (long long)p.ntiles * mblocks < 512) {
+        --MT;
+        mblocks = cdiv(p.mtiles, MT);
+    }
+    MT = cdiv(p.mtiles, mblocks);
+    if (geo == 0) return launch_igemm_mt<0>(MT, p, mblocks, st);
+    if (geo == 1) return launch_igemm_mt<1>(MT, p, mblocks, st);
+    return launch_igemm_mt<2>(MT, p, mblocks, st);
 }
 
 struct WgPlan { bool mfma; int geo, tiles_x, tiles_y, total_tiles, nsplit, tiles_per_split, coblocks, ciblocks; size_t partial_elems, dbias_elems; };

@@ -15,7 +15,7 @@ struct InP {
     float* mean; float* rstd;
     const float* dy; long long dybs;
     float* dz;
-    float* part;       // bwd: [N*C][2] = {sum g, sum g*xh}
+    float* part;       // bwd: [N*C][3] = {sum g, sum g*xh, sum dz}
 };
 
 // ---- forward, register-resident plane: HW % 4 == 0 and HW/4 <= VPT * blockDim
@@ -117,8 +117,9 @@ __global__ void in_bwd_kernel(const InP p) {
     }
     s1 = block_sum(s1, red);
     s2 = block_sum(s2, red);
-    if (threadIdx.x == 0 && p.part) { p.part[2 * plane] = s1; p.part[2 * plane + 1] = s2; }
+    if (threadIdx.x == 0 && p.part) { p.part[3 * plane] = s1; p.part[3 * plane + 1] = s2; }
     const float m1 = s1 / (float)p.HW, m2 = s2 / (float)p.HW, k = rstd * g;
+    float s3 = 0.f;                                    // sum of dz (gradient of a bias in front of the norm)
     if (VEC) {
         const int n4 = p.HW >> 2;
         const float4* z4 = reinterpret_cast<const float4*>(zs);
@@ -132,24 +133,36 @@ __global__ void in_bwd_kernel(const InP p) {
             xh = (zv.z - mean) * rstd; gy = gv.z * ((xh * g + b) > 0.f ? 1.f : p.slope); o.z = k * (gy - m1 - xh * m2);
             xh = (zv.w - mean) * rstd; gy = gv.w * ((xh * g + b) > 0.f ? 1.f : p.slope); o.w = k * (gy - m1 - xh * m2);
             d4[i] = o;
+            s3 += (o.x + o.y) + (o.z + o.w);
         }
     } else {
         for (int i = threadIdx.x; i < p.HW; i += blockDim.x) {
             const float xh = (zs[i] - mean) * rstd;
             const float gy = gs[i] * ((xh * g + b) > 0.f ? 1.f : p.slope);
-            ds[i] = k * (gy - m1 - xh * m2);
+            const float o = k * (gy - m1 - xh * m2);
+            ds[i] = o;
+            s3 += o;
         }
+    }
+    if (p.part) {
+        s3 = block_sum(s3, red);
+        if (threadIdx.x == 0) p.part[3 * plane + 2] = s3;
     }
 }
 
-// dgamma[c] = sum_n part[n,c,1] ; dbeta[c] = sum_n part[n,c,0]
-__global__ void in_dparam_kernel(const float* __restrict__ part, float* dgamma, float* dbeta, int N, int C, int accumulate) {
+// dgamma[c] = sum_n part[n,c,1] ; dbeta[c] = sum_n part[n,c,0] ; dbias_pre[c] = sum_n part[n,c,2]
+__global__ void in_dparam_kernel(const float* __restrict__ part, float* dgamma, float* dbeta, float* dbias_pre, int N,
+                                 int C, int accumulate) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    float sb = 0.f, sg = 0.f;
-    for (int n = 0; n < N; ++n) { sb += part[2 * ((size_t)n * C + c)]; sg += part[2 * ((size_t)n * C + c) + 1]; }
+    float sb = 0.f, sg = 0.f, sz = 0.f;
+    for (int n = 0; n < N; ++n) {
+        const float* q = part + 3 * ((size_t)n * C + c);
+        sb += q[0]; sg += q[1]; sz += q[2];
+    }
     if (dgamma) dgamma[c] = accumulate ? dgamma[c] + sg : sg;
     if (dbeta) dbeta[c] = accumulate ? dbeta[c] + sb : sb;
+    if (dbias_pre) dbias_pre[c] = accumulate ? dbias_pre[c] + sz : sz;
 }
 
 int fill(const mtbc_instnorm_args* a, InP* p) {
@@ -187,10 +200,10 @@ int mtbc_instnorm_lrelu_fwd(const mtbc_instnorm_args* a, void* stream) {
 int mtbc_instnorm_lrelu_bwd(const mtbc_instnorm_args* a, void* stream) {
     InP p; int rc = fill(a, &p); if (rc) return rc;
     if (!p.z || !p.dy || !p.dz || !p.mean || !p.rstd) return MTBC_E_BADARG;
-    const bool want = a->dgamma || a->dbeta;
+    const bool want = a->dgamma || a->dbeta || a->dbias_pre;
     const int planes = a->N * a->C;
     if (want) {
-        if (!a->workspace || a->workspace_bytes < (size_t)planes * 2 * sizeof(float)) return MTBC_E_WORKSPACE;
+        if (!a->workspace || a->workspace_bytes < (size_t)planes * 3 * sizeof(float)) return MTBC_E_WORKSPACE;
         p.part = reinterpret_cast<float*>(a->workspace);
     }
     hipStream_t st = (hipStream_t)stream;
@@ -200,8 +213,8 @@ int mtbc_instnorm_lrelu_bwd(const mtbc_instnorm_args* a, void* stream) {
     else hipLaunchKernelGGL(in_bwd_kernel<false>, dim3(planes), dim3(threads), 0, st, p);
     MTBC_CHECK_LAUNCH();
     if (want) {
-        hipLaunchKernelGGL(in_dparam_kernel, dim3(cdiv(a->C, 128)), dim3(128), 0, st, p.part, a->dgamma, a->dbeta, a->N,
-                           a->C, a->accumulate_dparams);
+        hipLaunchKernelGGL(in_dparam_kernel, dim3(cdiv(a->C, 128)), dim3(128), 0, st, p.part, a->dgamma, a->dbeta,
+                           a->dbias_pre, a->N, a->C, a->accumulate_dparams);
         MTBC_CHECK_LAUNCH();
     }
     return MTBC_OK;

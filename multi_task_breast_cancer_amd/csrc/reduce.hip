@@ -2,13 +2,22 @@
 #include "common.h"
 
 namespace {
+// out[i] (+)= sum_k partial[k][i].  Block = 64 consecutive elements x 4 split lanes: lane group g sums splits
+// g, g+4, ... (coalesced 256-B rows), the four partial sums are combined in a fixed order -> deterministic.
 __global__ void splitk_reduce_k(const float* __restrict__ partial, float* __restrict__ out, int nsplit, size_t elems,
                                 int accumulate) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= elems) return;
+    __shared__ float red[4][64];
+    const int e = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const size_t i = (size_t)blockIdx.x * 64 + e;
     float s = 0.f;
-    for (int k = 0; k < nsplit; ++k) s += partial[(size_t)k * elems + i];
-    out[i] = accumulate ? out[i] + s : s;
+    if (i < elems)
+        for (int k = g; k < nsplit; k += 4) s += partial[(size_t)k * elems + i];
+    red[g][e] = s;
+    __syncthreads();
+    if (g == 0 && i < elems) {
+        const float t = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+        out[i] = accumulate ? out[i] + t : t;
+    }
 }
 __global__ void plane_sum_k(const float* __restrict__ x, float* __restrict__ out, int HW) {
     __shared__ float red[32];
@@ -33,7 +42,7 @@ __global__ void sum_over_n_k(const float* __restrict__ planes, float* __restrict
 }  // namespace
 
 int mtbc_i_splitk_reduce(const float* partial, float* out, int nsplit, size_t elems, int accumulate, hipStream_t st) {
-    hipLaunchKernelGGL(splitk_reduce_k, dim3((unsigned)cdiv64(elems, 256)), dim3(256), 0, st, partial, out, nsplit, elems, accumulate);
+    hipLaunchKernelGGL(splitk_reduce_k, dim3((unsigned)cdiv64(elems, 64)), dim3(256), 0, st, partial, out, nsplit, elems, accumulate);
     MTBC_CHECK_LAUNCH();
     return MTBC_OK;
 }

@@ -222,11 +222,19 @@ class StepPlan:
             op.kind = L.OP_IN_BWD
             a = op.u.inorm
             a.dy, a.dy_batch_stride, a.dz = dy.data_ptr(), y.bstride, dy.data_ptr()
-            if gname:
-                acc = self._mark_param(gname)
-                self._mark_param(betaname)
-                a.dgamma, a.dbeta, a.accumulate_dparams = self.gv(gname).data_ptr(), self.gv(betaname).data_ptr(), acc
-                self._need_ws(op, "inorm", N * cout * 2 * 4)
+            if gname or bname:
+                acc = None
+                if gname:
+                    acc = self._mark_param(gname)
+                    self._mark_param(betaname)
+                    a.dgamma, a.dbeta = self.gv(gname).data_ptr(), self.gv(betaname).data_ptr()
+                if bname:                       # conv bias gradient = sum of dz, produced by the same pass
+                    accb = self._mark_param(bname)
+                    acc = accb if acc is None else acc
+                    assert acc == accb
+                    a.dbias_pre = self.gv(bname).data_ptr()
+                a.accumulate_dparams = acc
+                self._need_ws(op, "inorm", N * cout * 3 * 4)
             self.bwd_ops.append(op)
             # wgrad
             op = base_conv()
@@ -236,9 +244,6 @@ class StepPlan:
             a.dout = dy.data_ptr()
             a.accumulate_dw = self._mark_param(wname)
             a.dw = self.gv(wname).data_ptr()
-            if bname:
-                self._mark_param(bname)
-                a.dbias = self.gv(bname).data_ptr()
             self._need_ws(op, "conv3", self.lib.mtbc_conv3x3_wgrad_workspace(C.byref(a)))
             self.bwd_ops.append(op)
             # dgrad into every input that needs one

@@ -131,8 +131,11 @@ def test_instnorm_lrelu_fwd_bwd(N, C, H, W, affine, slope):
     if affine:
         _close(dg, gr.grad, 1e-4, 1e-3, "dgamma")
         _close(db, br.grad, 1e-4, 1e-3, "dbeta")
-    dz2, _, _ = ops.instnorm_lrelu_bwd(zd, dyd.clone(), mean, rstd, gd, bd, 1e-5, slope, inplace=True)
+    dbp = torch.empty(C, device=DEV)
+    dz2, _, _ = ops.instnorm_lrelu_bwd(zd, dyd.clone(), mean, rstd, gd, bd, 1e-5, slope, inplace=True, dbias_pre=dbp)
     assert torch.equal(dz2, dz)                       # in-place form is bit-identical
+    want = dz.double().sum(dim=(0, 2, 3)).cpu()       # fused conv-bias gradient = sum of the dz it just wrote
+    assert (dbp.cpu().double() - want).abs().max().item() <= 1e-5 * dz.abs().sum(dim=(0, 2, 3)).max().item() + 1e-6
 
 
 @pytest.mark.parametrize("N,C,H,W", [(2, 3, 8, 8), (1, 5, 6, 10), (2, 24, 64, 64)])
