@@ -250,12 +250,16 @@ __global__ __launch_bounds__(256, MT >= 3 ? 2 : 3) void conv3x3_igemm_kernel(con
             const bool fast = __all(all_px) && (mt0 + MT) * 16 <= p.Cout;
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
+                // the 4 rows a lane holds (channels co4 .. co4+3) sit in one segment: segment sizes are multiples of 8
+                // on this path (host check), so one table lookup serves all four
+                const int co4 = (mt0 + m) * 16 + kk * 4;
+                const SegL so = segl_ref(seg_out, co4 < p.Cout ? co4 : 0);
+                float* cb0 = so.ptr + (size_t)n * so.bs + (size_t)((co4 < p.Cout ? co4 : 0) - so.cb) * HW;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int co = (mt0 + m) * 16 + kk * 4 + r;
+                    const int co = co4 + r;
                     const bool row_ok = fast || co < p.Cout;
-                    const SegL so = segl_ref(seg_out, row_ok ? co : 0);
-                    float* cb = so.ptr + (size_t)n * so.bs + (size_t)((row_ok ? co : 0) - so.cb) * HW;
+                    float* cb = cb0 + (size_t)r * HW;
                     const float bv = (p.bias && row_ok) ? p.bias[co] : 0.f;
                     if (fast) {
                         float old[4];
@@ -501,6 +505,49 @@ __global__ void conv3x3_wgrad_direct_kernel(const DirWgP p) {
     }
 }
 
+// wgrad for very few input channels (the Cin=1 first layer: K=9 is not a dense contraction, HBM-bound):
+// block = one (n, co) plane pair; each thread walks float4 groups of dz and the 3x6 neighbourhood of x.
+// partial[n][co][ci][9], summed over n by the split-K reduce.  Needs W % 4 == 0.
+__global__ void conv3x3_wgrad_smallcin_kernel(const DirWgP p) {
+    __shared__ float red[32];
+    const int n = blockIdx.x / p.Cout, co = blockIdx.x % p.Cout;
+    const int HW = p.H * p.W, W4 = p.W >> 2, n4 = HW >> 2;
+    const float* g = p.dz + ((size_t)n * p.Cout + co) * HW;
+    for (int ci = 0; ci < p.Cin; ++ci) {
+        const SegRef si = seg_ref(p.in, ci);
+        const float* src = si.ptr + (size_t)n * si.bs + (size_t)(ci - si.cb) * HW;
+        float acc[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) acc[i] = 0.f;
+        for (int q = threadIdx.x; q < n4; q += blockDim.x) {
+            const int y = q / W4, x4 = (q % W4) * 4;
+            const float4 gv = *reinterpret_cast<const float4*>(g + (size_t)y * p.W + x4);
+            const float ge[4] = {gv.x, gv.y, gv.z, gv.w};
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const int yy = y + r - 1;
+                float xv[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                if (yy >= 0 && yy < p.H) {
+                    const float* row = src + (size_t)yy * p.W;
+                    const float4 c = *reinterpret_cast<const float4*>(row + x4);
+                    xv[1] = c.x; xv[2] = c.y; xv[3] = c.z; xv[4] = c.w;
+                    xv[0] = x4 > 0 ? row[x4 - 1] : 0.f;
+                    xv[5] = x4 + 4 < p.W ? row[x4 + 4] : 0.f;
+                }
+#pragma unroll
+                for (int s = 0; s < 3; ++s)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[r * 3 + s] = fmaf(ge[e], xv[e + s], acc[r * 3 + s]);
+            }
+        }
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const float t = block_sum(acc[tap], red);
+            if (threadIdx.x == 0) p.partial[(((size_t)n * p.Cout + co) * p.Cin + ci) * 9 + tap] = t;
+        }
+    }
+}
+
 // ------------------------------------------------------------------ host helpers
 bool mfma_ok(const mtbc_seg* segs, int nseg, int H, int W) {
     if (W % 4 != 0 || W < 8 || H < 8) return false;
@@ -564,7 +611,7 @@ int run_igemm(int N, int H, int W, int red, int rows, const SegTable& in, const 
     return launch_igemm_mt<2>(MT, p, mblocks, st);
 }
 
-struct WgPlan { bool mfma; int geo, tiles_x, tiles_y, total_tiles, nsplit, tiles_per_split, coblocks, ciblocks; size_t partial_elems, dbias_elems; };
+struct WgPlan { bool mfma; bool smallcin; int geo, tiles_x, tiles_y, total_tiles, nsplit, tiles_per_split, coblocks, ciblocks; size_t partial_elems, dbias_elems; };
 WgPlan plan_wgrad(const mtbc_conv3x3_args* a) {
     WgPlan w{};
     w.mfma = !a->force_direct && mfma_ok(a->in, a->n_in, a->H, a->W) && a->Cin >= 8 &&
@@ -585,7 +632,11 @@ WgPlan plan_wgrad(const mtbc_conv3x3_args* a) {
         w.tiles_per_split = cdiv(w.total_tiles, ns);
         w.nsplit = cdiv(w.total_tiles, w.tiles_per_split);
     } else {
-        w.nsplit = a->N < 16 ? a->N : 16;
+        bool al = a->W % 4 == 0 && (reinterpret_cast<uintptr_t>(a->dout) & 15) == 0;
+        for (int i = 0; al && i < a->n_in; ++i)
+            al = (reinterpret_cast<uintptr_t>(a->in[i].ptr) & 15) == 0 && a->in[i].batch_stride % 4 == 0;
+        w.smallcin = !a->force_direct && a->Cin <= 4 && al;
+        w.nsplit = w.smallcin ? a->N : (a->N < 16 ? a->N : 16);
     }
     w.partial_elems = (size_t)w.nsplit * wel;
     w.dbias_elems = a->dbias ? (size_t)a->N * a->Cout : 0;
@@ -648,7 +699,7 @@ int mtbc_conv3x3_dgrad(const mtbc_conv3x3_args* a, void* stream) {
     rc = make_segtable(a->in, a->n_in, a->Cin, &out); if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
     bool ok = a->w_packed && !a->force_direct && mfma_ok(&g, 1, a->H, a->W) && a->Cout % KC == 0;
-    for (int i = 0; ok && i < a->n_in; ++i) ok = a->in[i].ptr != nullptr;
+    for (int i = 0; ok && i < a->n_in; ++i) ok = a->in[i].ptr != nullptr && a->in[i].channels % 4 == 0;
     if (ok) return run_igemm(a->N, a->H, a->W, a->Cout, a->Cin, in, out, a->w_packed, nullptr, st);
     if (!a->w) return MTBC_E_BADARG;
     DirP p; p.N = a->N; p.H = a->H; p.W = a->W; p.Cin = a->Cout; p.Cout = a->Cin; p.in = in; p.out = out;
@@ -693,7 +744,10 @@ int mtbc_conv3x3_wgrad(const mtbc_conv3x3_args* a, void* stream) {
     } else {
         DirWgP p; p.N = a->N; p.H = a->H; p.W = a->W; p.Cin = a->Cin; p.Cout = a->Cout; p.nsplit = w.nsplit;
         p.in = in; p.dz = a->dout; p.partial = partial;
-        hipLaunchKernelGGL(conv3x3_wgrad_direct_kernel, dim3(a->Cout * a->Cin, w.nsplit), dim3(256), 0, st, p);
+        if (w.smallcin)
+            hipLaunchKernelGGL(conv3x3_wgrad_smallcin_kernel, dim3(a->N * a->Cout), dim3(256), 0, st, p);
+        else
+            hipLaunchKernelGGL(conv3x3_wgrad_direct_kernel, dim3(a->Cout * a->Cin, w.nsplit), dim3(256), 0, st, p);
         MTBC_CHECK_LAUNCH();
     }
     rc = mtbc_i_splitk_reduce(partial, a->dw, w.nsplit, wel, a->accumulate_dw, st); if (rc) return rc;

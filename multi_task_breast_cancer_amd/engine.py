@@ -17,6 +17,10 @@ import torch
 from . import _lib as L
 
 
+import os as _os
+_NOACC = _os.environ.get('MTBC_NOACC') == '1'     # timing probe only: results are wrong when set
+
+
 def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
@@ -148,7 +152,7 @@ class StepPlan:
             if grads:
                 g = self.grad_of(a)
                 arr[i].ptr = g.data_ptr()
-                arr[i].accumulate = 1 if a.grad_written else 0
+                arr[i].accumulate = 1 if (a.grad_written and not _NOACC) else 0
             else:
                 arr[i].ptr = a.data.data_ptr()
                 arr[i].accumulate = 0

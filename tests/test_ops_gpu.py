@@ -77,7 +77,8 @@ def test_conv3x3_mfma_fwd_dgrad_wgrad(N, segs, Cout, H, W):
     _close(dw2, 2 * wr.grad, 1e-4, 4e-5 * scale, "wgrad accumulate")
 
 
-@pytest.mark.parametrize("N,Cin,Cout,H,W", [(2, 1, 32, 64, 64), (1, 3, 5, 7, 9), (2, 12, 8, 4, 4), (1, 8, 8, 2, 2)])
+@pytest.mark.parametrize("N,Cin,Cout,H,W", [(2, 1, 32, 64, 64), (1, 3, 5, 7, 9), (2, 12, 8, 4, 4), (1, 8, 8, 2, 2),
+                                             (3, 1, 24, 40, 24), (2, 2, 5, 8, 12)])
 def test_conv3x3_direct_path(N, Cin, Cout, H, W):
     g = _g(Cin * 7 + H)
     x = (torch.rand(N, Cin, H, W, generator=g) * 255.0)
