@@ -8,6 +8,7 @@
 // packed weight image is already the LDS image ([mtile][ci][tap][16]) so its staging is a copy.
 // Replaces nn.Conv2d(k=3,padding=1) of MTnnUNet.py:12-16 and MONAI Convolution (MTUNetPlusPlus.py:47-81).
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -48,6 +49,7 @@ struct ConvP {
     const float* bias;
     int tiles_x, tiles_y, ntiles;
     int mtiles;
+    int dbg;      // timing probes only (env MTBC_DBG): 1 = no global loads, 2 = no epilogue, 4 = no LDS stores
 };
 
 constexpr int KC = 8;           // input channels per LDS chunk
@@ -107,21 +109,22 @@ __global__ __launch_bounds__(256, MT >= 3 ? 2 : 3) void conv3x3_igemm_kernel(con
     const int total = my_tiles * nchunks;
     if (total <= 0) return;
 
-    // ---- staging: per-slot indices are recomputed from the tile origin (cheap integer math) instead of being kept
-    //      live across the MFMA loop, which would cost ~15 VGPRs
-    int pn0 = 0, py0 = 0, px0 = 0;                     // origin of the tile being prefetched
+    // ---- staging: per tile, each slot keeps ONE 32-bit element offset (-1 = outside the image -> zero fill);
+    //      per chunk only a wave-uniform base pointer changes, so the prefetch costs ~3 VALU per 16-byte load
+    int pn0 = 0;
+    int x_off[XSLOTS], w_off[WSLOTS];
+#pragma unroll
+    for (int s = 0; s < WSLOTS; ++s) {
+        const int idx = tid + s * 256;
+        const int mt = idx / (KC * 36), r = idx % (KC * 36);
+        w_off[s] = (idx < WF4 && (mt0 + mt) < p.mtiles) ? ((mt0 + mt) * p.Cin) * 144 + r * 4 : -1;
+    }
     auto set_tile = [&](int tile) {
         int t = tile;
         const int tx = t % p.tiles_x; t /= p.tiles_x;
         const int ty = t % p.tiles_y; t /= p.tiles_y;
-        pn0 = t * G::IMG; px0 = tx * G::TW; py0 = ty * G::TH;
-    };
-    float4 xr[XSLOTS], wr[WSLOTS];
-    auto load_chunk = [&](int chunk) {
-        const int ci0 = chunk * KC;
-        const SegL sr = segl_ref(seg_in, ci0);
-        const float* base = sr.ptr + (size_t)(ci0 - sr.cb) * HW;
-        const long long bs = sr.bs;
+        pn0 = t * G::IMG;
+        const int px0 = tx * G::TW, py0 = ty * G::TH;
 #pragma unroll
         for (int s = 0; s < XSLOTS; ++s) {
             const int idx = tid + s * 256;
@@ -131,21 +134,36 @@ __global__ __launch_bounds__(256, MT >= 3 ? 2 : 3) void conv3x3_igemm_kernel(con
             const int row = rem / (G::LW / 4), c4 = rem % (G::LW / 4);
             const int y = py0 + row - 1, x = px0 - 4 + c4 * 4;
             const bool ok = idx < XF4 && (pn0 + img) < p.N && y >= 0 && y < p.H && x >= 0 && x < p.W;
-            // branch-free: an out-of-image slot reads the (always valid) first pixels of the segment and is zeroed
-            const size_t off = ok ? (size_t)(pn0 + img) * bs + (size_t)c * HW + y * p.W + x : 0;
+            // image index folded in per chunk (batch stride differs per segment): keep img in the low bits
+            x_off[s] = ok ? ((c * HW + y * p.W + x) << 2) | img : -1;
+        }
+    };
+    float4 xr[XSLOTS], wr[WSLOTS];
+#pragma unroll
+    for (int s = 0; s < XSLOTS; ++s) xr[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int s = 0; s < WSLOTS; ++s) wr[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto load_chunk = [&](int chunk) {
+        const int ci0 = chunk * KC;
+        const SegL sr = segl_ref(seg_in, ci0);
+        const float* base = sr.ptr + (size_t)(ci0 - sr.cb) * HW + (size_t)pn0 * sr.bs;
+        const long long bs = sr.bs;
+#pragma unroll
+        for (int s = 0; s < XSLOTS; ++s) {
+            const bool ok = x_off[s] >= 0;
+            const size_t off = ok ? (size_t)(x_off[s] >> 2) + (G::IMG > 1 ? (size_t)(x_off[s] & 3) * bs : 0) : 0;
             const float4 v = *reinterpret_cast<const float4*>(base + off);
             xr[s] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
         }
+        const float* wbase = p.wp + (size_t)ci0 * 144;
 #pragma unroll
         for (int s = 0; s < WSLOTS; ++s) {
-            const int idx = tid + s * 256;
-            const int mt = idx / (KC * 36), r = idx % (KC * 36);
-            const bool ok = idx < WF4 && (mt0 + mt) < p.mtiles;
-            const float4 v = *reinterpret_cast<const float4*>(p.wp + (ok ? ((size_t)(mt0 + mt) * p.Cin + ci0) * 144 + r * 4 : 0));
+            const bool ok = w_off[s] >= 0;
+            const float4 v = *reinterpret_cast<const float4*>(wbase + (ok ? w_off[s] : 0));
             wr[s] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
-    auto store_chunk = [&](float* buf) {
+    auto store_chunk = [&](int boff) {       // LDS is addressed as smem[offset]: no generic pointers in the loop
 #pragma unroll
         for (int s = 0; s < XSLOTS; ++s) {
             const int idx = tid + s * 256;
@@ -154,13 +172,13 @@ __global__ __launch_bounds__(256, MT >= 3 ? 2 : 3) void conv3x3_igemm_kernel(con
                 int rem = idx % XF4_PER_CH;
                 const int img = rem / (G::ROWS * G::LW / 4); rem %= (G::ROWS * G::LW / 4);
                 const int row = rem / (G::LW / 4), c4 = rem % (G::LW / 4);
-                *reinterpret_cast<float4*>(buf + c * G::PS + img * G::IMGS + row * G::LW + c4 * 4) = xr[s];
+                *reinterpret_cast<float4*>(&smem[boff + c * G::PS + img * G::IMGS + row * G::LW + c4 * 4]) = xr[s];
             }
         }
 #pragma unroll
         for (int s = 0; s < WSLOTS; ++s) {
             const int idx = tid + s * 256;
-            if (idx < WF4) *reinterpret_cast<float4*>(buf + XS + idx * 4) = wr[s];
+            if (idx < WF4) *reinterpret_cast<float4*>(&smem[boff + XS + idx * 4]) = wr[s];
         }
     };
 
@@ -181,17 +199,13 @@ __global__ __launch_bounds__(256, MT >= 3 ? 2 : 3) void conv3x3_igemm_kernel(con
 
     set_tile(blockIdx.x);
     load_chunk(0);
-    store_chunk(smem);
+    store_chunk(0);
     __syncthreads();
     int chunk = 0, tile = blockIdx.x;
     for (int it = 0; it < total; ++it) {
-        float* cur = smem + (it & 1) * BUF;
+        const int cur = (it & 1) * BUF;
         const bool more = it + 1 < total;
         const bool last = chunk + 1 == nchunks;
-        if (more) {
-            if (last) set_tile(tile + gridDim.x);
-            load_chunk(last ? 0 : chunk + 1);
-        }
         // 6 groups of 3 taps (fixed cs, kernel row r); the fragments of group q+1 are read from LDS before the MFMAs
         // of group q issue.  sched_barriers keep hipcc from hoisting every read of the chunk to the top (~90 VGPRs).
         float fa[2][3][MT], fb[2][3][4];
@@ -201,14 +215,14 @@ __global__ __launch_bounds__(256, MT >= 3 ? 2 : 3) void conv3x3_igemm_kernel(con
             for (int s3 = 0; s3 < 3; ++s3) {
                 const int tap = r * 3 + s3;
 #pragma unroll
-                for (int m = 0; m < MT; ++m) fa[slot][s3][m] = cur[aBase + m * (KC * 144) + cs * 576 + tap * 16];
+                for (int m = 0; m < MT; ++m) fa[slot][s3][m] = smem[cur + aBase + m * (KC * 144) + cs * 576 + tap * 16];
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     int toff;
                     if (GEO == 0) toff = (g >> 1) * G::LW + 16 * (g & 1);
                     else if (GEO == 1) toff = g * G::LW;
                     else toff = 2 * g * G::LW;
-                    fb[slot][s3][g] = cur[bBase + toff + cs * 4 * G::PS + r * G::LW + s3];
+                    fb[slot][s3][g] = smem[cur + bBase + toff + cs * 4 * G::PS + r * G::LW + s3];
                 }
             }
         };
@@ -216,7 +230,14 @@ __global__ __launch_bounds__(256, MT >= 3 ? 2 : 3) void conv3x3_igemm_kernel(con
 #pragma unroll
         for (int q = 0; q < 6; ++q) {
             if (q + 1 < 6) read_group(q + 1, (q + 1) & 1);
-            __builtin_amdgcn_sched_barrier(0);
+            if (q == 0 && more) {
+                // next item's global loads: issued here so that their address arithmetic runs in the shadow of the
+                // MFMAs below (24 of every 32 MFMA cycles leave the vector issue port free) instead of ahead of them
+                if (last) set_tile(tile + gridDim.x);
+                if (!(p.dbg & 1)) load_chunk(last ? 0 : chunk + 1);
+            } else {
+                __builtin_amdgcn_sched_barrier(0);
+            }
 #pragma unroll
             for (int s3 = 0; s3 < 3; ++s3)
 #pragma unroll
@@ -226,7 +247,7 @@ __global__ __launch_bounds__(256, MT >= 3 ? 2 : 3) void conv3x3_igemm_kernel(con
                         acc[m][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[q & 1][s3][m], fb[q & 1][s3][g], acc[m][g], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (more) store_chunk(smem + ((it + 1) & 1) * BUF);     // prefetch registers die here, before the epilogue
+        if (more && !(p.dbg & 4)) store_chunk(((it + 1) & 1) * BUF);     // prefetch registers die here, before the epilogue
         if (last) {
             // ---- epilogue of `tile`: D row = (lane>>4)*4 + reg (channel), col = lane&15 (pixel)
             int t = tile;
@@ -242,7 +263,7 @@ __global__ __launch_bounds__(256, MT >= 3 ? 2 : 3) void conv3x3_igemm_kernel(con
                 if (GEO == 0) { y = y0 + 2 * wv + (g >> 1); x = x0 + 16 * (g & 1) + j; }
                 else if (GEO == 1) { y = y0 + 4 * wv + g; x = x0 + j; }
                 else { y = y0 + 2 * g + (j >> 3); x = x0 + (j & 7); }
-                const bool ok = n < p.N && y < p.H && x < p.W;
+                const bool ok = n < p.N && y < p.H && x < p.W && !(p.dbg & 2);
                 all_px = all_px && ok;
                 poff[g] = ok ? y * p.W + x : -1;
             }
@@ -593,6 +614,8 @@ int run_igemm(int N, int H, int W, int red, int rows, const SegTable& in, const 
               const float* bias, hipStream_t st) {
     ConvP p;
     p.N = N; p.H = H; p.W = W; p.Cin = red; p.Cout = rows; p.in = in; p.out = out; p.wp = wp; p.bias = bias;
+    static const int dbg = getenv("MTBC_DBG") ? atoi(getenv("MTBC_DBG")) : 0;
+    p.dbg = dbg;
     const int geo = pick_geo(H, W);
     p.mtiles = cdiv(rows, 16);
     if (geo == 0) { p.tiles_x = cdiv(W, 32); p.tiles_y = cdiv(H, 8); p.ntiles = p.tiles_x * p.tiles_y * N; }
