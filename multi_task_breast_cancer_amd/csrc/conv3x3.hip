@@ -306,6 +306,217 @@ __global__ __launch_bounds__(256, MT >= 3 ? 2 : 3) void conv3x3_igemm_kernel(con
     }
 }
 
+// ------------------------------------------------------------------ igemm with LDS-DMA staging (wide / 16-wide maps)
+// Same tiling and fragment maps as conv3x3_igemm_kernel, but the halo tile and the packed weights go HBM -> LDS
+// directly (buffer_load_dwordx4 ... lds, 1 KiB per wave-instruction, out-of-image lanes zero-filled by the buffer
+// bounds check), into a 3-slot LDS ring: the DMA for item i+2 is issued while item i feeds the MFMAs, a counted
+// s_waitcnt vmcnt leaves it in flight across the raw s_barrier that publishes item i+1.  No staging VGPRs, no ds_write.
+template <int MT, int GEO> struct DmaCount {
+    using G = Geo<GEO>;
+    static constexpr int XF4 = KC * G::IMG * G::ROWS * G::LW / 4;
+    static constexpr int WF4 = MT * KC * 36;
+    static constexpr int XI = (XF4 + 63) / 64, WI = (WF4 + 63) / 64;     // wave-instructions per item
+    // wave w issues the instructions k = w, w+4, ... of each stream
+    static constexpr int of(int w) { return (XI - w + 3) / 4 + (WI - w + 3) / 4; }
+};
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+template <int MT, int GEO> __device__ __forceinline__ void wait_newest_in_flight(int wv) {
+    using D = DmaCount<MT, GEO>;
+    switch (wv) {                         // wave-uniform; the immediate must be a literal
+        case 0: wait_vmcnt<D::of(0)>(); break;
+        case 1: wait_vmcnt<D::of(1)>(); break;
+        case 2: wait_vmcnt<D::of(2)>(); break;
+        default: wait_vmcnt<D::of(3)>(); break;
+    }
+}
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+// RING = LDS slots: 3 -> DMA runs two items ahead (2 blocks/CU); 2 -> one item ahead, smaller footprint (3 blocks/CU)
+template <int MT, int GEO, int RING>
+__global__ __launch_bounds__(256, RING == 3 ? 2 : 3) void conv3x3_igemm_dma_kernel(const ConvP p) {
+    using G = Geo<GEO>;
+    using D = DmaCount<MT, GEO>;
+    static_assert(G::IMG == 1 && G::PS == G::ROWS * G::LW, "LDS image must be linear in the staging index");
+    constexpr int XS = KC * G::PS, WS = MT * KC * 144, BUF = XS + WS;
+    constexpr int XF4_PER_CH = G::ROWS * G::LW / 4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    SegL* seg_in = reinterpret_cast<SegL*>(smem + RING * BUF);
+    SegL* seg_out = seg_in + MTBC_MAX_SEGS;
+    segl_fill(seg_in, p.in);
+    segl_fill(seg_out, p.out);
+    __syncthreads();
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int HW = p.H * p.W;
+    const int mt0 = blockIdx.y * MT;
+    const int nchunks = p.Cin / KC;
+    const int my_tiles = (p.ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int total = my_tiles * nchunks;
+    if (total <= 0) return;
+
+    // ---- prefetch cursor (two items ahead of the compute cursor)
+    int ptile = blockIdx.x, pchunk = 0, pitem = 0;
+    int pn0 = 0, py0 = 0, px0 = 0;
+    auto set_ptile = [&]() {
+        int t = ptile;
+        const int tx = t % p.tiles_x; t /= p.tiles_x;
+        const int ty = t % p.tiles_y; t /= p.tiles_y;
+        pn0 = t; px0 = tx * G::TW; py0 = ty * G::TH;
+    };
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.wp), 0, (int)((size_t)p.mtiles * p.Cin * 144 * 4), 0x00020000);
+    auto issue = [&]() {            // DMA of item `pitem` into ring slot pitem % 3, then advance the cursor
+        const int slot = pitem % RING;
+        const int ci0 = pchunk * KC;
+        const SegL sr = segl_ref(seg_in, ci0);
+        const float* base = sr.ptr + (size_t)(ci0 - sr.cb) * HW + (size_t)pn0 * sr.bs;
+        // records: the KC channel planes of image pn0 starting at `base` (always inside the segment tensor)
+        // the segment entry came through LDS: tell the compiler the descriptor is wave-uniform (no waterfall loops)
+        const unsigned long long bp = reinterpret_cast<unsigned long long>(base);
+        const unsigned blo = __builtin_amdgcn_readfirstlane((unsigned)bp), bhi = __builtin_amdgcn_readfirstlane((unsigned)(bp >> 32));
+        float* ubase = reinterpret_cast<float*>(((unsigned long long)bhi << 32) | blo);
+        const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(ubase, 0, KC * HW * 4, 0x00020000);
+#pragma unroll
+        for (int k = 0; k < (D::XI + 3) / 4; ++k) {
+            const int inst = wv + 4 * k;                 // wave-uniform instruction index
+            if (inst < D::XI) {
+                const int idx = inst * 64 + lane;
+                const int c = idx / XF4_PER_CH, rem = idx % XF4_PER_CH;
+                const int row = rem / (G::LW / 4), c4 = rem % (G::LW / 4);
+                const int y = py0 + row - 1, x = px0 - 4 + c4 * 4;
+                const bool ok = idx < D::XF4 && y >= 0 && y < p.H && x >= 0 && x < p.W;
+                const unsigned voff = ok ? (unsigned)((c * HW + y * p.W + x) * 4) : 0xfffffff0u;   // OOB -> zeros
+                if (idx < D::XF4)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_ptr_t)(smem + slot * BUF + inst * 256), 16, voff, 0, 0, 0);
+            }
+        }
+        const unsigned wbase = (unsigned)(ci0 * 144 * 4);
+#pragma unroll
+        for (int k = 0; k < (D::WI + 3) / 4; ++k) {
+            const int inst = wv + 4 * k;
+            if (inst < D::WI) {
+                const int idx = inst * 64 + lane;
+                const int mt = idx / (KC * 36), r = idx % (KC * 36);
+                const bool ok = idx < D::WF4 && (mt0 + mt) < p.mtiles;
+                const unsigned voff = ok ? (unsigned)(((mt0 + mt) * p.Cin) * 144 * 4 + r * 16) + wbase : 0xfffffff0u;
+                if (idx < D::WF4)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_ptr_t)(smem + slot * BUF + XS + inst * 256), 16, voff, 0, 0, 0);
+            }
+        }
+        ++pitem;
+        if (++pchunk == nchunks) { pchunk = 0; ptile += gridDim.x; set_ptile(); }
+    };
+
+    // ---- per-lane fragment bases
+    const int j = lane & 15, kk = lane >> 4;
+    const int laneB = kk * G::PS + j;
+    const int gbase = GEO == 0 ? (2 * wv) * G::LW : (4 * wv) * G::LW;
+    const int bBase = laneB + gbase + 3;
+    const int aBase = XS + kk * 144 + j;
+
+    f32x4 acc[MT][4];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc[m][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    set_ptile();
+    issue();                                   // item 0
+    if (RING == 3 && total > 1) { issue(); wait_newest_in_flight<MT, GEO>(wv); } else { wait_vmcnt<0>(); }
+    __builtin_amdgcn_s_barrier();
+
+    int chunk = 0, tile = blockIdx.x;
+    for (int it = 0; it < total; ++it) {
+        const int cur = (it % RING) * BUF;
+        const bool last = chunk + 1 == nchunks;
+        const bool have2 = it + (RING - 1) < total;     // is there an item to prefetch now?
+        float fa[2][3][MT], fb[2][3][4];
+        auto read_group = [&](int q, int slot) {
+            const int cs = q / 3, r = q % 3;
+#pragma unroll
+            for (int s3 = 0; s3 < 3; ++s3) {
+                const int tap = r * 3 + s3;
+#pragma unroll
+                for (int m = 0; m < MT; ++m) fa[slot][s3][m] = smem[cur + aBase + m * (KC * 144) + cs * 576 + tap * 16];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int toff = GEO == 0 ? (g >> 1) * G::LW + 16 * (g & 1) : g * G::LW;
+                    fb[slot][s3][g] = smem[cur + bBase + toff + cs * 4 * G::PS + r * G::LW + s3];
+                }
+            }
+        };
+        read_group(0, 0);
+        if (have2) issue();                    // item it+2 -> slot (it+2)%3, last read during item it-1
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            if (q + 1 < 6) read_group(q + 1, (q + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s3 = 0; s3 < 3; ++s3)
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        acc[m][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[q & 1][s3][m], fb[q & 1][s3][g], acc[m][g], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        bool stored = false;
+        if (last) {
+            int t = tile;
+            const int tx = t % p.tiles_x; t /= p.tiles_x;
+            const int ty = t % p.tiles_y; t /= p.tiles_y;
+            const int n = t, x0 = tx * G::TW, y0 = ty * G::TH;
+            int poff[4];
+            bool all_px = true;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                int y, x;
+                if (GEO == 0) { y = y0 + 2 * wv + (g >> 1); x = x0 + 16 * (g & 1) + j; }
+                else { y = y0 + 4 * wv + g; x = x0 + j; }
+                const bool ok = y < p.H && x < p.W;
+                all_px = all_px && ok;
+                poff[g] = ok ? y * p.W + x : -1;
+            }
+            const bool fast = __all(all_px) && (mt0 + MT) * 16 <= p.Cout;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const int co4 = (mt0 + m) * 16 + kk * 4;
+                const SegL so = segl_ref(seg_out, co4 < p.Cout ? co4 : 0);
+                float* cb0 = so.ptr + (size_t)n * so.bs + (size_t)((co4 < p.Cout ? co4 : 0) - so.cb) * HW;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int co = co4 + r;
+                    const bool row_ok = fast || co < p.Cout;
+                    float* cb = cb0 + (size_t)r * HW;
+                    const float bv = (p.bias && row_ok) ? p.bias[co] : 0.f;
+                    if (fast) {
+                        float old[4];
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) old[g] = so.acc ? cb[poff[g]] : 0.f;
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) cb[poff[g]] = acc[m][g][r] + bv + old[g];
+                    } else if (row_ok) {
+#pragma unroll
+                        for (int g = 0; g < 4; ++g)
+                            if (poff[g] >= 0) cb[poff[g]] = acc[m][g][r] + bv + (so.acc ? cb[poff[g]] : 0.f);
+                    }
+                }
+#pragma unroll
+                for (int g = 0; g < 4; ++g) acc[m][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+            tile += gridDim.x;
+            chunk = 0;
+            stored = true;
+        } else {
+            ++chunk;
+        }
+        // item it+1 must have landed before anyone reads it; item it+2 (issued above) may stay in flight.  The epilogue's
+        // own loads/stores are younger than that DMA, so after an epilogue everything is drained instead.
+        if (RING == 3 && have2 && !stored) wait_newest_in_flight<MT, GEO>(wv); else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+    }
+}
+
 // ------------------------------------------------------------------ wgrad (MFMA, split-K)
 template <int GEO> struct WGeo;
 template <> struct WGeo<0> { static constexpr int TH = 4, TW = 32, ROWS = 6, LW = 40, IMG = 1, IMGS = 240, PSX = 258; };
@@ -584,6 +795,32 @@ int pick_geo(int H, int W) { return (W == 8 && H == 8) ? 2 : (W <= 16 ? 1 : 0); 
 template <int MT, int GEO>
 int launch_igemm(const ConvP& p, int mblocks, hipStream_t st) {
     using G = Geo<GEO>;
+    static const bool nodma = getenv("MTBC_NODMA") != nullptr;
+    // persistent grid: gridDim.x a multiple of 8 so that the channel blocks of one pixel tile (same blockIdx.x)
+    // land on one XCD and share its L2
+    if constexpr (GEO != 2) {
+        if (!nodma) {
+            constexpr int RING = 2;     // measured: occupancy (3 blocks/CU) beats the deeper 3-slot prefetch on every layer
+            static const int ring_env = getenv("MTBC_RING") ? atoi(getenv("MTBC_RING")) : 0;
+            const int ring = ring_env ? ring_env : RING;
+            const size_t lds = ((size_t)ring * (KC * G::PS + MT * KC * 144) + SEGL_FLOATS) * sizeof(float);
+            static bool attr_set = false;
+            if (!attr_set) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_igemm_dma_kernel<MT, GEO, 2>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_igemm_dma_kernel<MT, GEO, 3>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                attr_set = true;
+            }
+            int gx = ((ring == 3 ? 512 : 768) / mblocks + 7) / 8 * 8;      // resident blocks per CU: 2 or 3
+            if (gx < 8) gx = 8;
+            if (gx > p.ntiles) gx = p.ntiles;
+            if (ring == 3) hipLaunchKernelGGL((conv3x3_igemm_dma_kernel<MT, GEO, 3>), dim3(gx, mblocks), dim3(256), lds, st, p);
+            else hipLaunchKernelGGL((conv3x3_igemm_dma_kernel<MT, GEO, 2>), dim3(gx, mblocks), dim3(256), lds, st, p);
+            MTBC_CHECK_LAUNCH();
+            return MTBC_OK;
+        }
+    }
     const size_t lds = (2ull * (KC * G::PS + MT * KC * 144) + SEGL_FLOATS) * sizeof(float);
     static bool attr_set = false;   // >64 KiB dynamic LDS needs the opt-in once per kernel
     if (!attr_set) {
@@ -591,8 +828,6 @@ int launch_igemm(const ConvP& p, int mblocks, hipStream_t st) {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    // persistent grid: ~3 resident blocks per CU in total, gridDim.x a multiple of 8 so that the channel blocks of one
-    // pixel tile (same blockIdx.x) land on one XCD and share its L2
     int gx = (768 / mblocks + 7) / 8 * 8;
     if (gx < 8) gx = 8;
     if (gx > p.ntiles) gx = p.ntiles;
