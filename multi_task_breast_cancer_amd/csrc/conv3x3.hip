@@ -531,10 +531,11 @@ struct WgP {
     float* partial;            // [nsplit][Cout][Cin][9]
     int tiles_x, tiles_y, total_tiles, tiles_per_split;
     int ciblocks;
+    int dbg;      // timing probes (env MTBC_DBG): 1 = no global loads, 4 = no LDS commits
 };
 
 template <int GEO>
-__global__ __launch_bounds__(256, 2) void conv3x3_wgrad_mfma_kernel(const WgP p) {
+__global__ __launch_bounds__(256, 3) void conv3x3_wgrad_mfma_kernel(const WgP p) {
     using G = WGeo<GEO>;
     constexpr int XS = 32 * G::PSX;
     constexpr int XF4_PER_CH = G::IMG * G::ROWS * G::LW / 4;      // float4 per channel of the halo tile
@@ -615,25 +616,38 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_mfma_kernel(const WgP p)
 #pragma unroll
     for (int i = 0; i < 9; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    if (t_begin < t_end) prefetch(t_begin);
+#pragma unroll
+    for (int s = 0; s < XSLOTS; ++s) xr[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) zr[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (t_begin < t_end && !(p.dbg & 1)) prefetch(t_begin);
     for (int tile = t_begin; tile < t_end; ++tile) {
         __syncthreads();                       // everyone is done reading the previous tile
-        commit();
+        if (!(p.dbg & 4)) commit();
         __syncthreads();
-        if (tile + 1 < t_end) prefetch(tile + 1);   // in flight under the MFMAs below
-#pragma unroll
-        for (int p4 = 0; p4 < 32; ++p4) {
+        if (tile + 1 < t_end && !(p.dbg & 1)) prefetch(tile + 1);   // in flight under the MFMAs below
+        // 32 k-steps of 4 pixels; fragments of step s+1 are read before the MFMAs of step s (bounded live ranges:
+        // without the sched_barriers hipcc hoists all 320 LDS reads and needs >180 VGPRs, i.e. 2 waves/SIMD)
+        float fa[2], fb[2][9];
+        auto read_step = [&](int p4, int slot) {
             const int px = p4 * 4;
             int xoff;
             if (GEO == 0) xoff = (px / 32) * G::LW + px % 32;
             else if (GEO == 1) xoff = (px / 16) * G::LW + px % 16;
             else xoff = (px / 64) * G::IMGS + ((px % 64) / 8) * G::LW + px % 8;
-            const float a = Zs[aBase + px];
+            fa[slot] = Zs[aBase + px];
 #pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                const float b = Xs[bBase + xoff + (tap / 3) * G::LW + tap % 3];
-                acc[tap] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[tap], 0, 0, 0);
-            }
+            for (int tap = 0; tap < 9; ++tap) fb[slot][tap] = Xs[bBase + xoff + (tap / 3) * G::LW + tap % 3];
+        };
+        read_step(0, 0);
+#pragma unroll
+        for (int p4 = 0; p4 < 32; ++p4) {
+            if (p4 + 1 < 32) read_step(p4 + 1, (p4 + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap)
+                acc[tap] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[p4 & 1], fb[p4 & 1][tap], acc[tap], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
     // partial[split][co][ci][tap]; D row = co (kk*4+r), col = ci (j)
@@ -812,7 +826,7 @@ int launch_igemm(const ConvP& p, int mblocks, hipStream_t st) {
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
                 attr_set = true;
             }
-            int gx = ((ring == 3 ? 512 : 768) / mblocks + 7) / 8 * 8;      // resident blocks per CU: 2 or 3
+            int gx = ((ring == 3 ? 512 : 768) / mblocks) / 8 * 8;          // <= 2 or 3 resident blocks per CU, one wave of blocks
             if (gx < 8) gx = 8;
             if (gx > p.ntiles) gx = p.ntiles;
             if (ring == 3) hipLaunchKernelGGL((conv3x3_igemm_dma_kernel<MT, GEO, 3>), dim3(gx, mblocks), dim3(256), lds, st, p);
@@ -828,7 +842,7 @@ int launch_igemm(const ConvP& p, int mblocks, hipStream_t st) {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    int gx = (768 / mblocks + 7) / 8 * 8;
+    int gx = (768 / mblocks) / 8 * 8;
     if (gx < 8) gx = 8;
     if (gx > p.ntiles) gx = p.ntiles;
     hipLaunchKernelGGL((conv3x3_igemm_kernel<MT, GEO>), dim3(gx, mblocks), dim3(256), lds, st, p);
@@ -884,7 +898,7 @@ WgPlan plan_wgrad(const mtbc_conv3x3_args* a) {
         w.total_tiles = w.tiles_x * w.tiles_y * tn;
         w.coblocks = cdiv(a->Cout, 32); w.ciblocks = cdiv(a->Cin, 32);
         const int pairs = w.coblocks * w.ciblocks;
-        int ns = cdiv(1024, pairs);
+        int ns = 768 / pairs;               // <= 3 resident blocks per CU in ONE wave of blocks (a 769th block doubles the time)
         if (ns > w.total_tiles) ns = w.total_tiles;
         if (ns < 1) ns = 1;
         w.tiles_per_split = cdiv(w.total_tiles, ns);
@@ -987,6 +1001,8 @@ int mtbc_conv3x3_wgrad(const mtbc_conv3x3_args* a, void* stream) {
         WgP p; p.N = a->N; p.H = a->H; p.W = a->W; p.Cin = a->Cin; p.Cout = a->Cout; p.in = in; p.dz = a->dout;
         p.partial = partial; p.tiles_x = w.tiles_x; p.tiles_y = w.tiles_y; p.total_tiles = w.total_tiles;
         p.tiles_per_split = w.tiles_per_split; p.ciblocks = w.ciblocks;
+        static const int dbgw = getenv("MTBC_DBG") ? atoi(getenv("MTBC_DBG")) : 0;
+        p.dbg = dbgw;
         dim3 grid(w.nsplit, w.coblocks * w.ciblocks);
         if (w.geo == 0) {
             const size_t lds = (32 * WGeo<0>::PSX + 32 * PSZ) * sizeof(float);

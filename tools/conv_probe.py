@@ -15,3 +15,16 @@ for N,segs,co,H,W in cases:
     e.record(); e.synchronize()
     ms=s.elapsed_time(e)/10
     print(f"dbg={os.environ.get('MTBC_DBG','0')} {cin}->{co} @{H}: {ms:.3f} ms {2*N*H*W*cin*co*9/ms/1e9:.1f} TF")
+
+print('--- wgrad')
+for N,segs,co,H,W in cases:
+    xs=[torch.randn(N,c,H,W,device=DEV) for c in segs]; cin=sum(segs)
+    dz=torch.randn(N,co,H,W,device=DEV)
+    for _ in range(2): ops.conv3x3_wgrad(xs,dz,(co,cin,3,3))
+    torch.cuda.synchronize()
+    s,e=torch.cuda.Event(enable_timing=True),torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(5): ops.conv3x3_wgrad(xs,dz,(co,cin,3,3))
+    e.record(); e.synchronize()
+    ms=s.elapsed_time(e)/5
+    print(f"dbg={os.environ.get('MTBC_DBG','0')} wgrad {cin}->{co} @{H}: {ms:.3f} ms {2*N*H*W*cin*co*9/ms/1e9:.1f} TF")
