@@ -160,9 +160,19 @@ def main() -> None:
                     ms += s.elapsed_time(e)
                 wg_fl += conv_flops(prog.array[i]); wg_sec += ms / 3e3; wg_n += 1
         ach = fl / sec / 1e12
-        out["roofline"] = {"bound": "mfma", "kernel": "conv3x3_igemm_kernel (fwd + dgrad launches)",
+        # HBM traffic per launch of the same kernel from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE,
+        # tools/pmc_traffic.py); launch-count weighted over the template instances of the kernel
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
+        if os.path.exists(tpath):
+            ks = json.load(open(tpath))["kernels"]
+            sel = [v for k, v in ks.items() if k.startswith("conv3x3_igemm_dma_kernel") or k.startswith("conv3x3_igemm_kernel")]
+            if sel:
+                w = sum(v["launches_in_trace"] for v in sel)
+                traffic = round(sum(v["hbm_bytes_per_launch"] * v["launches_in_trace"] for v in sel) / w)
+        out["roofline"] = {"bound": "mfma", "kernel": "conv3x3_igemm_dma_kernel (fwd + dgrad launches)",
                            "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                           "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                           "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
                            "launches_per_step": n, "avg_launch_ms": round(sec / n * 1e3, 4),
                            "algorithmic_gflop_per_launch": round(fl / n / 1e9, 3),
                            "wgrad": {"kernel": "conv3x3_wgrad_mfma_kernel + split-K reduce",
