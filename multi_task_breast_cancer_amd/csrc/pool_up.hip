@@ -18,8 +18,9 @@ constexpr int GRS = 81;   // LDS row stride (floats): conflict-free for both fil
 // CS: void operator()(int m4, int col, f32x4 v)  -- rows m4..m4+3 (m4 % 4 == 0) of column col
 template <bool A_KCONTIG, bool B_KCONTIG, class AL, class BL, class CS>
 __device__ __forceinline__ void gemm_block_64x64(int m0, int c0, int kbeg, int kend, AL al, BL bl, CS cs) {
-    __shared__ float As[16 * GRS];
-    __shared__ float Bs[16 * GRS];
+    constexpr int BK = 32;                      // K per LDS stage; the next stage is prefetched into registers
+    __shared__ float As[BK * GRS];
+    __shared__ float Bs[BK * GRS];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int j = lane & 15, kk = lane >> 4;
     const int mrow = 32 * (wv >> 1), ccol = 32 * (wv & 1);
@@ -29,30 +30,34 @@ __device__ __forceinline__ void gemm_block_64x64(int m0, int c0, int kbeg, int k
 #pragma unroll
         for (int b = 0; b < 2; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    for (int k0 = kbeg; k0 < kend; k0 += 16) {
-        float ra[4], rb[4];
+    float ra[8], rb[8];
+    auto fetch = [&](int k0) {                  // 64 x BK elements of A and of B: 8 + 8 per thread
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < 8; ++i) {
             int m, k;
-            if (A_KCONTIG) { k = tid & 15; m = (tid >> 4) + 16 * i; } else { m = tid & 63; k = (tid >> 6) + 4 * i; }
+            if (A_KCONTIG) { k = tid & 31; m = (tid >> 5) + 8 * i; } else { m = tid & 63; k = (tid >> 6) + 4 * i; }
             ra[i] = (k0 + k < kend) ? al(m0 + m, k0 + k) : 0.f;
             int c, k2;
-            if (B_KCONTIG) { k2 = tid & 15; c = (tid >> 4) + 16 * i; } else { c = tid & 63; k2 = (tid >> 6) + 4 * i; }
+            if (B_KCONTIG) { k2 = tid & 31; c = (tid >> 5) + 8 * i; } else { c = tid & 63; k2 = (tid >> 6) + 4 * i; }
             rb[i] = (k0 + k2 < kend) ? bl(k0 + k2, c0 + c) : 0.f;
         }
+    };
+    fetch(kbeg);
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
         __syncthreads();
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < 8; ++i) {
             int m, k;
-            if (A_KCONTIG) { k = tid & 15; m = (tid >> 4) + 16 * i; } else { m = tid & 63; k = (tid >> 6) + 4 * i; }
+            if (A_KCONTIG) { k = tid & 31; m = (tid >> 5) + 8 * i; } else { m = tid & 63; k = (tid >> 6) + 4 * i; }
             As[k * GRS + m] = ra[i];
             int c, k2;
-            if (B_KCONTIG) { k2 = tid & 15; c = (tid >> 4) + 16 * i; } else { c = tid & 63; k2 = (tid >> 6) + 4 * i; }
+            if (B_KCONTIG) { k2 = tid & 31; c = (tid >> 5) + 8 * i; } else { c = tid & 63; k2 = (tid >> 6) + 4 * i; }
             Bs[k2 * GRS + c] = rb[i];
         }
         __syncthreads();
+        if (k0 + BK < kend) fetch(k0 + BK);     // in flight under the MFMAs below
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
+        for (int ks = 0; ks < BK / 4; ++ks) {
             float a[2], b[2];
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
@@ -175,7 +180,7 @@ void plan_ct_wgrad(const mtbc_convT_args* a, int* S, int* cols) {
     if (s > smax) s = smax;
     if (s < 1) s = 1;
     int c = cdiv(HW, s);
-    c = cdiv(c, 16) * 16;          // K chunks of 16
+    c = cdiv(c, 32) * 32;          // K stages of 32
     *cols = c; *S = cdiv(HW, c);
 }
 

@@ -1,0 +1,77 @@
+"""Data-parallel step with REAL kernels on 2 ranks (both on the one visible GPU, gloo as transport: RCCL refuses
+two ranks on one device): the sharded 2-rank step must reproduce the 1-rank step on the same global batch."""
+import os
+import socket
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    import torch.distributed as dist
+    from multi_task_breast_cancer_amd.miscellany import seed_everything
+    from multi_task_breast_cancer_amd.nets import MTUNetPlusPlus
+    from multi_task_breast_cancer_amd.optim import FusedAdam
+    from multi_task_breast_cancer_amd.trainer import FusedTrainStep
+    from oracle import torch_oracle as O
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dev = torch.device("cuda:0")
+        seed_everything(1993)
+        m = MTUNetPlusPlus(in_channels=1, out_channels=1, n_classes=3, deep_supervision=True).to(dev)
+        step = FusedTrainStep(m, FusedAdam(m, lr=1e-4, eps=1e-4), alpha=0.5, distributed=True, n_buckets=4)
+        img, mask, label = O.synthetic_batch(4, 64, 64, seed=7)          # the GLOBAL batch
+        per = 4 // world
+        sl = slice(rank * per, (rank + 1) * per)                          # equal contiguous shards
+        losses = step(img[sl].to(dev), mask[sl].to(dev), label[sl].to(dev))
+        torch.cuda.synchronize()
+        assert step.opt.grad_scale == 1.0 / world and len(step._buckets) >= 2
+        if rank == 0:
+            q.put((m.flat_p.cpu(), m.flat_g.cpu(), losses.cpu()))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_step_equals_single_rank_global_batch():
+    import torch.multiprocessing as mp
+    from multi_task_breast_cancer_amd.miscellany import seed_everything
+    from multi_task_breast_cancer_amd.nets import MTUNetPlusPlus
+    from multi_task_breast_cancer_amd.optim import FusedAdam
+    from multi_task_breast_cancer_amd.trainer import FusedTrainStep
+    from oracle import torch_oracle as O
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    p2, g2, l2 = q.get(timeout=300)
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    dev = torch.device("cuda:0")
+    seed_everything(1993)
+    m = MTUNetPlusPlus(in_channels=1, out_channels=1, n_classes=3, deep_supervision=True).to(dev)
+    step = FusedTrainStep(m, FusedAdam(m, lr=1e-4, eps=1e-4), alpha=0.5)
+    img, mask, label = O.synthetic_batch(4, 64, 64, seed=7)
+    l1 = step(img.to(dev), mask.to(dev), label.to(dev)).cpu()
+    p1, g1 = m.flat_p.cpu(), m.flat_g.cpu()
+    # rank-0 loss is the mean over ITS shard; the gradient (sum over ranks, scaled 1/world in Adam) is the global one
+    g2 = g2 / world
+    rel = (g2 - g1).norm().item() / g1.norm().item()
+    assert rel < 1e-5, rel
+    assert (p2 - p1).abs().max().item() < 2e-6
+    assert l2[3].item() == 0.0 and abs(l1[0].item()) > 0
