@@ -534,8 +534,10 @@ struct WgP {
     int dbg;      // timing probes (env MTBC_DBG): 1 = no global loads, 4 = no LDS commits
 };
 
-template <int GEO>
-__global__ __launch_bounds__(256, 3) void conv3x3_wgrad_mfma_kernel(const WgP p) {
+// COT = output-channel tiles per block (2 or 3): 128*COT threads, wave w = (co-tile w/2, ci-tile w%2).  COT = 3 serves
+// Cout = 48 (U-Net++ level 1) without padding the second 32-channel block half empty.
+template <int GEO, int COT>
+__global__ __launch_bounds__(128 * COT, 3) void conv3x3_wgrad_mfma_kernel(const WgP p) {
     using G = WGeo<GEO>;
     constexpr int XS = 32 * G::PSX;
     constexpr int XF4_PER_CH = G::IMG * G::ROWS * G::LW / 4;      // float4 per channel of the halo tile
@@ -546,15 +548,15 @@ __global__ __launch_bounds__(256, 3) void conv3x3_wgrad_mfma_kernel(const WgP p)
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int HW = p.H * p.W;
-    const int co0 = (blockIdx.y / p.ciblocks) * 32, ci0 = (blockIdx.y % p.ciblocks) * 32;
+    const int co0 = (blockIdx.y / p.ciblocks) * (16 * COT), ci0 = (blockIdx.y % p.ciblocks) * 32;
     const int split = blockIdx.x;
     const int t_begin = split * p.tiles_per_split;
     const int t_end = min(p.total_tiles, t_begin + p.tiles_per_split);
 
     // ---- staging role: thread -> (channel ch = tid/8, lane-in-channel q = tid%8), fixed for the block
-    const int ch = tid >> 3, q = tid & 7;
+    const int ch = tid >> 3, q = tid & 7;                 // ch < 16*COT; only ch < 32 stage X
     const int my_ci = ci0 + ch, my_co = co0 + ch;
-    const bool ci_ok = my_ci < p.Cin, co_ok = my_co < p.Cout;
+    const bool ci_ok = ch < 32 && my_ci < p.Cin, co_ok = my_co < p.Cout;
     const SegRef sr = seg_ref(p.in, ci_ok ? my_ci : 0);
     const float* xplane = sr.ptr + (size_t)((ci_ok ? my_ci : 0) - sr.cb) * HW;       // + n*bs + y*W + x
     const long long xbs = sr.bs;
@@ -592,7 +594,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_wgrad_mfma_kernel(const WgP p)
 #pragma unroll
         for (int s = 0; s < XSLOTS; ++s) {
             const int f = q + 8 * s;
-            if (f < XF4_PER_CH) {
+            if (f < XF4_PER_CH && ch < 32) {
                 const int img = f / (G::ROWS * G::LW / 4), rem = f % (G::ROWS * G::LW / 4);
                 const int row = rem / (G::LW / 4), c4 = rem % (G::LW / 4);
                 float* d = Xs + ch * G::PSX + img * G::IMGS + row * G::LW + c4 * 4;
@@ -883,7 +885,7 @@ int run_igemm(int N, int H, int W, int red, int rows, const SegTable& in, const 
     return launch_igemm_mt<2>(MT, p, mblocks, st);
 }
 
-struct WgPlan { bool mfma; bool smallcin; int geo, tiles_x, tiles_y, total_tiles, nsplit, tiles_per_split, coblocks, ciblocks; size_t partial_elems, dbias_elems; };
+struct WgPlan { bool mfma; bool smallcin; int cot; int geo, tiles_x, tiles_y, total_tiles, nsplit, tiles_per_split, coblocks, ciblocks; size_t partial_elems, dbias_elems; };
 WgPlan plan_wgrad(const mtbc_conv3x3_args* a) {
     WgPlan w{};
     w.mfma = !a->force_direct && mfma_ok(a->in, a->n_in, a->H, a->W) && a->Cin >= 8 &&
@@ -896,9 +898,14 @@ WgPlan plan_wgrad(const mtbc_conv3x3_args* a) {
         else if (w.geo == 1) { w.tiles_x = cdiv(a->W, 16); w.tiles_y = cdiv(a->H, 8); tn = a->N; }
         else { w.tiles_x = 1; w.tiles_y = 1; tn = cdiv(a->N, 2); }
         w.total_tiles = w.tiles_x * w.tiles_y * tn;
-        w.coblocks = cdiv(a->Cout, 32); w.ciblocks = cdiv(a->Cin, 32);
+        // 48-channel output blocks (3 tiles, 384 threads) when that pads less than 32-channel blocks (Cout = 48)
+        const int pad2 = cdiv(a->Cout, 32) * 32, pad3 = cdiv(a->Cout, 48) * 48;
+        w.cot = pad3 < pad2 ? 3 : 2;
+        w.coblocks = cdiv(a->Cout, 16 * w.cot); w.ciblocks = cdiv(a->Cin, 32);
         const int pairs = w.coblocks * w.ciblocks;
-        int ns = 768 / pairs;               // <= 3 resident blocks per CU in ONE wave of blocks (a 769th block doubles the time)
+        // resident blocks per CU: 3 (256 threads, 50 KB LDS) or 2 (384 threads, 58 KB) -- ONE wave of blocks, a
+        // block beyond that would double the launch time
+        int ns = (w.cot == 3 ? 512 : 768) / pairs;
         if (ns > w.total_tiles) ns = w.total_tiles;
         if (ns < 1) ns = 1;
         w.tiles_per_split = cdiv(w.total_tiles, ns);
@@ -1004,15 +1011,16 @@ int mtbc_conv3x3_wgrad(const mtbc_conv3x3_args* a, void* stream) {
         static const int dbgw = getenv("MTBC_DBG") ? atoi(getenv("MTBC_DBG")) : 0;
         p.dbg = dbgw;
         dim3 grid(w.nsplit, w.coblocks * w.ciblocks);
-        if (w.geo == 0) {
-            const size_t lds = (32 * WGeo<0>::PSX + 32 * PSZ) * sizeof(float);
-            hipLaunchKernelGGL(conv3x3_wgrad_mfma_kernel<0>, grid, dim3(256), lds, st, p);
-        } else if (w.geo == 1) {
-            const size_t lds = (32 * WGeo<1>::PSX + 32 * PSZ) * sizeof(float);
-            hipLaunchKernelGGL(conv3x3_wgrad_mfma_kernel<1>, grid, dim3(256), lds, st, p);
+        const int zch = 16 * w.cot;
+        const dim3 blk(128 * w.cot);
+        if (w.cot == 2) {
+            if (w.geo == 0) hipLaunchKernelGGL((conv3x3_wgrad_mfma_kernel<0, 2>), grid, blk, (32 * WGeo<0>::PSX + zch * PSZ) * sizeof(float), st, p);
+            else if (w.geo == 1) hipLaunchKernelGGL((conv3x3_wgrad_mfma_kernel<1, 2>), grid, blk, (32 * WGeo<1>::PSX + zch * PSZ) * sizeof(float), st, p);
+            else hipLaunchKernelGGL((conv3x3_wgrad_mfma_kernel<2, 2>), grid, blk, (32 * WGeo<2>::PSX + zch * PSZ) * sizeof(float), st, p);
         } else {
-            const size_t lds = (32 * WGeo<2>::PSX + 32 * PSZ) * sizeof(float);
-            hipLaunchKernelGGL(conv3x3_wgrad_mfma_kernel<2>, grid, dim3(256), lds, st, p);
+            if (w.geo == 0) hipLaunchKernelGGL((conv3x3_wgrad_mfma_kernel<0, 3>), grid, blk, (32 * WGeo<0>::PSX + zch * PSZ) * sizeof(float), st, p);
+            else if (w.geo == 1) hipLaunchKernelGGL((conv3x3_wgrad_mfma_kernel<1, 3>), grid, blk, (32 * WGeo<1>::PSX + zch * PSZ) * sizeof(float), st, p);
+            else hipLaunchKernelGGL((conv3x3_wgrad_mfma_kernel<2, 3>), grid, blk, (32 * WGeo<2>::PSX + zch * PSZ) * sizeof(float), st, p);
         }
         MTBC_CHECK_LAUNCH();
     } else {

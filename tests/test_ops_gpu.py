@@ -39,6 +39,9 @@ CONV_CASES = [
     (2, [320], 320, 8, 8),              # bottleneck, fewer images than a block holds
     (2, [320, 320], 256, 16, 16),
     (1, [384, 384, 384], 512, 16, 16),  # UNet++ classifier conv
+    (2, [48], 48, 32, 32),              # 48-channel output blocks (3 tiles, 384-thread wgrad blocks)
+    (2, [24, 24], 48, 16, 16),
+    (3, [64], 144, 8, 8),
 ]
 
 
