@@ -179,6 +179,33 @@ def main() -> None:
                                      "achieved": round(wg_fl / wg_sec / 1e12, 2), "launches_per_step": wg_n,
                                      "avg_launch_ms": round(wg_sec / max(1, wg_n) * 1e3, 4)},
                            "conv3x3_share_of_step": round((sec + wg_sec) / (dt / args.steps), 3)}
+    if rank == 0 and not args.no_roofline:
+        # HBM-bound kernels named by north_star (norm / upsample): algorithmic bytes / HIP-event time
+        def timed(prog, i):
+            ms = 0.0
+            for _ in range(3):
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record(); prog.run(i, 1); e.record(); e.synchronize()
+                ms += s.elapsed_time(e)
+            return ms / 3e3
+        hb = {"in_fwd": [0.0, 0.0, 0], "in_bwd": [0.0, 0.0, 0], "convT_fwd": [0.0, 0.0, 0]}
+        for pname in ("fwd", "bwd"):
+            prog = st.programs[pname]
+            for i in range(prog.n):
+                op = prog.array[i]
+                if op.kind == _lib.OP_IN_FWD:
+                    a = op.u.inorm; e = a.N * a.C * a.H * a.W * 4
+                    h = hb["in_fwd"]; h[0] += 2 * e; h[1] += timed(prog, i); h[2] += 1       # read z, write y
+                elif op.kind == _lib.OP_IN_BWD:
+                    a = op.u.inorm; e = a.N * a.C * a.H * a.W * 4
+                    h = hb["in_bwd"]; h[0] += 3 * e; h[1] += timed(prog, i); h[2] += 1       # read z, dy; write dz
+                elif op.kind == _lib.OP_CONVT_FWD:
+                    a = op.u.convT; px = a.N * a.H * a.W * 4
+                    h = hb["convT_fwd"]; h[0] += px * (a.Cin + a.Cout * a.k * a.k); h[1] += timed(prog, i); h[2] += 1
+        out["roofline_hbm"] = {k: {"bound": "hbm", "achieved": round(v[0] / v[1] / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+                                   "frac": round(v[0] / v[1] / 8e12, 4), "launches_per_step": v[2],
+                                   "algorithmic_MB_per_launch": round(v[0] / max(1, v[2]) / 1e6, 1)}
+                               for k, v in hb.items() if v[2]}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         note("cpu baseline (oracle on host cores)")
         out["cpu_baseline"] = cpu_baseline(args.arch, args.size, 4, 2)

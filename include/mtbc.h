@@ -100,6 +100,9 @@ typedef struct {
     /* backward */
     const float* dy;         /* grad wrt y, same addressing as y (dy_batch_stride)           */
     int64_t dy_batch_stride;
+    int32_t n_dy_extra;      /* gradient fan-in: up to 4 more contributions, added to dy on the */
+    const float* dy_extra[4];/* fly (same addressing) -- each consumer of y writes its own buffer
+                                with plain stores instead of read-modify-write accumulation      */
     float* dz;               /* (N,C,H,W) grad wrt z                                         */
     float* dgamma;           /* (C) or NULL */
     float* dbeta;            /* (C) or NULL */

@@ -40,6 +40,7 @@ class InstNormArgs(C.Structure):
                 ("y", C.c_void_p), ("y_batch_stride", C.c_int64),
                 ("mean", C.c_void_p), ("rstd", C.c_void_p),
                 ("dy", C.c_void_p), ("dy_batch_stride", C.c_int64),
+                ("n_dy_extra", C.c_int32), ("dy_extra", C.c_void_p * 4),
                 ("dz", C.c_void_p), ("dgamma", C.c_void_p), ("dbeta", C.c_void_p), ("dbias_pre", C.c_void_p),
                 ("accumulate_dparams", C.c_int32),
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]

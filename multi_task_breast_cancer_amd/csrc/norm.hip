@@ -14,6 +14,7 @@ struct InP {
     float* y; long long ybs;
     float* mean; float* rstd;
     const float* dy; long long dybs;
+    const float* dyx[4]; int nx;     // extra gradient contributions (fan-in), summed on the fly
     float* dz;
     float* part;       // bwd: [N*C][3] = {sum g, sum g*xh, sum dz}
 };
@@ -91,17 +92,31 @@ __global__ void in_bwd_kernel(const InP p) {
     __shared__ float red[32];
     const int plane = blockIdx.x, n = plane / p.C, c = plane % p.C;
     const float* zs = p.z + (size_t)plane * p.HW;
-    const float* gs = p.dy + (size_t)n * p.dybs + (size_t)c * p.HW;
+    const size_t goff = (size_t)n * p.dybs + (size_t)c * p.HW;
+    const float* gs = p.dy + goff;
     float* ds = p.dz + (size_t)plane * p.HW;
+    // dy + extras, always added in the same order (both passes see bit-identical sums)
+    auto g4sum = [&](int i) {
+        float4 v = reinterpret_cast<const float4*>(gs)[i];
+        for (int k = 0; k < p.nx; ++k) {
+            const float4 e = reinterpret_cast<const float4*>(p.dyx[k] + goff)[i];
+            v.x += e.x; v.y += e.y; v.z += e.z; v.w += e.w;
+        }
+        return v;
+    };
+    auto g1sum = [&](int i) {
+        float v = gs[i];
+        for (int k = 0; k < p.nx; ++k) v += (p.dyx[k] + goff)[i];
+        return v;
+    };
     const float mean = p.mean[plane], rstd = p.rstd[plane];
     const float g = p.gamma ? p.gamma[c] : 1.f, b = p.beta ? p.beta[c] : 0.f;
     float s1 = 0.f, s2 = 0.f;
     if (VEC) {
         const int n4 = p.HW >> 2;
         const float4* z4 = reinterpret_cast<const float4*>(zs);
-        const float4* g4 = reinterpret_cast<const float4*>(gs);
         for (int i = threadIdx.x; i < n4; i += blockDim.x) {
-            const float4 zv = z4[i], gv = g4[i];
+            const float4 zv = z4[i], gv = g4sum(i);
             float xh, gy;
             xh = (zv.x - mean) * rstd; gy = gv.x * ((xh * g + b) > 0.f ? 1.f : p.slope); s1 += gy; s2 += gy * xh;
             xh = (zv.y - mean) * rstd; gy = gv.y * ((xh * g + b) > 0.f ? 1.f : p.slope); s1 += gy; s2 += gy * xh;
@@ -111,7 +126,7 @@ __global__ void in_bwd_kernel(const InP p) {
     } else {
         for (int i = threadIdx.x; i < p.HW; i += blockDim.x) {
             const float xh = (zs[i] - mean) * rstd;
-            const float gy = gs[i] * ((xh * g + b) > 0.f ? 1.f : p.slope);
+            const float gy = g1sum(i) * ((xh * g + b) > 0.f ? 1.f : p.slope);
             s1 += gy; s2 += gy * xh;
         }
     }
@@ -123,10 +138,9 @@ __global__ void in_bwd_kernel(const InP p) {
     if (VEC) {
         const int n4 = p.HW >> 2;
         const float4* z4 = reinterpret_cast<const float4*>(zs);
-        const float4* g4 = reinterpret_cast<const float4*>(gs);
         float4* d4 = reinterpret_cast<float4*>(ds);
         for (int i = threadIdx.x; i < n4; i += blockDim.x) {
-            const float4 zv = z4[i], gv = g4[i];
+            const float4 zv = z4[i], gv = g4sum(i);
             float4 o; float xh, gy;
             xh = (zv.x - mean) * rstd; gy = gv.x * ((xh * g + b) > 0.f ? 1.f : p.slope); o.x = k * (gy - m1 - xh * m2);
             xh = (zv.y - mean) * rstd; gy = gv.y * ((xh * g + b) > 0.f ? 1.f : p.slope); o.y = k * (gy - m1 - xh * m2);
@@ -138,7 +152,7 @@ __global__ void in_bwd_kernel(const InP p) {
     } else {
         for (int i = threadIdx.x; i < p.HW; i += blockDim.x) {
             const float xh = (zs[i] - mean) * rstd;
-            const float gy = gs[i] * ((xh * g + b) > 0.f ? 1.f : p.slope);
+            const float gy = g1sum(i) * ((xh * g + b) > 0.f ? 1.f : p.slope);
             const float o = k * (gy - m1 - xh * m2);
             ds[i] = o;
             s3 += o;
@@ -170,6 +184,8 @@ int fill(const mtbc_instnorm_args* a, InP* p) {
     p->N = a->N; p->C = a->C; p->HW = a->H * a->W; p->eps = a->eps; p->slope = a->slope;
     p->z = a->z; p->gamma = a->gamma; p->beta = a->beta; p->y = a->y; p->ybs = a->y_batch_stride;
     p->mean = a->mean; p->rstd = a->rstd; p->dy = a->dy; p->dybs = a->dy_batch_stride; p->dz = a->dz; p->part = nullptr;
+    p->nx = a->n_dy_extra;
+    for (int k = 0; k < 4; ++k) p->dyx[k] = a->dy_extra[k];
     return MTBC_OK;
 }
 bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
@@ -200,6 +216,8 @@ int mtbc_instnorm_lrelu_fwd(const mtbc_instnorm_args* a, void* stream) {
 int mtbc_instnorm_lrelu_bwd(const mtbc_instnorm_args* a, void* stream) {
     InP p; int rc = fill(a, &p); if (rc) return rc;
     if (!p.z || !p.dy || !p.dz || !p.mean || !p.rstd) return MTBC_E_BADARG;
+    if (p.nx < 0 || p.nx > 4) return MTBC_E_BADARG;
+    for (int k = 0; k < p.nx; ++k) if (!p.dyx[k] || !al16(p.dyx[k])) return MTBC_E_BADARG;
     const bool want = a->dgamma || a->dbeta || a->dbias_pre;
     const int planes = a->N * a->C;
     if (want) {

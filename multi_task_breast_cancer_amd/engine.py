@@ -33,6 +33,8 @@ class Act:
     needs_grad: bool = True
     grad: Optional[torch.Tensor] = None
     grad_written: bool = False         # has any backward op produced (part of) this grad yet?
+    fanin_separate: bool = False       # conv-cell outputs: every further consumer writes its own buffer (plain
+    extra_grads: List[torch.Tensor] = field(default_factory=list)   # stores); IN-backward sums them on the fly
 
     @property
     def N(self): return self.data.shape[0]
@@ -135,6 +137,19 @@ class StepPlan:
             a.grad = self.alloc(*a.data.shape)
         return a.grad
 
+    def grad_slot(self, a: Act) -> Tuple[torch.Tensor, int]:
+        """Where the next backward contribution to `a` goes: (buffer, accumulate flag).  First writer overwrites the
+        primary buffer; later writers get a private buffer when the producer can sum them (conv cells, <= 4 extras),
+        else they read-modify-write the primary."""
+        if not a.grad_written:
+            a.grad_written = True
+            return self.grad_of(a), 0
+        if a.fanin_separate and len(a.extra_grads) < 4 and not _NOACC:
+            t = self.alloc(*a.data.shape)
+            a.extra_grads.append(t)
+            return t, 0
+        return self.grad_of(a), (0 if _NOACC else 1)
+
     def _need_ws(self, op: L.Op, fieldname: str, nbytes: int) -> None:
         self.ws_bytes = max(self.ws_bytes, int(nbytes))
         self.ws_users.append((op, fieldname))
@@ -150,9 +165,9 @@ class StepPlan:
     def _segs(self, arr, acts: Sequence[Act], grads: bool = False) -> None:
         for i, a in enumerate(acts):
             if grads:
-                g = self.grad_of(a)
+                g, acc = self.grad_slot(a)
                 arr[i].ptr = g.data_ptr()
-                arr[i].accumulate = 1 if (a.grad_written and not _NOACC) else 0
+                arr[i].accumulate = acc
             else:
                 arr[i].ptr = a.data.data_ptr()
                 arr[i].accumulate = 0
@@ -182,6 +197,9 @@ class StepPlan:
                 self.pack_ops.append(op)
         z = self.alloc(N, cout, H, W)
         y = self.new_act(out_name, cout, H, W)
+        # measured: private fan-in buffers summed by IN-backward (+1.25 ms there) cost more than the read-modify-write
+        # they remove from the dgrad epilogues (-0.6 ms); the capability stays behind this switch
+        y.fanin_separate = _os.environ.get('MTBC_FANIN') == '1'
         mean, rstd = self.alloc(N * cout), self.alloc(N * cout)
         self._tag += 1
         tag = self._tag
@@ -226,6 +244,9 @@ class StepPlan:
             op.kind = L.OP_IN_BWD
             a = op.u.inorm
             a.dy, a.dy_batch_stride, a.dz = dy.data_ptr(), y.bstride, dy.data_ptr()
+            a.n_dy_extra = len(y.extra_grads)
+            for k_, t_ in enumerate(y.extra_grads):
+                a.dy_extra[k_] = t_.data_ptr()
             if gname or bname:
                 acc = None
                 if gname:
@@ -262,8 +283,6 @@ class StepPlan:
                 a.dout = dy.data_ptr()
                 a.w_packed = _ptr(wp_d)
                 self.bwd_ops.append(op)
-                for a_ in inputs:
-                    a_.grad_written = True
 
         self.bwd_emitters.append(emit_bwd)
         return y
@@ -290,9 +309,8 @@ class StepPlan:
             op.kind = L.OP_POOL_BWD
             a = op.u.pool
             a.dy, a.dy_batch_stride = self.grad_of(y).data_ptr(), y.bstride
-            a.dx, a.dx_batch_stride = self.grad_of(x).data_ptr(), x.bstride
-            a.accumulate_dx = 1 if x.grad_written else 0
-            x.grad_written = True
+            gx, acc = self.grad_slot(x)
+            a.dx, a.dx_batch_stride, a.accumulate_dx = gx.data_ptr(), x.bstride, acc
             self.bwd_ops.append(op)
 
         self.bwd_emitters.append(emit_bwd)
@@ -337,9 +355,8 @@ class StepPlan:
                 op.kind = L.OP_CONVT_DGRAD
                 a = op.u.convT
                 a.dy, a.dy_batch_stride = dy.data_ptr(), y.bstride
-                a.dx, a.dx_batch_stride = self.grad_of(x).data_ptr(), x.bstride
-                a.accumulate_dx = 1 if x.grad_written else 0
-                x.grad_written = True
+                gx, acc = self.grad_slot(x)
+                a.dx, a.dx_batch_stride, a.accumulate_dx = gx.data_ptr(), x.bstride, acc
                 self.bwd_ops.append(op)
 
         self.bwd_emitters.append(emit_bwd)
@@ -380,9 +397,8 @@ class StepPlan:
                 op.kind = L.OP_CONV1_DGRAD
                 a = op.u.conv1
                 a.dy = dy.data_ptr()
-                a.dx, a.dx_batch_stride = self.grad_of(x).data_ptr(), x.bstride
-                a.accumulate_dx = 1 if x.grad_written else 0
-                x.grad_written = True
+                gx, acc = self.grad_slot(x)
+                a.dx, a.dx_batch_stride, a.accumulate_dx = gx.data_ptr(), x.bstride, acc
                 self.bwd_ops.append(op)
 
         self.bwd_emitters.append(emit_bwd)

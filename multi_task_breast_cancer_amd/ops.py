@@ -121,8 +121,8 @@ def instnorm_lrelu_fwd(z, gamma=None, beta=None, eps=1e-5, slope=0.01):
 
 
 def instnorm_lrelu_bwd(z, dy, mean, rstd, gamma=None, beta=None, eps=1e-5, slope=0.01, inplace=False,
-                       dbias_pre=None):
-    _chk(z, dy, mean, rstd, gamma, beta, dbias_pre)
+                       dbias_pre=None, dy_extra=()):
+    _chk(z, dy, mean, rstd, gamma, beta, dbias_pre, *dy_extra)
     N, Cc, H, W = z.shape
     dz = dy if inplace else torch.empty_like(z)
     dg = torch.empty(Cc, dtype=torch.float32, device=z.device) if gamma is not None else None
@@ -133,6 +133,9 @@ def instnorm_lrelu_bwd(z, dy, mean, rstd, gamma=None, beta=None, eps=1e-5, slope
     a.z, a.gamma, a.beta, a.mean, a.rstd = z.data_ptr(), _p(gamma), _p(beta), mean.data_ptr(), rstd.data_ptr()
     a.dy, a.dy_batch_stride, a.dz, a.dgamma, a.dbeta = dy.data_ptr(), Cc * H * W, dz.data_ptr(), _p(dg), _p(db)
     a.dbias_pre = _p(dbias_pre)
+    a.n_dy_extra = len(dy_extra)
+    for k_, t_ in enumerate(dy_extra):
+        a.dy_extra[k_] = t_.data_ptr()
     a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel() * 4
     L.check(L.load().mtbc_instnorm_lrelu_bwd(C.byref(a), _s()), "instnorm_bwd")
     return dz, dg, db

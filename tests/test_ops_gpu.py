@@ -138,6 +138,11 @@ def test_instnorm_lrelu_fwd_bwd(N, C, H, W, affine, slope):
     dbp = torch.empty(C, device=DEV)
     dz2, _, _ = ops.instnorm_lrelu_bwd(zd, dyd.clone(), mean, rstd, gd, bd, 1e-5, slope, inplace=True, dbias_pre=dbp)
     assert torch.equal(dz2, dz)                       # in-place form is bit-identical
+    # gradient fan-in: dy split into 3 private contributions must give the same dz as their sum
+    parts = [torch.randn(N, C, H, W, generator=g) for _ in range(2)]
+    first = dy - parts[0] - parts[1]
+    dz3, _, _ = ops.instnorm_lrelu_bwd(zd, first.to(DEV), mean, rstd, gd, bd, 1e-5, slope, dy_extra=[p_.to(DEV) for p_ in parts])
+    _close(dz3, zr.grad, 1e-4, 3e-5, "in bwd with fan-in extras")
     want = dz.double().sum(dim=(0, 2, 3)).cpu()       # fused conv-bias gradient = sum of the dz it just wrote
     assert (dbp.cpu().double() - want).abs().max().item() <= 1e-5 * dz.abs().sum(dim=(0, 2, 3)).max().item() + 1e-6
 
