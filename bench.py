@@ -24,6 +24,7 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3        # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
+PEAK_16BIT_MFMA_TFLOPS = 2500.0     # bf16 / fp16 dense
 
 
 def conv_flops(op) -> float:
@@ -65,6 +66,8 @@ def main() -> None:
     ap.add_argument("--arch", default="MTUNetPlusPlus")
     ap.add_argument("--batch", type=int, default=32, help="per-GPU batch")
     ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16", "f16"],
+                    help="conv3x3 MFMA operand type (storage/accumulation always fp32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -93,6 +96,7 @@ def main() -> None:
 
     seed_everything(1993)                                          # identical initial weights on every rank
     model = init_multitask_model(args.arch, sequences=1, regions=1, n_classes=3, deep_supervision=True).to(dev)
+    model.set_compute(args.dtype)
     opt = init_optimizer(model, "Adam", 1e-4)
     step = FusedTrainStep(model, opt, alpha=0.5, inversely_weighted=True, distributed=world > 1)
     batches = [synthetic_batch(args.batch, args.size, args.size, seed=s, device=dev, rank=rank) for s in range(2)]
@@ -125,9 +129,9 @@ def main() -> None:
         "metric": "training images/sec (1-ch 256x256, U-Net++ MT)", "value": round(args.batch * world * args.steps / dt, 2),
         "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"{args.arch} seg+cls deep-supervision step (Dice+Focal, alpha=0.5, Adam eps 1e-4), "
-                               f"per-GPU batch {args.batch}, 1x{args.size}x{args.size} fp32, random-init weights",
+                               f"per-GPU batch {args.batch}, 1x{args.size}x{args.size} {args.dtype} MFMA operands / fp32 storage, random-init weights",
                    "global_batch": args.batch * world, "parallelism": f"dp{world}"},
         "final_loss": round(losses[0], 6),
     }
@@ -170,9 +174,11 @@ def main() -> None:
             if sel:
                 w = sum(v["launches_in_trace"] for v in sel)
                 traffic = round(sum(v["hbm_bytes_per_launch"] * v["launches_in_trace"] for v in sel) / w)
-        out["roofline"] = {"bound": "mfma", "kernel": "conv3x3_igemm_dma_kernel (fwd + dgrad launches)",
-                           "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                           "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+        peak = PEAK_F32_MFMA_TFLOPS if args.dtype == "f32" else PEAK_16BIT_MFMA_TFLOPS
+        kname = "conv3x3_igemm_dma_kernel" if args.dtype == "f32" else "conv3x3_igemm_lp_kernel"
+        out["roofline"] = {"bound": "mfma", "kernel": kname + " (fwd + dgrad launches)",
+                           "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+                           "frac": round(ach / peak, 4), "traffic": traffic if args.dtype == "f32" else None,
                            "launches_per_step": n, "avg_launch_ms": round(sec / n * 1e3, 4),
                            "algorithmic_gflop_per_launch": round(fl / n / 1e9, 3),
                            "wgrad": {"kernel": "conv3x3_wgrad_mfma_kernel + split-K reduce",

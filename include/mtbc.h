@@ -71,12 +71,19 @@ typedef struct {
     float* stats_partial;
     void* workspace;                 /* wgrad split-K partials                               */
     size_t workspace_bytes;
+    int32_t compute;                 /* MFMA operand type: 0 = fp32 (exact, the parity path), 1 = bf16,
+                                        2 = fp16 -- storage and accumulation stay fp32; fwd/dgrad then need
+                                        w_packed from mtbc_conv3x3_pack_lp                    */
 } mtbc_conv3x3_args;
 
 size_t mtbc_conv3x3_packed_elems(int32_t Cin, int32_t Cout);          /* fwd image size      */
 size_t mtbc_conv3x3_packed_dgrad_elems(int32_t Cin, int32_t Cout);    /* dgrad image size    */
 int mtbc_conv3x3_pack_fwd(const float* w, float* packed, int32_t Cin, int32_t Cout, void* stream);
 int mtbc_conv3x3_pack_dgrad(const float* w, float* packed, int32_t Cin, int32_t Cout, void* stream);
+/* 16-bit operand images for compute = 1 (bf16) / 2 (fp16): [mtile][chunk32][tap][16][40] 16-bit elements;
+ * dgrad = 0 packs the forward image, 1 the flipped/transposed dgrad image.  Pass as w_packed. */
+size_t mtbc_conv3x3_packed_lp_elems(int32_t Cin, int32_t Cout, int32_t dgrad);
+int mtbc_conv3x3_pack_lp(const float* w, void* packed, int32_t Cin, int32_t Cout, int32_t dgrad, int32_t compute, void* stream);
 size_t mtbc_conv3x3_wgrad_workspace(const mtbc_conv3x3_args* a);
 int mtbc_conv3x3_fwd(const mtbc_conv3x3_args* a, void* stream);
 int mtbc_conv3x3_dgrad(const mtbc_conv3x3_args* a, void* stream);
@@ -273,7 +280,7 @@ enum {
     MTBC_OP_CONV1_FWD, MTBC_OP_CONV1_DGRAD, MTBC_OP_CONV1_WGRAD,
     MTBC_OP_GAP_FWD, MTBC_OP_GAP_BWD, MTBC_OP_LINEAR_FWD, MTBC_OP_LINEAR_BWD,
     MTBC_OP_DICE_FWD, MTBC_OP_DICE_BWD, MTBC_OP_FOCAL, MTBC_OP_LOSS_MIX, MTBC_OP_ADAM,
-    MTBC_OP_MEMSET, MTBC_OP_DICE_COUNTS
+    MTBC_OP_MEMSET, MTBC_OP_DICE_COUNTS, MTBC_OP_CONV3_PACK_LP
 };
 
 typedef struct {
@@ -290,7 +297,7 @@ typedef struct {
         mtbc_dice_args dice;
         mtbc_focal_args focal;
         mtbc_adam_args adam;
-        struct { const float* w; float* packed; int32_t Cin, Cout; } pack;
+        struct { const float* w; float* packed; int32_t Cin, Cout; int32_t dgrad, compute; } pack;
         struct { const float* seg; const float* cls; float alpha; float* out4; } mix;
         struct { void* ptr; size_t bytes; } memset0;
         struct { const float* logits; const float* target; int64_t n; double* out3; } counts;

@@ -30,7 +30,8 @@ class Conv3x3Args(C.Structure):
                 ("w", C.c_void_p), ("w_packed", C.c_void_p), ("bias", C.c_void_p),
                 ("out", C.c_void_p), ("dout", C.c_void_p), ("dw", C.c_void_p), ("dbias", C.c_void_p),
                 ("accumulate_dw", C.c_int32), ("force_direct", C.c_int32),
-                ("stats_partial", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]
+                ("stats_partial", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+                ("compute", C.c_int32)]
 
 
 class InstNormArgs(C.Structure):
@@ -110,7 +111,8 @@ class AdamArgs(C.Structure):
 
 
 class _PackArgs(C.Structure):
-    _fields_ = [("w", C.c_void_p), ("packed", C.c_void_p), ("Cin", C.c_int32), ("Cout", C.c_int32)]
+    _fields_ = [("w", C.c_void_p), ("packed", C.c_void_p), ("Cin", C.c_int32), ("Cout", C.c_int32),
+                ("dgrad", C.c_int32), ("compute", C.c_int32)]
 
 
 class _MixArgs(C.Structure):
@@ -140,7 +142,7 @@ class Op(C.Structure):
 (OP_CONV3_FWD, OP_CONV3_DGRAD, OP_CONV3_WGRAD, OP_CONV3_PACK_FWD, OP_CONV3_PACK_DGRAD,
  OP_IN_FWD, OP_IN_BWD, OP_POOL_FWD, OP_POOL_BWD, OP_CONVT_FWD, OP_CONVT_DGRAD, OP_CONVT_WGRAD,
  OP_CONV1_FWD, OP_CONV1_DGRAD, OP_CONV1_WGRAD, OP_GAP_FWD, OP_GAP_BWD, OP_LINEAR_FWD, OP_LINEAR_BWD,
- OP_DICE_FWD, OP_DICE_BWD, OP_FOCAL, OP_LOSS_MIX, OP_ADAM, OP_MEMSET, OP_DICE_COUNTS) = range(1, 27)
+ OP_DICE_FWD, OP_DICE_BWD, OP_FOCAL, OP_LOSS_MIX, OP_ADAM, OP_MEMSET, OP_DICE_COUNTS, OP_CONV3_PACK_LP) = range(1, 28)
 
 OP_UNION_FIELD = {
     OP_CONV3_FWD: "conv3", OP_CONV3_DGRAD: "conv3", OP_CONV3_WGRAD: "conv3",
@@ -150,14 +152,14 @@ OP_UNION_FIELD = {
     OP_CONV1_FWD: "conv1", OP_CONV1_DGRAD: "conv1", OP_CONV1_WGRAD: "conv1",
     OP_GAP_FWD: "gap", OP_GAP_BWD: "gap", OP_LINEAR_FWD: "linear", OP_LINEAR_BWD: "linear",
     OP_DICE_FWD: "dice", OP_DICE_BWD: "dice", OP_FOCAL: "focal", OP_LOSS_MIX: "mix", OP_ADAM: "adam",
-    OP_MEMSET: "memset0", OP_DICE_COUNTS: "counts",
+    OP_MEMSET: "memset0", OP_DICE_COUNTS: "counts", OP_CONV3_PACK_LP: "pack",
 }
 
 # every symbol include/mtbc.h declares (tests check the library exports all of them)
 EXPORTS = [
     "mtbc_version", "mtbc_strerror", "mtbc_arch",
     "mtbc_conv3x3_packed_elems", "mtbc_conv3x3_packed_dgrad_elems", "mtbc_conv3x3_pack_fwd",
-    "mtbc_conv3x3_pack_dgrad", "mtbc_conv3x3_wgrad_workspace", "mtbc_conv3x3_fwd", "mtbc_conv3x3_dgrad",
+    "mtbc_conv3x3_pack_dgrad", "mtbc_conv3x3_packed_lp_elems", "mtbc_conv3x3_pack_lp", "mtbc_conv3x3_wgrad_workspace", "mtbc_conv3x3_fwd", "mtbc_conv3x3_dgrad",
     "mtbc_conv3x3_wgrad", "mtbc_instnorm_lrelu_fwd", "mtbc_instnorm_lrelu_bwd", "mtbc_maxpool2_fwd",
     "mtbc_maxpool2_bwd", "mtbc_convT_wgrad_workspace", "mtbc_convT_fwd", "mtbc_convT_dgrad", "mtbc_convT_wgrad",
     "mtbc_conv1x1_wgrad_workspace", "mtbc_conv1x1_fwd", "mtbc_conv1x1_dgrad", "mtbc_conv1x1_wgrad",
@@ -185,6 +187,10 @@ def load() -> C.CDLL:
     for name in ("mtbc_conv3x3_packed_elems", "mtbc_conv3x3_packed_dgrad_elems"):
         getattr(lib, name).restype = C.c_size_t
         getattr(lib, name).argtypes = [C.c_int32, C.c_int32]
+    lib.mtbc_conv3x3_packed_lp_elems.restype = C.c_size_t
+    lib.mtbc_conv3x3_packed_lp_elems.argtypes = [C.c_int32, C.c_int32, C.c_int32]
+    lib.mtbc_conv3x3_pack_lp.restype = C.c_int
+    lib.mtbc_conv3x3_pack_lp.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
     for name in ("mtbc_conv3x3_pack_fwd", "mtbc_conv3x3_pack_dgrad"):
         getattr(lib, name).restype = C.c_int
         getattr(lib, name).argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]

@@ -517,6 +517,200 @@ __global__ __launch_bounds__(256, RING == 3 ? 2 : 3) void conv3x3_igemm_dma_kern
     }
 }
 
+// 16-bit MFMA operand helpers (bf16 / fp16), shared by the low-precision igemm and wgrad kernels
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+template <bool F16> struct LP;
+template <> struct LP<false> {
+    typedef bf16x8 frag;
+    static __device__ __forceinline__ frag pack(const float* f) { frag r;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) r[i] = (__bf16)f[i];
+        return r; }
+    static __device__ __forceinline__ f32x4 mfma(frag a, frag b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+};
+template <> struct LP<true> {
+    typedef f16x8 frag;
+    static __device__ __forceinline__ frag pack(const float* f) { frag r;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) r[i] = (_Float16)f[i];
+        return r; }
+    static __device__ __forceinline__ f32x4 mfma(frag a, frag b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+};
+
+// ------------------------------------------------------------------ igemm on the 16-bit MFMA (optional compute mode)
+// fwd / dgrad with bf16 (or fp16) MFMA operands, fp32 accumulate, fp32 tensors in HBM.  v_mfma_f32_16x16x32 wants 8
+// consecutive K per lane, K = input channels at one tap, so the LDS image is channel-interleaved: [halo pixel][32 ch]
+// as 16-bit, 80-byte pixel stride (5*px + kg spreads the 16-B slots of a ds_read_b128).  Staging: each lane owns one
+// halo pixel and one 8-channel group, reads its 8 channels with 8 dword loads (a wave reads 256 contiguous bytes of
+// one plane per load), converts, and writes ONE ds_write_b128.  Weights come pre-converted: [mtile][chunk32][tap][16][40].
+// With the matrix pipe 16x faster these convs are load-bound; the structure is therefore the simple one (single LDS
+// buffer, 3 blocks per CU overlap each other).
+constexpr int LPKC = 32;                 // channels per chunk = K of one MFMA
+constexpr int LPROW = 40;                // 16-bit elements per LDS row (32 + 8 pad) = 80 bytes
+template <int GEO> struct GeoLP;
+template <> struct GeoLP<0> { static constexpr int TH = 8, TW = 32, IMG = 1; };
+template <> struct GeoLP<1> { static constexpr int TH = 16, TW = 16, IMG = 1; };
+template <> struct GeoLP<2> { static constexpr int TH = 8, TW = 8, IMG = 4; };
+
+__global__ void pack_lp_kernel(const float* __restrict__ w, unsigned short* __restrict__ p, int Cin, int Cout, int dgrad,
+                               int f16, long long total) {
+    // fwd  : rows = co (Cout), K = ci      value = w[co][ci][tap]
+    // dgrad: rows = ci (Cin),  K = co      value = w[co][ci][8-tap]
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int rows = dgrad ? Cin : Cout, red = dgrad ? Cout : Cin;
+    const int nch = (red + LPKC - 1) / LPKC;
+    const int kk = idx % LPROW; long long t = idx / LPROW;
+    const int i = t % 16; t /= 16;
+    const int tap = t % 9; t /= 9;
+    const int cb = t % nch; const int mt = t / nch;
+    const int r = mt * 16 + i, k = cb * LPKC + kk;
+    float v = 0.f;
+    if (kk < LPKC && r < rows && k < red)
+        v = dgrad ? w[((size_t)k * Cin + r) * 9 + (8 - tap)] : w[((size_t)r * Cin + k) * 9 + tap];
+    unsigned short bits;
+    if (f16) { _Float16 h = (_Float16)v; bits = *reinterpret_cast<unsigned short*>(&h); }
+    else { __bf16 h = (__bf16)v; bits = *reinterpret_cast<unsigned short*>(&h); }
+    p[idx] = bits;
+}
+
+template <int MT, int GEO, bool F16>
+__global__ __launch_bounds__(256, 3) void conv3x3_igemm_lp_kernel(const ConvP p) {
+    using G = GeoLP<GEO>;
+    using T = LP<F16>;
+    constexpr int HR = G::TH + 2, HC = G::TW + 2, HP = G::IMG * HR * HC;       // halo pixels
+    constexpr int XB = HP * LPROW;                                             // 16-bit elements
+    constexpr int WB = MT * 9 * 16 * LPROW;
+    extern __shared__ __attribute__((aligned(16))) unsigned short smem16[];
+    unsigned short* Xs = smem16;
+    unsigned short* Ws = smem16 + XB;
+    SegL* seg_in = reinterpret_cast<SegL*>(smem16 + XB + WB);
+    SegL* seg_out = seg_in + MTBC_MAX_SEGS;
+    segl_fill(seg_in, p.in);
+    segl_fill(seg_out, p.out);
+    __syncthreads();
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int HW = p.H * p.W;
+    const int mt0 = blockIdx.y * MT;
+    const int nchunks = (p.Cin + LPKC - 1) / LPKC;
+    const int j = lane & 15, kg = lane >> 4;
+
+    // fragment read bases (16-bit element offsets)
+    int bpix[4];                      // halo-pixel index of this lane's output pixel in group g, tap (0,0)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        int img = 0, y, x;
+        if (GEO == 0) { y = 2 * wv + (g >> 1); x = 16 * (g & 1) + j; }
+        else if (GEO == 1) { y = 4 * wv + g; x = j; }
+        else { img = wv; y = 2 * g + (j >> 3); x = j & 7; }
+        bpix[g] = (img * HR + y) * HC + x;
+    }
+
+    for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+        int t = tile;
+        const int tx = t % p.tiles_x; t /= p.tiles_x;
+        const int ty = t % p.tiles_y; t /= p.tiles_y;
+        const int n0 = t * G::IMG, x0 = tx * G::TW, y0 = ty * G::TH;
+        f32x4 acc[MT][4];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) acc[m][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+        for (int ch = 0; ch < nchunks; ++ch) {
+            const int ci0 = ch * LPKC;
+            __syncthreads();                      // previous chunk's fragments are consumed
+            // ---- X: items = (8-channel group, halo pixel); lanes run along pixels
+            for (int it = tid; it < 4 * HP; it += 256) {
+                const int kgc = it / HP, hp = it % HP;
+                const int img = hp / (HR * HC), rem = hp % (HR * HC);
+                const int row = rem / HC, col = rem % HC;
+                const int n = n0 + img, y = y0 + row - 1, x = x0 + col - 1;
+                const int c0 = ci0 + 8 * kgc;
+                float f[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] = 0.f;
+                if (c0 < p.Cin && n < p.N && y >= 0 && y < p.H && x >= 0 && x < p.W) {
+                    const SegL sr = segl_ref(seg_in, c0);
+                    const float* src = sr.ptr + (size_t)n * sr.bs + (size_t)(c0 - sr.cb) * HW + y * p.W + x;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) f[e] = src[(size_t)e * HW];
+                }
+                *reinterpret_cast<typename T::frag*>(Xs + hp * LPROW + 8 * kgc) = T::pack(f);
+            }
+            // ---- W: straight 16-byte copies of the pre-converted image
+            {
+                constexpr int W16 = WB / 8;           // 16-byte pieces
+                for (int it = tid; it < W16; it += 256) {
+                    const int mt = it / (9 * 16 * LPROW / 8), r = it % (9 * 16 * LPROW / 8);
+                    uint4 v = make_uint4(0, 0, 0, 0);
+                    if ((mt0 + mt) < p.mtiles)
+                        v = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(p.wp) +
+                                                            ((size_t)(mt0 + mt) * nchunks + ch) * (9 * 16 * LPROW) + r * 8);
+                    *reinterpret_cast<uint4*>(Ws + it * 8) = v;
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int toff = ((tap / 3) * HC + tap % 3) * LPROW + 8 * kg;
+                typename T::frag a[MT], b[4];
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+                    a[m] = *reinterpret_cast<const typename T::frag*>(Ws + ((m * 9 + tap) * 16 + j) * LPROW + 8 * kg);
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    b[g] = *reinterpret_cast<const typename T::frag*>(Xs + bpix[g] * LPROW + toff);
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) acc[m][g] = T::mfma(a[m], b[g], acc[m][g]);
+            }
+        }
+        // ---- epilogue (same fragment map as the fp32 kernels)
+        int poff[4];
+        const int n = GEO == 2 ? n0 + wv : n0;
+        bool all_px = n < p.N;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            int y, x;
+            if (GEO == 0) { y = y0 + 2 * wv + (g >> 1); x = x0 + 16 * (g & 1) + j; }
+            else if (GEO == 1) { y = y0 + 4 * wv + g; x = x0 + j; }
+            else { y = y0 + 2 * g + (j >> 3); x = x0 + (j & 7); }
+            const bool ok = n < p.N && y < p.H && x < p.W;
+            all_px = all_px && ok;
+            poff[g] = ok ? y * p.W + x : -1;
+        }
+        const bool fast = __all(all_px) && (mt0 + MT) * 16 <= p.Cout;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int co4 = (mt0 + m) * 16 + kg * 4;
+            const SegL so = segl_ref(seg_out, co4 < p.Cout ? co4 : 0);
+            float* cb0 = so.ptr + (size_t)n * so.bs + (size_t)((co4 < p.Cout ? co4 : 0) - so.cb) * HW;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = co4 + r;
+                const bool row_ok = fast || co < p.Cout;
+                float* cb = cb0 + (size_t)r * HW;
+                const float bv = (p.bias && row_ok) ? p.bias[co] : 0.f;
+                if (fast) {
+                    float old[4];
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) old[g] = so.acc ? cb[poff[g]] : 0.f;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) cb[poff[g]] = acc[m][g][r] + bv + old[g];
+                } else if (row_ok) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        if (poff[g] >= 0) cb[poff[g]] = acc[m][g][r] + bv + (so.acc ? cb[poff[g]] : 0.f);
+                }
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------ wgrad (MFMA, split-K)
 template <int GEO> struct WGeo;
 template <> struct WGeo<0> { static constexpr int TH = 4, TW = 32, ROWS = 6, LW = 40, IMG = 1, IMGS = 240, PSX = 258; };
@@ -658,6 +852,144 @@ __global__ __launch_bounds__(128 * COT, 3) void conv3x3_wgrad_mfma_kernel(const 
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int co = co0 + (wv >> 1) * 16 + kk * 4 + r;
+            if (co >= p.Cout) continue;
+            float* d = p.partial + (((size_t)split * p.Cout + co) * p.Cin + ci) * 9;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) d[tap] = acc[tap][r];
+        }
+    }
+}
+
+// ------------------------------------------------------------------ wgrad on the 16-bit MFMA (optional compute mode)
+// Same block structure as conv3x3_wgrad_mfma_kernel, but the contraction runs on v_mfma_f32_16x16x32_{bf16,f16}
+// (fp32 accumulate).  K = pixels is the contiguous dimension of an NCHW plane, so a lane's 8 K-values are 8 consecutive
+// pixels: two aligned ds_read_b128 for dZ, and one aligned 16-float window per kernel row of X from which the three
+// horizontally shifted taps are cut in registers (v_cvt_pk_* packs pairs, so the shift costs nothing).  fp32 stays the
+// storage type in HBM and LDS; only the MFMA operands are rounded.
+template <int GEO> struct WGeoLP;      // 16-byte aligned channel strides, stride/4 odd (b128 reads spread over slots)
+template <> struct WGeoLP<0> { static constexpr int PSX = 244; };
+template <> struct WGeoLP<1> { static constexpr int PSX = 244; };
+template <> struct WGeoLP<2> { static constexpr int PSX = 324; };
+constexpr int PSZ_LP = 132;
+
+template <int GEO, int COT, bool F16>
+__global__ __launch_bounds__(128 * COT, 3) void conv3x3_wgrad_lp_kernel(const WgP p) {
+    using G = WGeo<GEO>;
+    using T = LP<F16>;
+    constexpr int PSX = WGeoLP<GEO>::PSX;
+    constexpr int XS = 32 * PSX;
+    constexpr int XF4_PER_CH = G::IMG * G::ROWS * G::LW / 4;
+    constexpr int XSLOTS = (XF4_PER_CH + 7) / 8;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Xs = smem;
+    float* Zs = smem + XS;
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int HW = p.H * p.W;
+    const int co0 = (blockIdx.y / p.ciblocks) * (16 * COT), ci0 = (blockIdx.y % p.ciblocks) * 32;
+    const int split = blockIdx.x;
+    const int t_begin = split * p.tiles_per_split;
+    const int t_end = min(p.total_tiles, t_begin + p.tiles_per_split);
+
+    const int ch = tid >> 3, q = tid & 7;
+    const int my_ci = ci0 + ch, my_co = co0 + ch;
+    const bool ci_ok = ch < 32 && my_ci < p.Cin, co_ok = my_co < p.Cout;
+    const SegRef sr = seg_ref(p.in, ci_ok ? my_ci : 0);
+    const float* xplane = sr.ptr + (size_t)((ci_ok ? my_ci : 0) - sr.cb) * HW;
+    const long long xbs = sr.bs;
+    const float* zplane = p.dz + (size_t)(co_ok ? my_co : 0) * HW;
+    float4 xr[XSLOTS], zr[4];
+#pragma unroll
+    for (int s = 0; s < XSLOTS; ++s) xr[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) zr[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    auto prefetch = [&](int tile) {
+        int t = tile;
+        const int tx = t % p.tiles_x; t /= p.tiles_x;
+        const int ty = t % p.tiles_y; t /= p.tiles_y;
+        const int n0 = t * G::IMG, x0 = tx * G::TW, y0 = ty * G::TH;
+#pragma unroll
+        for (int s = 0; s < XSLOTS; ++s) {
+            const int f = q + 8 * s;
+            const int img = f / (G::ROWS * G::LW / 4), rem = f % (G::ROWS * G::LW / 4);
+            const int row = rem / (G::LW / 4), c4 = rem % (G::LW / 4);
+            const int y = y0 + row - 1, x = x0 - 4 + c4 * 4, n = n0 + img;
+            const bool ok = f < XF4_PER_CH && ci_ok && n < p.N && y >= 0 && y < p.H && x >= 0 && x < p.W;
+            const float4 v = *reinterpret_cast<const float4*>(xplane + (ok ? (size_t)n * xbs + y * p.W + x : 0));
+            xr[s] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int px = (q + 8 * s) * 4;
+            int n, y, x;
+            if (GEO == 0) { n = n0; y = y0 + px / 32; x = x0 + px % 32; }
+            else if (GEO == 1) { n = n0; y = y0 + px / 16; x = x0 + px % 16; }
+            else { n = n0 + px / 64; y = y0 + (px % 64) / 8; x = x0 + px % 8; }
+            const bool ok = co_ok && n < p.N && y < p.H && x < p.W;
+            const float4 v = *reinterpret_cast<const float4*>(zplane + (ok ? (size_t)n * p.Cout * HW + y * p.W + x : 0));
+            zr[s] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int s = 0; s < XSLOTS; ++s) {
+            const int f = q + 8 * s;
+            if (f < XF4_PER_CH && ch < 32) {
+                const int img = f / (G::ROWS * G::LW / 4), rem = f % (G::ROWS * G::LW / 4);
+                const int row = rem / (G::LW / 4), c4 = rem % (G::LW / 4);
+                *reinterpret_cast<float4*>(Xs + ch * PSX + img * G::IMGS + row * G::LW + c4 * 4) = xr[s];
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) *reinterpret_cast<float4*>(Zs + ch * PSZ_LP + (q + 8 * s) * 4) = zr[s];
+    };
+
+    const int j = lane & 15, kg = lane >> 4;
+    const int aBase = ((wv >> 1) * 16 + j) * PSZ_LP + 8 * kg;
+    int bLane;
+    if (GEO == 0) bLane = 8 * kg;
+    else if (GEO == 1) bLane = (kg >> 1) * G::LW + 8 * (kg & 1);
+    else bLane = kg * G::LW;
+    const int bBase = ((wv & 1) * 16 + j) * PSX + bLane;
+
+    f32x4 acc[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    if (t_begin < t_end) prefetch(t_begin);
+    for (int tile = t_begin; tile < t_end; ++tile) {
+        __syncthreads();
+        commit();
+        __syncthreads();
+        if (tile + 1 < t_end) prefetch(tile + 1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {            // 32 pixels per step
+            int xoff;
+            if (GEO == 0) xoff = ks * G::LW;
+            else if (GEO == 1) xoff = 2 * ks * G::LW;
+            else xoff = (ks >> 1) * G::IMGS + 4 * (ks & 1) * G::LW;
+            float fa[8];
+            *reinterpret_cast<float4*>(fa) = *reinterpret_cast<const float4*>(Zs + aBase + 32 * ks);
+            *reinterpret_cast<float4*>(fa + 4) = *reinterpret_cast<const float4*>(Zs + aBase + 32 * ks + 4);
+            const typename T::frag a = T::pack(fa);
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                float f[16];                        // aligned window: columns x .. x+15 of halo row (row + r)
+#pragma unroll
+                for (int v4 = 0; v4 < 4; ++v4)
+                    *reinterpret_cast<float4*>(f + 4 * v4) = *reinterpret_cast<const float4*>(Xs + bBase + xoff + r * G::LW + 4 * v4);
+#pragma unroll
+                for (int s3 = 0; s3 < 3; ++s3)      // tap (r, s3): input pixel x + s3 - 1 -> halo column x + 3 + s3
+                    acc[r * 3 + s3] = T::mfma(a, T::pack(f + 3 + s3), acc[r * 3 + s3]);
+            }
+        }
+    }
+    const int ci = ci0 + (wv & 1) * 16 + j;
+    if (ci < p.Cin) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int co = co0 + (wv >> 1) * 16 + kg * 4 + r;
             if (co >= p.Cout) continue;
             float* d = p.partial + (((size_t)split * p.Cout + co) * p.Cin + ci) * 9;
 #pragma unroll
@@ -860,9 +1192,39 @@ int launch_igemm_mt(int MT, const ConvP& p, int mblocks, hipStream_t st) {
     }
 }
 
-// shared by fwd and dgrad: `rows` = channels written, `red` = channels read
+template <int MT, int GEO>
+int launch_igemm_lp(const ConvP& p, int mblocks, bool f16, hipStream_t st) {
+    using G = GeoLP<GEO>;
+    constexpr int HP = G::IMG * (G::TH + 2) * (G::TW + 2);
+    const size_t lds = ((size_t)HP * LPROW + (size_t)MT * 9 * 16 * LPROW) * 2 + SEGL_FLOATS * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_igemm_lp_kernel<MT, GEO, false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_igemm_lp_kernel<MT, GEO, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    int gx = (768 / mblocks) / 8 * 8;
+    if (gx < 8) gx = 8;
+    if (gx > p.ntiles) gx = p.ntiles;
+    if (f16) hipLaunchKernelGGL((conv3x3_igemm_lp_kernel<MT, GEO, true>), dim3(gx, mblocks), dim3(256), lds, st, p);
+    else hipLaunchKernelGGL((conv3x3_igemm_lp_kernel<MT, GEO, false>), dim3(gx, mblocks), dim3(256), lds, st, p);
+    MTBC_CHECK_LAUNCH();
+    return MTBC_OK;
+}
+template <int GEO>
+int launch_igemm_lp_mt(int MT, const ConvP& p, int mblocks, bool f16, hipStream_t st) {
+    switch (MT) {
+        case 1: return launch_igemm_lp<1, GEO>(p, mblocks, f16, st);
+        case 2: return launch_igemm_lp<2, GEO>(p, mblocks, f16, st);
+        default: return launch_igemm_lp<3, GEO>(p, mblocks, f16, st);
+    }
+}
+
+// shared by fwd and dgrad: `rows` = channels written, `red` = channels read; compute: 0 fp32, 1 bf16, 2 fp16 operands
 int run_igemm(int N, int H, int W, int red, int rows, const SegTable& in, const SegTable& out, const float* wp,
-              const float* bias, hipStream_t st) {
+              const float* bias, int compute, hipStream_t st) {
     ConvP p;
     p.N = N; p.H = H; p.W = W; p.Cin = red; p.Cout = rows; p.in = in; p.out = out; p.wp = wp; p.bias = bias;
     static const int dbg = getenv("MTBC_DBG") ? atoi(getenv("MTBC_DBG")) : 0;
@@ -880,6 +1242,11 @@ int run_igemm(int N, int H, int W, int red, int rows, const SegTable& in, const 
         mblocks = cdiv(p.mtiles, MT);
     }
     MT = cdiv(p.mtiles, mblocks);
+    if (compute != 0) {
+        if (geo == 0) return launch_igemm_lp_mt<0>(MT, p, mblocks, compute == 2, st);
+        if (geo == 1) return launch_igemm_lp_mt<1>(MT, p, mblocks, compute == 2, st);
+        return launch_igemm_lp_mt<2>(MT, p, mblocks, compute == 2, st);
+    }
     if (geo == 0) return launch_igemm_mt<0>(MT, p, mblocks, st);
     if (geo == 1) return launch_igemm_mt<1>(MT, p, mblocks, st);
     return launch_igemm_mt<2>(MT, p, mblocks, st);
@@ -945,6 +1312,19 @@ int mtbc_conv3x3_pack_dgrad(const float* w, float* packed, int32_t Cin, int32_t 
     return MTBC_OK;
 }
 
+size_t mtbc_conv3x3_packed_lp_elems(int32_t Cin, int32_t Cout, int32_t dgrad) {
+    const int rows = dgrad ? Cin : Cout, red = dgrad ? Cout : Cin;
+    return (size_t)cdiv(rows, 16) * cdiv(red, LPKC) * 9 * 16 * LPROW;      // 16-bit elements
+}
+int mtbc_conv3x3_pack_lp(const float* w, void* packed, int32_t Cin, int32_t Cout, int32_t dgrad, int32_t compute, void* stream) {
+    if (!w || !packed || Cin <= 0 || Cout <= 0 || (compute != 1 && compute != 2)) return MTBC_E_BADARG;
+    const long long total = (long long)mtbc_conv3x3_packed_lp_elems(Cin, Cout, dgrad);
+    hipLaunchKernelGGL(pack_lp_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, (hipStream_t)stream, w,
+                       reinterpret_cast<unsigned short*>(packed), Cin, Cout, dgrad, compute == 2 ? 1 : 0, total);
+    MTBC_CHECK_LAUNCH();
+    return MTBC_OK;
+}
+
 static int check_conv(const mtbc_conv3x3_args* a) {
     if (!a) return MTBC_E_BADARG;
     if (a->N <= 0 || a->H <= 0 || a->W <= 0 || a->Cin <= 0 || a->Cout <= 0) return MTBC_E_BADSHAPE;
@@ -960,7 +1340,7 @@ int mtbc_conv3x3_fwd(const mtbc_conv3x3_args* a, void* stream) {
     rc = make_segtable(&o, 1, a->Cout, &out); if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
     if (a->w_packed && !a->force_direct && mfma_ok(a->in, a->n_in, a->H, a->W))
-        return run_igemm(a->N, a->H, a->W, a->Cin, a->Cout, in, out, a->w_packed, a->bias, st);
+        return run_igemm(a->N, a->H, a->W, a->Cin, a->Cout, in, out, a->w_packed, a->bias, a->compute, st);
     if (!a->w) return MTBC_E_BADARG;
     DirP p; p.N = a->N; p.H = a->H; p.W = a->W; p.Cin = a->Cin; p.Cout = a->Cout; p.in = in; p.out = out;
     p.w = a->w; p.bias = a->bias; p.mode = 0; p.wCin = a->Cin;
@@ -979,7 +1359,7 @@ int mtbc_conv3x3_dgrad(const mtbc_conv3x3_args* a, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     bool ok = a->w_packed && !a->force_direct && mfma_ok(&g, 1, a->H, a->W) && a->Cout % KC == 0;
     for (int i = 0; ok && i < a->n_in; ++i) ok = a->in[i].ptr != nullptr && a->in[i].channels % 4 == 0;
-    if (ok) return run_igemm(a->N, a->H, a->W, a->Cout, a->Cin, in, out, a->w_packed, nullptr, st);
+    if (ok) return run_igemm(a->N, a->H, a->W, a->Cout, a->Cin, in, out, a->w_packed, nullptr, a->compute, st);
     if (!a->w) return MTBC_E_BADARG;
     DirP p; p.N = a->N; p.H = a->H; p.W = a->W; p.Cin = a->Cout; p.Cout = a->Cin; p.in = in; p.out = out;
     p.w = a->w; p.bias = nullptr; p.mode = 1; p.wCin = a->Cin;
@@ -1013,15 +1393,23 @@ int mtbc_conv3x3_wgrad(const mtbc_conv3x3_args* a, void* stream) {
         dim3 grid(w.nsplit, w.coblocks * w.ciblocks);
         const int zch = 16 * w.cot;
         const dim3 blk(128 * w.cot);
+        static const int lowp_env = getenv("MTBC_LOWP") ? atoi(getenv("MTBC_LOWP")) : -1;
+        const int lowp = lowp_env >= 0 ? lowp_env : a->compute;       // 0 fp32 (exact), 1 bf16, 2 fp16 MFMA operands
+#define MTBC_WG_LAUNCH(GEO_, COT_)                                                                                         \
+        do {                                                                                                               \
+            if (lowp == 1) hipLaunchKernelGGL((conv3x3_wgrad_lp_kernel<GEO_, COT_, false>), grid, blk,                     \
+                                              (32 * WGeoLP<GEO_>::PSX + zch * PSZ_LP) * sizeof(float), st, p);            \
+            else if (lowp == 2) hipLaunchKernelGGL((conv3x3_wgrad_lp_kernel<GEO_, COT_, true>), grid, blk,                 \
+                                                   (32 * WGeoLP<GEO_>::PSX + zch * PSZ_LP) * sizeof(float), st, p);       \
+            else hipLaunchKernelGGL((conv3x3_wgrad_mfma_kernel<GEO_, COT_>), grid, blk,                                    \
+                                    (32 * WGeo<GEO_>::PSX + zch * PSZ) * sizeof(float), st, p);                            \
+        } while (0)
         if (w.cot == 2) {
-            if (w.geo == 0) hipLaunchKernelGGL((conv3x3_wgrad_mfma_kernel<0, 2>), grid, blk, (32 * WGeo<0>::PSX + zch * PSZ) * sizeof(float), st, p);
-            else if (w.geo == 1) hipLaunchKernelGGL((conv3x3_wgrad_mfma_kernel<1, 2>), grid, blk, (32 * WGeo<1>::PSX + zch * PSZ) * sizeof(float), st, p);
-            else hipLaunchKernelGGL((conv3x3_wgrad_mfma_kernel<2, 2>), grid, blk, (32 * WGeo<2>::PSX + zch * PSZ) * sizeof(float), st, p);
+            if (w.geo == 0) MTBC_WG_LAUNCH(0, 2); else if (w.geo == 1) MTBC_WG_LAUNCH(1, 2); else MTBC_WG_LAUNCH(2, 2);
         } else {
-            if (w.geo == 0) hipLaunchKernelGGL((conv3x3_wgrad_mfma_kernel<0, 3>), grid, blk, (32 * WGeo<0>::PSX + zch * PSZ) * sizeof(float), st, p);
-            else if (w.geo == 1) hipLaunchKernelGGL((conv3x3_wgrad_mfma_kernel<1, 3>), grid, blk, (32 * WGeo<1>::PSX + zch * PSZ) * sizeof(float), st, p);
-            else hipLaunchKernelGGL((conv3x3_wgrad_mfma_kernel<2, 3>), grid, blk, (32 * WGeo<2>::PSX + zch * PSZ) * sizeof(float), st, p);
+            if (w.geo == 0) MTBC_WG_LAUNCH(0, 3); else if (w.geo == 1) MTBC_WG_LAUNCH(1, 3); else MTBC_WG_LAUNCH(2, 3);
         }
+#undef MTBC_WG_LAUNCH
         MTBC_CHECK_LAUNCH();
     } else {
         DirWgP p; p.N = a->N; p.H = a->H; p.W = a->W; p.Cin = a->Cin; p.Cout = a->Cout; p.nsplit = w.nsplit;

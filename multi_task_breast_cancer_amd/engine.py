@@ -99,8 +99,10 @@ class StepPlan:
     """
 
     def __init__(self, device: torch.device, N: int, param_view: Callable[[str], torch.Tensor],
-                 grad_view: Callable[[str], torch.Tensor], slots: Dict[str, ParamSlot], force_direct: bool = False):
+                 grad_view: Callable[[str], torch.Tensor], slots: Dict[str, ParamSlot], force_direct: bool = False,
+                 compute: int = 0):
         self.dev = device
+        self.compute = int(compute)      # MFMA operand type of the 3x3 convs: 0 fp32 (parity path), 1 bf16, 2 fp16
         self.N = N
         self.pv, self.gv, self.slots = param_view, grad_view, slots
         self.force_direct = 1 if force_direct else 0
@@ -185,7 +187,21 @@ class StepPlan:
         assert tuple(w.shape) == (cout, cin, 3, 3), (wname, tuple(w.shape), cout, cin)
         use_packed = cin % 8 == 0 and all(a.C % 8 == 0 for a in inputs)
         wp_f = wp_d = None
-        if use_packed:
+        if use_packed and self.compute:
+            # 16-bit operand images, re-converted from the fp32 master weights every step
+            for dg in (0, 1):
+                if dg == 1 and not (any(a.needs_grad for a in inputs) and cout % 8 == 0):
+                    continue
+                t = self.alloc(self.lib.mtbc_conv3x3_packed_lp_elems(cin, cout, dg), dtype=torch.int16)
+                op = _mk(L.OP_CONV3_PACK_LP)
+                op.u.pack.w, op.u.pack.packed, op.u.pack.Cin, op.u.pack.Cout = w.data_ptr(), t.data_ptr(), cin, cout
+                op.u.pack.dgrad, op.u.pack.compute = dg, self.compute
+                self.pack_ops.append(op)
+                if dg == 0:
+                    wp_f = t
+                else:
+                    wp_d = t
+        elif use_packed:
             wp_f = self.alloc(self.lib.mtbc_conv3x3_packed_elems(cin, cout))
             op = _mk(L.OP_CONV3_PACK_FWD)
             op.u.pack.w, op.u.pack.packed, op.u.pack.Cin, op.u.pack.Cout = w.data_ptr(), wp_f.data_ptr(), cin, cout
@@ -210,6 +226,7 @@ class StepPlan:
             a.N, a.H, a.W, a.Cin, a.Cout, a.n_in = N, H, W, cin, cout, len(inputs)
             a.w = w.data_ptr()
             a.force_direct = self.force_direct
+            a.compute = self.compute if use_packed else 0
             return op
 
         op = base_conv()

@@ -239,7 +239,8 @@ class CompiledStep:
     def __init__(self, net: "HipMultiTaskNet", N: int, H: int, W: int, fused_loss: Optional[dict] = None):
         dev = net.flat_p.device
         self.N, self.H, self.W = N, H, W
-        plan = StepPlan(dev, N, net._param_view, net._grad_view, net.slots, force_direct=net.force_direct)
+        plan = StepPlan(dev, N, net._param_view, net._grad_view, net.slots, force_direct=net.force_direct,
+                        compute=net.compute)
         self.x = Act("input", plan.alloc(N, net.in_channels, H, W), needs_grad=False)
         self.logits, self.segs = net._graph(plan, self.x)
         self.mask = self.onehot = None
@@ -271,6 +272,7 @@ class HipMultiTaskNet(nn.Module):
     def __init__(self, named_params: List[Tuple[str, torch.Tensor]], in_channels: int, deep_supervision: bool,
                  graph: Callable, force_direct: bool = False):
         super().__init__()
+        self.compute = 0          # 3x3-conv MFMA operand type: 0 fp32 (reference arithmetic), 1 bf16, 2 fp16; set_compute()
         self.in_channels = in_channels
         self.deep_supervision = deep_supervision
         self.deep_supervision_outputs = deep_supervision
@@ -294,6 +296,16 @@ class HipMultiTaskNet(nn.Module):
         self.flat_p: Optional[torch.Tensor] = None
         self.flat_g: Optional[torch.Tensor] = None
         self._steps: Dict[Tuple, CompiledStep] = {}
+
+    def set_compute(self, dtype) -> "HipMultiTaskNet":
+        """'f32' | 'bf16' | 'f16' (or 0/1/2): operand type of the conv3x3 MFMAs.  Master weights, activations in HBM,
+        accumulation, norm, losses and Adam stay fp32 in every mode."""
+        table = {"f32": 0, "fp32": 0, "bf16": 1, "f16": 2, "fp16": 2, 0: 0, 1: 1, 2: 2}
+        if dtype not in table:
+            raise ValueError(f"unknown compute dtype {dtype!r}")
+        self.compute = table[dtype]
+        self._steps.clear()
+        return self
 
     # ---- flat storage -------------------------------------------------------------------------
     def _named(self) -> Dict[str, nn.Parameter]:
@@ -342,7 +354,8 @@ class HipMultiTaskNet(nn.Module):
     # ---- compiled steps ---------------------------------------------------------------------
     def compiled(self, N: int, H: int, W: int, fused_loss: Optional[dict] = None) -> CompiledStep:
         self.ensure_flat()
-        key = (N, H, W, None if fused_loss is None else (fused_loss["alpha"], fused_loss["inversely_weighted"]))
+        key = (N, H, W, self.compute,
+               None if fused_loss is None else (fused_loss["alpha"], fused_loss["inversely_weighted"]))
         st = self._steps.get(key)
         if st is None or st.param_ptr != self.flat_p.data_ptr():
             st = CompiledStep(self, N, H, W, fused_loss)

@@ -56,6 +56,19 @@ def conv3x3_pack(w: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
     return pf, pd
 
 
+def conv3x3_pack_lp(w: torch.Tensor, compute: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """16-bit operand images (compute 1 = bf16, 2 = fp16) for fwd and dgrad, as int16 tensors."""
+    _chk(w)
+    lib = L.load()
+    cout, cin = w.shape[0], w.shape[1]
+    outs = []
+    for dgrad in (0, 1):
+        t = torch.empty(lib.mtbc_conv3x3_packed_lp_elems(cin, cout, dgrad), dtype=torch.int16, device=w.device)
+        L.check(lib.mtbc_conv3x3_pack_lp(w.data_ptr(), t.data_ptr(), cin, cout, dgrad, compute, _s()), "pack_lp")
+        outs.append(t)
+    return outs[0], outs[1]
+
+
 def _conv_args(xs, w, N, H, W):
     a = L.Conv3x3Args()
     cin = sum(x.shape[1] for x in xs)
@@ -65,29 +78,32 @@ def _conv_args(xs, w, N, H, W):
 
 
 def conv3x3_fwd(xs: Sequence[torch.Tensor], w: torch.Tensor, bias: Optional[torch.Tensor] = None,
-                packed: Optional[torch.Tensor] = None, force_direct: bool = False) -> torch.Tensor:
-    _chk(*xs, w, bias, packed)
+                packed: Optional[torch.Tensor] = None, force_direct: bool = False, compute: int = 0) -> torch.Tensor:
+    _chk(*xs, w, bias)
     N, _, H, W = xs[0].shape
     a = _conv_args(xs, w, N, H, W)
     _fill_segs(a.in_, xs)
     out = torch.empty(N, w.shape[0], H, W, dtype=torch.float32, device=w.device)
     a.w_packed, a.bias, a.out, a.force_direct = _p(packed), _p(bias), out.data_ptr(), int(force_direct)
+    a.compute = compute
     L.check(L.load().mtbc_conv3x3_fwd(C.byref(a), _s()), "conv3x3_fwd")
     return out
 
 
 def conv3x3_dgrad(dz: torch.Tensor, w: torch.Tensor, dxs: Sequence[torch.Tensor], accumulate: Sequence[int] = (),
-                  packed: Optional[torch.Tensor] = None, force_direct: bool = False) -> None:
-    _chk(dz, w, packed, *dxs)
+                  packed: Optional[torch.Tensor] = None, force_direct: bool = False, compute: int = 0) -> None:
+    _chk(dz, w, *dxs)
     N, _, H, W = dz.shape
     a = _conv_args(dxs, w, N, H, W)
     _fill_segs(a.in_, dxs, accumulate)
     a.w_packed, a.dout, a.force_direct = _p(packed), dz.data_ptr(), int(force_direct)
+    a.compute = compute
     L.check(L.load().mtbc_conv3x3_dgrad(C.byref(a), _s()), "conv3x3_dgrad")
 
 
 def conv3x3_wgrad(xs: Sequence[torch.Tensor], dz: torch.Tensor, w_shape, want_bias: bool = False,
-                  force_direct: bool = False, dw: Optional[torch.Tensor] = None, accumulate: bool = False):
+                  force_direct: bool = False, dw: Optional[torch.Tensor] = None, accumulate: bool = False,
+                  compute: int = 0):
     _chk(*xs, dz)
     N, _, H, W = dz.shape
     dev = dz.device
@@ -98,6 +114,7 @@ def conv3x3_wgrad(xs: Sequence[torch.Tensor], dz: torch.Tensor, w_shape, want_bi
     a.N, a.H, a.W, a.Cin, a.Cout, a.n_in = N, H, W, w_shape[1], w_shape[0], len(xs)
     _fill_segs(a.in_, xs)
     a.dout, a.dw, a.dbias, a.force_direct, a.accumulate_dw = dz.data_ptr(), dw.data_ptr(), _p(db), int(force_direct), int(accumulate)
+    a.compute = compute
     nb = L.load().mtbc_conv3x3_wgrad_workspace(C.byref(a))
     ws = _ws(nb, dev)
     a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel() * 4
