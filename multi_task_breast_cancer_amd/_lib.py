@@ -10,7 +10,7 @@ import os
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmtbc_hip.so")
+LIB_PATH = os.environ.get("MTBC_LIB") or os.path.join(_HERE, "libmtbc_hip.so")   # MTBC_LIB: A/B builds of the same ABI
 
 MAX_SEGS = 6
 c_float_p = C.POINTER(C.c_float)

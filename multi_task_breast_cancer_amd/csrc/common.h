@@ -18,6 +18,16 @@ static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 // Segment table passed by value to kernels (virtual channel concat).
+// Pointers that reach a kernel through LDS (segment tables) lose their address space and would compile to flat_*
+// loads / stores (slower, and they tie vmcnt to lgkmcnt); these types put them back into global memory.
+#ifdef MTBC_FLAT_AB   // A/B probe only
+typedef float gfloat;
+typedef char gchar;
+#else
+typedef __attribute__((address_space(1))) float gfloat;
+typedef __attribute__((address_space(1))) char gchar;
+#endif
+
 struct SegTable {
     float* ptr[MTBC_MAX_SEGS];
     long long bstride[MTBC_MAX_SEGS];

@@ -275,12 +275,12 @@ __global__ __launch_bounds__(256, MT >= 3 ? 2 : 3) void conv3x3_igemm_kernel(con
                 // on this path (host check), so one table lookup serves all four
                 const int co4 = (mt0 + m) * 16 + kk * 4;
                 const SegL so = segl_ref(seg_out, co4 < p.Cout ? co4 : 0);
-                float* cb0 = so.ptr + (size_t)n * so.bs + (size_t)((co4 < p.Cout ? co4 : 0) - so.cb) * HW;
+                gfloat* cb0 = (gfloat*)so.ptr + (size_t)n * so.bs + (size_t)((co4 < p.Cout ? co4 : 0) - so.cb) * HW;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int co = co4 + r;
                     const bool row_ok = fast || co < p.Cout;
-                    float* cb = cb0 + (size_t)r * HW;
+                    gfloat* cb = cb0 + (size_t)r * HW;
                     const float bv = (p.bias && row_ok) ? p.bias[co] : 0.f;
                     if (fast) {
                         float old[4];
@@ -319,6 +319,9 @@ template <int MT, int GEO> struct DmaCount {
     // wave w issues the instructions k = w, w+4, ... of each stream
     static constexpr int of(int w) { return (XI - w + 3) / 4 + (WI - w + 3) / 4; }
 };
+// workgroup barrier that publishes LDS only: unlike __syncthreads() it does not drain vmcnt, so global loads issued
+// before it (register prefetch, LDS-DMA) stay in flight across it
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 template <int MT, int GEO> __device__ __forceinline__ void wait_newest_in_flight(int wv) {
     using D = DmaCount<MT, GEO>;
@@ -482,12 +485,12 @@ __global__ __launch_bounds__(256, RING == 3 ? 2 : 3) void conv3x3_igemm_dma_kern
             for (int m = 0; m < MT; ++m) {
                 const int co4 = (mt0 + m) * 16 + kk * 4;
                 const SegL so = segl_ref(seg_out, co4 < p.Cout ? co4 : 0);
-                float* cb0 = so.ptr + (size_t)n * so.bs + (size_t)((co4 < p.Cout ? co4 : 0) - so.cb) * HW;
+                gfloat* cb0 = (gfloat*)so.ptr + (size_t)n * so.bs + (size_t)((co4 < p.Cout ? co4 : 0) - so.cb) * HW;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int co = co4 + r;
                     const bool row_ok = fast || co < p.Cout;
-                    float* cb = cb0 + (size_t)r * HW;
+                    gfloat* cb = cb0 + (size_t)r * HW;
                     const float bv = (p.bias && row_ok) ? p.bias[co] : 0.f;
                     if (fast) {
                         float old[4];
@@ -587,13 +590,15 @@ __global__ __launch_bounds__(256, 3) void conv3x3_igemm_lp_kernel(const ConvP p)
     unsigned short* Ws = smem16 + XB;
     SegL* seg_in = reinterpret_cast<SegL*>(smem16 + XB + WB);
     SegL* seg_out = seg_in + MTBC_MAX_SEGS;
-    segl_fill(seg_in, p.in);
-    segl_fill(seg_out, p.out);
-    __syncthreads();
-
+    float* bias_s = reinterpret_cast<float*>(seg_out + MTBC_MAX_SEGS);      // MT*16 floats
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int HW = p.H * p.W;
     const int mt0 = blockIdx.y * MT;
+    segl_fill(seg_in, p.in);
+    segl_fill(seg_out, p.out);
+    if (tid < MT * 16) { const int co = mt0 * 16 + tid; bias_s[tid] = (p.bias && co < p.Cout) ? p.bias[co] : 0.f; }
+    __syncthreads();
+
     const int nchunks = (p.Cin + LPKC - 1) / LPKC;
     const int j = lane & 15, kg = lane >> 4;
 
@@ -608,11 +613,78 @@ __global__ __launch_bounds__(256, 3) void conv3x3_igemm_lp_kernel(const ConvP p)
         bpix[g] = (img * HR + y) * HC + x;
     }
 
-    for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+    // The block walks the flattened (tile, chunk) list; the X values of step s+1 travel in registers while step s
+    // feeds the MFMAs, across tile boundaries too (HBM latency must not sit between barriers).  Staging is arranged
+    // so that almost all of its address arithmetic is scalar: wave w owns channel group w of the chunk (8 channels,
+    // one segment lookup per chunk, plane bases in SGPRs) and its lanes own halo pixels lane + 64q, whose byte
+    // offsets are computed once per tile -- each load is then one saddr + 32-bit-voffset instruction.
+    constexpr int XQ = (HP + 63) / 64;
+    float xf[XQ][8];
+    unsigned pixb[XQ];                            // byte offset y*W + x of the halo pixel inside a plane (0 if outside)
+    unsigned okm = 0;                             // bit q: halo pixel q of the fetched tile lies inside the image
+    const int wvu = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int fn0 = 0;                                  // first image of the tile pixb/okm describe
+    auto tile_origin = [&](int tile, int& n0, int& y0, int& x0) {
         int t = tile;
         const int tx = t % p.tiles_x; t /= p.tiles_x;
         const int ty = t % p.tiles_y; t /= p.tiles_y;
-        const int n0 = t * G::IMG, x0 = tx * G::TW, y0 = ty * G::TH;
+        n0 = t * G::IMG; x0 = tx * G::TW; y0 = ty * G::TH;
+    };
+    auto tile_geom = [&](int tile) {
+        int y0, x0;
+        tile_origin(tile, fn0, y0, x0);
+        okm = 0;
+#pragma unroll
+        for (int q = 0; q < XQ; ++q) {
+            const int hp = lane + 64 * q;
+            const int img = hp / (HR * HC), rem = hp % (HR * HC);
+            const int row = rem / HC, col = rem % HC;
+            const int y = y0 + row - 1, x = x0 + col - 1;
+            const bool ok = hp < HP && fn0 + img < p.N && y >= 0 && y < p.H && x >= 0 && x < p.W && !(p.dbg & 1);
+            pixb[q] = ok ? 4u * (unsigned)(y * p.W + x) : 0u;
+            okm |= ok ? (1u << q) : 0u;
+        }
+    };
+    // fetch_x only ISSUES the loads (outside pixels read offset 0 of the plane, an absent channel group reads
+    // nothing); the zeroing happens when the values are packed a step later -- any use of a loaded register here
+    // would put the s_waitcnt in front of the MFMAs and serialize the pipeline.
+    bool xgrp = false;                            // wave-uniform: the fetched channel group exists
+    auto fetch_x = [&](int chn) {
+        const int c0 = chn * LPKC + 8 * wvu;      // wave-uniform
+        xgrp = c0 < p.Cin;
+        if (xgrp) {
+            const SegL sr = segl_ref(seg_in, c0);
+            const unsigned long long pu = reinterpret_cast<unsigned long long>(sr.ptr);
+            const unsigned plo = __builtin_amdgcn_readfirstlane((unsigned)pu), phi = __builtin_amdgcn_readfirstlane((unsigned)(pu >> 32));
+            const unsigned blo = __builtin_amdgcn_readfirstlane((unsigned)sr.bs), bhi = __builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)sr.bs >> 32));
+            const int cb = __builtin_amdgcn_readfirstlane(sr.cb);
+            const long long bs = (long long)(((unsigned long long)bhi << 32) | blo);
+            const gchar* base = (const gchar*)(((unsigned long long)phi << 32) | plo) +
+                               4 * ((size_t)fn0 * bs + (size_t)(c0 - cb) * HW);
+#pragma unroll
+            for (int q = 0; q < XQ; ++q) {
+                unsigned off = pixb[q];
+                if (G::IMG > 1) off += ((okm >> q) & 1u) ? 4u * (unsigned)(((lane + 64 * q) / (HR * HC)) * bs) : 0u;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) xf[q][e] = *(const gfloat*)(base + (size_t)e * HW * 4 + off);
+            }
+        }
+    };
+    int w_have = -1;                              // chunk whose weights sit in Ws (mt0 is fixed per block)
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.wp), 0, (int)((size_t)p.mtiles * nchunks * (9 * 16 * LPROW) * 2), 0x00020000);
+    // XCD-aware walk: workgroups are dealt round-robin to the 8 XCDs (linear id % 8), each with its own L2.  Every
+    // XCD takes one contiguous eighth of the tile list and its blocks sweep it side by side, so the halo rows / the
+    // partly used cache lines two neighbouring tiles share are fetched into ONE L2 instead of two.
+    int tile, tstep, tend;
+    if ((gridDim.x & 7) == 0 && !(p.dbg & 16)) {
+        const int per = (p.ntiles + 7) >> 3, xcd = blockIdx.x & 7;
+        tile = xcd * per + (blockIdx.x >> 3); tstep = gridDim.x >> 3; tend = min(p.ntiles, (xcd + 1) * per);
+    } else { tile = blockIdx.x; tstep = gridDim.x; tend = p.ntiles; }
+    if (tile < tend) { tile_geom(tile); fetch_x(0); }
+    for (; tile < tend; tile += tstep) {
+        int n0, y0, x0;
+        tile_origin(tile, n0, y0, x0);
         f32x4 acc[MT][4];
 #pragma unroll
         for (int m = 0; m < MT; ++m)
@@ -620,39 +692,45 @@ __global__ __launch_bounds__(256, 3) void conv3x3_igemm_lp_kernel(const ConvP p)
             for (int g = 0; g < 4; ++g) acc[m][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
         for (int ch = 0; ch < nchunks; ++ch) {
-            const int ci0 = ch * LPKC;
-            __syncthreads();                      // previous chunk's fragments are consumed
-            // ---- X: items = (8-channel group, halo pixel); lanes run along pixels
-            for (int it = tid; it < 4 * HP; it += 256) {
-                const int kgc = it / HP, hp = it % HP;
-                const int img = hp / (HR * HC), rem = hp % (HR * HC);
-                const int row = rem / HC, col = rem % HC;
-                const int n = n0 + img, y = y0 + row - 1, x = x0 + col - 1;
-                const int c0 = ci0 + 8 * kgc;
-                float f[8];
+            lds_barrier();                        // previous step's fragments are consumed
+            // ---- W: LDS-DMA of the pre-converted image (L2-resident, shared by every block), 1 KB per wave
+            //      instruction, issued first so that waiting for it later leaves the X prefetch in flight; a
+            //      single-chunk conv keeps its weights in LDS for the whole launch
+            const bool wload = w_have != ch && !(p.dbg & 8);
+            if (wload) {
+                constexpr int W16 = WB / 8;       // 16-byte pieces
+                constexpr int WI = (W16 + 63) / 64;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) f[e] = 0.f;
-                if (c0 < p.Cin && n < p.N && y >= 0 && y < p.H && x >= 0 && x < p.W) {
-                    const SegL sr = segl_ref(seg_in, c0);
-                    const float* src = sr.ptr + (size_t)n * sr.bs + (size_t)(c0 - sr.cb) * HW + y * p.W + x;
+                for (int k = 0; k < (WI + 3) / 4; ++k) {
+                    const int inst = wvu + 4 * k;
+                    if (inst < WI) {
+                        const int idx = inst * 64 + lane;
+                        const int mt = idx / (9 * 16 * LPROW / 8), r = idx % (9 * 16 * LPROW / 8);
+                        const bool ok = idx < W16 && (mt0 + mt) < p.mtiles;
+                        const unsigned voff = ok ? (unsigned)((((mt0 + mt) * nchunks + ch) * (9 * 16 * LPROW / 8) + r) * 16) : 0xfffffff0u;
+                        if (idx < W16)
+                            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_ptr_t)(Ws + inst * 512), 16, voff, 0, 0, 0);
+                    }
+                }
+                w_have = ch;
+            }
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) f[e] = src[(size_t)e * HW];
-                }
-                *reinterpret_cast<typename T::frag*>(Xs + hp * LPROW + 8 * kgc) = T::pack(f);
+            for (int q = 0; q < XQ; ++q) {
+                const int hp = lane + 64 * q;
+                const bool live = xgrp && ((okm >> q) & 1u);
+                float xv[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) xv[e] = live ? xf[q][e] : 0.f;
+                if (hp < HP) *reinterpret_cast<typename T::frag*>(Xs + hp * LPROW + 8 * wvu) = T::pack(xv);
             }
-            // ---- W: straight 16-byte copies of the pre-converted image
-            {
-                constexpr int W16 = WB / 8;           // 16-byte pieces
-                for (int it = tid; it < W16; it += 256) {
-                    const int mt = it / (9 * 16 * LPROW / 8), r = it % (9 * 16 * LPROW / 8);
-                    uint4 v = make_uint4(0, 0, 0, 0);
-                    if ((mt0 + mt) < p.mtiles)
-                        v = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(p.wp) +
-                                                            ((size_t)(mt0 + mt) * nchunks + ch) * (9 * 16 * LPROW) + r * 8);
-                    *reinterpret_cast<uint4*>(Ws + it * 8) = v;
-                }
+            // next step's X: in flight under the MFMAs and the epilogue
+            bool fetched = false;
+            if (ch + 1 < nchunks) { fetch_x(ch + 1); fetched = xgrp; }
+            else if (tile + tstep < tend) { tile_geom(tile + tstep); fetch_x(0); fetched = xgrp; }
+            if (wload) {                          // the weight DMA is older than the X loads just issued
+                if (fetched) wait_vmcnt<8 * XQ>(); else wait_vmcnt<0>();
             }
-            __syncthreads();
+            lds_barrier();
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
                 const int toff = ((tap / 3) * HC + tap % 3) * LPROW + 8 * kg;
@@ -683,28 +761,29 @@ __global__ __launch_bounds__(256, 3) void conv3x3_igemm_lp_kernel(const ConvP p)
             all_px = all_px && ok;
             poff[g] = ok ? y * p.W + x : -1;
         }
-        const bool fast = __all(all_px) && (mt0 + MT) * 16 <= p.Cout;
+        if (p.dbg & 2) { if (acc[0][0][0] != 12345.678f) continue; }
+        // No load may sit here: vmcnt retires in order, so waiting for one (a bias, an old value to accumulate onto)
+        // would also wait for the whole X prefetch issued above.  The bias comes from LDS; accumulation into a
+        // fan-in gradient is a no-return global_atomic_add_f32 -- every element has exactly one writer per launch,
+        // so the sum is the same (old + (acc + bias)) as a read-modify-write, minus the round trip.
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
             const int co4 = (mt0 + m) * 16 + kg * 4;
             const SegL so = segl_ref(seg_out, co4 < p.Cout ? co4 : 0);
-            float* cb0 = so.ptr + (size_t)n * so.bs + (size_t)((co4 < p.Cout ? co4 : 0) - so.cb) * HW;
+            gfloat* cb0 = (gfloat*)so.ptr + (size_t)n * so.bs + (size_t)((co4 < p.Cout ? co4 : 0) - so.cb) * HW;
+            const f32x4 bv4 = *reinterpret_cast<const f32x4*>(bias_s + m * 16 + kg * 4);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int co = co4 + r;
-                const bool row_ok = fast || co < p.Cout;
-                float* cb = cb0 + (size_t)r * HW;
-                const float bv = (p.bias && row_ok) ? p.bias[co] : 0.f;
-                if (fast) {
-                    float old[4];
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) old[g] = so.acc ? cb[poff[g]] : 0.f;
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) cb[poff[g]] = acc[m][g][r] + bv + old[g];
-                } else if (row_ok) {
+                if (co4 + r >= p.Cout) continue;
+                gfloat* cb = cb0 + (size_t)r * HW;
+                if (so.acc) {
 #pragma unroll
                     for (int g = 0; g < 4; ++g)
-                        if (poff[g] >= 0) cb[poff[g]] = acc[m][g][r] + bv + (so.acc ? cb[poff[g]] : 0.f);
+                        if (poff[g] >= 0) __builtin_amdgcn_global_atomic_fadd_f32(cb + poff[g], acc[m][g][r] + bv4[r]);
+                } else {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        if (poff[g] >= 0) cb[poff[g]] = acc[m][g][r] + bv4[r];
                 }
             }
         }
@@ -1196,7 +1275,7 @@ template <int MT, int GEO>
 int launch_igemm_lp(const ConvP& p, int mblocks, bool f16, hipStream_t st) {
     using G = GeoLP<GEO>;
     constexpr int HP = G::IMG * (G::TH + 2) * (G::TW + 2);
-    const size_t lds = ((size_t)HP * LPROW + (size_t)MT * 9 * 16 * LPROW) * 2 + SEGL_FLOATS * sizeof(float);
+    const size_t lds = ((size_t)HP * LPROW + (size_t)MT * 9 * 16 * LPROW) * 2 + (SEGL_FLOATS + MT * 16) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_igemm_lp_kernel<MT, GEO, false>),

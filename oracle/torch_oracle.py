@@ -343,3 +343,56 @@ def synthetic_batch(n: int, h: int, w: int, seed: int = 0) -> Tuple[torch.Tensor
     ell = (((yy - cy) / ry) ** 2 + ((xx - cx) / rx) ** 2 <= 1.0).float()
     mask = (ell * (label.view(n, 1, 1) != 2).float()).view(n, 1, h, w)
     return img.contiguous(), mask.contiguous(), label
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Emulation of the product's optional 16-bit MFMA compute modes (NOT reference behaviour: the reference would use
+# torch.autocast; this restates what the HIP kernels do so the mode has an oracle of its own).  Every 3x3 conv rounds
+# its MFMA operands to bf16 / fp16 (round-to-nearest-even) and accumulates in the tensor dtype: forward rounds x and
+# w, dgrad rounds dy and w, wgrad rounds x and dy; everything else stays in the tensor dtype.
+class _LowpConv3x3(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, lp):
+        ctx.save_for_backward(x, w)
+        ctx.lp = lp
+        ctx.has_b = b is not None
+        r = lambda t: t.to(lp).to(t.dtype)
+        return torch.conv2d(r(x), r(w), b, 1, 1)      # not F.conv2d: that name is patched inside lowp_conv3x3
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        r = lambda t: t.to(ctx.lp).to(t.dtype)
+        dyr = r(dy)
+        dx = torch.nn.grad.conv2d_input(x.shape, r(w), dyr, padding=1)
+        dw = torch.nn.grad.conv2d_weight(r(x), w.shape, dyr, padding=1)
+        db = dy.sum(dim=(0, 2, 3)) if ctx.has_b else None
+        return dx, dw, db, None
+
+
+class lowp_conv3x3:
+    """Context manager: inside it every 3x3 / padding-1 F.conv2d (hence every nn.Conv2d of the oracle nets) runs
+    through _LowpConv3x3 with operands rounded to `mode` ('bf16' | 'f16')."""
+
+    def __init__(self, mode: str):
+        self.lp = {"bf16": torch.bfloat16, "f16": torch.float16}[mode]
+
+    def __enter__(self):
+        self._orig = F.conv2d
+        orig, lp = self._orig, self.lp
+
+        def conv2d(input, weight, bias=None, stride=1, padding=0, dilation=1, groups=1):
+            # same eligibility as the product's MFMA path (conv3x3.hip mfma_ok): maps >= 8x8 with W % 4 == 0 and
+            # channel counts in multiples of 8; everything else (the 1-channel stem, 4x4 maps) stays in fp32 there
+            H, W = input.shape[-2:]
+            if (tuple(weight.shape[-2:]) == (3, 3) and padding in (1, (1, 1)) and stride in (1, (1, 1)) and groups == 1
+                    and H >= 8 and W >= 8 and W % 4 == 0 and weight.shape[1] % 8 == 0 and weight.shape[0] % 8 == 0):
+                return _LowpConv3x3.apply(input, weight, bias, lp)
+            return orig(input, weight, bias, stride, padding, dilation, groups)
+
+        F.conv2d = conv2d
+        return self
+
+    def __exit__(self, *exc):
+        F.conv2d = self._orig
+        return False

@@ -226,35 +226,40 @@ def test_distributed_step_single_rank_rccl_equals_local_step():
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("dtype,tol_fwd", [("bf16", 3e-2), ("f16", 5e-3)])
-def test_16bit_mfma_modes_track_the_fp32_path(dtype, tol_fwd):
-    """Optional compute modes: conv3x3 MFMA operands rounded to bf16 / fp16 (fp32 storage + accumulation).
-    Not a parity path.  Contract checked here: the forward tracks the fp32 step (2^-9 / 2^-12 operand rounding over
-    ~50 conv layers), the loss agrees to 1e-3, and the bf16 gradients point the same way (cosine > 0.9 on every big
-    tensor: InstanceNorm backward subtracts the common mode of dy, which amplifies the *relative* size of unbiased
-    rounding noise, so a rel-L2 criterion is the wrong one; end-to-end quality is checked by tools/train_parity.py).
-    fp16 has no loss scaling yet (tiny dz underflows): forward only."""
-    img, mask, label = O.synthetic_batch(4, 64, 64, seed=21)
-    res = {}
-    for mode in ("f32", dtype):
-        seed_everything(1993)
-        m = MTUNetPlusPlus(in_channels=1, out_channels=1, n_classes=3, deep_supervision=True).to(DEV)
-        m.set_compute(mode)
-        step = FusedTrainStep(m, FusedAdam(m, lr=1e-4, eps=1e-4), alpha=0.5)
-        st = step.load_batch(img.to(DEV), mask.to(DEV), label.to(DEV))
-        l = step.run(st).cpu()
-        res[mode] = (l, m.flat_g.clone(), [s.data.clone() for s in st.segs], m)
-    l0, g0, s0, m0 = res["f32"]
-    l1, g1, s1, m1 = res[dtype]
-    assert abs(l1[0].item() - l0[0].item()) < 1e-3 * max(1.0, abs(l0[0].item()))
-    assert l1[3].item() == 0.0
-    for a, b in zip(s0, s1):
-        assert ((a - b).norm() / a.norm()).item() < tol_fwd
-    if dtype == "bf16":
-        for name in m0._order:
-            s = m0.slots[name]
-            if s.numel < 4096:
-                continue
-            a, b = g0[s.offset:s.offset + s.numel], g1[s.offset:s.offset + s.numel]
-            cos = (a * b).sum().item() / (a.norm().item() * b.norm().item() + 1e-30)
-            assert cos > 0.9, (name, cos)
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_16bit_mfma_modes_match_their_emulation(dtype):
+    """Optional compute modes: conv3x3 MFMA operands rounded to bf16 / fp16 (fp32 storage + accumulation).  Not the
+    reference-parity path (that is fp32); the oracle for it is oracle.lowp_conv3x3, which rounds the same operands
+    at the same places on the CPU (fwd: x, w; dgrad: dy, w; wgrad: x, dy; RNE).  Rounding to 16 bits is itself
+    ill-conditioned: a value that lands on the other side of a rounding boundary because the fp32 sum was taken in
+    another order moves by 2^-9, and the emulation run with fp32 accumulation already sits 6e-3 (forward) / 0.5
+    (first-layer gradients, N=4 at 64x64) away from the same emulation with fp64 accumulation.  So the HIP path is
+    judged like the fp32 test judges gradients: against the fp64-accumulating emulation, allowed 3x the distance the
+    fp32-accumulating CPU emulation has from it (and a small floor).  A wrong operand / rounding place shows up in
+    the forward as >= 3e-2.  fp16 has no loss scaling (tiny dz underflows to 0): forward only."""
+    import copy
+    N, size = 4, 64
+    prod, ref = _oracle_and_product("MTUNetPlusPlus", 1993)
+    prod.set_compute(dtype)
+    ref64 = copy.deepcopy(ref).double()
+    img, mask, label = O.synthetic_batch(N, size, size, seed=21)
+    step = FusedTrainStep(prod, FusedAdam(prod, lr=1e-4, eps=1e-4), alpha=0.5)
+    st = step.load_batch(img.to(DEV), mask.to(DEV), label.to(DEV))
+    losses = step.run(st).cpu()
+    with O.lowp_conv3x3(dtype):
+        t32 = O.train_step(ref, O.make_adam(ref, 1e-4), img, mask, label, 0.5, True, 3)
+        t64 = O.train_step(ref64, O.make_adam(ref64, 1e-4), img.double(), mask.double(), label, 0.5, True, 3)
+    assert losses[3].item() == 0.0
+    rel = lambda a, b: ((a.double().cpu() - b.double()).norm() / b.double().norm()).item()
+    assert abs(losses[0].item() - t64[0].item()) < max(3 * abs(t32[0].item() - t64[0].item()), 5e-4)
+    assert rel(st.logits.data.view(N, -1), t64[3][0]) < max(3 * rel(t32[3][0], t64[3][0]), 2e-3)
+    for got, w32, w64 in zip(st.segs, t32[4], t64[4]):
+        assert rel(got.data, w64) < max(3 * rel(w32, w64), 2e-3)
+    if dtype != "bf16":
+        return
+    g32, g64 = dict(ref.named_parameters()), dict(ref64.named_parameters())
+    for name in prod._order:
+        if name.endswith("conv.bias") or g64[name].grad.norm().item() == 0.0:
+            continue
+        e_hip, e_cpu = rel(prod._grad_view(name), g64[name].grad), rel(g32[name].grad, g64[name].grad)
+        assert e_hip < max(3 * e_cpu, 5e-2), (name, e_hip, e_cpu)

@@ -11,9 +11,11 @@ from multi_task_breast_cancer_amd.trainer import FusedTrainStep
 arch = sys.argv[1] if len(sys.argv) > 1 else "MTUNetPlusPlus"
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 32
 S = int(sys.argv[3]) if len(sys.argv) > 3 else 256
+DT = sys.argv[4] if len(sys.argv) > 4 else "f32"
 dev = torch.device("cuda:0")
 seed_everything(1993)
 model = init_multitask_model(arch, 1, 1, 3, deep_supervision=True).to(dev)
+model.set_compute(DT)
 step = FusedTrainStep(model, init_optimizer(model, "Adam", 1e-4), alpha=0.5)
 batch = synthetic_batch(B, S, S, 0, dev)
 for _ in range(3):
@@ -36,6 +38,7 @@ for pname in ("pack", "fwd", "loss", "bwd"):
             a = op.u.conv3
             fl = 2.0 * a.N * a.H * a.W * a.Cin * a.Cout * 9
             desc = f"{a.Cin}->{a.Cout} @{a.H}x{a.W} segs{a.n_in} {'mfma' if (a.w_packed or (op.kind == L.OP_CONV3_WGRAD and a.Cin >= 8)) else 'direct'}"
+            desc += f" {(a.N*a.H*a.W*4*(a.Cin+a.Cout))/1e6:.0f}MB"
         elif op.kind in (L.OP_CONVT_FWD, L.OP_CONVT_DGRAD, L.OP_CONVT_WGRAD):
             a = op.u.convT
             fl = 2.0 * a.N * a.H * a.W * a.Cin * a.Cout * a.k * a.k
