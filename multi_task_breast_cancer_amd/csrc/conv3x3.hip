@@ -345,20 +345,30 @@ __global__ __launch_bounds__(256, RING == 3 ? 2 : 3) void conv3x3_igemm_dma_kern
     extern __shared__ __attribute__((aligned(16))) float smem[];
     SegL* seg_in = reinterpret_cast<SegL*>(smem + RING * BUF);
     SegL* seg_out = seg_in + MTBC_MAX_SEGS;
-    segl_fill(seg_in, p.in);
-    segl_fill(seg_out, p.out);
-    __syncthreads();
-
+    float* bias_s = reinterpret_cast<float*>(seg_out + MTBC_MAX_SEGS);      // MT*16 floats
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int HW = p.H * p.W;
     const int mt0 = blockIdx.y * MT;
+    segl_fill(seg_in, p.in);
+    segl_fill(seg_out, p.out);
+    if (tid < MT * 16) { const int co = mt0 * 16 + tid; bias_s[tid] = (p.bias && co < p.Cout) ? p.bias[co] : 0.f; }
+    __syncthreads();
+
     const int nchunks = p.Cin / KC;
-    const int my_tiles = (p.ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    // XCD-aware walk: workgroups are dealt round-robin to the 8 XCDs (linear id % 8), each with its own L2.  Every
+    // XCD takes one contiguous eighth of the tile list and its blocks sweep it side by side, so the halo rows / the
+    // partly used cache lines two neighbouring tiles share are fetched into ONE L2 instead of two.
+    int tile0, tstep, tend;
+    if ((gridDim.x & 7) == 0 && !(p.dbg & 16)) {
+        const int per = (p.ntiles + 7) >> 3, xcd = blockIdx.x & 7;
+        tile0 = xcd * per + (blockIdx.x >> 3); tstep = gridDim.x >> 3; tend = min(p.ntiles, (xcd + 1) * per);
+    } else { tile0 = blockIdx.x; tstep = gridDim.x; tend = p.ntiles; }
+    const int my_tiles = tile0 < tend ? (tend - tile0 + tstep - 1) / tstep : 0;
     const int total = my_tiles * nchunks;
     if (total <= 0) return;
 
     // ---- prefetch cursor (two items ahead of the compute cursor)
-    int ptile = blockIdx.x, pchunk = 0, pitem = 0;
+    int ptile = tile0, pchunk = 0, pitem = 0;
     int pn0 = 0, py0 = 0, px0 = 0;
     auto set_ptile = [&]() {
         int t = ptile;
@@ -407,7 +417,7 @@ __global__ __launch_bounds__(256, RING == 3 ? 2 : 3) void conv3x3_igemm_dma_kern
             }
         }
         ++pitem;
-        if (++pchunk == nchunks) { pchunk = 0; ptile += gridDim.x; set_ptile(); }
+        if (++pchunk == nchunks) { pchunk = 0; ptile += tstep; set_ptile(); }
     };
 
     // ---- per-lane fragment bases
@@ -428,7 +438,7 @@ __global__ __launch_bounds__(256, RING == 3 ? 2 : 3) void conv3x3_igemm_dma_kern
     if (RING == 3 && total > 1) { issue(); wait_newest_in_flight<MT, GEO>(wv); } else { wait_vmcnt<0>(); }
     __builtin_amdgcn_s_barrier();
 
-    int chunk = 0, tile = blockIdx.x;
+    int chunk = 0, tile = tile0;
     for (int it = 0; it < total; ++it) {
         const int cur = (it % RING) * BUF;
         const bool last = chunk + 1 == nchunks;
@@ -463,7 +473,9 @@ __global__ __launch_bounds__(256, RING == 3 ? 2 : 3) void conv3x3_igemm_dma_kern
                         acc[m][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[q & 1][s3][m], fb[q & 1][s3][g], acc[m][g], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
-        bool stored = false;
+        // item it+1 must have landed before anyone reads it; item it+2 (RING 3) may stay in flight.  Waiting HERE, in
+        // front of the epilogue, keeps the epilogue's stores out of the wait: they drain under the next item's MFMAs.
+        if (RING == 3 && have2) wait_newest_in_flight<MT, GEO>(wv); else wait_vmcnt<0>();
         if (last) {
             int t = tile;
             const int tx = t % p.tiles_x; t /= p.tiles_x;
@@ -480,42 +492,37 @@ __global__ __launch_bounds__(256, RING == 3 ? 2 : 3) void conv3x3_igemm_dma_kern
                 all_px = all_px && ok;
                 poff[g] = ok ? y * p.W + x : -1;
             }
-            const bool fast = __all(all_px) && (mt0 + MT) * 16 <= p.Cout;
+            // No load may sit here (it would be waited for together with the DMA in flight): the bias comes from LDS and
+            // accumulation into a fan-in gradient is a no-return global_atomic_add_f32 -- each element has exactly one
+            // writer per launch, so this is the same fp32 sum old + (acc + bias) as a read-modify-write.
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
                 const int co4 = (mt0 + m) * 16 + kk * 4;
                 const SegL so = segl_ref(seg_out, co4 < p.Cout ? co4 : 0);
                 gfloat* cb0 = (gfloat*)so.ptr + (size_t)n * so.bs + (size_t)((co4 < p.Cout ? co4 : 0) - so.cb) * HW;
+                const f32x4 bv4 = *reinterpret_cast<const f32x4*>(bias_s + m * 16 + kk * 4);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int co = co4 + r;
-                    const bool row_ok = fast || co < p.Cout;
+                    if (co4 + r >= p.Cout) continue;
                     gfloat* cb = cb0 + (size_t)r * HW;
-                    const float bv = (p.bias && row_ok) ? p.bias[co] : 0.f;
-                    if (fast) {
-                        float old[4];
-#pragma unroll
-                        for (int g = 0; g < 4; ++g) old[g] = so.acc ? cb[poff[g]] : 0.f;
-#pragma unroll
-                        for (int g = 0; g < 4; ++g) cb[poff[g]] = acc[m][g][r] + bv + old[g];
-                    } else if (row_ok) {
+                    if (so.acc) {
 #pragma unroll
                         for (int g = 0; g < 4; ++g)
-                            if (poff[g] >= 0) cb[poff[g]] = acc[m][g][r] + bv + (so.acc ? cb[poff[g]] : 0.f);
+                            if (poff[g] >= 0) __builtin_amdgcn_global_atomic_fadd_f32(cb + poff[g], acc[m][g][r] + bv4[r]);
+                    } else {
+#pragma unroll
+                        for (int g = 0; g < 4; ++g)
+                            if (poff[g] >= 0) cb[poff[g]] = acc[m][g][r] + bv4[r];
                     }
                 }
 #pragma unroll
                 for (int g = 0; g < 4; ++g) acc[m][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
             }
-            tile += gridDim.x;
+            tile += tstep;
             chunk = 0;
-            stored = true;
         } else {
             ++chunk;
         }
-        // item it+1 must have landed before anyone reads it; item it+2 (issued above) may stay in flight.  The epilogue's
-        // own loads/stores are younger than that DMA, so after an epilogue everything is drained instead.
-        if (RING == 3 && have2 && !stored) wait_newest_in_flight<MT, GEO>(wv); else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
     }
 }
@@ -835,12 +842,14 @@ __global__ __launch_bounds__(128 * COT, 3) void conv3x3_wgrad_mfma_kernel(const 
     const long long xbs = sr.bs;
     const float* zplane = p.dz + (size_t)(co_ok ? my_co : 0) * HW;                    // + n*Cout*HW + y*W + x
     float4 xr[XSLOTS], zr[4];
+    unsigned live = 0;                      // bit s: slot s of the prefetched tile holds real data
 
     auto prefetch = [&](int tile) {
         int t = tile;
         const int tx = t % p.tiles_x; t /= p.tiles_x;
         const int ty = t % p.tiles_y; t /= p.tiles_y;
         const int n0 = t * G::IMG, x0 = tx * G::TW, y0 = ty * G::TH;
+        live = 0;
 #pragma unroll
         for (int s = 0; s < XSLOTS; ++s) {
             const int f = q + 8 * s;
@@ -848,8 +857,8 @@ __global__ __launch_bounds__(128 * COT, 3) void conv3x3_wgrad_mfma_kernel(const 
             const int row = rem / (G::LW / 4), c4 = rem % (G::LW / 4);
             const int y = y0 + row - 1, x = x0 - 4 + c4 * 4, n = n0 + img;
             const bool ok = f < XF4_PER_CH && ci_ok && n < p.N && y >= 0 && y < p.H && x >= 0 && x < p.W;
-            const float4 v = *reinterpret_cast<const float4*>(xplane + (ok ? (size_t)n * xbs + y * p.W + x : 0));
-            xr[s] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+            xr[s] = *reinterpret_cast<const float4*>(xplane + (ok ? (size_t)n * xbs + y * p.W + x : 0));
+            live |= ok ? (1u << s) : 0u;          // zeroed in commit(): touching xr here would wait for the load
         }
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
@@ -859,11 +868,21 @@ __global__ __launch_bounds__(128 * COT, 3) void conv3x3_wgrad_mfma_kernel(const 
             else if (GEO == 1) { n = n0; y = y0 + px / 16; x = x0 + px % 16; }
             else { n = n0 + px / 64; y = y0 + (px % 64) / 8; x = x0 + px % 8; }
             const bool ok = co_ok && n < p.N && y < p.H && x < p.W;
-            const float4 v = *reinterpret_cast<const float4*>(zplane + (ok ? (size_t)n * p.Cout * HW + y * p.W + x : 0));
-            zr[s] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+            zr[s] = *reinterpret_cast<const float4*>(zplane + (ok ? (size_t)n * p.Cout * HW + y * p.W + x : 0));
+            live |= ok ? (1u << (XSLOTS + s)) : 0u;
         }
     };
     auto commit = [&]() {       // registers -> LDS (8-byte aligned rows: stride PSX/PSZ == 2 mod 32)
+#pragma unroll
+        for (int s = 0; s < XSLOTS; ++s) {        // component-wise: a float4 ?: takes the array's address (scratch)
+            const bool l = (live >> s) & 1u;
+            xr[s].x = l ? xr[s].x : 0.f; xr[s].y = l ? xr[s].y : 0.f; xr[s].z = l ? xr[s].z : 0.f; xr[s].w = l ? xr[s].w : 0.f;
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const bool l = (live >> (XSLOTS + s)) & 1u;
+            zr[s].x = l ? zr[s].x : 0.f; zr[s].y = l ? zr[s].y : 0.f; zr[s].z = l ? zr[s].z : 0.f; zr[s].w = l ? zr[s].w : 0.f;
+        }
 #pragma unroll
         for (int s = 0; s < XSLOTS; ++s) {
             const int f = q + 8 * s;
@@ -978,6 +997,7 @@ __global__ __launch_bounds__(128 * COT, 3) void conv3x3_wgrad_lp_kernel(const Wg
     const long long xbs = sr.bs;
     const float* zplane = p.dz + (size_t)(co_ok ? my_co : 0) * HW;
     float4 xr[XSLOTS], zr[4];
+    unsigned live = 0;                      // bit s: slot s of the prefetched tile holds real data
 #pragma unroll
     for (int s = 0; s < XSLOTS; ++s) xr[s] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
@@ -988,6 +1008,7 @@ __global__ __launch_bounds__(128 * COT, 3) void conv3x3_wgrad_lp_kernel(const Wg
         const int tx = t % p.tiles_x; t /= p.tiles_x;
         const int ty = t % p.tiles_y; t /= p.tiles_y;
         const int n0 = t * G::IMG, x0 = tx * G::TW, y0 = ty * G::TH;
+        live = 0;
 #pragma unroll
         for (int s = 0; s < XSLOTS; ++s) {
             const int f = q + 8 * s;
@@ -995,8 +1016,8 @@ __global__ __launch_bounds__(128 * COT, 3) void conv3x3_wgrad_lp_kernel(const Wg
             const int row = rem / (G::LW / 4), c4 = rem % (G::LW / 4);
             const int y = y0 + row - 1, x = x0 - 4 + c4 * 4, n = n0 + img;
             const bool ok = f < XF4_PER_CH && ci_ok && n < p.N && y >= 0 && y < p.H && x >= 0 && x < p.W;
-            const float4 v = *reinterpret_cast<const float4*>(xplane + (ok ? (size_t)n * xbs + y * p.W + x : 0));
-            xr[s] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+            xr[s] = *reinterpret_cast<const float4*>(xplane + (ok ? (size_t)n * xbs + y * p.W + x : 0));
+            live |= ok ? (1u << s) : 0u;          // zeroed in commit(): touching xr here would wait for the load
         }
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
@@ -1006,11 +1027,21 @@ __global__ __launch_bounds__(128 * COT, 3) void conv3x3_wgrad_lp_kernel(const Wg
             else if (GEO == 1) { n = n0; y = y0 + px / 16; x = x0 + px % 16; }
             else { n = n0 + px / 64; y = y0 + (px % 64) / 8; x = x0 + px % 8; }
             const bool ok = co_ok && n < p.N && y < p.H && x < p.W;
-            const float4 v = *reinterpret_cast<const float4*>(zplane + (ok ? (size_t)n * p.Cout * HW + y * p.W + x : 0));
-            zr[s] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+            zr[s] = *reinterpret_cast<const float4*>(zplane + (ok ? (size_t)n * p.Cout * HW + y * p.W + x : 0));
+            live |= ok ? (1u << (XSLOTS + s)) : 0u;
         }
     };
     auto commit = [&]() {
+#pragma unroll
+        for (int s = 0; s < XSLOTS; ++s) {        // component-wise: a float4 ?: takes the array's address (scratch)
+            const bool l = (live >> s) & 1u;
+            xr[s].x = l ? xr[s].x : 0.f; xr[s].y = l ? xr[s].y : 0.f; xr[s].z = l ? xr[s].z : 0.f; xr[s].w = l ? xr[s].w : 0.f;
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const bool l = (live >> (XSLOTS + s)) & 1u;
+            zr[s].x = l ? zr[s].x : 0.f; zr[s].y = l ? zr[s].y : 0.f; zr[s].z = l ? zr[s].z : 0.f; zr[s].w = l ? zr[s].w : 0.f;
+        }
 #pragma unroll
         for (int s = 0; s < XSLOTS; ++s) {
             const int f = q + 8 * s;
@@ -1230,7 +1261,7 @@ int launch_igemm(const ConvP& p, int mblocks, hipStream_t st) {
             constexpr int RING = 2;     // measured: occupancy (3 blocks/CU) beats the deeper 3-slot prefetch on every layer
             static const int ring_env = getenv("MTBC_RING") ? atoi(getenv("MTBC_RING")) : 0;
             const int ring = ring_env ? ring_env : RING;
-            const size_t lds = ((size_t)ring * (KC * G::PS + MT * KC * 144) + SEGL_FLOATS) * sizeof(float);
+            const size_t lds = ((size_t)ring * (KC * G::PS + MT * KC * 144) + SEGL_FLOATS + MT * 16) * sizeof(float);
             static bool attr_set = false;
             if (!attr_set) {
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_igemm_dma_kernel<MT, GEO, 2>),
