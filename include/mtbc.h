@@ -84,6 +84,17 @@ int mtbc_conv3x3_pack_dgrad(const float* w, float* packed, int32_t Cin, int32_t 
  * dgrad = 0 packs the forward image, 1 the flipped/transposed dgrad image.  Pass as w_packed. */
 size_t mtbc_conv3x3_packed_lp_elems(int32_t Cin, int32_t Cout, int32_t dgrad);
 int mtbc_conv3x3_pack_lp(const float* w, void* packed, int32_t Cin, int32_t Cout, int32_t dgrad, int32_t compute, void* stream);
+
+/* Batched form of the four pack entry points above: every weight image a step needs in one launch (the images are
+ * re-made after each optimizer update; ~70 tiny launches cost more than the copies).  kind: 0 = mtbc_conv3x3_pack_fwd,
+ * 1 = _pack_dgrad, 2 = _pack_lp(dgrad=0), 3 = _pack_lp(dgrad=1); `compute` (1 bf16 | 2 fp16) is read for kinds 2,3. */
+typedef struct mtbc_pack_desc {
+    const float* w;
+    void* packed;
+    int32_t Cin, Cout;
+    int32_t kind, compute;
+} mtbc_pack_desc;
+int mtbc_conv3x3_pack_many(const mtbc_pack_desc* descs, int32_t n, void* stream);
 size_t mtbc_conv3x3_wgrad_workspace(const mtbc_conv3x3_args* a);
 int mtbc_conv3x3_fwd(const mtbc_conv3x3_args* a, void* stream);
 int mtbc_conv3x3_dgrad(const mtbc_conv3x3_args* a, void* stream);

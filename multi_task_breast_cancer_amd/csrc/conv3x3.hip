@@ -13,20 +13,24 @@
 namespace {
 
 // ------------------------------------------------------------------ packing
-__global__ void pack_fwd_kernel(const float* __restrict__ w, float* __restrict__ p, int Cin, int Cout, int total) {
-    int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= total) return;
+__device__ __forceinline__ void pack_fwd_elem(const float* __restrict__ w, float* __restrict__ p, int Cin, int Cout, int idx) {
     int i = idx & 15, tap = (idx >> 4) % 9, ci = (idx / 144) % Cin, mt = idx / (144 * Cin);
     int co = mt * 16 + i;
     p[idx] = co < Cout ? w[((size_t)co * Cin + ci) * 9 + tap] : 0.f;
 }
 // dgrad image: rows = input channels of the forward conv, K = (co, flipped tap)
-__global__ void pack_dgrad_kernel(const float* __restrict__ w, float* __restrict__ p, int Cin, int Cout, int total) {
-    int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= total) return;
+__device__ __forceinline__ void pack_dgrad_elem(const float* __restrict__ w, float* __restrict__ p, int Cin, int Cout, int idx) {
     int i = idx & 15, tap = (idx >> 4) % 9, co = (idx / 144) % Cout, mt = idx / (144 * Cout);
     int ci = mt * 16 + i;
     p[idx] = ci < Cin ? w[((size_t)co * Cin + ci) * 9 + (8 - tap)] : 0.f;
+}
+__global__ void pack_fwd_kernel(const float* __restrict__ w, float* __restrict__ p, int Cin, int Cout, int total) {
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < total) pack_fwd_elem(w, p, Cin, Cout, idx);
+}
+__global__ void pack_dgrad_kernel(const float* __restrict__ w, float* __restrict__ p, int Cin, int Cout, int total) {
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < total) pack_dgrad_elem(w, p, Cin, Cout, idx);
 }
 
 // ------------------------------------------------------------------ geometry
@@ -563,12 +567,10 @@ template <> struct GeoLP<0> { static constexpr int TH = 8, TW = 32, IMG = 1; };
 template <> struct GeoLP<1> { static constexpr int TH = 16, TW = 16, IMG = 1; };
 template <> struct GeoLP<2> { static constexpr int TH = 8, TW = 8, IMG = 4; };
 
-__global__ void pack_lp_kernel(const float* __restrict__ w, unsigned short* __restrict__ p, int Cin, int Cout, int dgrad,
-                               int f16, long long total) {
+__device__ __forceinline__ void pack_lp_elem(const float* __restrict__ w, unsigned short* __restrict__ p, int Cin, int Cout,
+                                             int dgrad, int f16, long long idx) {
     // fwd  : rows = co (Cout), K = ci      value = w[co][ci][tap]
     // dgrad: rows = ci (Cin),  K = co      value = w[co][ci][8-tap]
-    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= total) return;
     const int rows = dgrad ? Cin : Cout, red = dgrad ? Cout : Cin;
     const int nch = (red + LPKC - 1) / LPKC;
     const int kk = idx % LPROW; long long t = idx / LPROW;
@@ -583,6 +585,42 @@ __global__ void pack_lp_kernel(const float* __restrict__ w, unsigned short* __re
     if (f16) { _Float16 h = (_Float16)v; bits = *reinterpret_cast<unsigned short*>(&h); }
     else { __bf16 h = (__bf16)v; bits = *reinterpret_cast<unsigned short*>(&h); }
     p[idx] = bits;
+}
+__global__ void pack_lp_kernel(const float* __restrict__ w, unsigned short* __restrict__ p, int Cin, int Cout, int dgrad,
+                               int f16, long long total) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < total) pack_lp_elem(w, p, Cin, Cout, dgrad, f16, idx);
+}
+
+// Every weight image of a step in ONE launch (a step re-packs ~70 small tensors after each optimizer update; as 70
+// launches that is ~0.8 ms of launch latency).  The descriptors travel by value in the kernel arguments.
+constexpr int PACK_MANY = 96;
+struct PackManyP {
+    const float* w[PACK_MANY];
+    void* dst[PACK_MANY];
+    int Cin[PACK_MANY], Cout[PACK_MANY];
+    unsigned char kind[PACK_MANY];          // 0 fp32 fwd, 1 fp32 dgrad, 2 16-bit fwd, 3 16-bit dgrad
+    int first_block[PACK_MANY + 1];
+    int n, f16;
+};
+__global__ void pack_many_kernel(const PackManyP q) {
+    int d = 0;
+    while (d + 1 < q.n && (int)blockIdx.x >= q.first_block[d + 1]) ++d;          // scalar, uniform
+    const long long idx = (long long)((int)blockIdx.x - q.first_block[d]) * blockDim.x + threadIdx.x;
+    const int Cin = q.Cin[d], Cout = q.Cout[d], kind = q.kind[d];
+    const float* w = q.w[d];
+    if (kind < 2) {
+        const long long total = kind == 0 ? (long long)((Cout + 15) / 16) * Cin * 144 : (long long)((Cin + 15) / 16) * Cout * 144;
+        if (idx >= total) return;
+        if (kind == 0) pack_fwd_elem(w, static_cast<float*>(q.dst[d]), Cin, Cout, (int)idx);
+        else pack_dgrad_elem(w, static_cast<float*>(q.dst[d]), Cin, Cout, (int)idx);
+    } else {
+        const int dg = kind == 3;
+        const int rows = dg ? Cin : Cout, red = dg ? Cout : Cin;
+        const long long total = (long long)((rows + 15) / 16) * ((red + LPKC - 1) / LPKC) * 9 * 16 * LPROW;
+        if (idx >= total) return;
+        pack_lp_elem(w, static_cast<unsigned short*>(q.dst[d]), Cin, Cout, dg, q.f16, idx);
+    }
 }
 
 template <int MT, int GEO, bool F16>
@@ -1432,6 +1470,38 @@ int mtbc_conv3x3_pack_lp(const float* w, void* packed, int32_t Cin, int32_t Cout
     hipLaunchKernelGGL(pack_lp_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, (hipStream_t)stream, w,
                        reinterpret_cast<unsigned short*>(packed), Cin, Cout, dgrad, compute == 2 ? 1 : 0, total);
     MTBC_CHECK_LAUNCH();
+    return MTBC_OK;
+}
+
+int mtbc_conv3x3_pack_many(const mtbc_pack_desc* descs, int32_t n, void* stream) {
+    if (n < 0 || (n > 0 && !descs)) return MTBC_E_BADARG;
+    int done = 0;
+    while (done < n) {
+        PackManyP q;
+        q.n = 0; q.f16 = 0;
+        int blocks = 0, lp_mode = 0;
+        while (done < n && q.n < PACK_MANY) {
+            const mtbc_pack_desc& d = descs[done];
+            if (!d.w || !d.packed || d.Cin <= 0 || d.Cout <= 0 || d.kind < 0 || d.kind > 3) return MTBC_E_BADARG;
+            long long total;
+            if (d.kind < 2) total = d.kind == 0 ? (long long)mtbc_conv3x3_packed_elems(d.Cin, d.Cout) : (long long)mtbc_conv3x3_packed_dgrad_elems(d.Cin, d.Cout);
+            else {
+                if (d.compute != 1 && d.compute != 2) return MTBC_E_BADARG;
+                if (lp_mode && lp_mode != d.compute) break;          // one 16-bit format per launch
+                lp_mode = d.compute;
+                total = (long long)mtbc_conv3x3_packed_lp_elems(d.Cin, d.Cout, d.kind == 3);
+            }
+            const int i = q.n++;
+            q.w[i] = d.w; q.dst[i] = d.packed; q.Cin[i] = d.Cin; q.Cout[i] = d.Cout; q.kind[i] = (unsigned char)d.kind;
+            q.first_block[i] = blocks;
+            blocks += (int)cdiv64(total, 256);
+            ++done;
+        }
+        q.first_block[q.n] = blocks;
+        q.f16 = lp_mode == 2;
+        hipLaunchKernelGGL(pack_many_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, q);
+        MTBC_CHECK_LAUNCH();
+    }
     return MTBC_OK;
 }
 

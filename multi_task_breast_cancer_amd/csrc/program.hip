@@ -20,11 +20,30 @@ const char* mtbc_strerror(int code) {
     }
 }
 
+static inline bool is_pack(int32_t k) { return k == MTBC_OP_CONV3_PACK_FWD || k == MTBC_OP_CONV3_PACK_DGRAD || k == MTBC_OP_CONV3_PACK_LP; }
+
 int mtbc_program_run(const mtbc_op* ops, int32_t first, int32_t count, void* stream, int32_t* failed_index) {
     if (!ops || first < 0 || count < 0) return MTBC_E_BADARG;
     for (int32_t i = first; i < first + count; ++i) {
         const mtbc_op* o = &ops[i];
         int rc;
+        if (is_pack(o->kind)) {               // a run of weight-image ops becomes one batched launch
+            mtbc_pack_desc d[128];
+            int32_t n = 0;
+            while (n < 128 && i + n < first + count && is_pack(ops[i + n].kind)) {
+                const mtbc_op* q = &ops[i + n];
+                d[n].w = q->u.pack.w; d[n].packed = q->u.pack.packed; d[n].Cin = q->u.pack.Cin; d[n].Cout = q->u.pack.Cout;
+                d[n].compute = q->u.pack.compute;
+                d[n].kind = q->kind == MTBC_OP_CONV3_PACK_FWD ? 0 : q->kind == MTBC_OP_CONV3_PACK_DGRAD ? 1 : (q->u.pack.dgrad ? 3 : 2);
+                ++n;
+            }
+            if (n > 1) {
+                rc = mtbc_conv3x3_pack_many(d, n, stream);
+                if (rc != MTBC_OK) { if (failed_index) *failed_index = i; return rc; }
+                i += n - 1;
+                continue;
+            }
+        }
         switch (o->kind) {
             case MTBC_OP_CONV3_FWD: rc = mtbc_conv3x3_fwd(&o->u.conv3, stream); break;
             case MTBC_OP_CONV3_DGRAD: rc = mtbc_conv3x3_dgrad(&o->u.conv3, stream); break;

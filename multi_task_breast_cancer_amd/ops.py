@@ -69,6 +69,31 @@ def conv3x3_pack_lp(w: torch.Tensor, compute: int) -> Tuple[torch.Tensor, torch.
     return outs[0], outs[1]
 
 
+def conv3x3_pack_many(weights, compute: int = 0):
+    """All weight images of a list of conv weights in one launch (mtbc_conv3x3_pack_many).  Returns, per weight, the
+    (fwd, dgrad) images: fp32 tensors for compute 0, int16 tensors for compute 1 (bf16) / 2 (fp16)."""
+    lib = L.load()
+    descs = (L.PackDesc * (2 * len(weights)))()
+    outs = []
+    for i, w in enumerate(weights):
+        _chk(w)
+        cout, cin = w.shape[0], w.shape[1]
+        pair = []
+        for dg in (0, 1):
+            if compute:
+                t = torch.empty(lib.mtbc_conv3x3_packed_lp_elems(cin, cout, dg), dtype=torch.int16, device=w.device)
+            else:
+                n = lib.mtbc_conv3x3_packed_dgrad_elems(cin, cout) if dg else lib.mtbc_conv3x3_packed_elems(cin, cout)
+                t = torch.empty(n, dtype=torch.float32, device=w.device)
+            d = descs[2 * i + dg]
+            d.w, d.packed, d.Cin, d.Cout = w.data_ptr(), t.data_ptr(), cin, cout
+            d.kind, d.compute = (2 + dg if compute else dg), compute
+            pair.append(t)
+        outs.append(tuple(pair))
+    L.check(lib.mtbc_conv3x3_pack_many(descs, len(descs), _s()), "pack_many")
+    return outs
+
+
 def _conv_args(xs, w, N, H, W):
     a = L.Conv3x3Args()
     cin = sum(x.shape[1] for x in xs)

@@ -110,6 +110,19 @@ def test_conv3x3_mfma_equals_direct_kernel():
     _close(a, b.cpu(), 1e-5, 1e-5, "mfma vs direct")
 
 
+@pytest.mark.parametrize("compute", [0, 1, 2])
+def test_pack_many_equals_single_packs(compute):
+    """The batched weight-image launch must write bit-for-bit what the per-tensor entry points write (110 tensors:
+    more than one kernel-argument batch of 96)."""
+    g = torch.Generator().manual_seed(5)
+    shapes = [(24, 1), (24, 24), (48, 72), (40, 16), (96, 288), (7, 13), (384, 192)] * 8
+    ws = [torch.randn(co, ci, 3, 3, generator=g).to(DEV) for co, ci in shapes[:55]]
+    many = ops.conv3x3_pack_many(ws, compute)
+    for w, (pf, pd) in zip(ws, many):
+        rf, rd = ops.conv3x3_pack_lp(w, compute) if compute else ops.conv3x3_pack(w)
+        assert torch.equal(pf, rf) and torch.equal(pd, rd), tuple(w.shape)
+
+
 @pytest.mark.parametrize("N,C,H,W,affine,slope", [(2, 24, 256, 256, True, 0.1), (3, 5, 64, 64, False, 0.01),
                                                    (2, 7, 32, 32, True, 0.1), (4, 320, 8, 8, False, 0.01),
                                                    (2, 3, 16, 16, True, 0.1), (1, 2, 6, 5, True, 0.1),
