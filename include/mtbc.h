@@ -166,6 +166,7 @@ typedef struct {
     float* dw;       float* dbias;
     int32_t accumulate_dw;
     void* workspace; size_t workspace_bytes;
+    int32_t compute;                 /* k == 2 backward only: 0 = fp32 MFMA (exact), 1 = bf16, 2 = fp16 operands */
 } mtbc_convT_args;
 
 size_t mtbc_convT_wgrad_workspace(const mtbc_convT_args* a);

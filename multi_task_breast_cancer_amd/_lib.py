@@ -66,7 +66,7 @@ class ConvTArgs(C.Structure):
                 ("dx", C.c_void_p), ("dx_batch_stride", C.c_int64),
                 ("accumulate_dx", C.c_int32),
                 ("dw", C.c_void_p), ("dbias", C.c_void_p), ("accumulate_dw", C.c_int32),
-                ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("compute", C.c_int32)]
 
 
 class Conv1x1Args(C.Structure):

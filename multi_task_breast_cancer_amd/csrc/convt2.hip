@@ -1,0 +1,324 @@
+// ConvTranspose2d with kernel == stride == 2: dgrad and wgrad straight from HBM into MFMA fragments (gfx950).
+//
+// Replaces the backward of the up-convolutions (MONAI UpSample "deconv" in MTUNetPlusPlus.py:24-76 via
+// basic_unetplusplus UpCat; nn.ConvTranspose2d in MTnnUNet.py:96-100).  With k == s == 2 every output pixel has exactly
+// one contributing input pixel, so both gradients are plain GEMMs whose reduction index is CONTIGUOUS in memory:
+//
+//   dgrad  dX[ci][p]        = sum_k W[ci][k] * dY[k @ p]      k = (co, a, b): W rows are k-contiguous; for one input
+//                                                             pixel p = (i, jx) the four (a, b) values of a channel
+//                                                             are dY[co][2i+a][2jx+b]: two float2, and TWO neighbouring
+//                                                             pixels are one float4 per output row
+//   wgrad  dW[ci][(co,a,b)] = sum_p X[ci][p] * dY[(co,a,b)@p]  p-contiguous in X; in dY eight consecutive p of one
+//                                                             (co, a) are 16 consecutive floats with b interleaved
+//
+// v_mfma_f32_16x16x32_{bf16,f16} wants 8 consecutive reduction indices per lane, v_mfma_f32_16x16x4_f32 one -- and a
+// sum does not care how the 32 indices of a step are dealt to the 4 lane groups.  So ONE register layout serves both:
+// every lane loads 8 consecutive k (two float4), the 16-bit modes convert and issue one MFMA, the fp32 mode issues
+// eight 16x16x4 MFMAs (the i-th uses element i of every lane).  Nothing is staged in LDS and there is no barrier: a
+// wave is an independent task, its loads are whole 64..128-byte runs, and the next step's registers are in flight
+// while the current step is multiplied.  (The generic 64x64 LDS GEMM in pool_up.hip gathered dY 8 bytes at a time:
+// 26 TF on wgrad, 41 TF on dgrad.)  That kernel remains the fallback for k = 4, 8 and for odd shapes.
+#include "common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+// LP: 0 = fp32 (exact), 1 = bf16, 2 = fp16 operands; fp32 accumulation everywhere
+template <int LP> struct Frag;
+template <> struct Frag<0> {
+    float v[8];
+    __device__ __forceinline__ void set(const float* f) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = f[i];
+    }
+    static __device__ __forceinline__ f32x4 mma(const Frag& a, const Frag& b, f32x4 c) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.v[i], b.v[i], c, 0, 0, 0);
+        return c;
+    }
+};
+template <> struct Frag<1> {
+    bf16x8 v;
+    __device__ __forceinline__ void set(const float* f) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = (__bf16)f[i];
+    }
+    static __device__ __forceinline__ f32x4 mma(const Frag& a, const Frag& b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v, b.v, c, 0, 0, 0);
+    }
+};
+template <> struct Frag<2> {
+    f16x8 v;
+    __device__ __forceinline__ void set(const float* f) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = (_Float16)f[i];
+    }
+    static __device__ __forceinline__ f32x4 mma(const Frag& a, const Frag& b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(a.v, b.v, c, 0, 0, 0);
+    }
+};
+
+struct Ct2P {
+    int N, H, W, Cin, Cout;            // input H x W, output 2H x 2W
+    const float* x; long long xbs;
+    const float* w;                    // [Cin][Cout][2][2]
+    const float* dy; long long dybs;
+    float* dx; long long dxbs; int acc_dx;
+    float* partial;                    // wgrad: [nsplit][Cin][Cout][2][2]
+    int mblocks;                       // blocks of 48 input channels
+    int ctiles;                        // wgrad: tiles of 8 output channels
+    int steps_per_split, nsplit;       // wgrad: 32-pixel steps per split (over the flattened (n, step) list)
+    long long ntasks;
+};
+
+struct S0 { static constexpr int value = 0; };
+struct S1 { static constexpr int value = 1; };
+constexpr int MT = 3;                  // 16-row tiles of input channels per wave (48 = the U-Net++ channel quantum)
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
+// ------------------------------------------------------------------ dgrad
+// wave task = (48 input channels) x (32 consecutive input pixels); MFMA column j of tile E is pixel 2j, of tile O pixel
+// 2j+1, so one float4 of an output row feeds both.  Step = 8 output channels (32 k); lane group kg owns channels
+// 8s + 2kg, 8s + 2kg + 1.
+template <int LP>
+__global__ __launch_bounds__(256) void convT2_dgrad_kernel(const Ct2P p) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int j = lane & 15, kg = lane >> 4;
+    const long long task = (long long)blockIdx.x * 4 + wv;
+    if (task >= p.ntasks) return;
+    const int HW = p.H * p.W, oW = 2 * p.W, M4 = 4 * p.Cout;
+    const int groups = HW / 32;
+    const int mb = (int)(task % p.mblocks);
+    const long long t = task / p.mblocks;
+    const int g = (int)(t % groups), n = (int)(t / groups);
+    const int pix = g * 32 + 2 * j;
+    const int i = pix / p.W, jx = pix % p.W;
+    const float* dyn = p.dy + (size_t)n * p.dybs + (size_t)(2 * i) * oW + 2 * jx;      // + co*4HW + a*oW
+    const float* wrow[MT];
+    bool rok[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int ci = mb * 48 + m * 16 + j;
+        rok[m] = ci < p.Cin;
+        wrow[m] = p.w + (size_t)(rok[m] ? ci : 0) * M4;
+    }
+    f32x4 acc[MT][2];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) { acc[m][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[m][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+
+    const int nsteps = (p.Cout + 7) / 8;
+    // two register sets with COMPILE-TIME slot numbers (a runtime slot index would put the arrays in scratch)
+    float4 ra[2][MT][2], rb[2][4];
+    auto load = [&](int s, auto SL) {       // issue only; masking happens at use
+        constexpr int slot = decltype(SL)::value;
+        const int c0 = 8 * s + 2 * kg;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const float* q = c0 < p.Cout ? wrow[m] + 32 * s + 8 * kg : p.w;
+            ra[slot][m][0] = ld4(q); ra[slot][m][1] = ld4(q + 4);      // channels c0, c0 + 1 (Cout is even)
+        }
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int co = c0 + c < p.Cout ? c0 + c : 0;
+            const float* q = dyn + (size_t)co * 4 * HW;
+            rb[slot][2 * c] = ld4(q); rb[slot][2 * c + 1] = ld4(q + oW);
+        }
+    };
+    auto compute = [&](int s, auto SL) {
+        constexpr int cur = decltype(SL)::value;
+        const int c0 = 8 * s + 2 * kg;
+        const bool ok0 = c0 < p.Cout, ok1 = c0 + 1 < p.Cout;
+        float e[8], o[8];
+        e[0] = ok0 ? rb[cur][0].x : 0.f; e[1] = ok0 ? rb[cur][0].y : 0.f; e[2] = ok0 ? rb[cur][1].x : 0.f; e[3] = ok0 ? rb[cur][1].y : 0.f;
+        e[4] = ok1 ? rb[cur][2].x : 0.f; e[5] = ok1 ? rb[cur][2].y : 0.f; e[6] = ok1 ? rb[cur][3].x : 0.f; e[7] = ok1 ? rb[cur][3].y : 0.f;
+        o[0] = ok0 ? rb[cur][0].z : 0.f; o[1] = ok0 ? rb[cur][0].w : 0.f; o[2] = ok0 ? rb[cur][1].z : 0.f; o[3] = ok0 ? rb[cur][1].w : 0.f;
+        o[4] = ok1 ? rb[cur][2].z : 0.f; o[5] = ok1 ? rb[cur][2].w : 0.f; o[6] = ok1 ? rb[cur][3].z : 0.f; o[7] = ok1 ? rb[cur][3].w : 0.f;
+        Frag<LP> fe, fo;
+        fe.set(e); fo.set(o);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            float a[8];
+            const bool k0 = rok[m] && ok0, k1 = rok[m] && ok1;
+            a[0] = k0 ? ra[cur][m][0].x : 0.f; a[1] = k0 ? ra[cur][m][0].y : 0.f; a[2] = k0 ? ra[cur][m][0].z : 0.f; a[3] = k0 ? ra[cur][m][0].w : 0.f;
+            a[4] = k1 ? ra[cur][m][1].x : 0.f; a[5] = k1 ? ra[cur][m][1].y : 0.f; a[6] = k1 ? ra[cur][m][1].z : 0.f; a[7] = k1 ? ra[cur][m][1].w : 0.f;
+            Frag<LP> fa;
+            fa.set(a);
+            acc[m][0] = Frag<LP>::mma(fa, fe, acc[m][0]);
+            acc[m][1] = Frag<LP>::mma(fa, fo, acc[m][1]);
+        }
+    };
+    load(0, S0{});
+    for (int s = 0; s < nsteps; s += 2) {
+        if (s + 1 < nsteps) load(s + 1, S1{});
+        compute(s, S0{});
+        if (s + 1 < nsteps) {
+            if (s + 2 < nsteps) load(s + 2, S0{});
+            compute(s + 1, S1{});
+        }
+    }
+    // rows kg*4 + r of tile m, column j -> pixels (2j, 2j+1): one float2 per row
+    float* dxn = p.dx + (size_t)n * p.dxbs + g * 32 + 2 * j;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int ci = mb * 48 + m * 16 + kg * 4 + r;
+            if (ci >= p.Cin) continue;
+            float2* d = reinterpret_cast<float2*>(dxn + (size_t)ci * HW);
+            float2 v = make_float2(acc[m][0][r], acc[m][1][r]);
+            if (p.acc_dx) { const float2 old = *d; v.x += old.x; v.y += old.y; }
+            *d = v;
+        }
+}
+
+// ------------------------------------------------------------------ wgrad
+// wave task = (48 input channels) x (8 output channels) x (a run of 32-pixel steps of the flattened (image, step)
+// list).  MFMA column j is (co = 8*ct + j/2, a = j%2); b = 0 and b = 1 are two accumulator tiles fed by the even /
+// odd elements of the same 64 bytes.  Lane group kg owns pixels 8kg .. 8kg+7 of the step.
+template <int LP>
+__global__ __launch_bounds__(256) void convT2_wgrad_kernel(const Ct2P p) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int j = lane & 15, kg = lane >> 4;
+    const long long task = (long long)blockIdx.x * 4 + wv;
+    if (task >= p.ntasks) return;
+    const int HW = p.H * p.W, oW = 2 * p.W;
+    const int steps_per_img = HW / 32;
+    const int ct = (int)(task % p.ctiles);
+    const long long t = task / p.ctiles;
+    const int mb = (int)(t % p.mblocks), split = (int)(t / p.mblocks);
+    const int total_steps = p.N * steps_per_img;
+    const int g0 = split * p.steps_per_split, g1 = min(total_steps, g0 + p.steps_per_split);
+
+    const float* xrow[MT];
+    bool rok[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int ci = mb * 48 + m * 16 + j;
+        rok[m] = ci < p.Cin;
+        xrow[m] = p.x + (size_t)(rok[m] ? ci : 0) * HW + 8 * kg;
+    }
+    const int co = ct * 8 + (j >> 1);
+    const bool cok = co < p.Cout;
+    const float* dcol = p.dy + (size_t)(cok ? co : 0) * 4 * HW + (size_t)(j & 1) * oW;
+
+    f32x4 acc[MT][2];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) { acc[m][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[m][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+
+    float4 ra[2][MT][2], rb[2][4];
+    auto load = [&](int g, auto SL) {
+        constexpr int slot = decltype(SL)::value;
+        const int n = g / steps_per_img, st = g % steps_per_img;
+        const int pix = st * 32 + 8 * kg;
+        const int i = pix / p.W, jx = pix % p.W;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const float* q = xrow[m] + (size_t)n * p.xbs + st * 32;
+            ra[slot][m][0] = ld4(q); ra[slot][m][1] = ld4(q + 4);
+        }
+        const float* q = dcol + (size_t)n * p.dybs + (size_t)(2 * i) * oW + 2 * jx;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) rb[slot][k] = ld4(q + 4 * k);
+    };
+    auto compute = [&](auto SL) {
+        constexpr int cur = decltype(SL)::value;
+        float b0[8], b1[8];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            b0[2 * k] = cok ? rb[cur][k].x : 0.f; b1[2 * k] = cok ? rb[cur][k].y : 0.f;
+            b0[2 * k + 1] = cok ? rb[cur][k].z : 0.f; b1[2 * k + 1] = cok ? rb[cur][k].w : 0.f;
+        }
+        Frag<LP> f0, f1;
+        f0.set(b0); f1.set(b1);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            float a[8];
+            a[0] = rok[m] ? ra[cur][m][0].x : 0.f; a[1] = rok[m] ? ra[cur][m][0].y : 0.f; a[2] = rok[m] ? ra[cur][m][0].z : 0.f; a[3] = rok[m] ? ra[cur][m][0].w : 0.f;
+            a[4] = rok[m] ? ra[cur][m][1].x : 0.f; a[5] = rok[m] ? ra[cur][m][1].y : 0.f; a[6] = rok[m] ? ra[cur][m][1].z : 0.f; a[7] = rok[m] ? ra[cur][m][1].w : 0.f;
+            Frag<LP> fa;
+            fa.set(a);
+            acc[m][0] = Frag<LP>::mma(fa, f0, acc[m][0]);
+            acc[m][1] = Frag<LP>::mma(fa, f1, acc[m][1]);
+        }
+    };
+    if (g0 < g1) load(g0, S0{});
+    for (int g = g0; g < g1; g += 2) {
+        if (g + 1 < g1) load(g + 1, S1{});
+        compute(S0{});
+        if (g + 1 < g1) {
+            if (g + 2 < g1) load(g + 2, S0{});
+            compute(S1{});
+        }
+    }
+    if (!cok) return;
+    float* part = p.partial + (size_t)split * p.Cin * p.Cout * 4;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int ci = mb * 48 + m * 16 + kg * 4 + r;
+            if (ci >= p.Cin) continue;
+            *reinterpret_cast<float2*>(part + ((size_t)ci * p.Cout + co) * 4 + 2 * (j & 1)) = make_float2(acc[m][0][r], acc[m][1][r]);
+        }
+}
+
+bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
+
+void fill(const mtbc_convT_args* a, Ct2P* p) {
+    p->N = a->N; p->H = a->H; p->W = a->W; p->Cin = a->Cin; p->Cout = a->Cout;
+    p->x = a->x; p->xbs = a->x_batch_stride; p->w = a->w; p->dy = a->dy; p->dybs = a->dy_batch_stride;
+    p->dx = a->dx; p->dxbs = a->dx_batch_stride; p->acc_dx = a->accumulate_dx; p->partial = nullptr;
+    p->mblocks = cdiv(a->Cin, 48); p->ctiles = cdiv(a->Cout, 8); p->steps_per_split = 1; p->nsplit = 1; p->ntasks = 0;
+}
+
+}  // namespace
+
+// eligibility of the direct-to-fragment kernels (k == 2 only); everything else takes the generic GEMM in pool_up.hip
+bool mtbc_i_convT2_dgrad_ok(const mtbc_convT_args* a) {
+    const int HW = a->H * a->W;
+    return a->k == 2 && HW % 32 == 0 && a->W % 2 == 0 && a->Cout % 2 == 0 && al16(a->dy) && al16(a->w) && al16(a->dx) &&
+           a->dy_batch_stride % 4 == 0 && a->dx_batch_stride % 2 == 0;
+}
+bool mtbc_i_convT2_wgrad_ok(const mtbc_convT_args* a) {
+    const int HW = a->H * a->W;
+    return a->k == 2 && HW % 32 == 0 && a->W % 8 == 0 && al16(a->dy) && al16(a->x) && a->dy_batch_stride % 4 == 0 &&
+           a->x_batch_stride % 4 == 0;
+}
+// 32-pixel steps per split: ~4096 wave tasks in flight, at least 8 steps each (the partial sums are real traffic)
+void mtbc_i_convT2_wgrad_plan(const mtbc_convT_args* a, int* steps_per_split, int* nsplit) {
+    const long long total_steps = (long long)a->N * (a->H * a->W / 32);
+    const long long per_split_tasks = (long long)cdiv(a->Cin, 48) * cdiv(a->Cout, 8);
+    long long want = cdiv64(4096, per_split_tasks);
+    if (want < 1) want = 1;
+    long long sps = cdiv64(total_steps, want);
+    if (sps < 8) sps = 8;
+    if (sps > total_steps) sps = total_steps;
+    *steps_per_split = (int)sps;
+    *nsplit = (int)cdiv64(total_steps, sps);
+}
+
+int mtbc_i_convT2_dgrad(const mtbc_convT_args* a, int compute, hipStream_t st) {
+    Ct2P p; fill(a, &p);
+    p.ntasks = (long long)p.mblocks * a->N * (a->H * a->W / 32);
+    const unsigned blocks = (unsigned)cdiv64(p.ntasks, 4);
+    if (compute == 1) hipLaunchKernelGGL(convT2_dgrad_kernel<1>, dim3(blocks), dim3(256), 0, st, p);
+    else if (compute == 2) hipLaunchKernelGGL(convT2_dgrad_kernel<2>, dim3(blocks), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(convT2_dgrad_kernel<0>, dim3(blocks), dim3(256), 0, st, p);
+    MTBC_CHECK_LAUNCH();
+    return MTBC_OK;
+}
+
+int mtbc_i_convT2_wgrad(const mtbc_convT_args* a, int compute, float* partial, int steps_per_split, int nsplit, hipStream_t st) {
+    Ct2P p; fill(a, &p);
+    p.partial = partial; p.steps_per_split = steps_per_split; p.nsplit = nsplit;
+    p.ntasks = (long long)p.mblocks * p.ctiles * nsplit;
+    const unsigned blocks = (unsigned)cdiv64(p.ntasks, 4);
+    if (compute == 1) hipLaunchKernelGGL(convT2_wgrad_kernel<1>, dim3(blocks), dim3(256), 0, st, p);
+    else if (compute == 2) hipLaunchKernelGGL(convT2_wgrad_kernel<2>, dim3(blocks), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(convT2_wgrad_kernel<0>, dim3(blocks), dim3(256), 0, st, p);
+    MTBC_CHECK_LAUNCH();
+    return MTBC_OK;
+}

@@ -8,6 +8,7 @@
 // Replaces nn.ConvTranspose2d (MTnnUNet.py:96-100,106-116; MONAI UpSample "deconv"), nn.MaxPool2d(2,2)
 // (MTnnUNet.py:103; MONAI Down) and the 1x1 output convs (MTnnUNet.py:106-118; MTUNetPlusPlus.py:73-76).
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -341,8 +342,10 @@ int mtbc_convT_fwd(const mtbc_convT_args* a, void* stream) {
 int mtbc_convT_dgrad(const mtbc_convT_args* a, void* stream) {
     CtP p; int rc = fill_ct(a, &p); if (rc) return rc;
     if (!p.dy || !p.w || !p.dx) return MTBC_E_BADARG;
-    dim3 grid(cdiv(a->H * a->W, 64), cdiv(a->Cin, 64), a->N);
     hipStream_t st = (hipStream_t)stream;
+    static const bool generic = getenv("MTBC_CONVT_GENERIC") != nullptr;      // A/B switch
+    if (!generic && mtbc_i_convT2_dgrad_ok(a)) return mtbc_i_convT2_dgrad(a, a->compute, st);
+    dim3 grid(cdiv(a->H * a->W, 64), cdiv(a->Cin, 64), a->N);
     if (a->k == 2) hipLaunchKernelGGL(convT_dgrad_kernel<2>, grid, dim3(256), 0, st, p);
     else if (a->k == 4) hipLaunchKernelGGL(convT_dgrad_kernel<4>, grid, dim3(256), 0, st, p);
     else hipLaunchKernelGGL(convT_dgrad_kernel<8>, grid, dim3(256), 0, st, p);
@@ -352,7 +355,12 @@ int mtbc_convT_dgrad(const mtbc_convT_args* a, void* stream) {
 size_t mtbc_convT_wgrad_workspace(const mtbc_convT_args* a) {
     CtP p; if (fill_ct(a, &p)) return 0;
     int S, cols; plan_ct_wgrad(a, &S, &cols);
-    return ((size_t)a->N * S * a->Cin * p.M + (a->dbias ? (size_t)a->N * a->Cout : 0)) * sizeof(float);
+    size_t splits = (size_t)a->N * S;
+    if (mtbc_i_convT2_wgrad_ok(a)) {          // pointer alignment may still send the call to the generic kernel: cover both
+        int sps, ns; mtbc_i_convT2_wgrad_plan(a, &sps, &ns);
+        if ((size_t)ns > splits) splits = ns;
+    }
+    return (splits * a->Cin * p.M + (a->dbias ? (size_t)a->N * a->Cout : 0)) * sizeof(float);
 }
 int mtbc_convT_wgrad(const mtbc_convT_args* a, void* stream) {
     CtP p; int rc = fill_ct(a, &p); if (rc) return rc;
@@ -360,13 +368,19 @@ int mtbc_convT_wgrad(const mtbc_convT_args* a, void* stream) {
     if (!a->workspace || a->workspace_bytes < mtbc_convT_wgrad_workspace(a)) return MTBC_E_WORKSPACE;
     int S, cols; plan_ct_wgrad(a, &S, &cols);
     p.partial = reinterpret_cast<float*>(a->workspace); p.S = S; p.cols_per_split = cols;
-    const int nsplit = a->N * S;
-    dim3 grid(cdiv(p.M, 64), cdiv(a->Cin, 64), nsplit);
+    int nsplit = a->N * S;
     hipStream_t st = (hipStream_t)stream;
-    if (a->k == 2) hipLaunchKernelGGL(convT_wgrad_kernel<2>, grid, dim3(256), 0, st, p);
-    else if (a->k == 4) hipLaunchKernelGGL(convT_wgrad_kernel<4>, grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL(convT_wgrad_kernel<8>, grid, dim3(256), 0, st, p);
-    MTBC_CHECK_LAUNCH();
+    static const bool generic = getenv("MTBC_CONVT_GENERIC") != nullptr;      // A/B switch
+    if (!generic && mtbc_i_convT2_wgrad_ok(a)) {
+        int sps; mtbc_i_convT2_wgrad_plan(a, &sps, &nsplit);
+        rc = mtbc_i_convT2_wgrad(a, a->compute, p.partial, sps, nsplit, st); if (rc) return rc;
+    } else {
+        dim3 grid(cdiv(p.M, 64), cdiv(a->Cin, 64), nsplit);
+        if (a->k == 2) hipLaunchKernelGGL(convT_wgrad_kernel<2>, grid, dim3(256), 0, st, p);
+        else if (a->k == 4) hipLaunchKernelGGL(convT_wgrad_kernel<4>, grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL(convT_wgrad_kernel<8>, grid, dim3(256), 0, st, p);
+        MTBC_CHECK_LAUNCH();
+    }
     const size_t wel = (size_t)a->Cin * p.M;
     rc = mtbc_i_splitk_reduce(p.partial, a->dw, nsplit, wel, a->accumulate_dw, st); if (rc) return rc;
     if (a->dbias) {

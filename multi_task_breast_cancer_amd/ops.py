@@ -228,21 +228,23 @@ def convT_fwd(x, w, bias, k):
     return y
 
 
-def convT_dgrad(x, w, dy, k, dx=None, accumulate=False):
+def convT_dgrad(x, w, dy, k, dx=None, accumulate=False, compute=0):
     _chk(x, w, dy, dx)
     if dx is None:
         dx = torch.empty_like(x)
     a = _ct_args(x, w, k)
+    a.compute = compute
     a.dy, a.dy_batch_stride, a.dx, a.dx_batch_stride, a.accumulate_dx = dy.data_ptr(), dy[0].numel(), dx.data_ptr(), x[0].numel(), int(accumulate)
     L.check(L.load().mtbc_convT_dgrad(C.byref(a), _s()), "convT_dgrad")
     return dx
 
 
-def convT_wgrad(x, w, dy, k, want_bias=True):
+def convT_wgrad(x, w, dy, k, want_bias=True, compute=0):
     _chk(x, w, dy)
     dw = torch.empty_like(w)
     db = torch.empty(w.shape[1], dtype=torch.float32, device=x.device) if want_bias else None
     a = _ct_args(x, w, k)
+    a.compute = compute
     a.dy, a.dy_batch_stride, a.dw, a.dbias = dy.data_ptr(), dy[0].numel(), dw.data_ptr(), _p(db)
     ws = _ws(L.load().mtbc_convT_wgrad_workspace(C.byref(a)), x.device)
     a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel() * 4

@@ -178,7 +178,9 @@ def test_maxpool_fwd_bwd(N, C, H, W):
 
 
 @pytest.mark.parametrize("N,Cin,Cout,H,W,k", [(2, 48, 48, 16, 16, 2), (1, 96, 48, 8, 8, 2), (2, 20, 12, 6, 10, 2),
-                                               (2, 64, 64, 8, 8, 4), (1, 128, 128, 4, 4, 8), (3, 32, 32, 5, 3, 4)])
+                                               (2, 64, 64, 8, 8, 4), (1, 128, 128, 4, 4, 8), (3, 32, 32, 5, 3, 4),
+                                               (3, 40, 6, 8, 16, 2), (2, 100, 52, 16, 8, 2), (5, 48, 48, 32, 32, 2),
+                                               (2, 16, 2, 4, 8, 2), (1, 192, 96, 8, 8, 2)])
 def test_convT_fwd_dgrad_wgrad(N, Cin, Cout, H, W, k):
     g = _g(Cin + k)
     x = torch.randn(N, Cin, H, W, generator=g)
@@ -196,6 +198,16 @@ def test_convT_fwd_dgrad_wgrad(N, Cin, Cout, H, W, k):
     dw, db = ops.convT_wgrad(xd, wd, dyd, k)
     _close(dw, wr.grad, 1e-4, 2e-5 * max(1.0, wr.grad.abs().max().item()), "convT wgrad")
     _close(db, br.grad, 1e-4, 1e-4 * max(1.0, br.grad.abs().max().item()), "convT dbias")
+    if k == 2 and (H * W) % 32 == 0 and W % 8 == 0 and Cout % 2 == 0:
+        # 16-bit operand modes of the k == 2 backward kernels (shapes the generic fp32 kernel takes ignore `compute`):
+        # the same sums over rounded operands
+        for mode, lp in ((1, torch.bfloat16), (2, torch.float16)):
+            r = lambda t: t.to(lp).float()
+            xq, wq, dq = r(x).requires_grad_(True), r(w).requires_grad_(True), r(dy)
+            F.conv_transpose2d(xq, wq, None, stride=k).backward(dq)
+            _close(ops.convT_dgrad(xd, wd, dyd, k, compute=mode), xq.grad, 2e-5, 5e-5, f"convT dgrad lp{mode}")
+            dwq, _ = ops.convT_wgrad(xd, wd, dyd, k, compute=mode)
+            _close(dwq, wq.grad, 1e-4, 2e-5 * max(1.0, wq.grad.abs().max().item()), f"convT wgrad lp{mode}")
 
 
 @pytest.mark.parametrize("N,Cin,Cout,H,W", [(2, 16, 1, 32, 32), (1, 24, 1, 64, 64), (2, 12, 3, 8, 8), (1, 20, 10, 4, 4)])
