@@ -7,8 +7,11 @@
 
 One "step" = one optimisation step (pack -> fwd -> Dice+Focal -> bwd -> [all-reduce] -> Adam) on a per-GPU batch
 of 32 synthetic images already resident in HBM (BASELINE.json configs[1]; weak scaling: global batch = 32*N).
-Rank 0 prints ONE JSON line; `roofline` is measured live with HIP events around the dominant kernel (the fp32-MFMA
-implicit-GEMM conv3x3, forward + dgrad launches), `cpu_baseline` times the CPU oracle on the host cores.
+Default compute mode is the one configs[1] names: bf16 MFMA operands in the 3x3 convs (fp32 storage / accumulation
+/ norm statistics / losses / Adam); at N=1 the same step is also timed in the fp32 parity mode (`fp32_parity_mode`).
+Rank 0 prints ONE JSON line; `roofline` is measured live with HIP events around the dominant kernel family (the
+implicit-GEMM conv3x3, forward + dgrad launches) and priced against the roof the kernel's arithmetic intensity puts it
+under (fp32: MFMA; bf16: HBM); `cpu_baseline` times the CPU oracle on the host cores.
 """
 from __future__ import annotations
 
@@ -25,6 +28,7 @@ import torch  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3        # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
 PEAK_16BIT_MFMA_TFLOPS = 2500.0     # bf16 / fp16 dense
+PEAK_HBM_BYTES = 8.0e12             # HBM3E spec (6.29 TB/s is the measured copy rate, MI355X_MICROARCH.md)
 
 
 def conv_flops(op) -> float:
@@ -58,18 +62,163 @@ def note(msg: str) -> None:
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
+def conv_bytes(op, kind, L) -> float:
+    """Algorithmic HBM bytes of one conv3x3 launch: every operand plane once, fp32 storage."""
+    a = op.u.conv3
+    plane = a.N * a.H * a.W * 4.0
+    w = 9.0 * a.Cin * a.Cout * 4
+    if kind == L.OP_CONV3_FWD:
+        return (a.Cin + a.Cout) * plane + w
+    if kind == L.OP_CONV3_WGRAD:
+        return (a.Cin + a.Cout) * plane + w
+    acc = sum(a.in_[i].channels for i in range(a.n_in) if a.in_[i].accumulate)      # fan-in sums re-read dx
+    return (a.Cin + a.Cout + acc) * plane + w
+
+
+def time_op(prog, i, reps=3) -> float:
+    """Seconds per launch of op i of a step program, HIP events on the stream the program runs on."""
+    ms = 0.0
+    for _ in range(reps):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record(); prog.run(i, 1); e.record(); e.synchronize()
+        ms += s.elapsed_time(e)
+    return ms / reps / 1e3
+
+
+def run_mode(args, dtype, dev, rank, world, dist, want_roofline):
+    """Build the model in one compute mode, time `steps` optimisation steps, optionally price the kernels."""
+    from multi_task_breast_cancer_amd import _lib
+    from multi_task_breast_cancer_amd.experiment_init import init_multitask_model, init_optimizer
+    from multi_task_breast_cancer_amd.miscellany import seed_everything
+    from multi_task_breast_cancer_amd.synthetic import synthetic_batch
+    from multi_task_breast_cancer_amd.trainer import FusedTrainStep
+
+    seed_everything(1993)                                          # identical initial weights on every rank
+    model = init_multitask_model(args.arch, sequences=1, regions=1, n_classes=3, deep_supervision=True).to(dev)
+    model.set_compute(dtype)
+    opt = init_optimizer(model, "Adam", 1e-4)
+    step = FusedTrainStep(model, opt, alpha=0.5, inversely_weighted=True, distributed=world > 1)
+    batches = [synthetic_batch(args.batch, args.size, args.size, seed=s, device=dev, rank=rank) for s in range(2)]
+
+    def sync():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    note(f"[{dtype}] rank {rank}/{world}: model + {len(batches)} synthetic batches ready; warm-up x{args.warmup}")
+    for i in range(args.warmup):
+        step(*batches[i % 2])
+    sync()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(*batches[i % 2])
+    sync()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    step.check_nan()
+    losses = step.losses.cpu().tolist()
+    note(f"[{dtype}] timed {args.steps} steps in {dt:.3f} s; loss {losses[0]:.5f}")
+    res = {"value": round(args.batch * world * args.steps / dt, 2), "ms_per_step": round(dt / args.steps * 1e3, 3),
+           "final_loss": round(losses[0], 6)}
+    if not want_roofline:
+        return res
+
+    st = step._st
+    L = _lib
+    peak = PEAK_F32_MFMA_TFLOPS if dtype == "f32" else PEAK_16BIT_MFMA_TFLOPS
+    # ---- the 3x3 convolutions: every MFMA launch of a step, timed one by one
+    fam = {"igemm": [0.0, 0.0, 0.0, 0], "wgrad": [0.0, 0.0, 0.0, 0]}          # flops, bytes, seconds, launches
+    for prog in (st.programs["fwd"], st.programs["bwd"]):
+        for i in range(prog.n):
+            op = prog.array[i]
+            c = op.u.conv3
+            if op.kind in (L.OP_CONV3_FWD, L.OP_CONV3_DGRAD) and c.w_packed:          # Cin=1 stem runs the direct kernel
+                f = fam["igemm"]
+            elif op.kind == L.OP_CONV3_WGRAD and c.Cin >= 8:
+                f = fam["wgrad"]
+            else:
+                continue
+            f[0] += conv_flops(op); f[1] += conv_bytes(op, op.kind, L); f[2] += time_op(prog, i); f[3] += 1
+    fl = fam["igemm"][0] + fam["wgrad"][0]
+    by = fam["igemm"][1] + fam["wgrad"][1]
+    sec = fam["igemm"][2] + fam["wgrad"][2]
+    balance = peak * 1e12 / PEAK_HBM_BYTES                       # FLOP per byte at which the two roofs cross
+    bound = "mfma" if fl / by > balance else "hbm"
+    names = {"f32": ("conv3x3_igemm_dma_kernel", "conv3x3_wgrad_mfma_kernel"),
+             "bf16": ("conv3x3_igemm_lp_kernel", "conv3x3_wgrad_lp_kernel"),
+             "f16": ("conv3x3_igemm_lp_kernel", "conv3x3_wgrad_lp_kernel")}[dtype]
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", f"r01_hbm_traffic_{dtype}.json")
+    if os.path.exists(tpath):
+        ks = json.load(open(tpath))["kernels"]
+        sel = [v for k, v in ks.items() if k.startswith(names[0])]
+        if sel:
+            w = sum(v["launches_in_trace"] for v in sel)
+            traffic = round(sum(v["hbm_bytes_per_launch"] * v["launches_in_trace"] for v in sel) / w)
+    ig = fam["igemm"]
+    roof = {"bound": bound, "kernel": f"{names[0]} (fwd + dgrad launches of the 3x3 convs)",
+            "arithmetic_intensity_flop_per_byte": round(ig[0] / ig[1], 1), "roof_crossover_flop_per_byte": round(balance, 1)}
+    if bound == "mfma":
+        roof.update({"achieved": round(ig[0] / ig[2] / 1e12, 2), "peak": peak, "unit": "TFLOP/s",
+                     "frac": round(ig[0] / ig[2] / 1e12 / peak, 4)})
+    else:
+        roof.update({"achieved": round(ig[1] / ig[2] / 1e9, 1), "peak": PEAK_HBM_BYTES / 1e9, "unit": "GB/s",
+                     "frac": round(ig[1] / ig[2] / PEAK_HBM_BYTES, 4)})
+    roof.update({"traffic": traffic, "launches_per_step": ig[3], "avg_launch_ms": round(ig[2] / ig[3] * 1e3, 4),
+                 "algorithmic_gflop_per_launch": round(ig[0] / ig[3] / 1e9, 3),
+                 "algorithmic_MB_per_launch": round(ig[1] / ig[3] / 1e6, 1),
+                 "tflops": round(ig[0] / ig[2] / 1e12, 2), "frac_of_mfma_peak": round(ig[0] / ig[2] / 1e12 / peak, 4),
+                 "GBps": round(ig[1] / ig[2] / 1e9, 1), "frac_of_hbm_peak": round(ig[1] / ig[2] / PEAK_HBM_BYTES, 4)})
+    wg = fam["wgrad"]
+    roof["wgrad"] = {"kernel": names[1] + " + split-K reduce", "tflops": round(wg[0] / wg[2] / 1e12, 2),
+                     "frac_of_mfma_peak": round(wg[0] / wg[2] / 1e12 / peak, 4), "GBps": round(wg[1] / wg[2] / 1e9, 1),
+                     "frac_of_hbm_peak": round(wg[1] / wg[2] / PEAK_HBM_BYTES, 4), "launches_per_step": wg[3],
+                     "avg_launch_ms": round(wg[2] / max(1, wg[3]) * 1e3, 4)}
+    roof["all_3x3_conv"] = {"tflops": round(fl / sec / 1e12, 2), "frac_of_mfma_peak": round(fl / sec / 1e12 / peak, 4),
+                            "share_of_step": round(sec / (dt / args.steps), 3)}
+    res["roofline"] = roof
+    # ---- HBM-bound kernels named by north_star (norm / upsample): algorithmic bytes (SURVEY 8d) / HIP-event time
+    hb = {"in_fwd": [0.0, 0.0, 0], "in_bwd": [0.0, 0.0, 0], "convT_fwd": [0.0, 0.0, 0], "convT_dgrad": [0.0, 0.0, 0],
+          "convT_wgrad": [0.0, 0.0, 0]}
+    for pname in ("fwd", "bwd"):
+        prog = st.programs[pname]
+        for i in range(prog.n):
+            op = prog.array[i]
+            if op.kind == L.OP_IN_FWD:
+                a = op.u.inorm; e = a.N * a.C * a.H * a.W * 4
+                h = hb["in_fwd"]; h[0] += 2 * e; h[1] += time_op(prog, i); h[2] += 1       # read z, write y
+            elif op.kind == L.OP_IN_BWD:
+                a = op.u.inorm; e = a.N * a.C * a.H * a.W * 4
+                h = hb["in_bwd"]; h[0] += 3 * e; h[1] += time_op(prog, i); h[2] += 1       # read z, dy; write dz
+            elif op.kind in (L.OP_CONVT_FWD, L.OP_CONVT_DGRAD, L.OP_CONVT_WGRAD):
+                a = op.u.convT; px = a.N * a.H * a.W * 4
+                h = hb[{L.OP_CONVT_FWD: "convT_fwd", L.OP_CONVT_DGRAD: "convT_dgrad", L.OP_CONVT_WGRAD: "convT_wgrad"}[op.kind]]
+                h[0] += px * (a.Cin + a.Cout * a.k * a.k); h[1] += time_op(prog, i); h[2] += 1
+    res["roofline_hbm"] = {k: {"bound": "hbm", "achieved": round(v[0] / v[1] / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+                               "frac": round(v[0] / v[1] / 8e12, 4), "launches_per_step": v[2],
+                               "algorithmic_MB_per_launch": round(v[0] / max(1, v[2]) / 1e6, 1)}
+                           for k, v in hb.items() if v[2]}
+    return res
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--arch", default="MTUNetPlusPlus")
     ap.add_argument("--batch", type=int, default=32, help="per-GPU batch")
     ap.add_argument("--size", type=int, default=256)
-    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16", "f16"],
-                    help="conv3x3 MFMA operand type (storage/accumulation always fp32)")
+    ap.add_argument("--dtype", default="bf16", choices=["f32", "bf16", "f16"],
+                    help="MFMA operand type of the 3x3 convs (BASELINE.json configs[1] names bf16); storage, "
+                         "accumulation, norm statistics, losses and Adam are fp32 in every mode; f32 = the parity mode")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-parity-mode", action="store_true", help="skip the extra fp32 (parity mode) measurement at N=1")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -88,133 +237,30 @@ def main() -> None:
         dist = dist_
         dist.init_process_group("nccl", device_id=dev)
 
-    from multi_task_breast_cancer_amd import _lib
-    from multi_task_breast_cancer_amd.experiment_init import init_multitask_model, init_optimizer
-    from multi_task_breast_cancer_amd.miscellany import seed_everything
-    from multi_task_breast_cancer_amd.synthetic import synthetic_batch
-    from multi_task_breast_cancer_amd.trainer import FusedTrainStep
-
-    seed_everything(1993)                                          # identical initial weights on every rank
-    model = init_multitask_model(args.arch, sequences=1, regions=1, n_classes=3, deep_supervision=True).to(dev)
-    model.set_compute(args.dtype)
-    opt = init_optimizer(model, "Adam", 1e-4)
-    step = FusedTrainStep(model, opt, alpha=0.5, inversely_weighted=True, distributed=world > 1)
-    batches = [synthetic_batch(args.batch, args.size, args.size, seed=s, device=dev, rank=rank) for s in range(2)]
-
-    def sync():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    note(f"rank {rank}/{world}: model + {len(batches)} synthetic batches ready; warm-up x{args.warmup}")
-    for i in range(args.warmup):
-        step(*batches[i % 2])
-    sync()
-    note("warm-up done; timing")
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(*batches[i % 2])
-    sync()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    step.check_nan()
-    losses = step.losses.cpu().tolist()
-    note(f"timed {args.steps} steps in {dt:.3f} s; loss {losses[0]:.5f}")
-
+    main_res = run_mode(args, args.dtype, dev, rank, world, dist, rank == 0 and not args.no_roofline)
     out = {
-        "metric": "training images/sec (1-ch 256x256, U-Net++ MT)", "value": round(args.batch * world * args.steps / dt, 2),
+        "metric": "training images/sec (1-ch 256x256, U-Net++ MT)", "value": main_res["value"],
         "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": main_res["ms_per_step"], "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"{args.arch} seg+cls deep-supervision step (Dice+Focal, alpha=0.5, Adam eps 1e-4), "
-                               f"per-GPU batch {args.batch}, 1x{args.size}x{args.size} {args.dtype} MFMA operands / fp32 storage, random-init weights",
+                               f"per-GPU batch {args.batch}, 1x{args.size}x{args.size}, {args.dtype} MFMA operands in the 3x3 convs / "
+                               f"fp32 storage+accumulation, random-init weights (BASELINE.json configs[1])",
                    "global_batch": args.batch * world, "parallelism": f"dp{world}"},
-        "final_loss": round(losses[0], 6),
+        "final_loss": main_res["final_loss"],
     }
-    if rank == 0 and not args.no_roofline:
-        st = step._st
-        K = {_lib.OP_CONV3_FWD, _lib.OP_CONV3_DGRAD}
-        # only the MFMA launches (packed image present); the Cin=1 first conv runs the direct kernel
-        def mfma(p):
-            return [i for i in range(p.n) if p.array[i].kind in K and p.array[i].u.conv3.w_packed]
-        fl, sec, n = 0.0, 0.0, 0
-        for prog in (st.programs["fwd"], st.programs["bwd"]):
-            keep = set(mfma(prog))
-            # time each selected op individually
-            for i in sorted(keep):
-                f = conv_flops(prog.array[i])
-                ms = 0.0
-                for _ in range(3):
-                    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    s.record(); prog.run(i, 1); e.record(); e.synchronize()
-                    ms += s.elapsed_time(e)
-                fl += f; sec += ms / 3e3; n += 1
-        wg_fl, wg_sec, wg_n = 0.0, 0.0, 0
-        prog = st.programs["bwd"]
-        for i in range(prog.n):
-            if prog.array[i].kind == _lib.OP_CONV3_WGRAD and prog.array[i].u.conv3.Cin >= 8:
-                ms = 0.0
-                for _ in range(3):
-                    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    s.record(); prog.run(i, 1); e.record(); e.synchronize()
-                    ms += s.elapsed_time(e)
-                wg_fl += conv_flops(prog.array[i]); wg_sec += ms / 3e3; wg_n += 1
-        ach = fl / sec / 1e12
-        # HBM traffic per launch of the same kernel from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE,
-        # tools/pmc_traffic.py); launch-count weighted over the template instances of the kernel
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
-        if os.path.exists(tpath):
-            ks = json.load(open(tpath))["kernels"]
-            sel = [v for k, v in ks.items() if k.startswith("conv3x3_igemm_dma_kernel") or k.startswith("conv3x3_igemm_kernel")]
-            if sel:
-                w = sum(v["launches_in_trace"] for v in sel)
-                traffic = round(sum(v["hbm_bytes_per_launch"] * v["launches_in_trace"] for v in sel) / w)
-        peak = PEAK_F32_MFMA_TFLOPS if args.dtype == "f32" else PEAK_16BIT_MFMA_TFLOPS
-        kname = "conv3x3_igemm_dma_kernel" if args.dtype == "f32" else "conv3x3_igemm_lp_kernel"
-        out["roofline"] = {"bound": "mfma", "kernel": kname + " (fwd + dgrad launches)",
-                           "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                           "frac": round(ach / peak, 4), "traffic": traffic if args.dtype == "f32" else None,
-                           "launches_per_step": n, "avg_launch_ms": round(sec / n * 1e3, 4),
-                           "algorithmic_gflop_per_launch": round(fl / n / 1e9, 3),
-                           "wgrad": {"kernel": "conv3x3_wgrad_mfma_kernel + split-K reduce",
-                                     "achieved": round(wg_fl / wg_sec / 1e12, 2), "launches_per_step": wg_n,
-                                     "avg_launch_ms": round(wg_sec / max(1, wg_n) * 1e3, 4)},
-                           "conv3x3_share_of_step": round((sec + wg_sec) / (dt / args.steps), 3)}
-    if rank == 0 and not args.no_roofline:
-        # HBM-bound kernels named by north_star (norm / upsample): algorithmic bytes / HIP-event time
-        def timed(prog, i):
-            ms = 0.0
-            for _ in range(3):
-                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                s.record(); prog.run(i, 1); e.record(); e.synchronize()
-                ms += s.elapsed_time(e)
-            return ms / 3e3
-        hb = {"in_fwd": [0.0, 0.0, 0], "in_bwd": [0.0, 0.0, 0], "convT_fwd": [0.0, 0.0, 0]}
-        for pname in ("fwd", "bwd"):
-            prog = st.programs[pname]
-            for i in range(prog.n):
-                op = prog.array[i]
-                if op.kind == _lib.OP_IN_FWD:
-                    a = op.u.inorm; e = a.N * a.C * a.H * a.W * 4
-                    h = hb["in_fwd"]; h[0] += 2 * e; h[1] += timed(prog, i); h[2] += 1       # read z, write y
-                elif op.kind == _lib.OP_IN_BWD:
-                    a = op.u.inorm; e = a.N * a.C * a.H * a.W * 4
-                    h = hb["in_bwd"]; h[0] += 3 * e; h[1] += timed(prog, i); h[2] += 1       # read z, dy; write dz
-                elif op.kind == _lib.OP_CONVT_FWD:
-                    a = op.u.convT; px = a.N * a.H * a.W * 4
-                    h = hb["convT_fwd"]; h[0] += px * (a.Cin + a.Cout * a.k * a.k); h[1] += timed(prog, i); h[2] += 1
-        out["roofline_hbm"] = {k: {"bound": "hbm", "achieved": round(v[0] / v[1] / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
-                                   "frac": round(v[0] / v[1] / 8e12, 4), "launches_per_step": v[2],
-                                   "algorithmic_MB_per_launch": round(v[0] / max(1, v[2]) / 1e6, 1)}
-                               for k, v in hb.items() if v[2]}
+    for k in ("roofline", "roofline_hbm"):
+        if k in main_res:
+            out[k] = main_res[k]
+    if rank == 0 and world == 1 and args.dtype != "f32" and not args.no_parity_mode:
+        # the same step in the reference-parity arithmetic (exact fp32 MFMA), same run, same box
+        torch.cuda.empty_cache()
+        r = run_mode(args, "f32", dev, rank, world, dist, not args.no_roofline)
+        out["fp32_parity_mode"] = {"value": r["value"], "unit": "images/sec", "ms_per_step": r["ms_per_step"], "dtype": "f32",
+                                   "final_loss": r["final_loss"], **({"roofline": r["roofline"]} if "roofline" in r else {})}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         note("cpu baseline (oracle on host cores)")
-        out["cpu_baseline"] = cpu_baseline(args.arch, args.size, 4, 2)
+        out["cpu_baseline"] = cpu_baseline(args.arch, args.size, 8, 3)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:
