@@ -27,6 +27,7 @@ typedef char gchar;
 typedef __attribute__((address_space(1))) float gfloat;
 typedef __attribute__((address_space(1))) char gchar;
 #endif
+typedef __attribute__((address_space(1))) f32x4 gf32x4;
 
 struct SegTable {
     float* ptr[MTBC_MAX_SEGS];

@@ -535,11 +535,17 @@ __global__ __launch_bounds__(256, RING == 3 ? 2 : 3) void conv3x3_igemm_dma_kern
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 template <bool F16> struct LP;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 template <> struct LP<false> {
     typedef bf16x8 frag;
-    static __device__ __forceinline__ frag pack(const float* f) { frag r;
+    static __device__ __forceinline__ frag pack(const float* f) { frag r;      // four v_cvt_pk_bf16_f32
 #pragma unroll
-        for (int i = 0; i < 8; ++i) r[i] = (__bf16)f[i];
+        for (int i = 0; i < 4; ++i) {
+            const bf16x2 h = __builtin_convertvector((f32x2){f[2 * i], f[2 * i + 1]}, bf16x2);
+            r[2 * i] = h[0]; r[2 * i + 1] = h[1];
+        }
         return r; }
     static __device__ __forceinline__ f32x4 mfma(frag a, frag b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
 };
@@ -547,7 +553,10 @@ template <> struct LP<true> {
     typedef f16x8 frag;
     static __device__ __forceinline__ frag pack(const float* f) { frag r;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) r[i] = (_Float16)f[i];
+        for (int i = 0; i < 4; ++i) {
+            const f16x2 h = __builtin_convertvector((f32x2){f[2 * i], f[2 * i + 1]}, f16x2);
+            r[2 * i] = h[0]; r[2 * i + 1] = h[1];
+        }
         return r; }
     static __device__ __forceinline__ f32x4 mfma(frag a, frag b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
 };
@@ -678,7 +687,6 @@ __global__ __launch_bounds__(256, 3) void conv3x3_igemm_lp_kernel(const ConvP p)
     auto tile_geom = [&](int tile) {
         int y0, x0;
         tile_origin(tile, fn0, y0, x0);
-        okm = 0;
 #pragma unroll
         for (int q = 0; q < XQ; ++q) {
             const int hp = lane + 64 * q;
@@ -686,33 +694,36 @@ __global__ __launch_bounds__(256, 3) void conv3x3_igemm_lp_kernel(const ConvP p)
             const int row = rem / HC, col = rem % HC;
             const int y = y0 + row - 1, x = x0 + col - 1;
             const bool ok = hp < HP && fn0 + img < p.N && y >= 0 && y < p.H && x >= 0 && x < p.W && !(p.dbg & 1);
-            pixb[q] = ok ? 4u * (unsigned)(y * p.W + x) : 0u;
-            okm |= ok ? (1u << q) : 0u;
+            pixb[q] = ok ? 4u * (unsigned)(y * p.W + x) : 0xfffffff0u;      // out of range for the buffer: reads 0
+            if (G::IMG > 1) okm |= ok ? (1u << q) : 0u;
         }
     };
-    // fetch_x only ISSUES the loads (outside pixels read offset 0 of the plane, an absent channel group reads
-    // nothing); the zeroing happens when the values are packed a step later -- any use of a loaded register here
-    // would put the s_waitcnt in front of the MFMAs and serialize the pipeline.
-    bool xgrp = false;                            // wave-uniform: the fetched channel group exists
+    // fetch_x only ISSUES loads -- any use of a loaded register here would put the s_waitcnt in front of the MFMAs
+    // and serialize the pipeline.  They are raw buffer loads over the 8 channel planes of the group: the plane
+    // stride rides in the scalar offset, a halo pixel outside the image carries an out-of-range offset and an
+    // absent channel group gets an empty buffer, so the hardware returns the zeros and a load costs no VALU work.
     auto fetch_x = [&](int chn) {
         const int c0 = chn * LPKC + 8 * wvu;      // wave-uniform
-        xgrp = c0 < p.Cin;
-        if (xgrp) {
-            const SegL sr = segl_ref(seg_in, c0);
-            const unsigned long long pu = reinterpret_cast<unsigned long long>(sr.ptr);
-            const unsigned plo = __builtin_amdgcn_readfirstlane((unsigned)pu), phi = __builtin_amdgcn_readfirstlane((unsigned)(pu >> 32));
-            const unsigned blo = __builtin_amdgcn_readfirstlane((unsigned)sr.bs), bhi = __builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)sr.bs >> 32));
-            const int cb = __builtin_amdgcn_readfirstlane(sr.cb);
-            const long long bs = (long long)(((unsigned long long)bhi << 32) | blo);
-            const gchar* base = (const gchar*)(((unsigned long long)phi << 32) | plo) +
-                               4 * ((size_t)fn0 * bs + (size_t)(c0 - cb) * HW);
+        const bool xgrp = c0 < p.Cin;
+        const SegL sr = segl_ref(seg_in, xgrp ? c0 : 0);
+        const unsigned long long pu = reinterpret_cast<unsigned long long>(sr.ptr);
+        const unsigned plo = __builtin_amdgcn_readfirstlane((unsigned)pu), phi = __builtin_amdgcn_readfirstlane((unsigned)(pu >> 32));
+        const unsigned blo = __builtin_amdgcn_readfirstlane((unsigned)sr.bs), bhi = __builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)sr.bs >> 32));
+        const int cb = __builtin_amdgcn_readfirstlane(sr.cb);
+        const long long bs = (long long)(((unsigned long long)bhi << 32) | blo);
+        float* base = reinterpret_cast<float*>(((unsigned long long)phi << 32) | plo) +
+                      ((size_t)fn0 * bs + (size_t)((xgrp ? c0 : 0) - cb) * HW);
+        // records: 8 planes of image fn0 (GEO2: of the tile's 4 images, reached through the batch stride)
+        const unsigned span = G::IMG > 1 ? (unsigned)((G::IMG - 1) * bs + 8 * HW) * 4u : (unsigned)(8 * HW) * 4u;
+        const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(base, 0, xgrp ? (int)span : 0, 0x00020000);
+        const int plane = HW * 4;
 #pragma unroll
-            for (int q = 0; q < XQ; ++q) {
-                unsigned off = pixb[q];
-                if (G::IMG > 1) off += ((okm >> q) & 1u) ? 4u * (unsigned)(((lane + 64 * q) / (HR * HC)) * bs) : 0u;
+        for (int q = 0; q < XQ; ++q) {
+            unsigned off = pixb[q];
+            if (G::IMG > 1) off += ((okm >> q) & 1u) ? 4u * (unsigned)(((lane + 64 * q) / (HR * HC)) * bs) : 0u;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) xf[q][e] = *(const gfloat*)(base + (size_t)e * HW * 4 + off);
-            }
+            for (int e = 0; e < 8; ++e)
+                xf[q][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, (int)off, e * plane, 0));
         }
     };
     int w_have = -1;                              // chunk whose weights sit in Ws (mt0 is fixed per block)
@@ -762,16 +773,12 @@ __global__ __launch_bounds__(256, 3) void conv3x3_igemm_lp_kernel(const ConvP p)
 #pragma unroll
             for (int q = 0; q < XQ; ++q) {
                 const int hp = lane + 64 * q;
-                const bool live = xgrp && ((okm >> q) & 1u);
-                float xv[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) xv[e] = live ? xf[q][e] : 0.f;
-                if (hp < HP) *reinterpret_cast<typename T::frag*>(Xs + hp * LPROW + 8 * wvu) = T::pack(xv);
+                if (hp < HP) *reinterpret_cast<typename T::frag*>(Xs + hp * LPROW + 8 * wvu) = T::pack(xf[q]);
             }
             // next step's X: in flight under the MFMAs and the epilogue
             bool fetched = false;
-            if (ch + 1 < nchunks) { fetch_x(ch + 1); fetched = xgrp; }
-            else if (tile + tstep < tend) { tile_geom(tile + tstep); fetch_x(0); fetched = xgrp; }
+            if (ch + 1 < nchunks) { fetch_x(ch + 1); fetched = true; }
+            else if (tile + tstep < tend) { tile_geom(tile + tstep); fetch_x(0); fetched = true; }
             if (wload) {                          // the weight DMA is older than the X loads just issued
                 if (fetched) wait_vmcnt<8 * XQ>(); else wait_vmcnt<0>();
             }
@@ -789,22 +796,21 @@ __global__ __launch_bounds__(256, 3) void conv3x3_igemm_lp_kernel(const ConvP p)
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) acc[m][g] = T::mfma(a[m], b[g], acc[m][g]);
+                    for (int g = 0; g < 4; ++g) acc[m][g] = T::mfma(b[g], a[m], acc[m][g]);      // rows = pixels, cols = channels
             }
         }
-        // ---- epilogue (same fragment map as the fp32 kernels)
-        int poff[4];
+        // ---- epilogue.  The MFMAs ran as D = X^T W^T (pixels are the rows), so a lane holds FOUR CONSECUTIVE PIXELS
+        //      (4kg .. 4kg+3 of the 16-pixel group) of ONE output channel (16m + j): one 16-byte store per
+        //      accumulator tile instead of four 4-byte ones -- the epilogue is store-issue bound.
         const int n = GEO == 2 ? n0 + wv : n0;
-        bool all_px = n < p.N;
+        int poff[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             int y, x;
-            if (GEO == 0) { y = y0 + 2 * wv + (g >> 1); x = x0 + 16 * (g & 1) + j; }
-            else if (GEO == 1) { y = y0 + 4 * wv + g; x = x0 + j; }
-            else { y = y0 + 2 * g + (j >> 3); x = x0 + (j & 7); }
-            const bool ok = n < p.N && y < p.H && x < p.W;
-            all_px = all_px && ok;
-            poff[g] = ok ? y * p.W + x : -1;
+            if (GEO == 0) { y = y0 + 2 * wv + (g >> 1); x = x0 + 16 * (g & 1) + 4 * kg; }
+            else if (GEO == 1) { y = y0 + 4 * wv + g; x = x0 + 4 * kg; }
+            else { y = y0 + 2 * g + (kg >> 1); x = x0 + 4 * (kg & 1); }
+            poff[g] = (n < p.N && y < p.H && x < p.W) ? y * p.W + x : -1;        // W % 4 == 0: x < W covers x + 3
         }
         if (p.dbg & 2) { if (acc[0][0][0] != 12345.678f) continue; }
         // No load may sit here: vmcnt retires in order, so waiting for one (a bias, an old value to accumulate onto)
@@ -813,23 +819,22 @@ __global__ __launch_bounds__(256, 3) void conv3x3_igemm_lp_kernel(const ConvP p)
         // so the sum is the same (old + (acc + bias)) as a read-modify-write, minus the round trip.
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
-            const int co4 = (mt0 + m) * 16 + kg * 4;
-            const SegL so = segl_ref(seg_out, co4 < p.Cout ? co4 : 0);
-            gfloat* cb0 = (gfloat*)so.ptr + (size_t)n * so.bs + (size_t)((co4 < p.Cout ? co4 : 0) - so.cb) * HW;
-            const f32x4 bv4 = *reinterpret_cast<const f32x4*>(bias_s + m * 16 + kg * 4);
+            const int co = (mt0 + m) * 16 + j;
+            if (co >= p.Cout) continue;
+            const SegL so = segl_ref(seg_out, co);
+            gfloat* cb = (gfloat*)so.ptr + (size_t)n * so.bs + (size_t)(co - so.cb) * HW;
+            const float bv = bias_s[m * 16 + j];
+            if (so.acc) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                if (co4 + r >= p.Cout) continue;
-                gfloat* cb = cb0 + (size_t)r * HW;
-                if (so.acc) {
+                for (int g = 0; g < 4; ++g)
+                    if (poff[g] >= 0) {
 #pragma unroll
-                    for (int g = 0; g < 4; ++g)
-                        if (poff[g] >= 0) __builtin_amdgcn_global_atomic_fadd_f32(cb + poff[g], acc[m][g][r] + bv4[r]);
-                } else {
+                        for (int r = 0; r < 4; ++r) __builtin_amdgcn_global_atomic_fadd_f32(cb + poff[g] + r, acc[m][g][r] + bv);
+                    }
+            } else {
 #pragma unroll
-                    for (int g = 0; g < 4; ++g)
-                        if (poff[g] >= 0) cb[poff[g]] = acc[m][g][r] + bv4[r];
-                }
+                for (int g = 0; g < 4; ++g)
+                    if (poff[g] >= 0) *(gf32x4*)(cb + poff[g]) = acc[m][g] + bv;
             }
         }
     }
