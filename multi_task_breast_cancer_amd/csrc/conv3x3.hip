@@ -54,6 +54,7 @@ struct ConvP {
     int tiles_x, tiles_y, ntiles;
     int mtiles;
     int dbg;      // timing probes only (env MTBC_DBG): 1 = no global loads, 2 = no epilogue, 4 = no LDS stores
+    int pxrows;   // 16-bit igemm: 1 = pixels on the MFMA rows (16-byte stores; no segment accumulates), 0 = channels on the rows
 };
 
 constexpr int KC = 8;           // input channels per LDS chunk
@@ -326,6 +327,7 @@ template <int MT, int GEO> struct DmaCount {
 // workgroup barrier that publishes LDS only: unlike __syncthreads() it does not drain vmcnt, so global loads issued
 // before it (register prefetch, LDS-DMA) stay in flight across it
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+template <bool B> struct BoolC { static constexpr bool value = B; };
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 template <int MT, int GEO> __device__ __forceinline__ void wait_newest_in_flight(int wv) {
     using D = DmaCount<MT, GEO>;
@@ -632,7 +634,7 @@ __global__ void pack_many_kernel(const PackManyP q) {
     }
 }
 
-template <int MT, int GEO, bool F16>
+template <int MT, int GEO, bool F16, bool PX>
 __global__ __launch_bounds__(256, 3) void conv3x3_igemm_lp_kernel(const ConvP p) {
     using G = GeoLP<GEO>;
     using T = LP<F16>;
@@ -783,58 +785,88 @@ __global__ __launch_bounds__(256, 3) void conv3x3_igemm_lp_kernel(const ConvP p)
                 if (fetched) wait_vmcnt<8 * XQ>(); else wait_vmcnt<0>();
             }
             lds_barrier();
+            {
+                constexpr bool px = PX;
 #pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                const int toff = ((tap / 3) * HC + tap % 3) * LPROW + 8 * kg;
-                typename T::frag a[MT], b[4];
+                for (int tap = 0; tap < 9; ++tap) {
+                    const int toff = ((tap / 3) * HC + tap % 3) * LPROW + 8 * kg;
+                    typename T::frag a[MT], b[4];
 #pragma unroll
-                for (int m = 0; m < MT; ++m)
-                    a[m] = *reinterpret_cast<const typename T::frag*>(Ws + ((m * 9 + tap) * 16 + j) * LPROW + 8 * kg);
+                    for (int m = 0; m < MT; ++m)
+                        a[m] = *reinterpret_cast<const typename T::frag*>(Ws + ((m * 9 + tap) * 16 + j) * LPROW + 8 * kg);
 #pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    b[g] = *reinterpret_cast<const typename T::frag*>(Xs + bpix[g] * LPROW + toff);
+                    for (int g = 0; g < 4; ++g)
+                        b[g] = *reinterpret_cast<const typename T::frag*>(Xs + bpix[g] * LPROW + toff);
 #pragma unroll
-                for (int m = 0; m < MT; ++m)
+                    for (int m = 0; m < MT; ++m)
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) acc[m][g] = T::mfma(b[g], a[m], acc[m][g]);      // rows = pixels, cols = channels
+                        for (int g = 0; g < 4; ++g)
+                            acc[m][g] = px ? T::mfma(b[g], a[m], acc[m][g])      // rows = pixels, cols = channels
+                                           : T::mfma(a[m], b[g], acc[m][g]);     // rows = channels, cols = pixels
+                }
             }
         }
-        // ---- epilogue.  The MFMAs ran as D = X^T W^T (pixels are the rows), so a lane holds FOUR CONSECUTIVE PIXELS
-        //      (4kg .. 4kg+3 of the 16-pixel group) of ONE output channel (16m + j): one 16-byte store per
-        //      accumulator tile instead of four 4-byte ones -- the epilogue is store-issue bound.
+        // ---- epilogue.  No load may sit here: vmcnt retires in order, so waiting for one (a bias, an old value to
+        //      accumulate onto) would also wait for the whole X prefetch issued above.  The bias comes from LDS;
+        //      accumulation into a fan-in gradient is a no-return global_atomic_add_f32 -- every element has exactly
+        //      one writer per launch, so the sum is the same (old + (acc + bias)) as a read-modify-write.
         const int n = GEO == 2 ? n0 + wv : n0;
-        int poff[4];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            int y, x;
-            if (GEO == 0) { y = y0 + 2 * wv + (g >> 1); x = x0 + 16 * (g & 1) + 4 * kg; }
-            else if (GEO == 1) { y = y0 + 4 * wv + g; x = x0 + 4 * kg; }
-            else { y = y0 + 2 * g + (kg >> 1); x = x0 + 4 * (kg & 1); }
-            poff[g] = (n < p.N && y < p.H && x < p.W) ? y * p.W + x : -1;        // W % 4 == 0: x < W covers x + 3
-        }
         if (p.dbg & 2) { if (acc[0][0][0] != 12345.678f) continue; }
-        // No load may sit here: vmcnt retires in order, so waiting for one (a bias, an old value to accumulate onto)
-        // would also wait for the whole X prefetch issued above.  The bias comes from LDS; accumulation into a
-        // fan-in gradient is a no-return global_atomic_add_f32 -- every element has exactly one writer per launch,
-        // so the sum is the same (old + (acc + bias)) as a read-modify-write, minus the round trip.
+        if (PX) {
+            // D = X^T W^T: a lane holds FOUR CONSECUTIVE PIXELS (4kg .. 4kg+3 of the 16-pixel group) of ONE output
+            // channel (16m + j): one 16-byte store per accumulator tile (the epilogue is store-issue bound)
+            int poff[4];
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            const int co = (mt0 + m) * 16 + j;
-            if (co >= p.Cout) continue;
-            const SegL so = segl_ref(seg_out, co);
-            gfloat* cb = (gfloat*)so.ptr + (size_t)n * so.bs + (size_t)(co - so.cb) * HW;
-            const float bv = bias_s[m * 16 + j];
-            if (so.acc) {
+            for (int g = 0; g < 4; ++g) {
+                int y, x;
+                if (GEO == 0) { y = y0 + 2 * wv + (g >> 1); x = x0 + 16 * (g & 1) + 4 * kg; }
+                else if (GEO == 1) { y = y0 + 4 * wv + g; x = x0 + 4 * kg; }
+                else { y = y0 + 2 * g + (kg >> 1); x = x0 + 4 * (kg & 1); }
+                poff[g] = (n < p.N && y < p.H && x < p.W) ? y * p.W + x : -1;        // W % 4 == 0: x < W covers x + 3
+            }
 #pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    if (poff[g] >= 0) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) __builtin_amdgcn_global_atomic_fadd_f32(cb + poff[g] + r, acc[m][g][r] + bv);
-                    }
-            } else {
+            for (int m = 0; m < MT; ++m) {
+                const int co = (mt0 + m) * 16 + j;
+                if (co >= p.Cout) continue;
+                const SegL so = segl_ref(seg_out, co);
+                gfloat* cb = (gfloat*)so.ptr + (size_t)n * so.bs + (size_t)(co - so.cb) * HW;
+                const float bv = bias_s[m * 16 + j];
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
                     if (poff[g] >= 0) *(gf32x4*)(cb + poff[g]) = acc[m][g] + bv;
+            }
+        } else {
+            // D = W X: a lane holds one pixel (j of the group) of four channels; 16 lanes cover 64 contiguous bytes of a
+            // plane, which is what keeps the atomics of a fan-in launch coalesced
+            int poff[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                int y, x;
+                if (GEO == 0) { y = y0 + 2 * wv + (g >> 1); x = x0 + 16 * (g & 1) + j; }
+                else if (GEO == 1) { y = y0 + 4 * wv + g; x = x0 + j; }
+                else { y = y0 + 2 * g + (j >> 3); x = x0 + (j & 7); }
+                poff[g] = (n < p.N && y < p.H && x < p.W) ? y * p.W + x : -1;
+            }
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const int co4 = (mt0 + m) * 16 + kg * 4;
+                const SegL so = segl_ref(seg_out, co4 < p.Cout ? co4 : 0);
+                gfloat* cb0 = (gfloat*)so.ptr + (size_t)n * so.bs + (size_t)((co4 < p.Cout ? co4 : 0) - so.cb) * HW;
+                const f32x4 bv4 = *reinterpret_cast<const f32x4*>(bias_s + m * 16 + kg * 4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (co4 + r >= p.Cout) continue;
+                    gfloat* cb = cb0 + (size_t)r * HW;
+                    if (so.acc) {
+#pragma unroll
+                        for (int g = 0; g < 4; ++g)
+                            if (poff[g] >= 0) __builtin_amdgcn_global_atomic_fadd_f32(cb + poff[g], acc[m][g][r] + bv4[r]);
+                    } else {
+#pragma unroll
+                        for (int g = 0; g < 4; ++g)
+                            if (poff[g] >= 0) cb[poff[g]] = acc[m][g][r] + bv4[r];
+                    }
+                }
             }
         }
     }
@@ -1352,17 +1384,23 @@ int launch_igemm_lp(const ConvP& p, int mblocks, bool f16, hipStream_t st) {
     const size_t lds = ((size_t)HP * LPROW + (size_t)MT * 9 * 16 * LPROW) * 2 + (SEGL_FLOATS + MT * 16) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_igemm_lp_kernel<MT, GEO, false>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_igemm_lp_kernel<MT, GEO, true>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_igemm_lp_kernel<MT, GEO, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_igemm_lp_kernel<MT, GEO, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_igemm_lp_kernel<MT, GEO, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_igemm_lp_kernel<MT, GEO, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     int gx = (768 / mblocks) / 8 * 8;
     if (gx < 8) gx = 8;
     if (gx > p.ntiles) gx = p.ntiles;
-    if (f16) hipLaunchKernelGGL((conv3x3_igemm_lp_kernel<MT, GEO, true>), dim3(gx, mblocks), dim3(256), lds, st, p);
-    else hipLaunchKernelGGL((conv3x3_igemm_lp_kernel<MT, GEO, false>), dim3(gx, mblocks), dim3(256), lds, st, p);
+    const dim3 grid(gx, mblocks);
+    if (f16) {
+        if (p.pxrows) hipLaunchKernelGGL((conv3x3_igemm_lp_kernel<MT, GEO, true, true>), grid, dim3(256), lds, st, p);
+        else hipLaunchKernelGGL((conv3x3_igemm_lp_kernel<MT, GEO, true, false>), grid, dim3(256), lds, st, p);
+    } else {
+        if (p.pxrows) hipLaunchKernelGGL((conv3x3_igemm_lp_kernel<MT, GEO, false, true>), grid, dim3(256), lds, st, p);
+        else hipLaunchKernelGGL((conv3x3_igemm_lp_kernel<MT, GEO, false, false>), grid, dim3(256), lds, st, p);
+    }
     MTBC_CHECK_LAUNCH();
     return MTBC_OK;
 }
@@ -1382,6 +1420,8 @@ int run_igemm(int N, int H, int W, int red, int rows, const SegTable& in, const 
     p.N = N; p.H = H; p.W = W; p.Cin = red; p.Cout = rows; p.in = in; p.out = out; p.wp = wp; p.bias = bias;
     static const int dbg = getenv("MTBC_DBG") ? atoi(getenv("MTBC_DBG")) : 0;
     p.dbg = dbg;
+    p.pxrows = 1;
+    for (int i = 0; i < out.n; ++i) if (out.accumulate[i]) p.pxrows = 0;
     const int geo = pick_geo(H, W);
     p.mtiles = cdiv(rows, 16);
     if (geo == 0) { p.tiles_x = cdiv(W, 32); p.tiles_y = cdiv(H, 8); p.ntiles = p.tiles_x * p.tiles_y * N; }
