@@ -578,29 +578,33 @@ template <> struct GeoLP<0> { static constexpr int TH = 8, TW = 32, IMG = 1; };
 template <> struct GeoLP<1> { static constexpr int TH = 16, TW = 16, IMG = 1; };
 template <> struct GeoLP<2> { static constexpr int TH = 8, TW = 8, IMG = 4; };
 
-__device__ __forceinline__ void pack_lp_elem(const float* __restrict__ w, unsigned short* __restrict__ p, int Cin, int Cout,
-                                             int dgrad, int f16, long long idx) {
+// one thread = 8 consecutive K of one row of a 16-bit image (one 16-byte store); idx8 counts those groups
+__device__ __forceinline__ void pack_lp_elem8(const float* __restrict__ w, unsigned short* __restrict__ p, int Cin, int Cout,
+                                              int dgrad, int f16, long long idx8) {
     // fwd  : rows = co (Cout), K = ci      value = w[co][ci][tap]
     // dgrad: rows = ci (Cin),  K = co      value = w[co][ci][8-tap]
     const int rows = dgrad ? Cin : Cout, red = dgrad ? Cout : Cin;
     const int nch = (red + LPKC - 1) / LPKC;
-    const int kk = idx % LPROW; long long t = idx / LPROW;
+    const int kq = idx8 % (LPROW / 8); long long t = idx8 / (LPROW / 8);
     const int i = t % 16; t /= 16;
     const int tap = t % 9; t /= 9;
     const int cb = t % nch; const int mt = t / nch;
-    const int r = mt * 16 + i, k = cb * LPKC + kk;
-    float v = 0.f;
-    if (kk < LPKC && r < rows && k < red)
-        v = dgrad ? w[((size_t)k * Cin + r) * 9 + (8 - tap)] : w[((size_t)r * Cin + k) * 9 + tap];
-    unsigned short bits;
-    if (f16) { _Float16 h = (_Float16)v; bits = *reinterpret_cast<unsigned short*>(&h); }
-    else { __bf16 h = (__bf16)v; bits = *reinterpret_cast<unsigned short*>(&h); }
-    p[idx] = bits;
+    const int r = mt * 16 + i;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int kk = kq * 8 + e, k = cb * LPKC + kk;
+        v[e] = 0.f;
+        if (kk < LPKC && r < rows && k < red)
+            v[e] = dgrad ? w[((size_t)k * Cin + r) * 9 + (8 - tap)] : w[((size_t)r * Cin + k) * 9 + tap];
+    }
+    if (f16) *reinterpret_cast<f16x8*>(p + idx8 * 8) = LP<true>::pack(v);
+    else *reinterpret_cast<bf16x8*>(p + idx8 * 8) = LP<false>::pack(v);
 }
 __global__ void pack_lp_kernel(const float* __restrict__ w, unsigned short* __restrict__ p, int Cin, int Cout, int dgrad,
-                               int f16, long long total) {
+                               int f16, long long total8) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx < total) pack_lp_elem(w, p, Cin, Cout, dgrad, f16, idx);
+    if (idx < total8) pack_lp_elem8(w, p, Cin, Cout, dgrad, f16, idx);
 }
 
 // Every weight image of a step in ONE launch (a step re-packs ~70 small tensors after each optimizer update; as 70
@@ -628,9 +632,9 @@ __global__ void pack_many_kernel(const PackManyP q) {
     } else {
         const int dg = kind == 3;
         const int rows = dg ? Cin : Cout, red = dg ? Cout : Cin;
-        const long long total = (long long)((rows + 15) / 16) * ((red + LPKC - 1) / LPKC) * 9 * 16 * LPROW;
-        if (idx >= total) return;
-        pack_lp_elem(w, static_cast<unsigned short*>(q.dst[d]), Cin, Cout, dg, q.f16, idx);
+        const long long total8 = (long long)((rows + 15) / 16) * ((red + LPKC - 1) / LPKC) * 9 * 16 * (LPROW / 8);
+        if (idx >= total8) return;
+        pack_lp_elem8(w, static_cast<unsigned short*>(q.dst[d]), Cin, Cout, dg, q.f16, idx);
     }
 }
 
@@ -1512,8 +1516,8 @@ size_t mtbc_conv3x3_packed_lp_elems(int32_t Cin, int32_t Cout, int32_t dgrad) {
 int mtbc_conv3x3_pack_lp(const float* w, void* packed, int32_t Cin, int32_t Cout, int32_t dgrad, int32_t compute, void* stream) {
     if (!w || !packed || Cin <= 0 || Cout <= 0 || (compute != 1 && compute != 2)) return MTBC_E_BADARG;
     const long long total = (long long)mtbc_conv3x3_packed_lp_elems(Cin, Cout, dgrad);
-    hipLaunchKernelGGL(pack_lp_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, (hipStream_t)stream, w,
-                       reinterpret_cast<unsigned short*>(packed), Cin, Cout, dgrad, compute == 2 ? 1 : 0, total);
+    hipLaunchKernelGGL(pack_lp_kernel, dim3((unsigned)cdiv64(total / 8, 256)), dim3(256), 0, (hipStream_t)stream, w,
+                       reinterpret_cast<unsigned short*>(packed), Cin, Cout, dgrad, compute == 2 ? 1 : 0, total / 8);
     MTBC_CHECK_LAUNCH();
     return MTBC_OK;
 }
@@ -1534,7 +1538,7 @@ int mtbc_conv3x3_pack_many(const mtbc_pack_desc* descs, int32_t n, void* stream)
                 if (d.compute != 1 && d.compute != 2) return MTBC_E_BADARG;
                 if (lp_mode && lp_mode != d.compute) break;          // one 16-bit format per launch
                 lp_mode = d.compute;
-                total = (long long)mtbc_conv3x3_packed_lp_elems(d.Cin, d.Cout, d.kind == 3);
+                total = (long long)mtbc_conv3x3_packed_lp_elems(d.Cin, d.Cout, d.kind == 3) / 8;      // threads: 8 elements each
             }
             const int i = q.n++;
             q.w[i] = d.w; q.dst[i] = d.packed; q.Cin[i] = d.Cin; q.Cout[i] = d.Cout; q.kind[i] = (unsigned char)d.kind;
