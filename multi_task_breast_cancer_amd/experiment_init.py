@@ -82,6 +82,10 @@ def load_multitask_experiment_artefacts(config_data, config_model, config_opt, c
                                  n_classes=len(config_data["classes"]),
                                  deep_supervision=config_model["deep_supervision"],
                                  save_folder=Path(f"{run_path}/") if run_path is not None else None)
+    # optional key, absent from the reference's config.yaml (default = the reference's fp32 arithmetic):
+    #   model: {compute_dtype: bf16}   -> bf16 MFMA operands in the 3x3 convs, everything else fp32
+    if config_model.get("compute_dtype") is not None and hasattr(model, "set_compute"):
+        model.set_compute(str(config_model["compute_dtype"]))
     optimizer = init_optimizer(model=model, optimizer=config_opt["opt"], learning_rate=config_opt["lr"])
     segmentation_criterion = init_criterion_segmentation(loss_function=config_loss["function"])
     classification_criterion = init_criterion_classification(
