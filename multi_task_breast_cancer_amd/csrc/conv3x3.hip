@@ -922,12 +922,44 @@ __global__ __launch_bounds__(128 * COT, 3) void conv3x3_wgrad_mfma_kernel(const 
     const float* zplane = p.dz + (size_t)(co_ok ? my_co : 0) * HW;                    // + n*Cout*HW + y*W + x
     float4 xr[XSLOTS], zr[4];
     unsigned live = 0;                      // bit s: slot s of the prefetched tile holds real data
+    // Slot offsets relative to the tile origin are tile-invariant: computed once.  A tile that does not touch the
+    // image border then costs one 64-bit add per operand and one address instruction per load (the generic path
+    // below spends ~25 VALU instructions per slot on div/mod, bounds and 64-bit index math).
+    int xrel[XSLOTS], zrel[4];
+    unsigned slots_ok = 0;
+    if (G::IMG == 1) {
+#pragma unroll
+        for (int s = 0; s < XSLOTS; ++s) {
+            const int f = q + 8 * s, row = f / (G::LW / 4), c4 = f % (G::LW / 4);
+            xrel[s] = (row - 1) * p.W + (c4 * 4 - 4);
+            slots_ok |= (f < XF4_PER_CH && ci_ok) ? (1u << s) : 0u;
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int px = (q + 8 * s) * 4;
+            zrel[s] = (px / G::TW) * p.W + px % G::TW;
+            slots_ok |= co_ok ? (1u << (XSLOTS + s)) : 0u;
+        }
+    }
 
     auto prefetch = [&](int tile) {
         int t = tile;
         const int tx = t % p.tiles_x; t /= p.tiles_x;
         const int ty = t % p.tiles_y; t /= p.tiles_y;
         const int n0 = t * G::IMG, x0 = tx * G::TW, y0 = ty * G::TH;
+        if (G::IMG == 1) {
+            const bool interior = y0 >= 1 && y0 + G::TH + 1 <= p.H && x0 >= 4 && x0 + G::TW + 4 <= p.W && !(p.dbg & 1);   // uniform
+            if (interior) {
+                const float* xt = xplane + ((size_t)n0 * xbs + y0 * p.W + x0);
+                const float* zt = zplane + ((size_t)n0 * p.Cout * HW + y0 * p.W + x0);
+                live = slots_ok;
+#pragma unroll
+                for (int s = 0; s < XSLOTS; ++s) xr[s] = *reinterpret_cast<const float4*>(((slots_ok >> s) & 1u) ? xt + xrel[s] : xplane);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) zr[s] = *reinterpret_cast<const float4*>(co_ok ? zt + zrel[s] : zplane);
+                return;
+            }
+        }
         live = 0;
 #pragma unroll
         for (int s = 0; s < XSLOTS; ++s) {
@@ -1186,6 +1218,189 @@ __global__ __launch_bounds__(128 * COT, 3) void conv3x3_wgrad_lp_kernel(const Wg
         }
     }
 }
+
+// ------------------------------------------------------------------ wgrad on the 16-bit MFMA, 16-bit LDS image (wide maps)
+// Second generation of conv3x3_wgrad_lp_kernel for maps >= 32 wide.  That kernel keeps fp32 in LDS and converts at
+// fragment time: 4.4 v_cvt_pk per MFMA, every X value converted 3x (once per horizontal tap) by 2 waves -- it is
+// VALU-bound.  Here the tile is converted ONCE when it is committed to LDS (16-bit image, half the LDS bytes, one
+// ds_read_b128 per fragment) and the three horizontally shifted taps are cut from two aligned reads with
+// v_alignbit_b32 (a 16-bit funnel shift: 8 VALU per kernel row instead of 12 conversions + packs).  A wave owns TWO
+// output-channel tiles x one input-channel tile (the shifted X windows are shared by both), and the 4 waves are
+// (ci tile 0/1) x (tile rows 0-1 / 2-3); the two row halves are summed through LDS once, at the end of the block.
+//   LDS: Xs[32 ci][6 halo rows x 40] + Zs[32 co][128 + 16], 16-bit; channel strides == 16 mod 32 elements make every
+//   ds_read_b128 fragment conflict-free (brute-forced over the b128 lane groups of MI355X_MICROARCH.md).
+constexpr int W2_PSX = 240, W2_PSZ = 144;
+template <bool F16>
+__global__ __launch_bounds__(256, 2) void conv3x3_wgrad_lp2_kernel(const WgP p) {
+    using T = LP<F16>;
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    constexpr int TH = 4, TW = 32, ROWS = 6, LW = 40;
+    constexpr int XF4 = ROWS * LW / 4;                    // 60 float4 per channel
+    constexpr int XSLOTS = (XF4 + 7) / 8;                 // 8
+    extern __shared__ __attribute__((aligned(16))) unsigned short smem16w[];
+    unsigned short* Xs = smem16w;
+    unsigned short* Zs = smem16w + 32 * W2_PSX;
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int HW = p.H * p.W;
+    const int co0 = (blockIdx.y / p.ciblocks) * 32, ci0 = (blockIdx.y % p.ciblocks) * 32;
+    const int split = blockIdx.x;
+    const int t_begin = split * p.tiles_per_split;
+    const int t_end = min(p.total_tiles, t_begin + p.tiles_per_split);
+
+    // staging: thread = (channel tid/8, float4 slots q + 8s)
+    const int ch = tid >> 3, q = tid & 7;
+    const int my_ci = ci0 + ch, my_co = co0 + ch;
+    const bool ci_ok = my_ci < p.Cin, co_ok = my_co < p.Cout;
+    const SegRef sr = seg_ref(p.in, ci_ok ? my_ci : 0);
+    const float* xplane = sr.ptr + (size_t)((ci_ok ? my_ci : 0) - sr.cb) * HW;
+    const long long xbs = sr.bs;
+    const float* zplane = p.dz + (size_t)(co_ok ? my_co : 0) * HW;
+    float4 xr[XSLOTS], zr[4];
+    unsigned live = 0;                      // bit s: slot s of the prefetched tile holds real data
+    // Offsets of this thread's slots relative to the tile origin do not depend on the tile: computed once.  A tile
+    // that does not touch the image border (73 % of them at 256x256) then costs one 64-bit add per operand and one
+    // address instruction per load; only border tiles run the per-slot bounds checks.
+    int xrel[XSLOTS], zrel[4];
+    unsigned slots_ok = 0;                  // slots that exist for this thread (f < XF4, channel inside the tensor)
+#pragma unroll
+    for (int s = 0; s < XSLOTS; ++s) {
+        const int f = q + 8 * s, row = f / (LW / 4), c4 = f % (LW / 4);
+        xrel[s] = (row - 1) * p.W + (c4 * 4 - 4);
+        slots_ok |= (f < XF4 && ci_ok) ? (1u << s) : 0u;
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int px = (q + 8 * s) * 4;
+        zrel[s] = (px / TW) * p.W + px % TW;
+        slots_ok |= co_ok ? (1u << (XSLOTS + s)) : 0u;
+    }
+    auto prefetch = [&](int tile) {         // issue only: nothing may touch xr / zr before commit()
+        int t = tile;
+        const int tx = t % p.tiles_x; t /= p.tiles_x;
+        const int ty = t % p.tiles_y; t /= p.tiles_y;
+        const int n = t, x0 = tx * TW, y0 = ty * TH;
+        const float* xt = xplane + ((size_t)n * xbs + y0 * p.W + x0);
+        const float* zt = zplane + ((size_t)n * p.Cout * HW + y0 * p.W + x0);
+        const bool interior = y0 >= 1 && y0 + TH + 1 <= p.H && x0 >= 4 && x0 + TW + 4 <= p.W && !(p.dbg & 1);   // uniform
+        if (interior) {
+            live = slots_ok;
+#pragma unroll
+            for (int s = 0; s < XSLOTS; ++s) xr[s] = *reinterpret_cast<const float4*>(((slots_ok >> s) & 1u) ? xt + xrel[s] : xplane);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) zr[s] = *reinterpret_cast<const float4*>(co_ok ? zt + zrel[s] : zplane);
+            return;
+        }
+        live = 0;
+#pragma unroll
+        for (int s = 0; s < XSLOTS; ++s) {
+            const int f = q + 8 * s;
+            const int row = f / (LW / 4), c4 = f % (LW / 4);
+            const int y = y0 + row - 1, x = x0 - 4 + c4 * 4;
+            const bool ok = f < XF4 && ci_ok && y >= 0 && y < p.H && x >= 0 && x < p.W && !(p.dbg & 1);
+            xr[s] = *reinterpret_cast<const float4*>(ok ? xt + xrel[s] : xplane);
+            live |= ok ? (1u << s) : 0u;
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int px = (q + 8 * s) * 4;
+            const int y = y0 + px / TW, x = x0 + px % TW;
+            const bool ok = co_ok && y < p.H && x < p.W && !(p.dbg & 1);
+            zr[s] = *reinterpret_cast<const float4*>(ok ? zt + zrel[s] : zplane);
+            live |= ok ? (1u << (XSLOTS + s)) : 0u;
+        }
+    };
+    auto cvt4 = [&](const float4& v, bool l) {            // 4 floats -> 4 x 16 bit (zeros if the slot is dead)
+        float f[8] = {l ? v.x : 0.f, l ? v.y : 0.f, l ? v.z : 0.f, l ? v.w : 0.f, 0.f, 0.f, 0.f, 0.f};
+        const typename T::frag h = T::pack(f);
+        const u32x4 u = __builtin_bit_cast(u32x4, h);
+        return make_uint2(u[0], u[1]);
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int s = 0; s < XSLOTS; ++s) {
+            const int f = q + 8 * s;
+            if (f < XF4) *reinterpret_cast<uint2*>(Xs + ch * W2_PSX + f * 4) = cvt4(xr[s], (live >> s) & 1u);
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+            *reinterpret_cast<uint2*>(Zs + ch * W2_PSZ + (q + 8 * s) * 4) = cvt4(zr[s], (live >> (XSLOTS + s)) & 1u);
+    };
+
+    const int j = lane & 15, kg = lane >> 4;
+    const int it = wv & 1, kh = wv >> 1;                  // input-channel tile, row half of the 4-row tile
+    const unsigned short* zb = Zs + j * W2_PSZ + 8 * kg;                        // + ct*16*PSZ + row*32
+    const unsigned short* xb = Xs + (it * 16 + j) * W2_PSX + 8 * kg;            // + halo_row*40
+
+    f32x4 acc[2][9];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int i = 0; i < 9; ++i) acc[c][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    if (t_begin < t_end) prefetch(t_begin);
+    for (int tile = t_begin; tile < t_end; ++tile) {
+        __syncthreads();                       // everyone is done reading the previous tile
+        if (!(p.dbg & 4)) commit();
+        __syncthreads();
+        if (tile + 1 < t_end) prefetch(tile + 1);          // in flight under the MFMAs below
+#pragma unroll
+        for (int ksl = 0; ksl < 2; ++ksl) {
+            const int row = 2 * kh + ksl;                  // 32 pixels of one tile row per step
+            typename T::frag a[2];
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+                a[c] = *reinterpret_cast<const typename T::frag*>(zb + c * 16 * W2_PSZ + row * TW);
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                // elements e0..e15 of halo row (row + r) from column 8kg: pixel x0 + 8kg - 4 + e
+                const u32x4 lo = *reinterpret_cast<const u32x4*>(xb + (row + r) * LW);
+                const u32x4 hi = *reinterpret_cast<const u32x4*>(xb + (row + r) * LW + 8);
+                const unsigned d[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                u32x4 w0, w1, w2;                          // taps s3 = 0, 1, 2 start at elements 3, 4, 5
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    w0[k] = __builtin_amdgcn_alignbit(d[2 + k], d[1 + k], 16);
+                    w1[k] = d[2 + k];
+                    w2[k] = __builtin_amdgcn_alignbit(d[3 + k], d[2 + k], 16);
+                }
+                const typename T::frag b0 = __builtin_bit_cast(typename T::frag, w0);
+                const typename T::frag b1 = __builtin_bit_cast(typename T::frag, w1);
+                const typename T::frag b2 = __builtin_bit_cast(typename T::frag, w2);
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    acc[c][r * 3 + 0] = T::mfma(a[c], b0, acc[c][r * 3 + 0]);
+                    acc[c][r * 3 + 1] = T::mfma(a[c], b1, acc[c][r * 3 + 1]);
+                    acc[c][r * 3 + 2] = T::mfma(a[c], b2, acc[c][r * 3 + 2]);
+                }
+            }
+        }
+    }
+    // sum the two row halves (waves 2,3 -> waves 0,1) through LDS, then one partial per block
+    __syncthreads();
+    f32x4* red = reinterpret_cast<f32x4*>(smem16w);        // [it][18][64] f32x4 = 36 KB
+    if (kh == 1) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int i = 0; i < 9; ++i) red[(it * 18 + c * 9 + i) * 64 + lane] = acc[c][i];
+    }
+    __syncthreads();
+    if (kh == 1) return;
+    const int ci = ci0 + it * 16 + j;
+    if (ci >= p.Cin) return;
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int co = co0 + c * 16 + kg * 4 + r;
+            if (co >= p.Cout) continue;
+            float* d = p.partial + (((size_t)split * p.Cout + co) * p.Cin + ci) * 9;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) d[tap] = acc[c][tap][r] + red[(it * 18 + c * 9 + tap) * 64 + lane][r];
+        }
+}
+constexpr size_t W2_LDS = 2 * 18 * 64 * sizeof(f32x4);      // the end-of-block reduction is the larger user (36 KB)
 
 // ------------------------------------------------------------------ direct (VALU) fallbacks
 // One thread = one pixel x 8 output channels.  mode 0: fwd  (w[co][ci][tap])
@@ -1465,11 +1680,13 @@ WgPlan plan_wgrad(const mtbc_conv3x3_args* a) {
         // 48-channel output blocks (3 tiles, 384 threads) when that pads less than 32-channel blocks (Cout = 48)
         const int pad2 = cdiv(a->Cout, 32) * 32, pad3 = cdiv(a->Cout, 48) * 48;
         w.cot = pad3 < pad2 ? 3 : 2;
+        if (w.geo == 0 && a->compute != 0) w.cot = 2;      // conv3x3_wgrad_lp2_kernel: 32 x 32 channel blocks
         w.coblocks = cdiv(a->Cout, 16 * w.cot); w.ciblocks = cdiv(a->Cin, 32);
         const int pairs = w.coblocks * w.ciblocks;
         // resident blocks per CU: 3 (256 threads, 50 KB LDS) or 2 (384 threads, 58 KB) -- ONE wave of blocks, a
         // block beyond that would double the launch time
-        int ns = (w.cot == 3 ? 512 : 768) / pairs;
+        const bool lp2 = w.geo == 0 && a->compute != 0;      // conv3x3_wgrad_lp2_kernel: 216 VGPRs -> 2 blocks per CU
+        int ns = (w.cot == 3 || lp2 ? 512 : 768) / pairs;
         if (ns > w.total_tiles) ns = w.total_tiles;
         if (ns < 1) ns = 1;
         w.tiles_per_split = cdiv(w.total_tiles, ns);
@@ -1633,7 +1850,17 @@ int mtbc_conv3x3_wgrad(const mtbc_conv3x3_args* a, void* stream) {
             else hipLaunchKernelGGL((conv3x3_wgrad_mfma_kernel<GEO_, COT_>), grid, blk,                                    \
                                     (32 * WGeo<GEO_>::PSX + zch * PSZ) * sizeof(float), st, p);                            \
         } while (0)
-        if (w.cot == 2) {
+        static const bool lp1 = getenv("MTBC_WGRAD_LP1") != nullptr;      // A/B: first-generation 16-bit wgrad
+        if (w.geo == 0 && w.cot == 2 && lowp != 0 && !lp1) {
+            static bool attr2 = false;
+            if (!attr2) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wgrad_lp2_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wgrad_lp2_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+                attr2 = true;
+            }
+            if (lowp == 2) hipLaunchKernelGGL((conv3x3_wgrad_lp2_kernel<true>), grid, dim3(256), W2_LDS, st, p);
+            else hipLaunchKernelGGL((conv3x3_wgrad_lp2_kernel<false>), grid, dim3(256), W2_LDS, st, p);
+        } else if (w.cot == 2) {
             if (w.geo == 0) MTBC_WG_LAUNCH(0, 2); else if (w.geo == 1) MTBC_WG_LAUNCH(1, 2); else MTBC_WG_LAUNCH(2, 2);
         } else {
             if (w.geo == 0) MTBC_WG_LAUNCH(0, 3); else if (w.geo == 1) MTBC_WG_LAUNCH(1, 3); else MTBC_WG_LAUNCH(2, 3);
