@@ -1609,7 +1609,10 @@ int launch_igemm_lp(const ConvP& p, int mblocks, bool f16, hipStream_t st) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_igemm_lp_kernel<MT, GEO, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    int gx = (768 / mblocks) / 8 * 8;
+    // one wave of resident blocks: LDS allows 3 blocks per CU for MT <= 2 (51 KB) but only 2 for MT = 3 (62 KB); a grid
+    // sized for 3 would run a second, two-thirds-empty round
+    const int per_cu = lds * 3 <= 160 * 1024 ? 3 : 2;
+    int gx = (256 * per_cu / mblocks) / 8 * 8;
     if (gx < 8) gx = 8;
     if (gx > p.ntiles) gx = p.ntiles;
     const dim3 grid(gx, mblocks);
@@ -1647,7 +1650,11 @@ int run_igemm(int N, int H, int W, int red, int rows, const SegTable& in, const 
     else if (geo == 1) { p.tiles_x = cdiv(W, 16); p.tiles_y = cdiv(H, 16); p.ntiles = p.tiles_x * p.tiles_y * N; }
     else { p.tiles_x = 1; p.tiles_y = 1; p.ntiles = cdiv(N, 4); }
     // channel tiles per block: up to 3 (4 spills past 256 VGPRs), fewer when the launch would not fill 256 CUs twice over
-    int mblocks = cdiv(p.mtiles, 3);
+    static const int mtmax_env = getenv("MTBC_LP_MT") ? atoi(getenv("MTBC_LP_MT")) : 0;      // A/B probe
+    // 16-bit kernels: 2 tiles per block keep LDS at 51 KB = 3 blocks per CU; 3 tiles (62 KB, 2 blocks) measured slower
+    // on every layer (dgrad 144->24: 0.71 -> 0.56 ms) although the pixel tile is staged once more per channel block
+    const int mtmax = compute != 0 ? (mtmax_env ? mtmax_env : 2) : 3;
+    int mblocks = cdiv(p.mtiles, mtmax);
     int MT = cdiv(p.mtiles, mblocks);
     while (MT > 1 && (long long)p.ntiles * mblocks < 512) {
         --MT;
