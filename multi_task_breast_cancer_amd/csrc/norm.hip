@@ -4,6 +4,7 @@
 // wavefront shuffles (64 lanes) then across the waves through LDS -- deterministic.
 // Replaces nn.InstanceNorm2d + nn.LeakyReLU (MTnnUNet.py:35-36) and MONAI ADN "NDA" (MTUNetPlusPlus.py:20-22).
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -164,6 +165,75 @@ __global__ void in_bwd_kernel(const InP p) {
     }
 }
 
+// ---- backward, register-resident plane (HW % 4 == 0, HW/4 == VPT * blockDim exactly or less): xh stays in registers
+//      between the reduction pass and the output pass, and for planes <= 128x128 (VPT <= 4) so does gy -- the second
+//      pass then reads nothing (3 tensor passes = the algorithmic minimum; larger planes re-read only dy: 4 instead of
+//      the streaming kernel's 5).  Same per-thread summation order as in_bwd_kernel<true> -> bit-identical results.
+template <int VPT, bool BOTH>
+__global__ void in_bwd_reg_kernel(const InP p) {
+    __shared__ float red[32];
+    const int plane = blockIdx.x, n = plane / p.C, c = plane % p.C;
+    const float4* z4 = reinterpret_cast<const float4*>(p.z + (size_t)plane * p.HW);
+    const size_t goff = (size_t)n * p.dybs + (size_t)c * p.HW;
+    const float4* g4 = reinterpret_cast<const float4*>(p.dy + goff);
+    float4* d4 = reinterpret_cast<float4*>(p.dz + (size_t)plane * p.HW);
+    const int n4 = p.HW >> 2;
+    auto g4sum = [&](int i) {                // dy + extras, always in the same order
+        float4 v = g4[i];
+        for (int k = 0; k < p.nx; ++k) {
+            const float4 e = reinterpret_cast<const float4*>(p.dyx[k] + goff)[i];
+            v.x += e.x; v.y += e.y; v.z += e.z; v.w += e.w;
+        }
+        return v;
+    };
+    const float mean = p.mean[plane], rstd = p.rstd[plane];
+    const float g = p.gamma ? p.gamma[c] : 1.f, b = p.beta ? p.beta[c] : 0.f;
+    float4 xh[VPT], gy[BOTH ? VPT : 1];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+        const int idx = threadIdx.x + i * blockDim.x;
+        if (idx < n4) {
+            const float4 zv = z4[idx], gv = g4sum(idx);
+            float4 x, y;
+            x.x = (zv.x - mean) * rstd; y.x = gv.x * ((x.x * g + b) > 0.f ? 1.f : p.slope); s1 += y.x; s2 += y.x * x.x;
+            x.y = (zv.y - mean) * rstd; y.y = gv.y * ((x.y * g + b) > 0.f ? 1.f : p.slope); s1 += y.y; s2 += y.y * x.y;
+            x.z = (zv.z - mean) * rstd; y.z = gv.z * ((x.z * g + b) > 0.f ? 1.f : p.slope); s1 += y.z; s2 += y.z * x.z;
+            x.w = (zv.w - mean) * rstd; y.w = gv.w * ((x.w * g + b) > 0.f ? 1.f : p.slope); s1 += y.w; s2 += y.w * x.w;
+            xh[i] = x;
+            if (BOTH) gy[i] = y;
+        }
+    }
+    s1 = block_sum(s1, red);
+    s2 = block_sum(s2, red);
+    if (threadIdx.x == 0 && p.part) { p.part[3 * plane] = s1; p.part[3 * plane + 1] = s2; }
+    const float m1 = s1 / (float)p.HW, m2 = s2 / (float)p.HW, k = rstd * g;
+    float s3 = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+        const int idx = threadIdx.x + i * blockDim.x;
+        if (idx < n4) {
+            const float4 x = xh[i];
+            float4 y;
+            if (BOTH) y = gy[i];
+            else {
+                const float4 gv = g4sum(idx);
+                y.x = gv.x * ((x.x * g + b) > 0.f ? 1.f : p.slope); y.y = gv.y * ((x.y * g + b) > 0.f ? 1.f : p.slope);
+                y.z = gv.z * ((x.z * g + b) > 0.f ? 1.f : p.slope); y.w = gv.w * ((x.w * g + b) > 0.f ? 1.f : p.slope);
+            }
+            float4 o;
+            o.x = k * (y.x - m1 - x.x * m2); o.y = k * (y.y - m1 - x.y * m2);
+            o.z = k * (y.z - m1 - x.z * m2); o.w = k * (y.w - m1 - x.w * m2);
+            d4[idx] = o;
+            s3 += (o.x + o.y) + (o.z + o.w);
+        }
+    }
+    if (p.part) {
+        s3 = block_sum(s3, red);
+        if (threadIdx.x == 0) p.part[3 * plane + 2] = s3;
+    }
+}
+
 // dgamma[c] = sum_n part[n,c,1] ; dbeta[c] = sum_n part[n,c,0] ; dbias_pre[c] = sum_n part[n,c,2]
 __global__ void in_dparam_kernel(const float* __restrict__ part, float* dgamma, float* dbeta, float* dbias_pre, int N,
                                  int C, int accumulate) {
@@ -227,7 +297,16 @@ int mtbc_instnorm_lrelu_bwd(const mtbc_instnorm_args* a, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     const bool vec = p.HW % 4 == 0 && al16(p.z) && al16(p.dy) && al16(p.dz) && p.dybs % 4 == 0;
     const int threads = p.HW >= 16384 ? 1024 : (p.HW >= 1024 ? 256 : 64);
-    if (vec) hipLaunchKernelGGL(in_bwd_kernel<true>, dim3(planes), dim3(threads), 0, st, p);
+    static const bool stream_only = getenv("MTBC_IN_BWD_STREAM") != nullptr;      // A/B switch
+    const int vpt = vec ? cdiv(p.HW / 4, threads) : 0;
+    if (vec && !stream_only && vpt <= 16) {
+        const dim3 g(planes), b(threads);
+        if (vpt <= 1) hipLaunchKernelGGL((in_bwd_reg_kernel<1, true>), g, b, 0, st, p);
+        else if (vpt <= 2) hipLaunchKernelGGL((in_bwd_reg_kernel<2, true>), g, b, 0, st, p);
+        else if (vpt <= 4) hipLaunchKernelGGL((in_bwd_reg_kernel<4, true>), g, b, 0, st, p);
+        else if (vpt <= 8) hipLaunchKernelGGL((in_bwd_reg_kernel<8, true>), g, b, 0, st, p);
+        else hipLaunchKernelGGL((in_bwd_reg_kernel<16, false>), g, b, 0, st, p);
+    } else if (vec) hipLaunchKernelGGL(in_bwd_kernel<true>, dim3(planes), dim3(threads), 0, st, p);
     else hipLaunchKernelGGL(in_bwd_kernel<false>, dim3(planes), dim3(threads), 0, st, p);
     MTBC_CHECK_LAUNCH();
     if (want) {
