@@ -100,5 +100,5 @@ bool mtbc_i_convT2_dgrad_ok(const mtbc_convT_args* a);
 bool mtbc_i_convT2_wgrad_ok(const mtbc_convT_args* a);
 void mtbc_i_convT2_wgrad_plan(const mtbc_convT_args* a, int* steps_per_split, int* nsplit);
 int mtbc_i_convT2_dgrad(const mtbc_convT_args* a, int compute, hipStream_t st);
-int mtbc_i_convT2_wgrad(const mtbc_convT_args* a, int compute, float* partial, int steps_per_split, int nsplit, hipStream_t st);
+int mtbc_i_convT2_wgrad(const mtbc_convT_args* a, int compute, float* partial, float* dbias_part, int steps_per_split, int nsplit, hipStream_t st);
 int mtbc_i_channel_sums(const float* x, float* planes_ws, float* out, int N, int C, int HW, int accumulate, hipStream_t st);

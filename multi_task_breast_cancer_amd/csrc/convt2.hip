@@ -67,6 +67,7 @@ struct Ct2P {
     const float* dy; long long dybs;
     float* dx; long long dxbs; int acc_dx;
     float* partial;                    // wgrad: [nsplit][Cin][Cout][2][2]
+    float* dbias_part;                 // wgrad: [nsplit][Cout] per-split sums of dY (bias gradient), or nullptr
     int mblocks;                       // blocks of 48 input channels
     int ctiles;                        // wgrad: tiles of 8 output channels
     int steps_per_split, nsplit;       // wgrad: 32-pixel steps per split (over the flattened (n, step) list)
@@ -208,6 +209,8 @@ __global__ __launch_bounds__(256) void convT2_wgrad_kernel(const Ct2P p) {
 #pragma unroll
     for (int m = 0; m < MT; ++m) { acc[m][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[m][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
 
+    const bool want_bias = p.dbias_part != nullptr && mb == 0;      // uniform
+    float bsum = 0.f;
     float4 ra[2][MT][2], rb[2][4];
     auto load = [&](int g, auto SL) {
         constexpr int slot = decltype(SL)::value;
@@ -231,6 +234,10 @@ __global__ __launch_bounds__(256) void convT2_wgrad_kernel(const Ct2P p) {
             b0[2 * k] = cok ? rb[cur][k].x : 0.f; b1[2 * k] = cok ? rb[cur][k].y : 0.f;
             b0[2 * k + 1] = cok ? rb[cur][k].z : 0.f; b1[2 * k + 1] = cok ? rb[cur][k].w : 0.f;
         }
+        if (want_bias) {                   // the bias gradient is the plain sum of dY: it rides on the wave that reads it
+#pragma unroll
+            for (int k = 0; k < 8; ++k) bsum += b0[k] + b1[k];
+        }
         Frag<LP> f0, f1;
         f0.set(b0); f1.set(b1);
 #pragma unroll
@@ -253,6 +260,12 @@ __global__ __launch_bounds__(256) void convT2_wgrad_kernel(const Ct2P p) {
             compute(S1{});
         }
     }
+    if (want_bias) {                       // lanes (co, a) x 4 pixel groups -> one value per channel, fixed shuffle tree
+        bsum += __shfl_xor(bsum, 16);
+        bsum += __shfl_xor(bsum, 32);
+        bsum += __shfl_xor(bsum, 1);
+        if (kg == 0 && (j & 1) == 0 && cok) p.dbias_part[(size_t)split * p.Cout + co] = bsum;
+    }
     if (!cok) return;
     float* part = p.partial + (size_t)split * p.Cin * p.Cout * 4;
 #pragma unroll
@@ -270,7 +283,7 @@ bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
 void fill(const mtbc_convT_args* a, Ct2P* p) {
     p->N = a->N; p->H = a->H; p->W = a->W; p->Cin = a->Cin; p->Cout = a->Cout;
     p->x = a->x; p->xbs = a->x_batch_stride; p->w = a->w; p->dy = a->dy; p->dybs = a->dy_batch_stride;
-    p->dx = a->dx; p->dxbs = a->dx_batch_stride; p->acc_dx = a->accumulate_dx; p->partial = nullptr;
+    p->dx = a->dx; p->dxbs = a->dx_batch_stride; p->acc_dx = a->accumulate_dx; p->partial = nullptr; p->dbias_part = nullptr;
     p->mblocks = cdiv(a->Cin, 48); p->ctiles = cdiv(a->Cout, 8); p->steps_per_split = 1; p->nsplit = 1; p->ntasks = 0;
 }
 
@@ -311,9 +324,9 @@ int mtbc_i_convT2_dgrad(const mtbc_convT_args* a, int compute, hipStream_t st) {
     return MTBC_OK;
 }
 
-int mtbc_i_convT2_wgrad(const mtbc_convT_args* a, int compute, float* partial, int steps_per_split, int nsplit, hipStream_t st) {
+int mtbc_i_convT2_wgrad(const mtbc_convT_args* a, int compute, float* partial, float* dbias_part, int steps_per_split, int nsplit, hipStream_t st) {
     Ct2P p; fill(a, &p);
-    p.partial = partial; p.steps_per_split = steps_per_split; p.nsplit = nsplit;
+    p.partial = partial; p.dbias_part = dbias_part; p.steps_per_split = steps_per_split; p.nsplit = nsplit;
     p.ntasks = (long long)p.mblocks * p.ctiles * nsplit;
     const unsigned blocks = (unsigned)cdiv64(p.ntasks, 4);
     if (compute == 1) hipLaunchKernelGGL(convT2_wgrad_kernel<1>, dim3(blocks), dim3(256), 0, st, p);

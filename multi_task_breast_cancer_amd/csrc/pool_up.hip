@@ -360,7 +360,8 @@ size_t mtbc_convT_wgrad_workspace(const mtbc_convT_args* a) {
         int sps, ns; mtbc_i_convT2_wgrad_plan(a, &sps, &ns);
         if ((size_t)ns > splits) splits = ns;
     }
-    return (splits * a->Cin * p.M + (a->dbias ? (size_t)a->N * a->Cout : 0)) * sizeof(float);
+    const size_t brows = splits > (size_t)a->N ? splits : (size_t)a->N;      // per-split or per-image partial bias sums
+    return (splits * a->Cin * p.M + (a->dbias ? brows * a->Cout : 0)) * sizeof(float);
 }
 int mtbc_convT_wgrad(const mtbc_convT_args* a, void* stream) {
     CtP p; int rc = fill_ct(a, &p); if (rc) return rc;
@@ -371,9 +372,15 @@ int mtbc_convT_wgrad(const mtbc_convT_args* a, void* stream) {
     int nsplit = a->N * S;
     hipStream_t st = (hipStream_t)stream;
     static const bool generic = getenv("MTBC_CONVT_GENERIC") != nullptr;      // A/B switch
+    bool bias_done = false;
     if (!generic && mtbc_i_convT2_wgrad_ok(a)) {
         int sps; mtbc_i_convT2_wgrad_plan(a, &sps, &nsplit);
-        rc = mtbc_i_convT2_wgrad(a, a->compute, p.partial, sps, nsplit, st); if (rc) return rc;
+        float* bpart = a->dbias ? p.partial + (size_t)nsplit * a->Cin * p.M : nullptr;
+        rc = mtbc_i_convT2_wgrad(a, a->compute, p.partial, bpart, sps, nsplit, st); if (rc) return rc;
+        if (bpart) {       // the wgrad waves summed dY on the way: no second pass over the gradient
+            rc = mtbc_i_splitk_reduce(bpart, a->dbias, nsplit, (size_t)a->Cout, a->accumulate_dw, st); if (rc) return rc;
+            bias_done = true;
+        }
     } else {
         dim3 grid(cdiv(p.M, 64), cdiv(a->Cin, 64), nsplit);
         if (a->k == 2) hipLaunchKernelGGL(convT_wgrad_kernel<2>, grid, dim3(256), 0, st, p);
@@ -383,7 +390,7 @@ int mtbc_convT_wgrad(const mtbc_convT_args* a, void* stream) {
     }
     const size_t wel = (size_t)a->Cin * p.M;
     rc = mtbc_i_splitk_reduce(p.partial, a->dw, nsplit, wel, a->accumulate_dw, st); if (rc) return rc;
-    if (a->dbias) {
+    if (a->dbias && !bias_done) {
         if (p.dybs != (long long)a->Cout * a->H * a->W * a->k * a->k) return MTBC_E_UNSUPPORTED;
         rc = mtbc_i_channel_sums(p.dy, p.partial + (size_t)nsplit * wel, a->dbias, a->N, a->Cout, a->H * a->W * a->k * a->k,
                                  a->accumulate_dw, st);
