@@ -295,6 +295,13 @@ enum {
     MTBC_OP_MEMSET, MTBC_OP_DICE_COUNTS, MTBC_OP_CONV3_PACK_LP
 };
 
+/* ---- training-time augmentation: RandomHorizontalFlip(.5) -> RandomVerticalFlip(.5) ->
+ * RandomRotation(360) of training_multitask.py:193-197 / BUSI_dataset.py:142-147 on the joint (mask, image) stack,
+ * torchvision semantics (nearest, zero fill, centre rotation).  src/dst (N,C,H,W), src != dst; params (N,4) =
+ * {cos a, sin a, flip_h, flip_v} per sample, a = rotation angle (counter-clockwise, as torchvision's `angle`). */
+int mtbc_augment_flip_rotate(const float* src, float* dst, const float* params, int32_t N, int32_t C, int32_t H, int32_t W,
+                             void* stream);
+
 typedef struct {
     int32_t kind;
     int32_t tag;                     /* free for the caller (layer id) */

@@ -165,7 +165,7 @@ class PackDesc(C.Structure):
 EXPORTS = [
     "mtbc_version", "mtbc_strerror", "mtbc_arch",
     "mtbc_conv3x3_packed_elems", "mtbc_conv3x3_packed_dgrad_elems", "mtbc_conv3x3_pack_fwd",
-    "mtbc_conv3x3_pack_dgrad", "mtbc_conv3x3_packed_lp_elems", "mtbc_conv3x3_pack_lp", "mtbc_conv3x3_pack_many", "mtbc_conv3x3_wgrad_workspace", "mtbc_conv3x3_fwd", "mtbc_conv3x3_dgrad",
+    "mtbc_conv3x3_pack_dgrad", "mtbc_conv3x3_packed_lp_elems", "mtbc_conv3x3_pack_lp", "mtbc_conv3x3_pack_many", "mtbc_augment_flip_rotate", "mtbc_conv3x3_wgrad_workspace", "mtbc_conv3x3_fwd", "mtbc_conv3x3_dgrad",
     "mtbc_conv3x3_wgrad", "mtbc_instnorm_lrelu_fwd", "mtbc_instnorm_lrelu_bwd", "mtbc_maxpool2_fwd",
     "mtbc_maxpool2_bwd", "mtbc_convT_wgrad_workspace", "mtbc_convT_fwd", "mtbc_convT_dgrad", "mtbc_convT_wgrad",
     "mtbc_conv1x1_wgrad_workspace", "mtbc_conv1x1_fwd", "mtbc_conv1x1_dgrad", "mtbc_conv1x1_wgrad",
@@ -195,6 +195,8 @@ def load() -> C.CDLL:
         getattr(lib, name).argtypes = [C.c_int32, C.c_int32]
     lib.mtbc_conv3x3_packed_lp_elems.restype = C.c_size_t
     lib.mtbc_conv3x3_packed_lp_elems.argtypes = [C.c_int32, C.c_int32, C.c_int32]
+    lib.mtbc_augment_flip_rotate.restype = C.c_int
+    lib.mtbc_augment_flip_rotate.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
     lib.mtbc_conv3x3_pack_many.restype = C.c_int
     lib.mtbc_conv3x3_pack_many.argtypes = [C.POINTER(PackDesc), C.c_int32, C.c_void_p]
     lib.mtbc_conv3x3_pack_lp.restype = C.c_int

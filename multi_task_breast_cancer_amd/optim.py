@@ -16,7 +16,11 @@ from . import _lib as L
 class FusedAdam(torch.optim.Optimizer):
     def __init__(self, model, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8):
         self.model = model
-        super().__init__(list(model.parameters()), dict(lr=lr, betas=betas, eps=eps))
+        # the full hyper-parameter set of torch.optim.Adam, so that `state_dict()['param_groups']` loads into one
+        # (the reference saves / restores optimizer.state_dict(), training_multitask.py:246)
+        super().__init__(list(model.parameters()),
+                         dict(lr=lr, betas=betas, eps=eps, weight_decay=0, amsgrad=False, maximize=False, foreach=None,
+                              capturable=False, differentiable=False, fused=None, decoupled_weight_decay=False))
         self.step_count = 0
         self.exp_avg = None
         self.exp_avg_sq = None
@@ -53,19 +57,45 @@ class FusedAdam(torch.optim.Optimizer):
         L.check(L.load().mtbc_adam_step(C.byref(a), C.c_void_p(torch.cuda.current_stream().cuda_stream)), "adam")
         return loss
 
+    # ---- checkpoint interchange (training_multitask.py:243-249 saves `optimizer.state_dict()`): the layout is the one
+    #      torch.optim.Adam writes -- per-parameter {'step', 'exp_avg', 'exp_avg_sq'} keyed by parameter index -- so a
+    #      reference checkpoint resumes here and a checkpoint written here resumes under torch.optim.Adam.
     def state_dict(self):
         sd = super().state_dict()
-        sd["fused"] = {"step": self.step_count,
-                       "exp_avg": None if self.exp_avg is None else self.exp_avg.detach().cpu(),
-                       "exp_avg_sq": None if self.exp_avg_sq is None else self.exp_avg_sq.detach().cpu()}
+        if self.exp_avg is not None and self.step_count > 0:
+            m = self.model
+            state = {}
+            for i, name in enumerate(n for n, _ in m.named_parameters()):
+                s = m.slots[name]
+                state[i] = {"step": torch.tensor(float(self.step_count)),
+                            "exp_avg": self.exp_avg[s.offset:s.offset + s.numel].view(s.shape).detach().clone(),
+                            "exp_avg_sq": self.exp_avg_sq[s.offset:s.offset + s.numel].view(s.shape).detach().clone()}
+            sd["state"] = state
         return sd
 
     def load_state_dict(self, sd):
-        fused = sd.pop("fused", None) if isinstance(sd, dict) else None
-        super().load_state_dict(sd)
-        if fused is not None:
-            self.step_count = int(fused["step"])
-            if fused["exp_avg"] is not None:
+        sd = dict(sd)
+        legacy = sd.pop("fused", None)                 # round-1 private format
+        state = sd.get("state", {}) or {}
+        super().load_state_dict({"state": {}, "param_groups": sd["param_groups"]})
+        m = self.model
+        if state:
+            self._ensure_state()
+            steps = set()
+            for i, name in enumerate(n for n, _ in m.named_parameters()):
+                st = state.get(i, state.get(str(i)))
+                if st is None:
+                    continue
+                s = m.slots[name]
+                self.exp_avg[s.offset:s.offset + s.numel].copy_(st["exp_avg"].reshape(-1))
+                self.exp_avg_sq[s.offset:s.offset + s.numel].copy_(st["exp_avg_sq"].reshape(-1))
+                steps.add(int(float(st["step"])))
+            if len(steps) > 1:
+                raise ValueError(f"per-parameter step counts differ ({sorted(steps)}): not an Adam state this optimizer can hold")
+            self.step_count = steps.pop() if steps else 0
+        elif legacy is not None:
+            self.step_count = int(legacy["step"])
+            if legacy["exp_avg"] is not None:
                 self._ensure_state()
-                self.exp_avg.copy_(fused["exp_avg"])
-                self.exp_avg_sq.copy_(fused["exp_avg_sq"])
+                self.exp_avg.copy_(legacy["exp_avg"])
+                self.exp_avg_sq.copy_(legacy["exp_avg_sq"])

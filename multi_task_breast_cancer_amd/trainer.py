@@ -181,3 +181,75 @@ def dice_counts(logits: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
     L.check(L.load().mtbc_dice_counts(x.data_ptr(), t.data_ptr(), x.numel(), out.data_ptr(),
                                       C.c_void_p(torch.cuda.current_stream().cuda_stream)), "dice_counts")
     return out
+
+
+# ------------------------------------------------------------------------------------------------
+# validation / inference epoch
+# ------------------------------------------------------------------------------------------------
+class FusedEvalStep:
+    """Forward + losses + metrics of `validate_one_epoch` (training_multitask.py:119-159) with no host round trip per
+    batch: the step program runs pack -> forward -> fused Dice/Focal, `mtbc_dice_counts` gives the batch Dice of
+    `process_segmentation_predicted` (:66-71: sigmoid(last head) > .5 against the mask, `dice_score_from_tensor`), and
+    the 3x3 confusion matrix of `processes_classification_predicted` (:34-63, argmax of softmax vs argmax of the
+    one-hot label) accumulates on the device.  `result()` reads everything back once and returns the reference's
+    6-tuple (avg_val_loss, avg_val_dice, val_acc, val_f1, avg_seg_val_loss, avg_cls_val_loss)."""
+
+    def __init__(self, model, alpha: float, inversely_weighted: bool = True, n_classes: int = 3,
+                 focal_weight: Optional[torch.Tensor] = None):
+        if n_classes < 3:
+            raise NotImplementedError("binary head (n_classes == 2): the sigmoid > .5 branch of :53-61 is not wired yet")
+        self.model, self.alpha, self.iw, self.n_classes = model, float(alpha), bool(inversely_weighted), n_classes
+        self.focal_weight = focal_weight
+        self._helper = FusedTrainStep.__new__(FusedTrainStep)        # reuse load_batch / plan cache, never its optimizer
+        self._helper.model, self._helper.alpha, self._helper.iw = model, self.alpha, self.iw
+        self._helper.focal_weight, self._helper.n_buckets, self._helper._st, self._helper._buckets = focal_weight, 4, None, []
+        self.reset()
+
+    def reset(self) -> None:
+        self._acc = None          # device float64: [sum total, sum seg, sum cls, sum dice, batches]
+        self._conf = None         # device int64 (n_classes, n_classes): rows = ground truth, cols = prediction
+
+    @torch.no_grad()
+    def __call__(self, image: torch.Tensor, mask: torch.Tensor, label: torch.Tensor) -> None:
+        st = self._helper.load_batch(image, mask, label)
+        P = st.programs
+        P["pack"].run()
+        P["fwd"].run()
+        P["loss"].run()
+        dev = st.plan.loss_out.device
+        if self._acc is None:
+            self._acc = torch.zeros(5, dtype=torch.float64, device=dev)
+            self._conf = torch.zeros(self.n_classes, self.n_classes, dtype=torch.int64, device=dev)
+        counts = dice_counts(st.segs[-1].data, st.mask)                 # {tp, fp, fn} float64 on the device
+        tp, fp, fn = counts[0], counts[1], counts[2]
+        empty_gt = (tp + fn) == 0
+        dice = torch.where(empty_gt, torch.where((tp + fp) == 0, torch.ones_like(tp), torch.zeros_like(tp)),
+                           2 * tp / torch.clamp(2 * tp + fp + fn, min=1.0))          # metrics.py:255-267
+        self._acc[:3] += st.plan.loss_out[:3].double()
+        self._acc[3] += dice
+        self._acc[4] += 1
+        pred = st.logits.data.view(st.logits.data.shape[0], -1).argmax(dim=1)
+        gt = st.onehot.argmax(dim=1)
+        self._conf.view(-1).index_add_(0, gt * self.n_classes + pred, torch.ones_like(gt))
+
+    def result(self):
+        acc = self._acc.cpu().tolist()
+        conf = self._conf.cpu().numpy().astype(np.float64)
+        nb = max(acc[4], 1.0)
+        total = conf.sum()
+        accuracy = float(np.trace(conf) / total) if total else 0.0
+        # sklearn f1_score(labels=[0,1,2], average='weighted') (:155): per-class F1 weighted by support
+        support = conf.sum(axis=1)
+        tp = np.diag(conf)
+        denom = conf.sum(axis=0) + support
+        f1c = np.divide(2 * tp, denom, out=np.zeros_like(tp), where=denom > 0)
+        f1w = float((f1c * support).sum() / support.sum()) if support.sum() else 0.0
+        return acc[0] / nb, acc[3] / nb, accuracy, f1w, acc[1] / nb, acc[2] / nb
+
+
+def validate_one_epoch(step: FusedEvalStep, loader, device) -> tuple:
+    """training_multitask.py:119-159 on the fused evaluation step; `loader` yields the reference's batch dicts."""
+    step.reset()
+    for data in loader:
+        step(data["image"].to(device), data["mask"].to(device), data["label"].to(device))
+    return step.result()

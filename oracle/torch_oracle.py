@@ -396,3 +396,32 @@ class lowp_conv3x3:
     def __exit__(self, *exc):
         F.conv2d = self._orig
         return False
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Augmentation oracle: torchvision is absent here, so this restates what
+# torchvision.transforms.functional.{hflip, vflip, rotate} do for tensors (v0.15 _functional_tensor.py: rotate =
+# _get_inverse_affine_matrix(center 0, -angle) -> _gen_affine_grid -> grid_sample(nearest, zeros, align_corners=False)).
+# Parity unpinned (no torchvision to run); the grid construction and the sampler are torch's own.
+def tv_flip_rotate(stack: torch.Tensor, angles_deg, hflip, vflip) -> torch.Tensor:
+    import math
+    out = []
+    for i in range(stack.shape[0]):
+        img = stack[i:i + 1]
+        if hflip[i]:
+            img = img.flip(-1)
+        if vflip[i]:
+            img = img.flip(-2)
+        a = math.radians(float(angles_deg[i]))
+        # rotate(img, angle): matrix = inverse affine of (-angle) = [cos a, -sin a, 0, sin a, cos a, 0]
+        theta = torch.tensor([[math.cos(a), -math.sin(a), 0.0], [math.sin(a), math.cos(a), 0.0]], dtype=torch.float32).view(1, 2, 3)
+        h, w = img.shape[-2:]
+        d = 0.5
+        base = torch.empty(1, h, w, 3, dtype=torch.float32)
+        base[..., 0].copy_(torch.linspace(-w * 0.5 + d, w * 0.5 + d - 1, steps=w))
+        base[..., 1].copy_(torch.linspace(-h * 0.5 + d, h * 0.5 + d - 1, steps=h).unsqueeze(-1))
+        base[..., 2].fill_(1)
+        rescaled = theta.transpose(1, 2) / torch.tensor([0.5 * w, 0.5 * h], dtype=torch.float32)
+        grid = base.view(1, h * w, 3).bmm(rescaled).view(1, h, w, 2)
+        out.append(F.grid_sample(img, grid, mode="nearest", padding_mode="zeros", align_corners=False))
+    return torch.cat(out, dim=0)

@@ -1,0 +1,122 @@
+"""SURVEY 8(f) rows N2 / N3 / N4 on the GPU: augmentation gather, validation epoch, checkpoint interchange."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from multi_task_breast_cancer_amd import augment as AUG  # noqa: E402
+from multi_task_breast_cancer_amd import checkpoint as CK  # noqa: E402
+from multi_task_breast_cancer_amd.miscellany import seed_everything  # noqa: E402
+from multi_task_breast_cancer_amd.nets import MTnnUNet, MTUNetPlusPlus  # noqa: E402
+from multi_task_breast_cancer_amd.optim import FusedAdam  # noqa: E402
+from multi_task_breast_cancer_amd.trainer import FusedEvalStep, FusedTrainStep, validate_one_epoch  # noqa: E402
+from oracle import torch_oracle as O  # noqa: E402
+
+DEV = torch.device("cuda:0")
+
+
+@pytest.mark.parametrize("H,W", [(64, 64), (48, 80), (256, 256)])
+def test_flip_rotate_matches_torchvision_restatement(H, W):
+    g = torch.Generator().manual_seed(3)
+    n = 9
+    stack = torch.rand(n, 2, H, W, generator=g)
+    stack[:, 0] = (stack[:, 0] > 0.6).float()                       # a mask plane and an image plane
+    angles = [0.0, 90.0, -90.0, 180.0, 37.5, -123.4, 359.0, 12.0, -300.25]
+    hf = [0, 1, 0, 1, 1, 0, 1, 0, 1]
+    vf = [0, 0, 1, 1, 0, 1, 1, 0, 0]
+    want = O.tv_flip_rotate(stack, angles, hf, vf)
+    got = AUG.flip_rotate(stack.to(DEV), AUG.params_from(angles, hf, vf)).cpu()
+    # identical gather except where the source coordinate sits on a .5 tie and the fp32 products round differently
+    # (bmm vs fused multiply-add): a handful of pixels per image at most
+    diff = (got != want).float().mean(dim=(1, 2, 3))
+    assert diff.max().item() < 2e-3, diff
+    exact = [0, 3]                                                  # angle 0 / 180 with flips: pure index permutations
+    for i in exact:
+        assert torch.equal(got[i], want[i]), i
+    # mask and image move together: both planes come from the same source pixel
+    idx = AUG.flip_rotate(torch.arange(n * H * W, dtype=torch.float32).view(n, 1, H, W).repeat(1, 2, 1, 1).to(DEV),
+                          AUG.params_from(angles, hf, vf)).cpu()
+    assert torch.equal(idx[:, 0], idx[:, 1])
+    assert set(torch.unique(got[:, 0]).tolist()) <= {0.0, 1.0}     # nearest: a binary mask stays binary
+
+
+def test_random_params_distribution():
+    p = AUG.random_params(4000, np.random.default_rng(0))
+    assert abs(p[:, 2].mean().item() - 0.5) < 0.03 and abs(p[:, 3].mean().item() - 0.5) < 0.03
+    assert torch.allclose(p[:, 0] ** 2 + p[:, 1] ** 2, torch.ones(4000), atol=1e-6)
+
+
+def test_validation_epoch_matches_oracle():
+    """validate_one_epoch (training_multitask.py:119-159): losses, batch Dice, accuracy and weighted F1."""
+    from sklearn.metrics import accuracy_score, f1_score
+    seed_everything(11)
+    prod = MTUNetPlusPlus(in_channels=1, out_channels=1, n_classes=3, deep_supervision=True)
+    O.seed_everything(11)
+    ref = O.build_oracle_model("MTUNetPlusPlus", 1, 1, 3, True)
+    ref.load_state_dict(prod.state_dict())
+    prod = prod.to(DEV)
+    batches = []
+    for s in range(3):
+        img, mask, label = O.synthetic_batch(4, 64, 64, seed=40 + s)
+        batches.append({"image": img, "mask": mask, "label": label})
+    step = FusedEvalStep(prod, alpha=0.5, inversely_weighted=True)
+    got = validate_one_epoch(step, batches, DEV)
+    # oracle: the reference's loop
+    tot = seg_s = cls_s = dice_s = 0.0
+    gts, preds = [], []
+    ref.train(False)
+    with torch.no_grad():
+        for b in batches:
+            onehot = torch.nn.functional.one_hot(b["label"].flatten().long(), 3).float()
+            logits, outs = ref(b["image"])
+            seg, cls = O.multitask_losses(outs, b["mask"], logits, onehot, True)
+            tot += (0.5 * seg + 0.5 * cls).item(); seg_s += seg.item(); cls_s += cls.item()
+            d = O.dice_score_from_tensor(b["mask"], torch.sigmoid(outs[-1]) > .5)
+            dice_s += float(d)
+            lg = torch.mean(torch.stack(logits, dim=0), dim=0)
+            preds += torch.softmax(lg, dim=1).argmax(dim=1).tolist()
+            gts += onehot.argmax(dim=1).tolist()
+    want = (tot / 3, dice_s / 3, accuracy_score(gts, preds), f1_score(gts, preds, labels=[0, 1, 2], average="weighted"),
+            seg_s / 3, cls_s / 3)
+    for g, w in zip(got, want):
+        assert abs(g - w) < 1e-4, (got, want)
+
+
+def test_checkpoint_interchanges_with_torch_adam(tmp_path):
+    """A checkpoint written here resumes under torch.optim.Adam on the oracle model (and vice versa): same model keys,
+    optimizer state in torch.optim.Adam's layout; the next step then agrees."""
+    seed_everything(5)
+    prod = MTnnUNet(1, 1, 3).to(DEV)
+    opt = FusedAdam(prod, lr=1e-4, eps=1e-4)
+    step = FusedTrainStep(prod, opt, alpha=0.5)
+    img, mask, label = O.synthetic_batch(2, 64, 64, seed=1)
+    step(img.to(DEV), mask.to(DEV), label.to(DEV))
+    path = str(tmp_path / "model_fold_0")
+    CK.save_checkpoint(path, 3, prod, opt, 0.123)
+    ck = torch.load(path, map_location="cpu", weights_only=False)
+    assert set(ck) == {"epoch", "model_state_dict", "optimizer_state_dict", "scheduler", "val_loss"}
+    # -> into the CPU oracle + torch.optim.Adam
+    ref = O.build_oracle_model("MTnnUNet", 1, 1, 3, True)
+    ref.load_state_dict(ck["model_state_dict"])
+    ropt = O.make_adam(ref, 1e-4)
+    ropt.load_state_dict(ck["optimizer_state_dict"])
+    img2, mask2, label2 = O.synthetic_batch(2, 64, 64, seed=2)
+    O.train_step(ref, ropt, img2, mask2, label2, 0.5, True, 3)
+    step(img2.to(DEV), mask2.to(DEV), label2.to(DEV))
+    for (k, a), (_, b) in zip(prod.state_dict().items(), ref.state_dict().items()):
+        assert (a.cpu() - b).abs().max().item() < 2.5e-4, k            # second Adam step from the restored moments
+    # <- and back: a torch.optim.Adam checkpoint into a fresh HIP model / FusedAdam
+    torch.save({"epoch": 4, "model_state_dict": ref.state_dict(), "optimizer_state_dict": ropt.state_dict(),
+                "scheduler": "scheduler", "val_loss": 0.1}, path)
+    seed_everything(99)
+    fresh = MTnnUNet(1, 1, 3).to(DEV)
+    fopt = FusedAdam(fresh, lr=1e-4, eps=1e-4)
+    CK.load_pretrained_model(fresh, path, optimizer=fopt)
+    assert fopt.step_count == 2
+    for (k, a), (_, b) in zip(fresh.state_dict().items(), ref.state_dict().items()):
+        assert torch.equal(a.cpu(), b), k
+    sd = fopt.state_dict()["state"]
+    rsd = ropt.state_dict()["state"]
+    for i in rsd:
+        assert torch.allclose(sd[i]["exp_avg"].cpu(), rsd[i]["exp_avg"]) and torch.allclose(sd[i]["exp_avg_sq"].cpu(), rsd[i]["exp_avg_sq"])
