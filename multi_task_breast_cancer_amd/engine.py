@@ -489,7 +489,8 @@ class StepPlan:
 
     # ------------------------------------------------------------------ losses (fused-step path)
     def fused_losses(self, seg_heads: Sequence[Act], logits: Act, mask: torch.Tensor, onehot: torch.Tensor,
-                     alpha: float, inversely_weighted: bool, focal_weight: Optional[torch.Tensor] = None):
+                     alpha: float, inversely_weighted: bool, focal_weight: Optional[torch.Tensor] = None,
+                     loss_scale: float = 1.0):
         """criterions.py:52-76 + training_multitask.py:98 on device: Dice over the heads (weights 1/(j+1) from the
         LAST head backwards), Focal on the logits, alpha-mix, NaN flag.  Gradients land in the heads' grad buffers."""
         nh = len(seg_heads)
@@ -516,13 +517,13 @@ class StepPlan:
         for i, h in enumerate(seg_heads):
             op.u.dice.dx[i] = self.grad_of(h).data_ptr()
             h.grad_written = True
-        op.u.dice.gscale = alpha
+        op.u.dice.gscale = alpha * loss_scale      # loss_scale: fp16 mode keeps dz inside the fp16 range; Adam divides it out
         self.loss_ops.append(op)
         op = _mk(L.OP_FOCAL)
         a = op.u.focal
         a.N, a.C, a.alpha, a.gamma = N, logits.C, 1.0, 2.0
         a.x, a.target, a.weight = logits.data.data_ptr(), onehot.data_ptr(), _ptr(focal_weight)
-        a.loss, a.dx, a.gscale = self.focal_loss.data_ptr(), self.grad_of(logits).data_ptr(), 1.0 - alpha
+        a.loss, a.dx, a.gscale = self.focal_loss.data_ptr(), self.grad_of(logits).data_ptr(), (1.0 - alpha) * loss_scale
         logits.grad_written = True
         self.loss_ops.append(op)
         op = _mk(L.OP_LOSS_MIX)

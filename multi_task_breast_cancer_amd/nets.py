@@ -248,8 +248,9 @@ class CompiledStep:
             self.mask = plan.alloc(N, self.segs[0].C, H, W)
             self.onehot = plan.alloc(N, self.logits.C)
             heads = self.segs if net.deep_supervision_outputs else self.segs[-1:]
+            self.loss_scale = float(net.loss_scale)
             plan.fused_losses(heads, self.logits, self.mask, self.onehot, fused_loss["alpha"],
-                              fused_loss["inversely_weighted"], fused_loss.get("focal_weight"))
+                              fused_loss["inversely_weighted"], fused_loss.get("focal_weight"), loss_scale=self.loss_scale)
         else:
             for h in (self.segs if net.deep_supervision_outputs else self.segs[-1:]):
                 plan.grad_of(h)
@@ -273,6 +274,7 @@ class HipMultiTaskNet(nn.Module):
                  graph: Callable, force_direct: bool = False):
         super().__init__()
         self.compute = 0          # 3x3-conv MFMA operand type: 0 fp32 (reference arithmetic), 1 bf16, 2 fp16; set_compute()
+        self.loss_scale = 1.0     # fused step only: dL is multiplied by this, Adam's grad_scale divides it out (fp16: 4096)
         self.in_channels = in_channels
         self.deep_supervision = deep_supervision
         self.deep_supervision_outputs = deep_supervision
@@ -304,6 +306,9 @@ class HipMultiTaskNet(nn.Module):
         if dtype not in table:
             raise ValueError(f"unknown compute dtype {dtype!r}")
         self.compute = table[dtype]
+        # fp16 operands: a static loss scale keeps the back-propagated dz (1e-7 .. 1e-3 unscaled) out of fp16's
+        # subnormals when the MFMA operands are rounded; storage and accumulation are fp32, so 2^12 cannot overflow
+        self.loss_scale = 4096.0 if self.compute == 2 else 1.0
         self._steps.clear()
         return self
 
@@ -355,7 +360,7 @@ class HipMultiTaskNet(nn.Module):
     def compiled(self, N: int, H: int, W: int, fused_loss: Optional[dict] = None) -> CompiledStep:
         self.ensure_flat()
         key = (N, H, W, self.compute,
-               None if fused_loss is None else (fused_loss["alpha"], fused_loss["inversely_weighted"]))
+               None if fused_loss is None else (fused_loss["alpha"], fused_loss["inversely_weighted"], self.loss_scale))
         st = self._steps.get(key)
         if st is None or st.param_ptr != self.flat_p.data_ptr():
             st = CompiledStep(self, N, H, W, fused_loss)

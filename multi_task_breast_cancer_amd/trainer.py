@@ -150,6 +150,7 @@ class FusedTrainStep:
             if done < P["bwd"].n:
                 P["bwd"].run(done, P["bwd"].n - done)
             cur.wait_stream(self.comm_stream)
+        self.opt.grad_scale = (1.0 / self.world) / getattr(st, "loss_scale", 1.0)
         self.opt.step(grads_in_flat=True)
         self.losses = st.plan.loss_out
         return self.losses

@@ -303,14 +303,20 @@ def make_adam(model: nn.Module, lr: float = 1e-4) -> torch.optim.Optimizer:
 
 
 def train_step(model: nn.Module, optimizer, image: torch.Tensor, mask: torch.Tensor,
-               label: torch.Tensor, alpha: float, inversely_weighted: bool = True, n_classes: int = 3):
-    """Returns (total, seg, cls) python floats plus the raw outputs of the forward pass."""
+               label: torch.Tensor, alpha: float, inversely_weighted: bool = True, n_classes: int = 3,
+               loss_scale: float = 1.0):
+    """Returns (total, seg, cls) python floats plus the raw outputs of the forward pass.  loss_scale != 1 mirrors the
+    product's fp16 mode: the loss is scaled before backward and the gradients unscaled before the optimizer."""
     onehot = F.one_hot(label.flatten().to(torch.int64), num_classes=n_classes).to(torch.float)
     optimizer.zero_grad(set_to_none=True)
     logits, outputs = model(image)
     seg, cls = multitask_losses(outputs, mask, logits, onehot, inversely_weighted)
     total = alpha * seg + (1.0 - alpha) * cls
-    total.backward()
+    (total * loss_scale).backward()
+    if loss_scale != 1.0:
+        for p in model.parameters():
+            if p.grad is not None:
+                p.grad.div_(loss_scale)
     optimizer.step()
     return total.detach(), seg.detach(), cls.detach(), logits, outputs
 

@@ -236,7 +236,7 @@ def test_16bit_mfma_modes_match_their_emulation(dtype):
     (first-layer gradients, N=4 at 64x64) away from the same emulation with fp64 accumulation.  So the HIP path is
     judged like the fp32 test judges gradients: against the fp64-accumulating emulation, allowed 3x the distance the
     fp32-accumulating CPU emulation has from it (and a small floor).  A wrong operand / rounding place shows up in
-    the forward as >= 3e-2.  fp16 has no loss scaling (tiny dz underflows to 0): forward only."""
+    the forward as >= 3e-2.  fp16 runs with the static loss scale 4096 on both sides (unscaled, dz underflows fp16)."""
     import copy
     N, size = 4, 64
     prod, ref = _oracle_and_product("MTUNetPlusPlus", 1993)
@@ -246,20 +246,19 @@ def test_16bit_mfma_modes_match_their_emulation(dtype):
     step = FusedTrainStep(prod, FusedAdam(prod, lr=1e-4, eps=1e-4), alpha=0.5)
     st = step.load_batch(img.to(DEV), mask.to(DEV), label.to(DEV))
     losses = step.run(st).cpu()
+    ls = prod.loss_scale                      # 4096 in fp16 mode (dz would underflow fp16 otherwise), 1 in bf16
     with O.lowp_conv3x3(dtype):
-        t32 = O.train_step(ref, O.make_adam(ref, 1e-4), img, mask, label, 0.5, True, 3)
-        t64 = O.train_step(ref64, O.make_adam(ref64, 1e-4), img.double(), mask.double(), label, 0.5, True, 3)
+        t32 = O.train_step(ref, O.make_adam(ref, 1e-4), img, mask, label, 0.5, True, 3, loss_scale=ls)
+        t64 = O.train_step(ref64, O.make_adam(ref64, 1e-4), img.double(), mask.double(), label, 0.5, True, 3, loss_scale=ls)
     assert losses[3].item() == 0.0
     rel = lambda a, b: ((a.double().cpu() - b.double()).norm() / b.double().norm()).item()
     assert abs(losses[0].item() - t64[0].item()) < max(3 * abs(t32[0].item() - t64[0].item()), 5e-4)
     assert rel(st.logits.data.view(N, -1), t64[3][0]) < max(3 * rel(t32[3][0], t64[3][0]), 2e-3)
     for got, w32, w64 in zip(st.segs, t32[4], t64[4]):
         assert rel(got.data, w64) < max(3 * rel(w32, w64), 2e-3)
-    if dtype != "bf16":
-        return
     g32, g64 = dict(ref.named_parameters()), dict(ref64.named_parameters())
     for name in prod._order:
         if name.endswith("conv.bias") or g64[name].grad.norm().item() == 0.0:
             continue
-        e_hip, e_cpu = rel(prod._grad_view(name), g64[name].grad), rel(g32[name].grad, g64[name].grad)
+        e_hip, e_cpu = rel(prod._grad_view(name) / ls, g64[name].grad), rel(g32[name].grad, g64[name].grad)
         assert e_hip < max(3 * e_cpu, 5e-2), (name, e_hip, e_cpu)
