@@ -2,22 +2,30 @@
 #include "common.h"
 
 namespace {
-// out[i] (+)= sum_k partial[k][i].  Block = 64 consecutive elements x 4 split lanes: lane group g sums splits
-// g, g+4, ... (coalesced 256-B rows), the four partial sums are combined in a fixed order -> deterministic.
+// out[i] (+)= sum_k partial[k][i].  Block = 64 consecutive elements x G split lanes: lane group g sums splits
+// g, g+G, ... (coalesced 256-B rows), the G partial sums are combined by a fixed pairwise tree -> deterministic.
+// G = 16 for the many-split partials of the wide maps (a level-0 wgrad has 512 splits of only ~5k elements: with 4
+// lanes each thread walked 128 dependent rows and the launch took 18 us for 10 MB).
+template <int G>
 __global__ void splitk_reduce_k(const float* __restrict__ partial, float* __restrict__ out, int nsplit, size_t elems,
                                 int accumulate) {
-    __shared__ float red[4][64];
+    __shared__ float red[G][64];
     const int e = threadIdx.x & 63, g = threadIdx.x >> 6;
     const size_t i = (size_t)blockIdx.x * 64 + e;
-    float s = 0.f;
-    if (i < elems)
-        for (int k = g; k < nsplit; k += 4) s += partial[(size_t)k * elems + i];
-    red[g][e] = s;
-    __syncthreads();
-    if (g == 0 && i < elems) {
-        const float t = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
-        out[i] = accumulate ? out[i] + t : t;
+    float s0 = 0.f, s1 = 0.f;               // two independent chains per thread, combined in a fixed order
+    if (i < elems) {
+        int k = g;
+        for (; k + G < nsplit; k += 2 * G) { s0 += partial[(size_t)k * elems + i]; s1 += partial[(size_t)(k + G) * elems + i]; }
+        if (k < nsplit) s0 += partial[(size_t)k * elems + i];
     }
+    red[g][e] = s0 + s1;
+    __syncthreads();
+#pragma unroll
+    for (int w = G / 2; w >= 1; w >>= 1) {
+        if (g < w) red[g][e] += red[g + w][e];
+        __syncthreads();
+    }
+    if (g == 0 && i < elems) out[i] = accumulate ? out[i] + red[0][e] : red[0][e];
 }
 __global__ void plane_sum_k(const float* __restrict__ x, float* __restrict__ out, int HW) {
     __shared__ float red[32];
@@ -42,7 +50,8 @@ __global__ void sum_over_n_k(const float* __restrict__ planes, float* __restrict
 }  // namespace
 
 int mtbc_i_splitk_reduce(const float* partial, float* out, int nsplit, size_t elems, int accumulate, hipStream_t st) {
-    hipLaunchKernelGGL(splitk_reduce_k, dim3((unsigned)cdiv64(elems, 64)), dim3(256), 0, st, partial, out, nsplit, elems, accumulate);
+    if (nsplit > 32) hipLaunchKernelGGL(splitk_reduce_k<16>, dim3((unsigned)cdiv64(elems, 64)), dim3(1024), 0, st, partial, out, nsplit, elems, accumulate);
+    else hipLaunchKernelGGL(splitk_reduce_k<4>, dim3((unsigned)cdiv64(elems, 64)), dim3(256), 0, st, partial, out, nsplit, elems, accumulate);
     MTBC_CHECK_LAUNCH();
     return MTBC_OK;
 }
