@@ -54,7 +54,6 @@ struct ConvP {
     int tiles_x, tiles_y, ntiles;
     int mtiles;
     int dbg;      // timing probes only (env MTBC_DBG): 1 = no global loads, 2 = no epilogue, 4 = no LDS stores
-    int pxrows;   // 16-bit igemm: 1 = pixels on the MFMA rows (16-byte stores; no segment accumulates), 0 = channels on the rows
 };
 
 constexpr int KC = 8;           // input channels per LDS chunk
@@ -476,7 +475,7 @@ __global__ __launch_bounds__(256, RING == 3 ? 2 : 3) void conv3x3_igemm_dma_kern
                 for (int m = 0; m < MT; ++m)
 #pragma unroll
                     for (int g = 0; g < 4; ++g)
-                        acc[m][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[q & 1][s3][m], fb[q & 1][s3][g], acc[m][g], 0, 0, 0);
+                        acc[m][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[q & 1][s3][g], fa[q & 1][s3][m], acc[m][g], 0, 0, 0);      // rows = pixels
             __builtin_amdgcn_sched_barrier(0);
         }
         // item it+1 must have landed before anyone reads it; item it+2 (RING 3) may stay in flight.  Waiting HERE, in
@@ -487,38 +486,35 @@ __global__ __launch_bounds__(256, RING == 3 ? 2 : 3) void conv3x3_igemm_dma_kern
             const int tx = t % p.tiles_x; t /= p.tiles_x;
             const int ty = t % p.tiles_y; t /= p.tiles_y;
             const int n = t, x0 = tx * G::TW, y0 = ty * G::TH;
+            // D = X^T W^T (pixels on the MFMA rows): a lane holds 4 consecutive pixels (4kk .. 4kk+3 of the 16-pixel
+            // group) of ONE channel (16m + j) -> one 16-byte store per accumulator tile; the bias comes from LDS; a fan-in
+            // segment of dgrad is a 16-byte read-modify-write (its loads are younger than the DMA waited for above).
             int poff[4];
-            bool all_px = true;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 int y, x;
-                if (GEO == 0) { y = y0 + 2 * wv + (g >> 1); x = x0 + 16 * (g & 1) + j; }
-                else { y = y0 + 4 * wv + g; x = x0 + j; }
-                const bool ok = y < p.H && x < p.W;
-                all_px = all_px && ok;
-                poff[g] = ok ? y * p.W + x : -1;
+                if (GEO == 0) { y = y0 + 2 * wv + (g >> 1); x = x0 + 16 * (g & 1) + 4 * kk; }
+                else { y = y0 + 4 * wv + g; x = x0 + 4 * kk; }
+                poff[g] = (y < p.H && x < p.W) ? y * p.W + x : -1;          // W % 4 == 0: x < W covers x + 3
             }
-            // No load may sit here (it would be waited for together with the DMA in flight): the bias comes from LDS and
-            // accumulation into a fan-in gradient is a no-return global_atomic_add_f32 -- each element has exactly one
-            // writer per launch, so this is the same fp32 sum old + (acc + bias) as a read-modify-write.
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
-                const int co4 = (mt0 + m) * 16 + kk * 4;
-                const SegL so = segl_ref(seg_out, co4 < p.Cout ? co4 : 0);
-                gfloat* cb0 = (gfloat*)so.ptr + (size_t)n * so.bs + (size_t)((co4 < p.Cout ? co4 : 0) - so.cb) * HW;
-                const f32x4 bv4 = *reinterpret_cast<const f32x4*>(bias_s + m * 16 + kk * 4);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if (co4 + r >= p.Cout) continue;
-                    gfloat* cb = cb0 + (size_t)r * HW;
+                const int co = (mt0 + m) * 16 + j;
+                if (co < p.Cout) {
+                    const SegL so = segl_ref(seg_out, co);
+                    gfloat* cb = (gfloat*)so.ptr + (size_t)n * so.bs + (size_t)(co - so.cb) * HW;
+                    const float bv = bias_s[m * 16 + j];
                     if (so.acc) {
+                        f32x4 old[4];
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) old[g] = poff[g] >= 0 ? *(const gf32x4*)(cb + poff[g]) : (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                         for (int g = 0; g < 4; ++g)
-                            if (poff[g] >= 0) __builtin_amdgcn_global_atomic_fadd_f32(cb + poff[g], acc[m][g][r] + bv4[r]);
+                            if (poff[g] >= 0) *(gf32x4*)(cb + poff[g]) = old[g] + (acc[m][g] + bv);
                     } else {
 #pragma unroll
                         for (int g = 0; g < 4; ++g)
-                            if (poff[g] >= 0) cb[poff[g]] = acc[m][g][r] + bv4[r];
+                            if (poff[g] >= 0) *(gf32x4*)(cb + poff[g]) = acc[m][g] + bv;
                     }
                 }
 #pragma unroll
@@ -638,7 +634,7 @@ __global__ void pack_many_kernel(const PackManyP q) {
     }
 }
 
-template <int MT, int GEO, bool F16, bool PX>
+template <int MT, int GEO, bool F16>
 __global__ __launch_bounds__(256, 3) void conv3x3_igemm_lp_kernel(const ConvP p) {
     using G = GeoLP<GEO>;
     using T = LP<F16>;
@@ -789,88 +785,57 @@ __global__ __launch_bounds__(256, 3) void conv3x3_igemm_lp_kernel(const ConvP p)
                 if (fetched) wait_vmcnt<8 * XQ>(); else wait_vmcnt<0>();
             }
             lds_barrier();
-            {
-                constexpr bool px = PX;
 #pragma unroll
-                for (int tap = 0; tap < 9; ++tap) {
-                    const int toff = ((tap / 3) * HC + tap % 3) * LPROW + 8 * kg;
-                    typename T::frag a[MT], b[4];
+            for (int tap = 0; tap < 9; ++tap) {
+                const int toff = ((tap / 3) * HC + tap % 3) * LPROW + 8 * kg;
+                typename T::frag a[MT], b[4];
 #pragma unroll
-                    for (int m = 0; m < MT; ++m)
-                        a[m] = *reinterpret_cast<const typename T::frag*>(Ws + ((m * 9 + tap) * 16 + j) * LPROW + 8 * kg);
+                for (int m = 0; m < MT; ++m)
+                    a[m] = *reinterpret_cast<const typename T::frag*>(Ws + ((m * 9 + tap) * 16 + j) * LPROW + 8 * kg);
 #pragma unroll
-                    for (int g = 0; g < 4; ++g)
-                        b[g] = *reinterpret_cast<const typename T::frag*>(Xs + bpix[g] * LPROW + toff);
+                for (int g = 0; g < 4; ++g)
+                    b[g] = *reinterpret_cast<const typename T::frag*>(Xs + bpix[g] * LPROW + toff);
 #pragma unroll
-                    for (int m = 0; m < MT; ++m)
+                for (int m = 0; m < MT; ++m)
 #pragma unroll
-                        for (int g = 0; g < 4; ++g)
-                            acc[m][g] = px ? T::mfma(b[g], a[m], acc[m][g])      // rows = pixels, cols = channels
-                                           : T::mfma(a[m], b[g], acc[m][g]);     // rows = channels, cols = pixels
-                }
+                    for (int g = 0; g < 4; ++g) acc[m][g] = T::mfma(b[g], a[m], acc[m][g]);      // rows = pixels, cols = channels
             }
         }
-        // ---- epilogue.  No load may sit here: vmcnt retires in order, so waiting for one (a bias, an old value to
-        //      accumulate onto) would also wait for the whole X prefetch issued above.  The bias comes from LDS;
-        //      accumulation into a fan-in gradient is a no-return global_atomic_add_f32 -- every element has exactly
-        //      one writer per launch, so the sum is the same (old + (acc + bias)) as a read-modify-write.
+        // ---- epilogue.  The MFMAs ran as D = X^T W^T (pixels on the rows): a lane holds FOUR CONSECUTIVE PIXELS
+        //      (4kg .. 4kg+3 of the 16-pixel group) of ONE output channel (16m + j), i.e. one 16-byte store per
+        //      accumulator tile -- the epilogue is store-issue bound.  The bias comes from LDS (a global load here would
+        //      be waited for together with the whole X prefetch: vmcnt retires in order).  A fan-in segment of dgrad is a
+        //      16-byte read-modify-write: measured against no-return float atomics (4 per store, coalesced only with
+        //      channels on the rows) it is 7 % faster over the step's dgrads even though its loads queue behind the prefetch.
         const int n = GEO == 2 ? n0 + wv : n0;
         if (p.dbg & 2) { if (acc[0][0][0] != 12345.678f) continue; }
-        if (PX) {
-            // D = X^T W^T: a lane holds FOUR CONSECUTIVE PIXELS (4kg .. 4kg+3 of the 16-pixel group) of ONE output
-            // channel (16m + j): one 16-byte store per accumulator tile (the epilogue is store-issue bound)
-            int poff[4];
+        int poff[4];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                int y, x;
-                if (GEO == 0) { y = y0 + 2 * wv + (g >> 1); x = x0 + 16 * (g & 1) + 4 * kg; }
-                else if (GEO == 1) { y = y0 + 4 * wv + g; x = x0 + 4 * kg; }
-                else { y = y0 + 2 * g + (kg >> 1); x = x0 + 4 * (kg & 1); }
-                poff[g] = (n < p.N && y < p.H && x < p.W) ? y * p.W + x : -1;        // W % 4 == 0: x < W covers x + 3
-            }
+        for (int g = 0; g < 4; ++g) {
+            int y, x;
+            if (GEO == 0) { y = y0 + 2 * wv + (g >> 1); x = x0 + 16 * (g & 1) + 4 * kg; }
+            else if (GEO == 1) { y = y0 + 4 * wv + g; x = x0 + 4 * kg; }
+            else { y = y0 + 2 * g + (kg >> 1); x = x0 + 4 * (kg & 1); }
+            poff[g] = (n < p.N && y < p.H && x < p.W) ? y * p.W + x : -1;        // W % 4 == 0: x < W covers x + 3
+        }
 #pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                const int co = (mt0 + m) * 16 + j;
-                if (co >= p.Cout) continue;
-                const SegL so = segl_ref(seg_out, co);
-                gfloat* cb = (gfloat*)so.ptr + (size_t)n * so.bs + (size_t)(co - so.cb) * HW;
-                const float bv = bias_s[m * 16 + j];
+        for (int m = 0; m < MT; ++m) {
+            const int co = (mt0 + m) * 16 + j;
+            if (co >= p.Cout) continue;
+            const SegL so = segl_ref(seg_out, co);
+            gfloat* cb = (gfloat*)so.ptr + (size_t)n * so.bs + (size_t)(co - so.cb) * HW;
+            const float bv = bias_s[m * 16 + j];
+            if (so.acc) {
+                f32x4 old[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) old[g] = poff[g] >= 0 ? *(const gf32x4*)(cb + poff[g]) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    if (poff[g] >= 0) *(gf32x4*)(cb + poff[g]) = old[g] + (acc[m][g] + bv);
+            } else {
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
                     if (poff[g] >= 0) *(gf32x4*)(cb + poff[g]) = acc[m][g] + bv;
-            }
-        } else {
-            // D = W X: a lane holds one pixel (j of the group) of four channels; 16 lanes cover 64 contiguous bytes of a
-            // plane, which is what keeps the atomics of a fan-in launch coalesced
-            int poff[4];
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                int y, x;
-                if (GEO == 0) { y = y0 + 2 * wv + (g >> 1); x = x0 + 16 * (g & 1) + j; }
-                else if (GEO == 1) { y = y0 + 4 * wv + g; x = x0 + j; }
-                else { y = y0 + 2 * g + (j >> 3); x = x0 + (j & 7); }
-                poff[g] = (n < p.N && y < p.H && x < p.W) ? y * p.W + x : -1;
-            }
-#pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                const int co4 = (mt0 + m) * 16 + kg * 4;
-                const SegL so = segl_ref(seg_out, co4 < p.Cout ? co4 : 0);
-                gfloat* cb0 = (gfloat*)so.ptr + (size_t)n * so.bs + (size_t)((co4 < p.Cout ? co4 : 0) - so.cb) * HW;
-                const f32x4 bv4 = *reinterpret_cast<const f32x4*>(bias_s + m * 16 + kg * 4);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if (co4 + r >= p.Cout) continue;
-                    gfloat* cb = cb0 + (size_t)r * HW;
-                    if (so.acc) {
-#pragma unroll
-                        for (int g = 0; g < 4; ++g)
-                            if (poff[g] >= 0) __builtin_amdgcn_global_atomic_fadd_f32(cb + poff[g], acc[m][g][r] + bv4[r]);
-                    } else {
-#pragma unroll
-                        for (int g = 0; g < 4; ++g)
-                            if (poff[g] >= 0) cb[poff[g]] = acc[m][g][r] + bv4[r];
-                    }
-                }
             }
         }
     }
@@ -1603,10 +1568,8 @@ int launch_igemm_lp(const ConvP& p, int mblocks, bool f16, hipStream_t st) {
     const size_t lds = ((size_t)HP * LPROW + (size_t)MT * 9 * 16 * LPROW) * 2 + (SEGL_FLOATS + MT * 16) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_igemm_lp_kernel<MT, GEO, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_igemm_lp_kernel<MT, GEO, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_igemm_lp_kernel<MT, GEO, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_igemm_lp_kernel<MT, GEO, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_igemm_lp_kernel<MT, GEO, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_igemm_lp_kernel<MT, GEO, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     // one wave of resident blocks: LDS allows 3 blocks per CU for MT <= 2 (51 KB) but only 2 for MT = 3 (62 KB); a grid
@@ -1616,13 +1579,8 @@ int launch_igemm_lp(const ConvP& p, int mblocks, bool f16, hipStream_t st) {
     if (gx < 8) gx = 8;
     if (gx > p.ntiles) gx = p.ntiles;
     const dim3 grid(gx, mblocks);
-    if (f16) {
-        if (p.pxrows) hipLaunchKernelGGL((conv3x3_igemm_lp_kernel<MT, GEO, true, true>), grid, dim3(256), lds, st, p);
-        else hipLaunchKernelGGL((conv3x3_igemm_lp_kernel<MT, GEO, true, false>), grid, dim3(256), lds, st, p);
-    } else {
-        if (p.pxrows) hipLaunchKernelGGL((conv3x3_igemm_lp_kernel<MT, GEO, false, true>), grid, dim3(256), lds, st, p);
-        else hipLaunchKernelGGL((conv3x3_igemm_lp_kernel<MT, GEO, false, false>), grid, dim3(256), lds, st, p);
-    }
+    if (f16) hipLaunchKernelGGL((conv3x3_igemm_lp_kernel<MT, GEO, true>), grid, dim3(256), lds, st, p);
+    else hipLaunchKernelGGL((conv3x3_igemm_lp_kernel<MT, GEO, false>), grid, dim3(256), lds, st, p);
     MTBC_CHECK_LAUNCH();
     return MTBC_OK;
 }
@@ -1642,8 +1600,7 @@ int run_igemm(int N, int H, int W, int red, int rows, const SegTable& in, const 
     p.N = N; p.H = H; p.W = W; p.Cin = red; p.Cout = rows; p.in = in; p.out = out; p.wp = wp; p.bias = bias;
     static const int dbg = getenv("MTBC_DBG") ? atoi(getenv("MTBC_DBG")) : 0;
     p.dbg = dbg;
-    p.pxrows = 1;
-    for (int i = 0; i < out.n; ++i) if (out.accumulate[i]) p.pxrows = 0;
+
     const int geo = pick_geo(H, W);
     p.mtiles = cdiv(rows, 16);
     if (geo == 0) { p.tiles_x = cdiv(W, 32); p.tiles_y = cdiv(H, 8); p.ntiles = p.tiles_x * p.tiles_y * N; }
