@@ -82,3 +82,30 @@ def test_metrics_file_and_early_stopping(tmp_path):
     assert es.patience == 3 and es.should_stop and es.best == 0.9
     with pytest.raises(ValueError):
         CK.load_pretrained_model(None, str(tmp_path / "missing.tar"))
+
+
+def test_prediction_refining_rules():
+    """utils/models.py:325-332 / :366-376 restated literally (batch-1 loops) against the batched tensor version."""
+    import torch
+    from multi_task_breast_cancer_amd.inference import refine_predictions
+    g = torch.Generator().manual_seed(0)
+    n = 12
+    seg_logits = [torch.randn(n, 1, 16, 16, generator=g) for _ in range(4)]
+    seg_logits[-1][3] = -5.0                                   # no tumour pixel predicted
+    seg_logits[-1][7] = -5.0
+    cls_logits = [torch.randn(n, 3, generator=g)]
+    cls_logits[0][5] = torch.tensor([0.0, 0.0, 9.0])           # predicted "normal" with a non-empty mask
+    for rule_seg in (False, True):
+        for rule_cls in (False, True):
+            seg, cls = refine_predictions(cls_logits, seg_logits, rule_seg, rule_cls)
+            for i in range(n):                                 # the reference's per-patient logic
+                features_map = seg_logits[-1][i:i + 1]
+                test_outputs = (torch.sigmoid(features_map) > .5).float().numpy()
+                pred_class = torch.mean(torch.stack([c[i:i + 1] for c in cls_logits], dim=0), dim=0)
+                pc = [pl.argmax() for pl in pred_class]
+                if rule_seg and pc[0].item() == 2:
+                    test_outputs[test_outputs > 0] = 0
+                tumour = int(((torch.sigmoid(seg_logits[-1][i:i + 1]) > .5).float().numpy() == 1).sum())
+                want_cls = 2 if (rule_cls and tumour == 0) else int(pc[0].item())
+                assert np.array_equal(seg[i:i + 1].numpy(), test_outputs), (i, rule_seg, rule_cls)
+                assert int(cls[i].item()) == want_cls, (i, rule_seg, rule_cls)
