@@ -1,5 +1,5 @@
 import sys, os, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from multi_task_breast_cancer_amd.miscellany import seed_everything
 from multi_task_breast_cancer_amd.nets import MTUNetPlusPlus
 from multi_task_breast_cancer_amd.optim import FusedAdam
