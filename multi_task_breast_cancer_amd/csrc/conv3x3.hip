@@ -1419,6 +1419,46 @@ __global__ void conv3x3_direct_kernel(const DirP p) {
     }
 }
 
+// Stem convolution (Cin == 1, e.g. 1 -> 24 @256x256): K = 9 is not a dense contraction, the layer is bound by writing
+// Cout planes.  One thread = 4 consecutive pixels x 8 output channels: the 3 x 6 input window sits in registers and
+// every plane gets 16-byte stores (the generic direct kernel wrote 4 bytes per thread per plane: 0.8 TB/s).  Same
+// fmaf order over the taps as conv3x3_direct_kernel -> bit-identical results.
+__global__ void conv3x3_stem_fwd_kernel(const float* __restrict__ x, long long xbs, const float* __restrict__ w,
+                                        const float* __restrict__ bias, float* __restrict__ out, int N, int H, int W, int Cout) {
+    const int w4 = W >> 2;
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;           // float4 index inside a plane
+    const int cog = blockIdx.y * 8, n = blockIdx.z;
+    if (q >= H * w4) return;
+    const int y = q / w4, x0 = (q % w4) * 4;
+    const float* src = x + (size_t)n * xbs;
+    float v[3][6];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const int yy = y + r - 1;
+        const bool rowok = yy >= 0 && yy < H;
+        const float4 mid = rowok ? *reinterpret_cast<const float4*>(src + (size_t)yy * W + x0) : make_float4(0.f, 0.f, 0.f, 0.f);
+        v[r][0] = (rowok && x0 > 0) ? src[(size_t)yy * W + x0 - 1] : 0.f;
+        v[r][1] = mid.x; v[r][2] = mid.y; v[r][3] = mid.z; v[r][4] = mid.w;
+        v[r][5] = (rowok && x0 + 4 < W) ? src[(size_t)yy * W + x0 + 4] : 0.f;
+    }
+    const size_t HW = (size_t)H * W;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int co = cog + i;
+        if (co >= Cout) break;
+        float wk[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) wk[t] = w[co * 9 + t];
+        float a[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a[e] = fmaf(wk[t], v[t / 3][e + t % 3], a[e]);
+        const float b = bias ? bias[co] : 0.f;
+        *reinterpret_cast<float4*>(out + ((size_t)n * Cout + co) * HW + (size_t)y * W + x0) = make_float4(a[0] + b, a[1] + b, a[2] + b, a[3] + b);
+    }
+}
+
 // wgrad direct: block = (co, ci, split over n); 9 sums per thread, block-reduced.  partial[split][co][ci][9]
 struct DirWgP {
     int N, H, W, Cin, Cout, nsplit;
@@ -1752,6 +1792,13 @@ int mtbc_conv3x3_fwd(const mtbc_conv3x3_args* a, void* stream) {
     if (a->w_packed && !a->force_direct && mfma_ok(a->in, a->n_in, a->H, a->W))
         return run_igemm(a->N, a->H, a->W, a->Cin, a->Cout, in, out, a->w_packed, a->bias, a->compute, st);
     if (!a->w) return MTBC_E_BADARG;
+    if (a->Cin == 1 && a->n_in == 1 && !a->force_direct && a->W % 4 == 0 && a->in[0].batch_stride % 4 == 0 &&
+        (reinterpret_cast<uintptr_t>(a->in[0].ptr) & 15) == 0 && (reinterpret_cast<uintptr_t>(a->out) & 15) == 0) {
+        hipLaunchKernelGGL(conv3x3_stem_fwd_kernel, dim3(cdiv(a->H * (a->W / 4), 128), cdiv(a->Cout, 8), a->N), dim3(128), 0, st,
+                           a->in[0].ptr, (long long)a->in[0].batch_stride, a->w, a->bias, a->out, a->N, a->H, a->W, a->Cout);
+        MTBC_CHECK_LAUNCH();
+        return MTBC_OK;
+    }
     DirP p; p.N = a->N; p.H = a->H; p.W = a->W; p.Cin = a->Cin; p.Cout = a->Cout; p.in = in; p.out = out;
     p.w = a->w; p.bias = a->bias; p.mode = 0; p.wCin = a->Cin;
     hipLaunchKernelGGL(conv3x3_direct_kernel, dim3(cdiv(a->H * a->W, 128), cdiv(a->Cout, 8), a->N), dim3(128), 0, st, p);

@@ -100,6 +100,17 @@ def test_conv3x3_direct_path(N, Cin, Cout, H, W):
     _close(dw, wr.grad, 1e-4, 1e-4 * max(1.0, wr.grad.abs().max().item()), "direct wgrad")
 
 
+@pytest.mark.parametrize("N,Cout,H,W", [(2, 24, 64, 64), (1, 5, 8, 12), (3, 32, 40, 24)])
+def test_stem_kernel_equals_direct_kernel_bitwise(N, Cout, H, W):
+    """Cin == 1: the vectorised stem kernel keeps the direct kernel's fmaf order -> identical bits (bias included)."""
+    g = _g(Cout + H)
+    x = (torch.rand(N, 1, H, W, generator=g) * 255.0).to(DEV)
+    w = (torch.randn(Cout, 1, 3, 3, generator=g) * 0.1).to(DEV)
+    b = torch.randn(Cout, generator=g).to(DEV)
+    assert torch.equal(ops.conv3x3_fwd([x], w, b), ops.conv3x3_fwd([x], w, b, force_direct=True))
+    assert torch.equal(ops.conv3x3_fwd([x], w, None), ops.conv3x3_fwd([x], w, None, force_direct=True))
+
+
 def test_conv3x3_mfma_equals_direct_kernel():
     g = _g(11)
     x = torch.randn(2, 16, 32, 32, generator=g).to(DEV)
