@@ -622,9 +622,22 @@ __global__ void pack_many_kernel(const PackManyP q) {
     const float* w = q.w[d];
     if (kind < 2) {
         const long long total = kind == 0 ? (long long)((Cout + 15) / 16) * Cin * 144 : (long long)((Cin + 15) / 16) * Cout * 144;
+        if (kind == 0) {
+            // forward image = per 16-channel tile the transpose of a [16 co][9*Cin] slab: read 16 consecutive K of a
+            // row (64 contiguous bytes; element-wise the 16 lanes of a tile row hit 16 different weight rows), turn
+            // the 16x16 patch through LDS, write 1 KB contiguous
+            __shared__ float tile[16][17];
+            const int K9 = 9 * Cin;
+            const long long g = (long long)((int)blockIdx.x - q.first_block[d]) * 16 + (threadIdx.x & 15);
+            const int ir = threadIdx.x >> 4;
+            const int mt = (int)(g / K9), k = (int)(g % K9), co = mt * 16 + ir;
+            tile[ir][threadIdx.x & 15] = (g * 16 < total && co < Cout) ? w[(size_t)co * K9 + k] : 0.f;
+            __syncthreads();
+            if (idx < total) static_cast<float*>(q.dst[d])[idx] = tile[threadIdx.x & 15][threadIdx.x >> 4];
+            return;
+        }
         if (idx >= total) return;
-        if (kind == 0) pack_fwd_elem(w, static_cast<float*>(q.dst[d]), Cin, Cout, (int)idx);
-        else pack_dgrad_elem(w, static_cast<float*>(q.dst[d]), Cin, Cout, (int)idx);
+        pack_dgrad_elem(w, static_cast<float*>(q.dst[d]), Cin, Cout, (int)idx);
     } else {
         const int dg = kind == 3;
         const int rows = dg ? Cin : Cout, red = dg ? Cout : Cin;
