@@ -37,11 +37,15 @@ def test_ctypes_layout_matches_header(tmp_path):
     structs = {"mtbc_seg": L.Seg, "mtbc_conv3x3_args": L.Conv3x3Args, "mtbc_instnorm_args": L.InstNormArgs,
                "mtbc_maxpool_args": L.MaxPoolArgs, "mtbc_convT_args": L.ConvTArgs, "mtbc_conv1x1_args": L.Conv1x1Args,
                "mtbc_gap_args": L.GapArgs, "mtbc_linear_args": L.LinearArgs, "mtbc_dice_args": L.DiceArgs,
-               "mtbc_focal_args": L.FocalArgs, "mtbc_adam_args": L.AdamArgs, "mtbc_op": L.Op}
+               "mtbc_focal_args": L.FocalArgs, "mtbc_adam_args": L.AdamArgs, "mtbc_op": L.Op,
+               "mtbc_pack_desc": L.PackDesc}
     offs = [("mtbc_conv3x3_args", "workspace_bytes", L.Conv3x3Args.workspace_bytes.offset),
             ("mtbc_conv3x3_args", "w_packed", L.Conv3x3Args.w_packed.offset),
             ("mtbc_instnorm_args", "dgamma", L.InstNormArgs.dgamma.offset),
             ("mtbc_convT_args", "accumulate_dw", L.ConvTArgs.accumulate_dw.offset),
+            ("mtbc_convT_args", "compute", L.ConvTArgs.compute.offset),
+            ("mtbc_conv3x3_args", "compute", L.Conv3x3Args.compute.offset),
+            ("mtbc_pack_desc", "kind", L.PackDesc.kind.offset),
             ("mtbc_dice_args", "gscale_dev", L.DiceArgs.gscale_dev.offset),
             ("mtbc_adam_args", "zero_grad", L.AdamArgs.zero_grad.offset),
             ("mtbc_op", "u", L.Op.u.offset)]
