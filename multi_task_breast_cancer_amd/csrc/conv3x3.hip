@@ -848,10 +848,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_igemm_lp_kernel(const ConvP p)
             } else {
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
-                    if (poff[g] >= 0) {
-                        if (p.dbg & 32) __builtin_nontemporal_store(acc[m][g] + bv, (gf32x4*)(cb + poff[g]));      // probe
-                        else *(gf32x4*)(cb + poff[g]) = acc[m][g] + bv;
-                    }
+                    if (poff[g] >= 0) *(gf32x4*)(cb + poff[g]) = acc[m][g] + bv;
             }
         }
     }
