@@ -278,6 +278,86 @@ __global__ __launch_bounds__(256) void convT2_wgrad_kernel(const Ct2P p) {
         }
 }
 
+// ------------------------------------------------------------------ forward, weights resident in LDS (small Cin)
+// Y[(co,a,b)][p] = bias[co] + sum_ci W[ci][(co,a,b)] X[ci][p]: the reduction index is the strided one for both
+// operands.  A first attempt in the style of the kernels above (8 strided weight loads per fragment from global) was
+// latency-bound; here the whole weight matrix (Cin x 4*Cout <= 192 fp32) sits in LDS for the life of a persistent
+// block, rows padded to a stride == 16 mod 32 (conflict-free ds_read_b32 fragments), and X arrives as one float2
+// per (lane, k): pixels 2j / 2j+1 feed the two column tiles E / O.  Exact fp32: MFMA i of a group contracts
+// ci = 4i .. 4i+3 (lane group kg holds ci = 4i + kg), so any Cin % 4 == 0 runs without padding K.  MFMA rows are
+// (co, a, b) with 4 channels per tile: lane (j, kg) ends up with the four (a, b) of channel 4*tile + kg at pixels
+// 2j, 2j+1 -> one float4 per output row, 16 lanes = 256 contiguous bytes.
+constexpr int FMT = 12;                // row tiles: 4*Cout <= 192
+constexpr int FKI = 16;                // Cin <= 64 -> at most 16 MFMA k-groups
+template <int KI>
+__global__ __launch_bounds__(256, 2) void convT2_fwd_lds_kernel(const Ct2P p, const float* __restrict__ bias, float* __restrict__ y,
+                                                                long long ybs, int wstride) {
+    extern __shared__ float Wsm[];                  // [Cin][wstride]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int j = lane & 15, kg = lane >> 4;
+    const int HW = p.H * p.W, oW = 2 * p.W, M4 = 4 * p.Cout;
+    for (int idx = tid; idx < p.Cin * (M4 / 4); idx += 256) {          // 16-byte copies, rows re-strided
+        const int ci = idx / (M4 / 4), c4 = idx % (M4 / 4);
+        *reinterpret_cast<float4*>(Wsm + ci * wstride + 4 * c4) = *reinterpret_cast<const float4*>(p.w + (size_t)ci * M4 + 4 * c4);
+    }
+    __syncthreads();
+    const int nmt = (M4 + 15) / 16;                                     // uniform, <= FMT
+    const int groups = HW / 32;
+    const long long ngroups = (long long)p.N * groups;
+    const long long gstride = (long long)gridDim.x * 4;
+    long long gi = (long long)blockIdx.x * 4 + wv;
+    float2 xv[2][KI];
+    auto loadx = [&](long long g, auto SL) {
+        constexpr int sl = decltype(SL)::value;
+        const int n = (int)(g / groups), gg = (int)(g % groups);
+        const float* xn = p.x + (size_t)n * p.xbs + gg * 32 + 2 * j + (size_t)kg * HW;
+#pragma unroll
+        for (int i = 0; i < KI; ++i) xv[sl][i] = *reinterpret_cast<const float2*>(xn + (size_t)(4 * i < p.Cin ? 4 * i : 0) * HW);
+    };
+    auto compute = [&](long long g, auto SL) {
+        constexpr int sl = decltype(SL)::value;
+        f32x4 acc[FMT][2];
+#pragma unroll
+        for (int m = 0; m < FMT; ++m) { acc[m][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[m][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int i = 0; i < KI; ++i) {
+            if (4 * i < p.Cin) {                                         // uniform
+                const float* wr = Wsm + (4 * i + kg) * wstride + j;
+#pragma unroll
+                for (int m = 0; m < FMT; ++m) {
+                    if (m < nmt) {
+                        const float a = (16 * m + j < M4) ? wr[16 * m] : 0.f;
+                        acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, xv[sl][i].x, acc[m][0], 0, 0, 0);
+                        acc[m][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, xv[sl][i].y, acc[m][1], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        const int n = (int)(g / groups), gg = (int)(g % groups);
+        const int pix = gg * 32 + 2 * j;
+        const int iy = pix / p.W, jx = pix % p.W;
+        float* yn = y + (size_t)n * ybs + (size_t)(2 * iy) * oW + 2 * jx;
+#pragma unroll
+        for (int m = 0; m < FMT; ++m) {
+            const int co = 4 * m + kg;
+            if (m >= nmt || co >= p.Cout) continue;
+            const float bv = bias ? bias[co] : 0.f;
+            float* d = yn + (size_t)co * 4 * HW;
+            *reinterpret_cast<float4*>(d) = make_float4(acc[m][0][0] + bv, acc[m][0][1] + bv, acc[m][1][0] + bv, acc[m][1][1] + bv);
+            *reinterpret_cast<float4*>(d + oW) = make_float4(acc[m][0][2] + bv, acc[m][0][3] + bv, acc[m][1][2] + bv, acc[m][1][3] + bv);
+        }
+    };
+    if (gi < ngroups) loadx(gi, S0{});
+    for (; gi < ngroups; gi += 2 * gstride) {
+        if (gi + gstride < ngroups) loadx(gi + gstride, S1{});
+        compute(gi, S0{});
+        if (gi + gstride < ngroups) {
+            if (gi + 2 * gstride < ngroups) loadx(gi + 2 * gstride, S0{});
+            compute(gi + gstride, S1{});
+        }
+    }
+}
+
 bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
 
 void fill(const mtbc_convT_args* a, Ct2P* p) {
@@ -311,6 +391,33 @@ void mtbc_i_convT2_wgrad_plan(const mtbc_convT_args* a, int* steps_per_split, in
     if (sps > total_steps) sps = total_steps;
     *steps_per_split = (int)sps;
     *nsplit = (int)cdiv64(total_steps, sps);
+}
+
+// forward fast path: k == 2, the whole weight matrix fits LDS (Cin <= 64, 4*Cout <= 192)
+bool mtbc_i_convT2_fwd_ok(const mtbc_convT_args* a) {
+    const int HW = a->H * a->W;
+    return a->k == 2 && HW % 32 == 0 && a->W % 2 == 0 && a->Cin % 4 == 0 && a->Cin <= 4 * FKI && 4 * a->Cout <= 16 * FMT &&
+           al16(a->x) && al16(a->y) && al16(a->w) && a->x_batch_stride % 2 == 0 && a->y_batch_stride % 4 == 0;
+}
+int mtbc_i_convT2_fwd(const mtbc_convT_args* a, hipStream_t st) {
+    Ct2P p; fill(a, &p);
+    const int wstride = (4 * a->Cout + 31) / 32 * 32 + 16;             // == 16 mod 32
+    const size_t lds = (size_t)a->Cin * wstride * sizeof(float);
+    const long long groups = (long long)a->N * (a->H * a->W / 32);
+    int blocks = (int)(groups < 4 * 512 ? cdiv64(groups, 4) : 512);      // 2 resident blocks per CU (register-limited)
+    const int ki = cdiv(a->Cin, 4);
+#define MTBC_CT2F(KI_)                                                                                                     \
+    do {                                                                                                                   \
+        static bool attr = false;                                                                                          \
+        if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&convT2_fwd_lds_kernel<KI_>),                 \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); attr = true; }     \
+        hipLaunchKernelGGL(convT2_fwd_lds_kernel<KI_>, dim3(blocks), dim3(256), lds, st, p, a->bias, a->y,                 \
+                           (long long)a->y_batch_stride, wstride);                                                         \
+    } while (0)
+    if (ki <= 8) MTBC_CT2F(8); else if (ki <= 12) MTBC_CT2F(12); else MTBC_CT2F(16);
+#undef MTBC_CT2F
+    MTBC_CHECK_LAUNCH();
+    return MTBC_OK;
 }
 
 int mtbc_i_convT2_dgrad(const mtbc_convT_args* a, int compute, hipStream_t st) {

@@ -331,6 +331,8 @@ int mtbc_convT_fwd(const mtbc_convT_args* a, void* stream) {
     CtP p; int rc = fill_ct(a, &p); if (rc) return rc;
     if (!p.x || !p.w || !p.y) return MTBC_E_BADARG;
     if (!al16(p.y) || (p.ybs & 3) || ((a->W * a->k) & 3)) return MTBC_E_UNSUPPORTED;
+    static const bool generic_f = getenv("MTBC_CONVT_GENERIC") != nullptr;      // A/B switch
+    if (!generic_f && mtbc_i_convT2_fwd_ok(a)) return mtbc_i_convT2_fwd(a, (hipStream_t)stream);
     dim3 grid(cdiv(a->H * a->W, 64), cdiv(p.M, 64), a->N);
     hipStream_t st = (hipStream_t)stream;
     if (a->k == 2) hipLaunchKernelGGL(convT_fwd_kernel<2>, grid, dim3(256), 0, st, p);
