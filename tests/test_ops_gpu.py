@@ -339,3 +339,57 @@ def test_dice_counts_exact(golden_dir):
     assert c.tolist() == [tp, fp, fn]                                # integer counts: bit-exact
     z = torch.zeros(1, 1, 8, 8, device=DEV)
     assert dice_score_from_counts(dice_counts(z - 1, z)) == 1.0       # empty / empty -> 1 (metrics.py:262-263)
+
+
+# ------------------------------------------------------------------ full-size properties (BASELINE.json configs[1] shapes)
+@pytest.mark.parametrize("compute,tol", [(0, 2e-5), (1, 5e-3)])
+@pytest.mark.parametrize("segs,Cout,H", [([24, 24, 48], 24, 256), ([48], 48, 128)])
+def test_conv3x3_adjoint_identities_at_bench_size(compute, tol, segs, Cout, H):
+    """At N=32 the CPU oracle is too slow to be the checker; the bilinear form is: for y = conv(x; w),
+    <y, dz> = <x, dgrad(dz; w)> = <w, wgrad(x, dz)>.  Any indexing / padding / segment bug breaks one of the three.
+    (16-bit mode: each side rounds its own operands, so the identities hold to the rounding level only.)"""
+    N, W = 32, H
+    g = _g(H + Cout)
+    xs = [torch.randn(N, c, H, W, generator=g).to(DEV) for c in segs]
+    cin = sum(segs)
+    w = (torch.randn(Cout, cin, 3, 3, generator=g) * 0.05).to(DEV)
+    dz = torch.randn(N, Cout, H, W, generator=g).to(DEV)
+    if compute:
+        pf, pd = ops.conv3x3_pack_lp(w, compute)
+    else:
+        pf, pd = ops.conv3x3_pack(w)
+    y = ops.conv3x3_fwd(xs, w, None, packed=pf, compute=compute)
+    dxs = [torch.zeros_like(x) for x in xs]
+    ops.conv3x3_dgrad(dz, w, dxs, [0] * len(xs), packed=pd, compute=compute)
+    dw, _ = ops.conv3x3_wgrad(xs, dz, tuple(w.shape), compute=compute)
+    s_y = (y.double() * dz.double()).sum().item()
+    s_x = sum((x.double() * d.double()).sum().item() for x, d in zip(xs, dxs))
+    s_w = (w.double() * dw.double()).sum().item()
+    scale = y.double().norm().item() * dz.double().norm().item()
+    assert abs(s_y - s_x) < tol * scale and abs(s_y - s_w) < tol * scale, (s_y, s_x, s_w, scale)
+    # linearity in x (forward), exact-fp32 mode only: conv(2x) = 2 conv(x) bit for bit (a power of two commutes with RNE)
+    if compute == 0:
+        y2 = ops.conv3x3_fwd([2.0 * x for x in xs], w, None, packed=pf)
+        assert torch.equal(y2, 2.0 * y)
+
+
+def test_instnorm_and_convT_properties_at_bench_size():
+    N, C, H = 32, 24, 256
+    g = _g(77)
+    z = (torch.randn(N, C, H, H, generator=g) * 3.0 + 1.5).to(DEV)
+    y, mean, rstd = ops.instnorm_lrelu_fwd(z, None, None, slope=1.0)   # slope 1: plain instance norm
+    m = y.double().mean(dim=(2, 3))
+    v = y.double().var(dim=(2, 3), unbiased=False)
+    assert m.abs().max().item() < 1e-5 and (v - 1.0).abs().max().item() < 1e-4
+    # ConvT k=2: <convT(x; w), dy> = <x, dgrad(dy; w)> = <w, wgrad(x, dy)>
+    x = torch.randn(N, 48, 128, 128, generator=g).to(DEV)
+    w = (torch.randn(48, 48, 2, 2, generator=g) * 0.1).to(DEV)
+    dy = torch.randn(N, 48, 256, 256, generator=g).to(DEV)
+    yt = ops.convT_fwd(x, w, None, 2)
+    dx = ops.convT_dgrad(x, w, dy, 2)
+    dw, _ = ops.convT_wgrad(x, w, dy, 2, want_bias=False)
+    s_y = (yt.double() * dy.double()).sum().item()
+    s_x = (x.double() * dx.double()).sum().item()
+    s_w = (w.double() * dw.double()).sum().item()
+    scale = yt.double().norm().item() * dy.double().norm().item()
+    assert abs(s_y - s_x) < 2e-5 * scale and abs(s_y - s_w) < 2e-5 * scale, (s_y, s_x, s_w)
