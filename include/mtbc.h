@@ -292,8 +292,29 @@ enum {
     MTBC_OP_CONV1_FWD, MTBC_OP_CONV1_DGRAD, MTBC_OP_CONV1_WGRAD,
     MTBC_OP_GAP_FWD, MTBC_OP_GAP_BWD, MTBC_OP_LINEAR_FWD, MTBC_OP_LINEAR_BWD,
     MTBC_OP_DICE_FWD, MTBC_OP_DICE_BWD, MTBC_OP_FOCAL, MTBC_OP_LOSS_MIX, MTBC_OP_ADAM,
-    MTBC_OP_MEMSET, MTBC_OP_DICE_COUNTS, MTBC_OP_CONV3_PACK_LP
+    MTBC_OP_MEMSET, MTBC_OP_DICE_COUNTS, MTBC_OP_CONV3_PACK_LP, MTBC_OP_HEAD_COMBINE, MTBC_OP_HEAD_EXPAND
 };
+
+/* ---- deep-supervision head of MTnnUNet: ConvTranspose2d(Cin->Cmid, k=s) followed by Conv2d(Cmid->R, 1x1)
+ * (MTnnUNet.py:106-116: output4 k=8, output3 k=4, output2 k=2).  With no non-linearity in between the pair is ONE
+ * transposed conv with Wc[ci][r][a][b] = sum_co wT[ci][co][a][b] * w1[r][co], bc[r] = sum_co bT[co] * w1[r][co] + b1[r]:
+ * the Cmid x (kH x kW) intermediate (2.1 GB at B=64, k=8) and 128x the FLOPs disappear.  `combine` builds Wc / bc
+ * (every step: the weights move), the ordinary mtbc_convT_{fwd,dgrad,wgrad} run with Cout = R, and `expand` maps the
+ * gradient G of Wc and gb of bc back onto the four parameter tensors:
+ *   dwT[ci][co][ab] = sum_r G[ci][r][ab] w1[r][co]        dbT[co] = sum_r gb[r] w1[r][co]
+ *   dw1[r][co] = sum_{ci,ab} G[ci][r][ab] wT[ci][co][ab] + gb[r] bT[co]        db1[r] = gb[r]
+ * Same function as the reference's two layers up to fp32 re-association (checked against the reference's goldens). */
+typedef struct {
+    int32_t Cin, Cmid, R, k;
+    const float* wT; const float* bT;     /* (Cin,Cmid,k,k), (Cmid) */
+    const float* w1; const float* b1;     /* (R,Cmid), (R)          */
+    float* Wc; float* bc;                 /* (Cin,R,k,k), (R): written by combine */
+    const float* G; const float* gb;      /* gradients of Wc / bc: read by expand  */
+    float* dwT; float* dbT; float* dw1; float* db1;
+    int32_t acc_wT, acc_bT, acc_w1, acc_b1;
+} mtbc_head_fuse_args;
+int mtbc_convT_head_combine(const mtbc_head_fuse_args* a, void* stream);
+int mtbc_convT_head_expand(const mtbc_head_fuse_args* a, void* stream);
 
 /* ---- training-time augmentation: RandomHorizontalFlip(.5) -> RandomVerticalFlip(.5) ->
  * RandomRotation(360) of training_multitask.py:193-197 / BUSI_dataset.py:142-147 on the joint (mask, image) stack,
@@ -320,6 +341,7 @@ typedef struct {
         struct { const float* seg; const float* cls; float alpha; float* out4; } mix;
         struct { void* ptr; size_t bytes; } memset0;
         struct { const float* logits; const float* target; int64_t n; double* out3; } counts;
+        mtbc_head_fuse_args head;
     } u;
 } mtbc_op;
 

@@ -127,11 +127,20 @@ class _CountsArgs(C.Structure):
     _fields_ = [("logits", C.c_void_p), ("target", C.c_void_p), ("n", C.c_int64), ("out3", C.c_void_p)]
 
 
+class HeadFuseArgs(C.Structure):
+    """mtbc_head_fuse_args (include/mtbc.h)."""
+    _fields_ = [("Cin", C.c_int32), ("Cmid", C.c_int32), ("R", C.c_int32), ("k", C.c_int32),
+                ("wT", C.c_void_p), ("bT", C.c_void_p), ("w1", C.c_void_p), ("b1", C.c_void_p),
+                ("Wc", C.c_void_p), ("bc", C.c_void_p), ("G", C.c_void_p), ("gb", C.c_void_p),
+                ("dwT", C.c_void_p), ("dbT", C.c_void_p), ("dw1", C.c_void_p), ("db1", C.c_void_p),
+                ("acc_wT", C.c_int32), ("acc_bT", C.c_int32), ("acc_w1", C.c_int32), ("acc_b1", C.c_int32)]
+
+
 class _OpUnion(C.Union):
     _fields_ = [("conv3", Conv3x3Args), ("inorm", InstNormArgs), ("pool", MaxPoolArgs), ("convT", ConvTArgs),
                 ("conv1", Conv1x1Args), ("gap", GapArgs), ("linear", LinearArgs), ("dice", DiceArgs),
                 ("focal", FocalArgs), ("adam", AdamArgs), ("pack", _PackArgs), ("mix", _MixArgs),
-                ("memset0", _MemsetArgs), ("counts", _CountsArgs)]
+                ("memset0", _MemsetArgs), ("counts", _CountsArgs), ("head", HeadFuseArgs)]
 
 
 class Op(C.Structure):
@@ -142,7 +151,8 @@ class Op(C.Structure):
 (OP_CONV3_FWD, OP_CONV3_DGRAD, OP_CONV3_WGRAD, OP_CONV3_PACK_FWD, OP_CONV3_PACK_DGRAD,
  OP_IN_FWD, OP_IN_BWD, OP_POOL_FWD, OP_POOL_BWD, OP_CONVT_FWD, OP_CONVT_DGRAD, OP_CONVT_WGRAD,
  OP_CONV1_FWD, OP_CONV1_DGRAD, OP_CONV1_WGRAD, OP_GAP_FWD, OP_GAP_BWD, OP_LINEAR_FWD, OP_LINEAR_BWD,
- OP_DICE_FWD, OP_DICE_BWD, OP_FOCAL, OP_LOSS_MIX, OP_ADAM, OP_MEMSET, OP_DICE_COUNTS, OP_CONV3_PACK_LP) = range(1, 28)
+ OP_DICE_FWD, OP_DICE_BWD, OP_FOCAL, OP_LOSS_MIX, OP_ADAM, OP_MEMSET, OP_DICE_COUNTS, OP_CONV3_PACK_LP,
+ OP_HEAD_COMBINE, OP_HEAD_EXPAND) = range(1, 30)
 
 OP_UNION_FIELD = {
     OP_CONV3_FWD: "conv3", OP_CONV3_DGRAD: "conv3", OP_CONV3_WGRAD: "conv3",
@@ -153,6 +163,7 @@ OP_UNION_FIELD = {
     OP_GAP_FWD: "gap", OP_GAP_BWD: "gap", OP_LINEAR_FWD: "linear", OP_LINEAR_BWD: "linear",
     OP_DICE_FWD: "dice", OP_DICE_BWD: "dice", OP_FOCAL: "focal", OP_LOSS_MIX: "mix", OP_ADAM: "adam",
     OP_MEMSET: "memset0", OP_DICE_COUNTS: "counts", OP_CONV3_PACK_LP: "pack",
+    OP_HEAD_COMBINE: "head", OP_HEAD_EXPAND: "head",
 }
 
 # every symbol include/mtbc.h declares (tests check the library exports all of them)
@@ -165,7 +176,7 @@ class PackDesc(C.Structure):
 EXPORTS = [
     "mtbc_version", "mtbc_strerror", "mtbc_arch",
     "mtbc_conv3x3_packed_elems", "mtbc_conv3x3_packed_dgrad_elems", "mtbc_conv3x3_pack_fwd",
-    "mtbc_conv3x3_pack_dgrad", "mtbc_conv3x3_packed_lp_elems", "mtbc_conv3x3_pack_lp", "mtbc_conv3x3_pack_many", "mtbc_augment_flip_rotate", "mtbc_conv3x3_wgrad_workspace", "mtbc_conv3x3_fwd", "mtbc_conv3x3_dgrad",
+    "mtbc_conv3x3_pack_dgrad", "mtbc_conv3x3_packed_lp_elems", "mtbc_conv3x3_pack_lp", "mtbc_conv3x3_pack_many", "mtbc_augment_flip_rotate", "mtbc_convT_head_combine", "mtbc_convT_head_expand", "mtbc_conv3x3_wgrad_workspace", "mtbc_conv3x3_fwd", "mtbc_conv3x3_dgrad",
     "mtbc_conv3x3_wgrad", "mtbc_instnorm_lrelu_fwd", "mtbc_instnorm_lrelu_bwd", "mtbc_maxpool2_fwd",
     "mtbc_maxpool2_bwd", "mtbc_convT_wgrad_workspace", "mtbc_convT_fwd", "mtbc_convT_dgrad", "mtbc_convT_wgrad",
     "mtbc_conv1x1_wgrad_workspace", "mtbc_conv1x1_fwd", "mtbc_conv1x1_dgrad", "mtbc_conv1x1_wgrad",
@@ -195,6 +206,9 @@ def load() -> C.CDLL:
         getattr(lib, name).argtypes = [C.c_int32, C.c_int32]
     lib.mtbc_conv3x3_packed_lp_elems.restype = C.c_size_t
     lib.mtbc_conv3x3_packed_lp_elems.argtypes = [C.c_int32, C.c_int32, C.c_int32]
+    for _n in ("mtbc_convT_head_combine", "mtbc_convT_head_expand"):
+        getattr(lib, _n).restype = C.c_int
+        getattr(lib, _n).argtypes = [C.POINTER(HeadFuseArgs), C.c_void_p]
     lib.mtbc_augment_flip_rotate.restype = C.c_int
     lib.mtbc_augment_flip_rotate.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
     lib.mtbc_conv3x3_pack_many.restype = C.c_int

@@ -484,3 +484,72 @@ int mtbc_conv1x1_wgrad(const mtbc_conv1x1_args* a, void* stream) {
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------- fused ConvT + 1x1 head (MTnnUNet deep supervision)
+namespace {
+__global__ void head_combine_kernel(const mtbc_head_fuse_args a) {
+    const int kk = a.k * a.k;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int total = a.Cin * a.R * kk;
+    if (idx < total) {
+        const int ab = idx % kk, r = (idx / kk) % a.R, ci = idx / (kk * a.R);
+        float s = 0.f;
+        for (int co = 0; co < a.Cmid; ++co) s = fmaf(a.wT[((size_t)ci * a.Cmid + co) * kk + ab], a.w1[(size_t)r * a.Cmid + co], s);
+        a.Wc[idx] = s;
+    }
+    if (idx < a.R) {
+        float s = a.b1 ? a.b1[idx] : 0.f;
+        if (a.bT) for (int co = 0; co < a.Cmid; ++co) s = fmaf(a.bT[co], a.w1[(size_t)idx * a.Cmid + co], s);
+        a.bc[idx] = s;
+    }
+}
+// block (r, co): dw1[r][co]; thread-strided part: dwT
+__global__ void head_expand_dwT_kernel(const mtbc_head_fuse_args a) {
+    const int kk = a.k * a.k;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int total = a.Cin * a.Cmid * kk;
+    if (idx >= total) return;
+    const int ab = idx % kk, co = (idx / kk) % a.Cmid, ci = idx / (kk * a.Cmid);
+    float s = 0.f;
+    for (int r = 0; r < a.R; ++r) s = fmaf(a.G[((size_t)ci * a.R + r) * kk + ab], a.w1[(size_t)r * a.Cmid + co], s);
+    a.dwT[idx] = a.acc_wT ? a.dwT[idx] + s : s;
+}
+__global__ void head_expand_small_kernel(const mtbc_head_fuse_args a) {
+    __shared__ float red[32];
+    const int r = blockIdx.x / a.Cmid, co = blockIdx.x % a.Cmid, kk = a.k * a.k;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < a.Cin * kk; i += blockDim.x) {
+        const int ci = i / kk, ab = i % kk;
+        s = fmaf(a.G[((size_t)ci * a.R + r) * kk + ab], a.wT[((size_t)ci * a.Cmid + co) * kk + ab], s);
+    }
+    s = block_sum(s, red);
+    if (threadIdx.x != 0) return;
+    if (a.bT) s = fmaf(a.gb[r], a.bT[co], s);
+    a.dw1[(size_t)r * a.Cmid + co] = a.acc_w1 ? a.dw1[(size_t)r * a.Cmid + co] + s : s;
+    if (r == 0 && a.dbT) {
+        float t = 0.f;
+        for (int q = 0; q < a.R; ++q) t = fmaf(a.gb[q], a.w1[(size_t)q * a.Cmid + co], t);
+        a.dbT[co] = a.acc_bT ? a.dbT[co] + t : t;
+    }
+    if (co == 0 && a.db1) a.db1[r] = a.acc_b1 ? a.db1[r] + a.gb[r] : a.gb[r];
+}
+}  // namespace
+
+extern "C" int mtbc_convT_head_combine(const mtbc_head_fuse_args* a, void* stream) {
+    if (!a || !a->wT || !a->w1 || !a->Wc || !a->bc) return MTBC_E_BADARG;
+    if (a->Cin <= 0 || a->Cmid <= 0 || a->R <= 0 || a->k <= 0) return MTBC_E_BADSHAPE;
+    const int total = a->Cin * a->R * a->k * a->k;
+    hipLaunchKernelGGL(head_combine_kernel, dim3(cdiv(total > a->R ? total : a->R, 128)), dim3(128), 0, (hipStream_t)stream, *a);
+    MTBC_CHECK_LAUNCH();
+    return MTBC_OK;
+}
+extern "C" int mtbc_convT_head_expand(const mtbc_head_fuse_args* a, void* stream) {
+    if (!a || !a->wT || !a->w1 || !a->G || !a->gb || !a->dwT || !a->dw1) return MTBC_E_BADARG;
+    if (a->Cin <= 0 || a->Cmid <= 0 || a->R <= 0 || a->k <= 0) return MTBC_E_BADSHAPE;
+    const int total = a->Cin * a->Cmid * a->k * a->k;
+    hipLaunchKernelGGL(head_expand_dwT_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, *a);
+    MTBC_CHECK_LAUNCH();
+    hipLaunchKernelGGL(head_expand_small_kernel, dim3(a->R * a->Cmid), dim3(256), 0, (hipStream_t)stream, *a);
+    MTBC_CHECK_LAUNCH();
+    return MTBC_OK;
+}

@@ -379,6 +379,72 @@ class StepPlan:
         self.bwd_emitters.append(emit_bwd)
         return y
 
+    def convT_head(self, x: Act, cmid: int, k: int, wTname: str, bTname: str, w1name: str, b1name: str, out_name: str) -> Act:
+        """ConvTranspose2d(x.C -> cmid, k = s) followed by Conv2d(cmid -> R, 1x1) as ONE transposed conv with the
+        combined weights (mtbc_convT_head_combine / _expand, include/mtbc.h): the cmid-channel full-resolution
+        intermediate is never formed."""
+        wT, w1 = self.pv(wTname), self.pv(w1name)
+        R = w1.shape[0]
+        assert tuple(wT.shape) == (x.C, cmid, k, k) and tuple(w1.shape) == (R, cmid, 1, 1), (wTname, w1name)
+        Wc, bc = self.alloc(x.C, R, k, k), self.alloc(R)
+        G, gb = self.alloc(x.C, R, k, k), self.alloc(R)
+        y = self.new_act(out_name, R, x.H * k, x.W * k)
+
+        def head() -> L.Op:
+            op = _mk(0)
+            a = op.u.head
+            a.Cin, a.Cmid, a.R, a.k = x.C, cmid, R, k
+            a.wT, a.bT, a.w1, a.b1 = wT.data_ptr(), _ptr(self.pv(bTname)), w1.data_ptr(), _ptr(self.pv(b1name))
+            a.Wc, a.bc, a.G, a.gb = Wc.data_ptr(), bc.data_ptr(), G.data_ptr(), gb.data_ptr()
+            return op
+
+        def base() -> L.Op:
+            op = _mk(0)
+            a = op.u.convT
+            a.N, a.H, a.W, a.Cin, a.Cout, a.k = self.N, x.H, x.W, x.C, R, k
+            a.x, a.x_batch_stride = x.data.data_ptr(), x.bstride
+            a.w, a.bias = Wc.data_ptr(), bc.data_ptr()
+            a.y, a.y_batch_stride = y.data.data_ptr(), y.bstride
+            return op
+
+        op = head()
+        op.kind = L.OP_HEAD_COMBINE
+        self.fwd_ops.append(op)
+        op = base()
+        op.kind = L.OP_CONVT_FWD
+        self.fwd_ops.append(op)
+
+        def emit_bwd() -> None:
+            if not y.grad_written:
+                return
+            dy = self.grad_of(y)
+            op = base()
+            op.kind = L.OP_CONVT_WGRAD
+            a = op.u.convT
+            a.dy, a.dy_batch_stride = dy.data_ptr(), y.bstride
+            a.dw, a.dbias, a.accumulate_dw = G.data_ptr(), gb.data_ptr(), 0
+            self._need_ws(op, "convT", self.lib.mtbc_convT_wgrad_workspace(C.byref(a)))
+            self.bwd_ops.append(op)
+            op = head()
+            op.kind = L.OP_HEAD_EXPAND
+            a = op.u.head
+            a.acc_wT, a.acc_bT = self._mark_param(wTname), self._mark_param(bTname)
+            a.acc_w1, a.acc_b1 = self._mark_param(w1name), self._mark_param(b1name)
+            a.dwT, a.dbT = self.gv(wTname).data_ptr(), self.gv(bTname).data_ptr()
+            a.dw1, a.db1 = self.gv(w1name).data_ptr(), self.gv(b1name).data_ptr()
+            self.bwd_ops.append(op)
+            if x.needs_grad:
+                op = base()
+                op.kind = L.OP_CONVT_DGRAD
+                a = op.u.convT
+                a.dy, a.dy_batch_stride = dy.data_ptr(), y.bstride
+                gx, acc = self.grad_slot(x)
+                a.dx, a.dx_batch_stride, a.accumulate_dx = gx.data_ptr(), x.bstride, acc
+                self.bwd_ops.append(op)
+
+        self.bwd_emitters.append(emit_bwd)
+        return y
+
     def conv1x1(self, x: Act, cout: int, wname: str, bname: str, out_name: str) -> Act:
         w = self.pv(wname)
         assert tuple(w.shape) == (cout, x.C, 1, 1), (wname, tuple(w.shape))

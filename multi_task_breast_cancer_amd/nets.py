@@ -10,6 +10,8 @@ data-parallel all-reduce works on contiguous buckets; each nn.Parameter is a vie
 """
 from __future__ import annotations
 
+import os
+
 from typing import Callable, Dict, List, Optional, Sequence, Tuple
 
 import torch
@@ -170,12 +172,19 @@ def _graph_mtnnunet(plan: StepPlan, x: Act):
     n_cls = plan.pv("classifier.5.weight").shape[0]
     logits = plan.linear(h, n_cls, "classifier.5.weight", "classifier.5.bias", False, "logits")
     regions = plan.pv("output1.weight").shape[0]
-    o4 = plan.conv1x1(plan.convT(dec[4], w[2], 8, "output4.0.weight", "output4.0.bias", "o4up"), regions,
-                      "output4.1.weight", "output4.1.bias", "output4")
-    o3 = plan.conv1x1(plan.convT(dec[3], w[1], 4, "output3.0.weight", "output3.0.bias", "o3up"), regions,
-                      "output3.1.weight", "output3.1.bias", "output3")
-    o2 = plan.conv1x1(plan.convT(dec[2], w[0], 2, "output2.0.weight", "output2.0.bias", "o2up"), regions,
-                      "output2.1.weight", "output2.1.bias", "output2")
+    # deep-supervision heads: ConvT(k = 8 / 4 / 2) + 1x1 conv with nothing in between -> one transposed conv with the
+    # combined weights (StepPlan.convT_head); MTBC_NOFUSE_HEADS=1 keeps the reference's two layers (A/B, parity check)
+    if os.environ.get("MTBC_NOFUSE_HEADS"):
+        o4 = plan.conv1x1(plan.convT(dec[4], w[2], 8, "output4.0.weight", "output4.0.bias", "o4up"), regions,
+                          "output4.1.weight", "output4.1.bias", "output4")
+        o3 = plan.conv1x1(plan.convT(dec[3], w[1], 4, "output3.0.weight", "output3.0.bias", "o3up"), regions,
+                          "output3.1.weight", "output3.1.bias", "output3")
+        o2 = plan.conv1x1(plan.convT(dec[2], w[0], 2, "output2.0.weight", "output2.0.bias", "o2up"), regions,
+                          "output2.1.weight", "output2.1.bias", "output2")
+    else:
+        o4 = plan.convT_head(dec[4], w[2], 8, "output4.0.weight", "output4.0.bias", "output4.1.weight", "output4.1.bias", "output4")
+        o3 = plan.convT_head(dec[3], w[1], 4, "output3.0.weight", "output3.0.bias", "output3.1.weight", "output3.1.bias", "output3")
+        o2 = plan.convT_head(dec[2], w[0], 2, "output2.0.weight", "output2.0.bias", "output2.1.weight", "output2.1.bias", "output2")
     o1 = plan.conv1x1(dec[1], regions, "output1.weight", "output1.bias", "output1")
     return logits, [o4, o3, o2, o1]
 

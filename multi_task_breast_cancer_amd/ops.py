@@ -367,3 +367,28 @@ def adam_step(p, g, m, v, lr, step, beta1=0.9, beta2=0.999, eps=1e-4, grad_scale
     a.n, a.p, a.g, a.m, a.v = p.numel(), p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr()
     a.lr, a.beta1, a.beta2, a.eps, a.grad_scale, a.step, a.zero_grad = lr, beta1, beta2, eps, grad_scale, step, int(zero_grad)
     L.check(L.load().mtbc_adam_step(C.byref(a), _s()), "adam")
+
+
+# ------------------------------------------------------------------ fused ConvT + 1x1 head (MTnnUNet deep supervision)
+def convT_head_fwd_bwd(x, wT, bT, w1, b1, k, dout):
+    """Forward and backward of Conv2d_1x1(ConvTranspose2d_k(x)) through the combined-weight path
+    (mtbc_convT_head_combine -> mtbc_convT_* with Cout = R -> mtbc_convT_head_expand).
+    Returns (y, dx, dwT, dbT, dw1, db1)."""
+    _chk(x, wT, bT, w1, b1, dout)
+    lib = L.load()
+    cin, cmid, R = wT.shape[0], wT.shape[1], w1.shape[0]
+    dev = x.device
+    Wc, bc = torch.empty(cin, R, k, k, device=dev), torch.empty(R, device=dev)
+    a = L.HeadFuseArgs()
+    a.Cin, a.Cmid, a.R, a.k = cin, cmid, R, k
+    a.wT, a.bT, a.w1, a.b1 = wT.data_ptr(), bT.data_ptr(), w1.data_ptr(), b1.data_ptr()
+    a.Wc, a.bc = Wc.data_ptr(), bc.data_ptr()
+    L.check(lib.mtbc_convT_head_combine(C.byref(a), _s()), "head_combine")
+    y = convT_fwd(x, Wc, bc, k)
+    dx = convT_dgrad(x, Wc, dout, k)
+    G, gb = convT_wgrad(x, Wc, dout, k)
+    dwT, dbT, dw1, db1 = torch.empty_like(wT), torch.empty_like(bT), torch.empty_like(w1), torch.empty_like(b1)
+    a.G, a.gb = G.data_ptr(), gb.data_ptr()
+    a.dwT, a.dbT, a.dw1, a.db1 = dwT.data_ptr(), dbT.data_ptr(), dw1.data_ptr(), db1.data_ptr()
+    L.check(lib.mtbc_convT_head_expand(C.byref(a), _s()), "head_expand")
+    return y, dx, dwT, dbT, dw1, db1

@@ -393,3 +393,23 @@ def test_instnorm_and_convT_properties_at_bench_size():
     s_w = (w.double() * dw.double()).sum().item()
     scale = yt.double().norm().item() * dy.double().norm().item()
     assert abs(s_y - s_x) < 2e-5 * scale and abs(s_y - s_w) < 2e-5 * scale, (s_y, s_x, s_w)
+
+
+@pytest.mark.parametrize("N,Cin,Cmid,R,H,W,k", [(2, 16, 12, 1, 8, 8, 8), (1, 24, 20, 3, 6, 10, 4), (3, 32, 32, 1, 16, 16, 2)])
+def test_fused_convT_1x1_head_equals_the_two_layers(N, Cin, Cmid, R, H, W, k):
+    """MTnnUNet.py:106-116: ConvTranspose2d(k = s) then Conv2d 1x1, no non-linearity in between == one transposed conv
+    with combined weights; forward and every parameter gradient against autograd of the two layers."""
+    g = _g(Cin + k)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    wT = torch.randn(Cin, Cmid, k, k, generator=g) * 0.2
+    bT = torch.randn(Cmid, generator=g)
+    w1 = torch.randn(R, Cmid, 1, 1, generator=g) * 0.3
+    b1 = torch.randn(R, generator=g)
+    dout = torch.randn(N, R, H * k, W * k, generator=g)
+    leaves = [t.clone().requires_grad_(True) for t in (x, wT, bT, w1, b1)]
+    y = F.conv2d(F.conv_transpose2d(leaves[0], leaves[1], leaves[2], stride=k), leaves[3], leaves[4])
+    y.backward(dout)
+    got = ops.convT_head_fwd_bwd(*(t.to(DEV) for t in (x, wT, bT, w1, b1)), k, dout.to(DEV))
+    want = [y.detach()] + [t.grad for t in leaves]
+    for name, a, b in zip(("y", "dx", "dwT", "dbT", "dw1", "db1"), got, want):
+        _close(a, b, 1e-4, 2e-5 * max(1.0, b.abs().max().item()), "head " + name)
