@@ -54,14 +54,19 @@ def init_criterion_segmentation(loss_function: str = "dice") -> torch.nn.Module:
 
 
 def init_criterion_classification(n_classes: int = 2, classes_weighted=None, classification_criterion="CE"):
-    if n_classes == 2 or classification_criterion != "Focal":
-        raise ValueError("only the 3-class Focal criterion (config.yaml:19) is on the MI355X hot path")
+    """experiment_init.py:235-263.  The 3-class Focal criterion (config.yaml:19) is the HIP kernel that the fused step
+    also uses; binary (BCEWithLogitsLoss) and CrossEntropyLoss are torch's own modules, exactly as in the reference --
+    they run on the HIP model's outputs through autograd (drop-in loop only; FusedTrainStep is Focal-only)."""
+    if n_classes == 2:
+        return torch.nn.BCEWithLogitsLoss()
     weight = None
     if classes_weighted:
         freq = torch.tensor(classes_weighted, dtype=torch.float)
         cw = 1.0 / freq
         weight = (cw / cw.sum()).to("cuda")
-    return FocalLoss(alpha=1, gamma=2, reduction="mean", weight=weight)
+    if classification_criterion == "Focal":
+        return FocalLoss(alpha=1, gamma=2, reduction="mean", weight=weight)
+    return torch.nn.CrossEntropyLoss(reduction="mean", weight=weight)
 
 
 def init_lr_scheduler(optimizer, scheduler: str = "cosine", t_max: int = 20, factor: float = 0.5,

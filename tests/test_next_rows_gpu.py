@@ -120,3 +120,44 @@ def test_checkpoint_interchanges_with_torch_adam(tmp_path):
     rsd = ropt.state_dict()["state"]
     for i in rsd:
         assert torch.allclose(sd[i]["exp_avg"].cpu(), rsd[i]["exp_avg"]) and torch.allclose(sd[i]["exp_avg_sq"].cpu(), rsd[i]["exp_avg_sq"])
+
+
+@pytest.mark.parametrize("n_classes,criterion", [(3, "CE"), (2, "CE")])
+def test_dropin_loop_with_torch_classification_criteria(n_classes, criterion):
+    """experiment_init.py:235-263: binary -> BCEWithLogitsLoss, otherwise CE / Focal.  The torch criteria run on the HIP
+    model's outputs through autograd in the reference's loop (training_multitask.py:87-103); one step vs the oracle."""
+    from multi_task_breast_cancer_amd import criterions as CR
+    from multi_task_breast_cancer_amd.experiment_init import init_criterion_classification, init_criterion_segmentation
+    seed_everything(3)
+    prod = MTnnUNet(1, 1, n_classes)
+    ref = O.build_oracle_model("MTnnUNet", 1, 1, n_classes, True)
+    ref.load_state_dict(prod.state_dict())
+    prod = prod.to(DEV)
+    cls_c = init_criterion_classification(n_classes=n_classes, classes_weighted=None, classification_criterion=criterion)
+    assert isinstance(cls_c, torch.nn.BCEWithLogitsLoss if n_classes == 2 else torch.nn.CrossEntropyLoss)
+    seg_c = init_criterion_segmentation("DICE")
+    img, mask, label = O.synthetic_batch(2, 64, 64, seed=8)
+    if n_classes == 2:
+        label = (label > 0).float()
+        target_dev, target_cpu = label.to(DEV), label
+    else:
+        onehot = torch.nn.functional.one_hot(label.flatten().long(), 3).float()
+        target_dev, target_cpu = onehot.to(DEV), onehot
+    opt = FusedAdam(prod, lr=1e-4, eps=1e-4)
+    opt.zero_grad(set_to_none=True)
+    logits, outs = prod(img.to(DEV))
+    seg, cls = CR.apply_criterion_multitask_segmentation_classification(seg_c, mask.to(DEV), outs, cls_c, target_dev, logits, True)
+    total = 0.5 * seg + 0.5 * cls
+    total.backward()
+    opt.step()
+    rl, ro = ref(img)
+    rseg = sum(O.dice_loss_sigmoid_sq(o, mask) / (j + 1) for j, o in enumerate(reversed(ro)))
+    rcls = sum((torch.nn.BCEWithLogitsLoss() if n_classes == 2 else torch.nn.CrossEntropyLoss())(l, target_cpu) for l in reversed(rl))
+    rtot = 0.5 * rseg + 0.5 * rcls
+    ropt = O.make_adam(ref, 1e-4)
+    ropt.zero_grad()
+    rtot.backward()
+    ropt.step()
+    assert abs(total.item() - rtot.item()) < 1e-4
+    for (k, a), (_, b) in zip(prod.state_dict().items(), ref.state_dict().items()):
+        assert (a.cpu() - b).abs().max().item() < 2.0e-4, k
