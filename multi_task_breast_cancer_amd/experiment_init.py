@@ -41,15 +41,27 @@ def init_multitask_model(architecture: str, sequences: int = 1, regions: int = 1
 
 
 def init_optimizer(model: torch.nn.Module, optimizer: str, learning_rate: float = 0.001):
+    """experiment_init.py:177-196.  'Adam' (config.yaml) is the fused HIP optimizer; 'SGD' / 'AdamW' / the reference's
+    SGD fallback for unknown names are torch's own optimizers over the same parameters (drop-in loop only)."""
     if optimizer == "Adam":
         return FusedAdam(model, lr=learning_rate, eps=1e-4)          # experiment_init.py:187: eps=1e-4
-    raise ValueError(f"optimizer {optimizer!r}: only 'Adam' is on the MI355X hot path")
+    if optimizer == "SGD":
+        return torch.optim.SGD(model.parameters(), lr=learning_rate, momentum=0.9, nesterov=True)
+    if optimizer == "AdamW":
+        return torch.optim.AdamW(model.parameters(), lr=learning_rate)
+    logging.info(f"The optimizer '{optimizer}' is not recognized. SGD will be used instead.")
+    return torch.optim.SGD(model.parameters(), lr=0.001, momentum=0.9, nesterov=True)
 
 
 def init_criterion_segmentation(loss_function: str = "dice") -> torch.nn.Module:
+    """experiment_init.py:199-232.  'DICE' (config.yaml) is the HIP kernel; 'BCE' is torch's module as in the
+    reference; the remaining names are MONAI losses (not installed here, not on the hot path) -> same exit as the
+    reference takes for an unknown name."""
     if loss_function == "DICE":
         return DiceLoss(include_background=True, sigmoid=True, smooth_dr=1, smooth_nr=1, squared_pred=True)
-    logging.info("Select a loss function allowed on the MI355X hot path: ['DICE']")
+    if loss_function == "BCE":
+        return torch.nn.BCEWithLogitsLoss()
+    logging.info("Select a loss function allowed on the MI355X hot path: ['DICE', 'BCE']")
     sys.exit()
 
 

@@ -161,3 +161,41 @@ def test_dropin_loop_with_torch_classification_criteria(n_classes, criterion):
     assert abs(total.item() - rtot.item()) < 1e-4
     for (k, a), (_, b) in zip(prod.state_dict().items(), ref.state_dict().items()):
         assert (a.cpu() - b).abs().max().item() < 2.0e-4, k
+
+
+def test_factory_torch_optimizers_step_the_flat_parameters():
+    """experiment_init.py:186-195: SGD / AdamW are torch optimizers over the HIP model's parameters (views of the flat
+    buffer): one drop-in step moves the weights exactly as the same optimizer moves the oracle's."""
+    from multi_task_breast_cancer_amd import criterions as CR
+    from multi_task_breast_cancer_amd.experiment_init import init_optimizer
+    for name, make_ref in (("SGD", lambda ps: torch.optim.SGD(ps, lr=1e-3, momentum=0.9, nesterov=True)),
+                           ("AdamW", lambda ps: torch.optim.AdamW(ps, lr=1e-3))):
+        seed_everything(4)
+        prod = MTnnUNet(1, 1, 3)
+        ref = O.build_oracle_model("MTnnUNet", 1, 1, 3, True)
+        ref.load_state_dict(prod.state_dict())
+        prod = prod.to(DEV)
+        opt = init_optimizer(prod, name, 1e-3)
+        assert type(opt).__name__ == name
+        img, mask, label = O.synthetic_batch(2, 64, 64, seed=2)
+        onehot = torch.nn.functional.one_hot(label.flatten().long(), 3).float()
+        opt.zero_grad(set_to_none=True)
+        logits, outs = prod(img.to(DEV))
+        seg, cls = CR.apply_criterion_multitask_segmentation_classification(CR.DiceLoss(), mask.to(DEV), outs, CR.FocalLoss(), onehot.to(DEV), logits, True)
+        (0.5 * seg + 0.5 * cls).backward()
+        opt.step()
+        ropt = make_ref(ref.parameters())
+        rl, ro = ref(img)
+        rseg, rcls = O.multitask_losses(ro, mask, rl, onehot, True)
+        ropt.zero_grad()
+        (0.5 * rseg + 0.5 * rcls).backward()
+        ropt.step()
+        for (k, a), (_, b) in zip(prod.state_dict().items(), ref.state_dict().items()):
+            d = (a.cpu() - b).abs()
+            if name == "SGD":                       # update = lr * (1.9 g): as exact as the gradient
+                assert d.max().item() < 5e-5, (name, k, d.max().item())
+            else:                                   # AdamW, eps 1e-8, step 1: update = lr * sign(g) -- an element whose
+                assert d.max().item() <= 2.1e-3     # gradient is rounding noise may go the other way (2 lr), few do
+                assert (d > 1e-4).float().mean().item() < 0.02, (name, k)
+        # the step landed in the flat buffer (parameters are views of it)
+        assert torch.equal(prod._param_view(prod._order[0]), dict(prod.named_parameters())[prod._order[0]].detach())
