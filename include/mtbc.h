@@ -132,6 +132,9 @@ typedef struct {
     size_t workspace_bytes;
 } mtbc_instnorm_args;
 
+/* workspace bytes the forward can use for planes > 64K elements (chunked statistics: 2 reads + 1 write instead of the
+ * streaming kernel's 3 + 1); 0 for smaller planes.  Passing no workspace is valid (streaming kernel). */
+size_t mtbc_instnorm_fwd_workspace(const mtbc_instnorm_args* a);
 int mtbc_instnorm_lrelu_fwd(const mtbc_instnorm_args* a, void* stream);
 int mtbc_instnorm_lrelu_bwd(const mtbc_instnorm_args* a, void* stream);
 

@@ -177,7 +177,7 @@ EXPORTS = [
     "mtbc_version", "mtbc_strerror", "mtbc_arch",
     "mtbc_conv3x3_packed_elems", "mtbc_conv3x3_packed_dgrad_elems", "mtbc_conv3x3_pack_fwd",
     "mtbc_conv3x3_pack_dgrad", "mtbc_conv3x3_packed_lp_elems", "mtbc_conv3x3_pack_lp", "mtbc_conv3x3_pack_many", "mtbc_augment_flip_rotate", "mtbc_convT_head_combine", "mtbc_convT_head_expand", "mtbc_conv3x3_wgrad_workspace", "mtbc_conv3x3_fwd", "mtbc_conv3x3_dgrad",
-    "mtbc_conv3x3_wgrad", "mtbc_instnorm_lrelu_fwd", "mtbc_instnorm_lrelu_bwd", "mtbc_maxpool2_fwd",
+    "mtbc_conv3x3_wgrad", "mtbc_instnorm_fwd_workspace", "mtbc_instnorm_lrelu_fwd", "mtbc_instnorm_lrelu_bwd", "mtbc_maxpool2_fwd",
     "mtbc_maxpool2_bwd", "mtbc_convT_wgrad_workspace", "mtbc_convT_fwd", "mtbc_convT_dgrad", "mtbc_convT_wgrad",
     "mtbc_conv1x1_wgrad_workspace", "mtbc_conv1x1_fwd", "mtbc_conv1x1_dgrad", "mtbc_conv1x1_wgrad",
     "mtbc_gap_fwd", "mtbc_gap_bwd", "mtbc_linear_fwd", "mtbc_linear_bwd", "mtbc_dice_fwd", "mtbc_dice_bwd",
@@ -209,6 +209,8 @@ def load() -> C.CDLL:
     for _n in ("mtbc_convT_head_combine", "mtbc_convT_head_expand"):
         getattr(lib, _n).restype = C.c_int
         getattr(lib, _n).argtypes = [C.POINTER(HeadFuseArgs), C.c_void_p]
+    lib.mtbc_instnorm_fwd_workspace.restype = C.c_size_t
+    lib.mtbc_instnorm_fwd_workspace.argtypes = [C.POINTER(InstNormArgs)]
     lib.mtbc_augment_flip_rotate.restype = C.c_int
     lib.mtbc_augment_flip_rotate.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
     lib.mtbc_conv3x3_pack_many.restype = C.c_int

@@ -65,6 +65,68 @@ __global__ void in_fwd_reg_kernel(const InP p) {
     }
 }
 
+// ---- forward, planes too large for one workgroup's registers (512x512 and up): chunks of <= 64K elements.
+//      Kernel 1: one workgroup per (plane, chunk) holds its chunk in registers and writes the chunk's exact
+//      (count, mean, M2); kernel 2 combines the chunks of its plane with Chan's formula in a fixed order (every
+//      workgroup of the plane redundantly -- S <= 64 triples) and normalises its chunk: 2 reads + 1 write of the
+//      tensor instead of the streaming kernel's 3 + 1.
+constexpr int IN_CHUNK4 = 16 * 1024;           // float4 per chunk = 16 per thread x 1024 threads
+__global__ void in_fwd_chunk_stats_kernel(const InP p, float* __restrict__ part, int S) {
+    __shared__ float red[32];
+    const int plane = blockIdx.x / S, chunk = blockIdx.x % S;
+    const int n4 = p.HW >> 2, lo = chunk * IN_CHUNK4, cnt4 = min(IN_CHUNK4, n4 - lo);
+    const float4* src = reinterpret_cast<const float4*>(p.z + (size_t)plane * p.HW) + lo;
+    float4 v[16];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int idx = threadIdx.x + i * 1024;
+        v[i] = idx < cnt4 ? src[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
+        s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+    const float n = 4.f * (float)cnt4;
+    const float mean = block_sum(s, red) / n;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int idx = threadIdx.x + i * 1024;
+        if (idx < cnt4) {
+            const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+            q += (a * a + b * b) + (c * c + d * d);
+        }
+    }
+    q = block_sum(q, red);
+    if (threadIdx.x == 0) { float* o = part + 3 * (size_t)blockIdx.x; o[0] = n; o[1] = mean; o[2] = q; }
+}
+__global__ void in_fwd_chunk_apply_kernel(const InP p, const float* __restrict__ part, int S) {
+    const int plane = blockIdx.x / S, chunk = blockIdx.x % S, n = plane / p.C, c = plane % p.C;
+    // Chan et al.: combine (n, mean, M2) left to right -- same order in every workgroup of the plane
+    const float* q = part + 3 * (size_t)plane * S;
+    float cn = q[0], cm = q[1], cM2 = q[2];
+    for (int k = 1; k < S; ++k) {
+        const float nb = q[3 * k], mb = q[3 * k + 1], Mb = q[3 * k + 2];
+        const float tot = cn + nb, delta = mb - cm;
+        cm += delta * (nb / tot);
+        cM2 += Mb + delta * delta * (cn * nb / tot);
+        cn = tot;
+    }
+    const float mean = cm, rstd = 1.0f / sqrtf(cM2 / cn + p.eps);
+    if (chunk == 0 && threadIdx.x == 0) { p.mean[plane] = mean; p.rstd[plane] = rstd; }
+    const float g = p.gamma ? p.gamma[c] : 1.f, b = p.beta ? p.beta[c] : 0.f;
+    const int n4 = p.HW >> 2, lo = chunk * IN_CHUNK4, cnt4 = min(IN_CHUNK4, n4 - lo);
+    const float4* src = reinterpret_cast<const float4*>(p.z + (size_t)plane * p.HW) + lo;
+    float4* dst = reinterpret_cast<float4*>(p.y + (size_t)n * p.ybs + (size_t)c * p.HW) + lo;
+    for (int idx = threadIdx.x; idx < cnt4; idx += blockDim.x) {
+        const float4 v = src[idx];
+        float4 o; float t;
+        t = (v.x - mean) * rstd * g + b; o.x = t > 0.f ? t : t * p.slope;
+        t = (v.y - mean) * rstd * g + b; o.y = t > 0.f ? t : t * p.slope;
+        t = (v.z - mean) * rstd * g + b; o.z = t > 0.f ? t : t * p.slope;
+        t = (v.w - mean) * rstd * g + b; o.w = t > 0.f ? t : t * p.slope;
+        dst[idx] = o;
+    }
+}
+
 // ---- forward, streaming (any HW): three passes, the last two hit L2
 __global__ void in_fwd_stream_kernel(const InP p) {
     __shared__ float red[32];
@@ -267,6 +329,14 @@ bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
 
 extern "C" {
 
+// bytes of workspace the forward wants for planes larger than 64K elements (0 otherwise; without it the streaming kernel runs)
+size_t mtbc_instnorm_fwd_workspace(const mtbc_instnorm_args* a) {
+    if (!a || a->N <= 0 || a->C <= 0 || a->H <= 0 || a->W <= 0) return 0;
+    const long long n4 = (long long)a->H * a->W / 4;
+    if (((long long)a->H * a->W) % 4 != 0 || n4 <= IN_CHUNK4) return 0;
+    return (size_t)a->N * a->C * cdiv64(n4, IN_CHUNK4) * 3 * sizeof(float);
+}
+
 int mtbc_instnorm_lrelu_fwd(const mtbc_instnorm_args* a, void* stream) {
     InP p; int rc = fill(a, &p); if (rc) return rc;
     if (!p.z || !p.y || !p.mean || !p.rstd) return MTBC_E_BADARG;
@@ -279,6 +349,12 @@ int mtbc_instnorm_lrelu_fwd(const mtbc_instnorm_args* a, void* stream) {
         else if (n4 <= 4 * 256) hipLaunchKernelGGL(in_fwd_reg_kernel<4>, dim3(planes), dim3(256), 0, st, p);
         else if (n4 <= 16 * 256) hipLaunchKernelGGL(in_fwd_reg_kernel<16>, dim3(planes), dim3(256), 0, st, p);
         else hipLaunchKernelGGL(in_fwd_reg_kernel<16>, dim3(planes), dim3(1024), 0, st, p);
+    } else if (vec && a->workspace && a->workspace_bytes >= mtbc_instnorm_fwd_workspace(a)) {
+        const int S = cdiv(n4, IN_CHUNK4);
+        float* part = reinterpret_cast<float*>(a->workspace);
+        hipLaunchKernelGGL(in_fwd_chunk_stats_kernel, dim3(planes * S), dim3(1024), 0, st, p, part, S);
+        MTBC_CHECK_LAUNCH();
+        hipLaunchKernelGGL(in_fwd_chunk_apply_kernel, dim3(planes * S), dim3(1024), 0, st, p, part, S);
     } else {
         hipLaunchKernelGGL(in_fwd_stream_kernel, dim3(planes), dim3(HW >= 4096 ? 1024 : 256), 0, st, p);
     }

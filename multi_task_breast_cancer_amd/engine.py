@@ -250,6 +250,9 @@ class StepPlan:
         op = base_in()
         op.kind = L.OP_IN_FWD
         op.u.inorm.y, op.u.inorm.y_batch_stride = y.data.data_ptr(), y.bstride
+        nb = self.lib.mtbc_instnorm_fwd_workspace(C.byref(op.u.inorm))      # > 0 only for planes larger than 64K elements
+        if nb:
+            self._need_ws(op, "inorm", nb)
         self.fwd_ops.append(op)
 
         def emit_bwd() -> None:

@@ -158,6 +158,10 @@ def instnorm_lrelu_fwd(z, gamma=None, beta=None, eps=1e-5, slope=0.01):
     a.N, a.C, a.H, a.W, a.eps, a.slope = N, Cc, H, W, eps, slope
     a.z, a.gamma, a.beta, a.y, a.y_batch_stride = z.data_ptr(), _p(gamma), _p(beta), y.data_ptr(), Cc * H * W
     a.mean, a.rstd = mean.data_ptr(), rstd.data_ptr()
+    nb = L.load().mtbc_instnorm_fwd_workspace(C.byref(a))
+    if nb:
+        ws = _ws(nb, z.device)
+        a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel() * 4
     L.check(L.load().mtbc_instnorm_lrelu_fwd(C.byref(a), _s()), "instnorm_fwd")
     return y, mean, rstd
 

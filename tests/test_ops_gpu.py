@@ -135,6 +135,7 @@ def test_pack_many_equals_single_packs(compute):
 
 
 @pytest.mark.parametrize("N,C,H,W,affine,slope", [(2, 24, 256, 256, True, 0.1), (3, 5, 64, 64, False, 0.01),
+                                                      (1, 3, 512, 512, True, 0.1), (2, 2, 300, 304, False, 0.01),
                                                    (2, 7, 32, 32, True, 0.1), (4, 320, 8, 8, False, 0.01),
                                                    (2, 3, 16, 16, True, 0.1), (1, 2, 6, 5, True, 0.1),
                                                    (1, 2, 2, 2, False, 0.01)])
