@@ -42,7 +42,11 @@ __global__ __launch_bounds__(256, 3) void conv_c8_kernel(const P p) {
     constexpr int XB = 4 * HPP * 8, WB = MT * 9 * 16 * LPROW;           // 16-bit elements
     extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
     unsigned short* Xs = smem;                  // [4 groups][352 halo px][8 ch]
+#ifdef PREFETCH
+    unsigned short* Ws = smem + 2 * XB;
+#else
     unsigned short* Ws = smem + XB;
+#endif
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 15, kg = lane >> 4, HW = p.H * p.W;
     const int mt0 = blockIdx.y * MT, nchunks = (p.Cin + 31) / 32;
@@ -61,6 +65,7 @@ __global__ __launch_bounds__(256, 3) void conv_c8_kernel(const P p) {
         }
         f32x4 acc[MT][4];
         for (int m = 0; m < MT; ++m) for (int g = 0; g < 4; ++g) acc[m][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#ifndef PREFETCH
         for (int ch = 0; ch < nchunks; ++ch) {
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             // X: wave w = channel group w of the chunk, 6 DMA instructions of 1 KB (64 halo pixels x 16 bytes)
@@ -99,6 +104,52 @@ __global__ __launch_bounds__(256, 3) void conv_c8_kernel(const P p) {
                     for (int g = 0; g < 4; ++g) acc[m][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[g], a[m], acc[m][g], 0, 0, 0);
             }
         }
+#else
+        // X ring of 2 (the DMA of chunk c+1 flies under the MFMAs of chunk c), W single-buffered
+        auto issue_x = [&](int ch, int slot) {
+            const int g8 = ch * 4 + wv;
+            const __bf16* base = p.x8 + ((size_t)n * (p.Cin / 8) + (g8 < p.Cin / 8 ? g8 : 0)) * HW * 8;
+            const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(base), 0, g8 < p.Cin / 8 ? HW * 16 : 0, 0x00020000);
+#pragma unroll
+            for (int q = 0; q < 6; ++q)
+                if (lane + 64 * q < HPP)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_ptr_t)(Xs + slot * XB + (wv * HPP + 64 * q) * 8), 16, pixo[q], 0, 0, 0);
+        };
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        issue_x(0, 0);
+        for (int ch = 0; ch < nchunks; ++ch) {
+            const int slot = ch & 1;
+            {
+                constexpr int W16 = WB / 8, WI = (W16 + 63) / 64;
+#pragma unroll
+                for (int k = 0; k < (WI + 3) / 4; ++k) {
+                    const int inst = wv + 4 * k;
+                    if (inst < WI) {
+                        const int idx = inst * 64 + lane, mt = idx / 720, r = idx % 720;
+                        const bool ok = idx < W16 && (mt0 + mt) < p.mtiles;
+                        const unsigned voff = ok ? (unsigned)((((mt0 + mt) * nchunks + ch) * 720 + r) * 16) : 0xfffffff0u;
+                        if (idx < W16) __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_ptr_t)(Ws + inst * 512), 16, voff, 0, 0, 0);
+                    }
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");        // X(ch) and W(ch) landed
+            if (ch + 1 < nchunks) issue_x(ch + 1, slot ^ 1);                       // other slot: last read during chunk ch-1
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int toff = (tap / 3) * HC + tap % 3;
+                bf16x8 a[MT], b[4];
+#pragma unroll
+                for (int m = 0; m < MT; ++m) a[m] = *reinterpret_cast<const bf16x8*>(Ws + ((m * 9 + tap) * 16 + j) * LPROW + 8 * kg);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) b[g] = *reinterpret_cast<const bf16x8*>(Xs + slot * XB + (kg * HPP + bpix[g] + toff) * 8);
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) acc[m][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[g], a[m], acc[m][g], 0, 0, 0);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");       // everyone done with Ws / this X slot
+        }
+#endif
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
             const int co = (mt0 + m) * 16 + j;
@@ -131,9 +182,15 @@ int main(int argc, char** argv) {
     P p{N, H, W, Cin, Cout, W / TW, H / TH, (W / TW) * (H / TH) * N, mtiles, dx8, dwp, dout};
     constexpr int MT = 2;
     const int mblocks = (mtiles + MT - 1) / MT;
+#ifdef PREFETCH
+    const size_t lds = (2 * 4 * HPP * 8 + MT * 9 * 16 * LPROW) * 2;
+    const int resident = 512;
+#else
     const size_t lds = (4 * HPP * 8 + MT * 9 * 16 * LPROW) * 2;
+    const int resident = 768;
+#endif
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_c8_kernel<MT>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-    const int gx = (768 / mblocks) / 8 * 8;
+    const int gx = (resident / mblocks) / 8 * 8;
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (int i = 0; i < 3; ++i) conv_c8_kernel<MT><<<dim3(gx, mblocks), 256, lds>>>(p);
     CK(hipDeviceSynchronize());
