@@ -13,6 +13,11 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
 
+#ifdef OUT_C8
+#define MMA(A, B, C) __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, B, C, 0, 0, 0)      /* rows = channels */
+#else
+#define MMA(A, B, C) __builtin_amdgcn_mfma_f32_16x16x32_bf16(B, A, C, 0, 0, 0)      /* rows = pixels   */
+#endif
 constexpr int LPROW = 40, TH = 8, TW = 32, HR = TH + 2, HC = TW + 2, HP = HR * HC, HPP = 352;   // 340 halo pixels, padded
 
 __global__ void to_c8_kernel(const float* __restrict__ x, __bf16* __restrict__ y, int N, int C, int HW) {
@@ -35,7 +40,7 @@ __global__ void pack_w_kernel(const float* __restrict__ w, __bf16* __restrict__ 
     const int r = mt * 16 + i, k = cb * 32 + kk;
     p[idx] = (__bf16)((kk < 32 && r < Cout && k < Cin) ? w[((size_t)r * Cin + k) * 9 + tap] : 0.f);
 }
-struct P { int N, H, W, Cin, Cout, tiles_x, tiles_y, ntiles, mtiles; const __bf16* x8; const __bf16* wp; float* out; };
+struct P { int N, H, W, Cin, Cout, tiles_x, tiles_y, ntiles, mtiles; const __bf16* x8; const __bf16* wp; float* out; __bf16* out8; };
 
 template <int MT>
 __global__ __launch_bounds__(256, 3) void conv_c8_kernel(const P p) {
@@ -101,7 +106,7 @@ __global__ __launch_bounds__(256, 3) void conv_c8_kernel(const P p) {
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) acc[m][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[g], a[m], acc[m][g], 0, 0, 0);
+                    for (int g = 0; g < 4; ++g) acc[m][g] = MMA(a[m], b[g], acc[m][g]);
             }
         }
 #else
@@ -145,11 +150,12 @@ __global__ __launch_bounds__(256, 3) void conv_c8_kernel(const P p) {
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) acc[m][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[g], a[m], acc[m][g], 0, 0, 0);
+                    for (int g = 0; g < 4; ++g) acc[m][g] = MMA(a[m], b[g], acc[m][g]);
             }
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");       // everyone done with Ws / this X slot
         }
 #endif
+#ifndef OUT_C8
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
             const int co = (mt0 + m) * 16 + j;
@@ -161,6 +167,26 @@ __global__ __launch_bounds__(256, 3) void conv_c8_kernel(const P p) {
                 if (y < p.H && x < p.W) *reinterpret_cast<f32x4*>(cb + y * p.W + x) = acc[m][g];
             }
         }
+    #else
+        // bf16 channel-blocked OUTPUT: channels on the MFMA rows (see the mfma call), lane (j, kg) holds channels
+        // 16m + 4kg .. +3 of pixel j: one 8-byte store = half of a 16-byte piece, the lane pair (kg, kg^1) completes it
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int c4 = (mt0 + m) * 16 + 4 * kg;
+            if (c4 >= p.Cout) continue;
+            __bf16* ob = p.out8 + ((size_t)n * (p.Cout / 8) + (c4 >> 3)) * HW * 8 + 4 * (kg & 1);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int y = y0 + 2 * wv + (g >> 1), x = x0 + 16 * (g & 1) + j;
+                if (y < p.H && x < p.W) {
+                    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+                    bf16x4 v;
+                    for (int r = 0; r < 4; ++r) v[r] = (__bf16)acc[m][g][r];
+                    *reinterpret_cast<bf16x4*>(ob + (size_t)(y * p.W + x) * 8) = v;
+                }
+            }
+        }
+#endif
     }
 }
 
@@ -179,7 +205,8 @@ int main(int argc, char** argv) {
     const long long tot8 = (long long)N * (Cin / 8) * HW;
     to_c8_kernel<<<(unsigned)((tot8 + 255) / 256), 256>>>(dx, dx8, N, Cin, HW);
     pack_w_kernel<<<(unsigned)((wtotal + 255) / 256), 256>>>(dw, dwp, Cin, Cout, wtotal);
-    P p{N, H, W, Cin, Cout, W / TW, H / TH, (W / TW) * (H / TH) * N, mtiles, dx8, dwp, dout};
+    __bf16* dout8; CK(hipMalloc(&dout8, (size_t)N * ((Cout + 7) / 8) * 8 * HW * 2));
+    P p{N, H, W, Cin, Cout, W / TW, H / TH, (W / TW) * (H / TH) * N, mtiles, dx8, dwp, dout, dout8};
     constexpr int MT = 2;
     const int mblocks = (mtiles + MT - 1) / MT;
 #ifdef PREFETCH
@@ -200,7 +227,16 @@ int main(int argc, char** argv) {
     float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= 20;
     // verify a sample of outputs against a host reference on bf16-rounded operands
     std::vector<float> ho((size_t)N * Cout * HW);
+#ifdef OUT_C8
+    {
+        std::vector<__bf16> h8((size_t)N * (Cout / 8) * HW * 8);
+        CK(hipMemcpy(h8.data(), dout8, h8.size() * 2, hipMemcpyDeviceToHost));
+        for (int n = 0; n < N; ++n) for (int c = 0; c < Cout; ++c) for (int px = 0; px < HW; ++px)
+            ho[((size_t)n * Cout + c) * HW + px] = (float)h8[(((size_t)n * (Cout / 8) + c / 8) * HW + px) * 8 + c % 8];
+    }
+#else
     CK(hipMemcpy(ho.data(), dout, ho.size() * 4, hipMemcpyDeviceToHost));
+#endif
     auto rb = [](float v) { __bf16 h = (__bf16)v; return (float)h; };
     double maxerr = 0;
     for (int s = 0; s < 400; ++s) {
@@ -213,8 +249,13 @@ int main(int argc, char** argv) {
         }
         maxerr = fmax(maxerr, fabs(ref - ho[((size_t)n * Cout + co) * HW + y * W + x]));
     }
-    const double gf = 2.0 * N * HW * Cin * Cout * 9 / 1e9, gb = ((double)N * Cin * HW * 2 + (double)N * Cout * HW * 4) / 1e9;
-    printf("c8 igemm %d->%d @%dx%d N=%d: %.3f ms  %.1f TF  %.2f TB/s (bf16 in, fp32 out)  max|err| %.2e  grid %dx%d lds %zu\n", Cin, Cout, H, W, N, ms,
-           gf / ms, gb / ms, maxerr, gx, mblocks, lds);
+    #ifdef OUT_C8
+    const int obytes = 2;
+#else
+    const int obytes = 4;
+#endif
+    const double gf = 2.0 * N * HW * Cin * Cout * 9 / 1e9, gb = ((double)N * Cin * HW * 2 + (double)N * Cout * HW * obytes) / 1e9;
+    printf("c8 igemm %d->%d @%dx%d N=%d: %.3f ms  %.1f TF  %.2f TB/s (bf16 in, %d-byte out)  max|err| %.2e  grid %dx%d lds %zu\n", Cin, Cout, H, W, N, ms,
+           gf / ms, gb / ms, obytes, maxerr, gx, mblocks, lds);
     return 0;
 }
