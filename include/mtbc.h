@@ -74,7 +74,26 @@ typedef struct {
     int32_t compute;                 /* MFMA operand type: 0 = fp32 (exact, the parity path), 1 = bf16,
                                         2 = fp16 -- storage and accumulation stay fp32; fwd/dgrad then need
                                         w_packed from mtbc_conv3x3_pack_lp                    */
+    int32_t operand_layout;          /* how the tensors the MFMA READS are stored (fwd: `in`; dgrad: `dout`;
+                                        wgrad: `in` and `dout`):
+                                          0 = fp32 planar (N,C,H,W), converted while staging (default);
+                                          1 = MTBC_LAYOUT_C8: already in the 16-bit type of `compute` (1 or 2),
+                                              channel-blocked [N][C/8][H*W][8] (mtbc_c8_pack) -- pointers are
+                                              passed through the float* / const float* fields, batch strides count
+                                              16-bit elements, every segment holds a multiple of 8 channels and is
+                                              16-byte aligned.  What the kernels WRITE (z, dx segments, dw, dbias)
+                                              stays fp32 planar.  No fallback: shapes the MFMA kernels do not take
+                                              (W % 4 != 0, H or W < 8) return MTBC_E_UNSUPPORTED.                 */
 } mtbc_conv3x3_args;
+#define MTBC_LAYOUT_PLANAR 0
+#define MTBC_LAYOUT_C8 1
+
+/* fp32 planar (N,C,H,W; batch stride in elements) -> 16-bit channel-blocked [N][C/8][H*W][8] in the type of
+ * `compute` (1 = bf16, 2 = fp16; round to nearest even -- the same conversion the staging of operand_layout 0 does),
+ * and back (exact).  C % 8 == 0, dst 16-byte aligned.  Producers that write this layout themselves (next step:
+ * InstanceNorm+LeakyReLU, pooling, ConvTranspose) make the 3x3 convolutions' staging pure LDS-DMA.           */
+int mtbc_c8_pack(const float* src, int64_t src_batch_stride, void* dst, int32_t N, int32_t C, int32_t HW, int32_t compute, void* stream);
+int mtbc_c8_unpack(const void* src, float* dst, int32_t N, int32_t C, int32_t HW, int32_t compute, void* stream);
 
 size_t mtbc_conv3x3_packed_elems(int32_t Cin, int32_t Cout);          /* fwd image size      */
 size_t mtbc_conv3x3_packed_dgrad_elems(int32_t Cin, int32_t Cout);    /* dgrad image size    */

@@ -20,6 +20,9 @@ class MtbcError(RuntimeError):
     pass
 
 
+LAYOUT_PLANAR, LAYOUT_C8 = 0, 1
+
+
 class Seg(C.Structure):
     _fields_ = [("ptr", C.c_void_p), ("batch_stride", C.c_int64), ("channels", C.c_int32), ("accumulate", C.c_int32)]
 
@@ -31,7 +34,7 @@ class Conv3x3Args(C.Structure):
                 ("out", C.c_void_p), ("dout", C.c_void_p), ("dw", C.c_void_p), ("dbias", C.c_void_p),
                 ("accumulate_dw", C.c_int32), ("force_direct", C.c_int32),
                 ("stats_partial", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
-                ("compute", C.c_int32)]
+                ("compute", C.c_int32), ("operand_layout", C.c_int32)]
 
 
 class InstNormArgs(C.Structure):
@@ -176,7 +179,7 @@ class PackDesc(C.Structure):
 EXPORTS = [
     "mtbc_version", "mtbc_strerror", "mtbc_arch",
     "mtbc_conv3x3_packed_elems", "mtbc_conv3x3_packed_dgrad_elems", "mtbc_conv3x3_pack_fwd",
-    "mtbc_conv3x3_pack_dgrad", "mtbc_conv3x3_packed_lp_elems", "mtbc_conv3x3_pack_lp", "mtbc_conv3x3_pack_many", "mtbc_augment_flip_rotate", "mtbc_convT_head_combine", "mtbc_convT_head_expand", "mtbc_conv3x3_wgrad_workspace", "mtbc_conv3x3_fwd", "mtbc_conv3x3_dgrad",
+    "mtbc_conv3x3_pack_dgrad", "mtbc_conv3x3_packed_lp_elems", "mtbc_conv3x3_pack_lp", "mtbc_conv3x3_pack_many", "mtbc_c8_pack", "mtbc_c8_unpack", "mtbc_augment_flip_rotate", "mtbc_convT_head_combine", "mtbc_convT_head_expand", "mtbc_conv3x3_wgrad_workspace", "mtbc_conv3x3_fwd", "mtbc_conv3x3_dgrad",
     "mtbc_conv3x3_wgrad", "mtbc_instnorm_fwd_workspace", "mtbc_instnorm_lrelu_fwd", "mtbc_instnorm_lrelu_bwd", "mtbc_maxpool2_fwd",
     "mtbc_maxpool2_bwd", "mtbc_convT_wgrad_workspace", "mtbc_convT_fwd", "mtbc_convT_dgrad", "mtbc_convT_wgrad",
     "mtbc_conv1x1_wgrad_workspace", "mtbc_conv1x1_fwd", "mtbc_conv1x1_dgrad", "mtbc_conv1x1_wgrad",
@@ -215,6 +218,10 @@ def load() -> C.CDLL:
     lib.mtbc_augment_flip_rotate.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
     lib.mtbc_conv3x3_pack_many.restype = C.c_int
     lib.mtbc_conv3x3_pack_many.argtypes = [C.POINTER(PackDesc), C.c_int32, C.c_void_p]
+    lib.mtbc_c8_pack.restype = C.c_int
+    lib.mtbc_c8_pack.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
+    lib.mtbc_c8_unpack.restype = C.c_int
+    lib.mtbc_c8_unpack.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
     lib.mtbc_conv3x3_pack_lp.restype = C.c_int
     lib.mtbc_conv3x3_pack_lp.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
     for name in ("mtbc_conv3x3_pack_fwd", "mtbc_conv3x3_pack_dgrad"):

@@ -854,6 +854,171 @@ __global__ __launch_bounds__(256, 3) void conv3x3_igemm_lp_kernel(const ConvP p)
     }
 }
 
+// ------------------------------------------------------------------ 16-bit channel-blocked operands ("c8")
+// The tensor the MFMA reads is ALREADY stored in the MFMA's 16-bit type as [n][C/8][H*W][8]: one 16-byte piece = 8
+// channels of one pixel = one lane's share of a 16x16x32 fragment.  Staging is then pure LDS-DMA -- no staging VGPRs, no
+// conversions, half the bytes -- and the fragment reads are the same ds_read_b128 as above on a [4 groups][halo pixel][8]
+// image.  Everything after the staging (MFMA order, epilogue, fp32 planar output with fan-in read-modify-write) is the
+// kernel above, so results are bit-identical to it on the same rounded operands.  SegL.ptr carries the 16-bit base and
+// SegL.bs the batch stride in 16-bit elements; every segment holds a multiple of 8 channels.
+// Measured stand-alone (tools/experiments/c8_igemm_probe.hip): fwd 144->24 @256x256 N=32 0.27 ms against 0.46 ms.
+template <int MT, int GEO, bool F16>
+__global__ __launch_bounds__(256, 3) void conv3x3_igemm_c8_kernel(const ConvP p) {
+    using G = GeoLP<GEO>;
+    using T = LP<F16>;
+    constexpr int HR = G::TH + 2, HC = G::TW + 2, HP = G::IMG * HR * HC;       // halo pixels
+    constexpr int HPP = (HP + 31) / 32 * 32;
+    constexpr int XB = 4 * HPP * 8;                                            // 16-bit elements
+    constexpr int WB = MT * 9 * 16 * LPROW;
+    constexpr int XQ = (HPP + 63) / 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned short smem16[];
+    unsigned short* Xs = smem16;
+    unsigned short* Ws = smem16 + XB;
+    SegL* seg_in = reinterpret_cast<SegL*>(smem16 + XB + WB);
+    SegL* seg_out = seg_in + MTBC_MAX_SEGS;
+    float* bias_s = reinterpret_cast<float*>(seg_out + MTBC_MAX_SEGS);      // MT*16 floats
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wvu = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int HW = p.H * p.W;
+    const int mt0 = blockIdx.y * MT;
+    segl_fill(seg_in, p.in);
+    segl_fill(seg_out, p.out);
+    if (tid < MT * 16) { const int co = mt0 * 16 + tid; bias_s[tid] = (p.bias && co < p.Cout) ? p.bias[co] : 0.f; }
+    __syncthreads();
+
+    const int nchunks = (p.Cin + LPKC - 1) / LPKC;
+    const int j = lane & 15, kg = lane >> 4;
+    int bpix[4];                      // halo-pixel index of this lane's output pixel in group g, tap (0,0)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        int img = 0, y, x;
+        if (GEO == 0) { y = 2 * wv + (g >> 1); x = 16 * (g & 1) + j; }
+        else if (GEO == 1) { y = 4 * wv + g; x = j; }
+        else { img = wv; y = 2 * g + (j >> 3); x = j & 7; }
+        bpix[g] = (img * HR + y) * HC + x;
+    }
+    int w_have = -1;
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.wp), 0, (int)((size_t)p.mtiles * nchunks * (9 * 16 * LPROW) * 2), 0x00020000);
+    int tile, tstep, tend;            // XCD-aware walk, as above
+    if ((gridDim.x & 7) == 0 && !(p.dbg & 16)) {
+        const int per = (p.ntiles + 7) >> 3, xcd = blockIdx.x & 7;
+        tile = xcd * per + (blockIdx.x >> 3); tstep = gridDim.x >> 3; tend = min(p.ntiles, (xcd + 1) * per);
+    } else { tile = blockIdx.x; tstep = gridDim.x; tend = p.ntiles; }
+    for (; tile < tend; tile += tstep) {
+        int t = tile;
+        const int tx = t % p.tiles_x; t /= p.tiles_x;
+        const int ty = t % p.tiles_y; t /= p.tiles_y;
+        const int n0 = t * G::IMG, x0 = tx * G::TW, y0 = ty * G::TH;
+        unsigned pixo[XQ];            // byte offset of the halo pixel's piece inside a channel group (out of range: reads 0)
+        int pimg[XQ];
+#pragma unroll
+        for (int q = 0; q < XQ; ++q) {
+            const int hp = lane + 64 * q;
+            const int img = hp / (HR * HC), rem = hp % (HR * HC);
+            const int row = rem / HC, col = rem % HC;
+            const int y = y0 + row - 1, x = x0 + col - 1;
+            const bool ok = hp < HP && n0 + img < p.N && y >= 0 && y < p.H && x >= 0 && x < p.W && !(p.dbg & 1);
+            pixo[q] = ok ? 16u * (unsigned)(y * p.W + x) : 0xfffffff0u;
+            pimg[q] = ok ? img : 0;
+        }
+        f32x4 acc[MT][4];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) acc[m][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+        for (int ch = 0; ch < nchunks; ++ch) {
+            lds_barrier();                        // the previous step's fragments are consumed
+            {   // ---- X: wave w brings channel group w of the chunk, XQ instructions of 64 halo pixels x 16 bytes
+                const int c0 = ch * LPKC + 8 * wvu;
+                const bool xgrp = c0 < p.Cin;
+                const SegL sr = segl_ref(seg_in, xgrp ? c0 : 0);
+                const unsigned long long pu = reinterpret_cast<unsigned long long>(sr.ptr);
+                const unsigned plo = __builtin_amdgcn_readfirstlane((unsigned)pu), phi = __builtin_amdgcn_readfirstlane((unsigned)(pu >> 32));
+                const unsigned blo = __builtin_amdgcn_readfirstlane((unsigned)sr.bs), bhi = __builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)sr.bs >> 32));
+                const int cb = __builtin_amdgcn_readfirstlane(sr.cb);
+                const long long bs = (long long)(((unsigned long long)bhi << 32) | blo);
+                unsigned short* base = reinterpret_cast<unsigned short*>(((unsigned long long)phi << 32) | plo) +
+                                       ((size_t)n0 * bs + (size_t)((xgrp ? c0 : 0) - cb) * HW);
+                const unsigned span = (G::IMG > 1 ? (unsigned)((G::IMG - 1) * bs) * 2u : 0u) + (unsigned)HW * 16u;
+                const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(base, 0, xgrp ? (int)span : 0, 0x00020000);
+#pragma unroll
+                for (int q = 0; q < XQ; ++q) {
+                    unsigned off = pixo[q];
+                    if (G::IMG > 1) off += 2u * (unsigned)(pimg[q] * bs);
+                    if (lane + 64 * q < HPP)
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_ptr_t)(Xs + (wvu * HPP + 64 * q) * 8), 16, off, 0, 0, 0);
+                }
+            }
+            if (w_have != ch && !(p.dbg & 8)) {   // ---- W: a single-chunk conv keeps its weights in LDS for the whole launch
+                constexpr int W16 = WB / 8, WI = (W16 + 63) / 64;
+#pragma unroll
+                for (int k = 0; k < (WI + 3) / 4; ++k) {
+                    const int inst = wvu + 4 * k;
+                    if (inst < WI) {
+                        const int idx = inst * 64 + lane;
+                        const int mt = idx / (9 * 16 * LPROW / 8), r = idx % (9 * 16 * LPROW / 8);
+                        const bool ok = idx < W16 && (mt0 + mt) < p.mtiles;
+                        const unsigned voff = ok ? (unsigned)((((mt0 + mt) * nchunks + ch) * (9 * 16 * LPROW / 8) + r) * 16) : 0xfffffff0u;
+                        if (idx < W16)
+                            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_ptr_t)(Ws + inst * 512), 16, voff, 0, 0, 0);
+                    }
+                }
+                w_have = ch;
+            }
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int toff = (tap / 3) * HC + tap % 3;
+                typename T::frag a[MT], b[4];
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+                    a[m] = *reinterpret_cast<const typename T::frag*>(Ws + ((m * 9 + tap) * 16 + j) * LPROW + 8 * kg);
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    b[g] = *reinterpret_cast<const typename T::frag*>(Xs + (kg * HPP + bpix[g] + toff) * 8);
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) acc[m][g] = T::mfma(b[g], a[m], acc[m][g]);      // rows = pixels, cols = channels
+            }
+        }
+        // ---- epilogue: identical to conv3x3_igemm_lp_kernel (fp32 planar output, 16-byte stores / read-modify-write)
+        const int n = GEO == 2 ? n0 + wv : n0;
+        if (p.dbg & 2) { if (acc[0][0][0] != 12345.678f) continue; }
+        int poff[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            int y, x;
+            if (GEO == 0) { y = y0 + 2 * wv + (g >> 1); x = x0 + 16 * (g & 1) + 4 * kg; }
+            else if (GEO == 1) { y = y0 + 4 * wv + g; x = x0 + 4 * kg; }
+            else { y = y0 + 2 * g + (kg >> 1); x = x0 + 4 * (kg & 1); }
+            poff[g] = (n < p.N && y < p.H && x < p.W) ? y * p.W + x : -1;
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int co = (mt0 + m) * 16 + j;
+            if (co >= p.Cout) continue;
+            const SegL so = segl_ref(seg_out, co);
+            gfloat* cb = (gfloat*)so.ptr + (size_t)n * so.bs + (size_t)(co - so.cb) * HW;
+            const float bv = bias_s[m * 16 + j];
+            if (so.acc) {
+                f32x4 old[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) old[g] = poff[g] >= 0 ? *(const gf32x4*)(cb + poff[g]) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    if (poff[g] >= 0) *(gf32x4*)(cb + poff[g]) = old[g] + (acc[m][g] + bv);
+            } else {
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    if (poff[g] >= 0) *(gf32x4*)(cb + poff[g]) = acc[m][g] + bv;
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------ wgrad (MFMA, split-K)
 template <int GEO> struct WGeo;
 template <> struct WGeo<0> { static constexpr int TH = 4, TW = 32, ROWS = 6, LW = 40, IMG = 1, IMGS = 240, PSX = 258; };
@@ -1380,6 +1545,206 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_lp2_kernel(const WgP p) 
 }
 constexpr size_t W2_LDS = 2 * 18 * 64 * sizeof(f32x4);      // the end-of-block reduction is the larger user (36 KB)
 
+// ------------------------------------------------------------------ wgrad on 16-bit channel-blocked operands ("c8")
+// Both operands are already stored as [n][C/8][H*W][8] in the MFMA's 16-bit type (see conv3x3_igemm_c8_kernel).  The
+// contraction runs over PIXELS, so a lane's fragment (8 consecutive pixels of one channel) is the transpose of a stored
+// piece (8 channels of one pixel): LDS-DMA copies the pieces into a [group][pixel][8 ch] image without touching a VGPR
+// and `ds_read_b64_tr_b16` delivers 4 pixels x 16 channels column-major -- its 16 columns are two 8-channel groups that
+// sit in different images (each lane of the instruction supplies its own row address).  Group strides of 204 / 132
+// pieces (3264 / 2112 B = 192 / 64 mod 256) put the two groups, and the two 16-lane blocks of a 32-lane half 8 pixels
+// apart, on disjoint banks.  The +-1 pixel taps: three 4-pixel blocks per halo row give elements e0..e11 from halo
+// column 8kg; tap s uses e_s..e_(s+7) (s = 1 through v_alignbit).  Block structure as conv3x3_wgrad_lp2_kernel
+// (32 co x 32 ci, 4x32-pixel tiles, waves = ci-tile x row-half); no staging registers -> 4 blocks per CU.
+// dbias rides along on the matrix pipe: dz x ones on the ci-block-0 / ci-tile-0 waves.
+// Measured stand-alone (tools/experiments/c8_wgrad_probe.hip): 144->24 @256x256 N=32 0.30 ms against 0.65 ms.
+constexpr int C8W_TH = 4, C8W_TW = 32, C8W_HR = 6, C8W_LW = 34;
+constexpr int C8W_XG = C8W_HR * C8W_LW;          // 204 pieces per input-channel group
+constexpr int C8W_ZG = C8W_TH * C8W_TW + 4;      // 132 pieces per output-channel group
+constexpr int C8W_XI = (C8W_XG + 63) / 64;       // 4 DMA instructions per group (the last one 12 lanes wide)
+constexpr int C8W_BUF16 = (4 * C8W_XG + 16 + 4 * C8W_ZG) * 8;      // 16-bit elements of the stage buffer
+constexpr size_t C8W_LDS = (2 * 18 + 2) * 64 * sizeof(f32x4);      // the end-of-block reduction is the larger user (38 KB)
+static_assert(C8W_BUF16 * 2 <= (int)C8W_LDS, "stage buffer must fit the reduction area");
+struct WgC8P {
+    int N, H, W, Cin, Cout;
+    SegTable in;                       // ptr = 16-bit base, bstride in 16-bit elements, channels % 8 == 0
+    const unsigned short* dz;          // [N][Cout/8][HW][8]
+    float* partial;                    // [nsplit][Cout][Cin][9]
+    float* dbias_partial;              // [nsplit][Cout] or nullptr
+    int tiles_x, tiles_y, total_tiles, tiles_per_split, ciblocks;
+};
+template <bool F16>
+__global__ __launch_bounds__(256, 4) void conv3x3_wgrad_c8_kernel(const WgC8P p) {
+    using T = LP<F16>;
+    typedef short s16x4 __attribute__((ext_vector_type(4)));
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) s16x4* lds_s16x4_t;
+    constexpr int TW = C8W_TW, LW = C8W_LW, XG = C8W_XG, ZG = C8W_ZG, ZBASE = (4 * XG + 16) * 8;
+    extern __shared__ __attribute__((aligned(16))) unsigned short smemc8[];
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int HW = p.H * p.W;
+    const int cib = blockIdx.y % p.ciblocks;
+    const int co0 = (blockIdx.y / p.ciblocks) * 32, ci0 = cib * 32;
+    const int split = blockIdx.x;
+    const int t_begin = split * p.tiles_per_split, t_end = min(p.total_tiles, t_begin + p.tiles_per_split);
+
+    // DMA: wave w brings input-channel group w (4 instructions) and output-channel group w (2 instructions) of the block
+    const int cx = ci0 + 8 * wv, cz = co0 + 8 * wv;
+    const bool xg_ok = cx < p.Cin, zg_ok = cz < p.Cout;
+    const SegRef sr = seg_ref(p.in, xg_ok ? cx : 0);
+    const long long xbs = sr.bs;
+    const unsigned short* xgrp = reinterpret_cast<const unsigned short*>(sr.ptr) + (size_t)((xg_ok ? cx : 0) - sr.cb) * HW;
+    const unsigned short* zgrp = p.dz + (size_t)(zg_ok ? cz : 0) * HW;
+    int xrow[C8W_XI], xcol[C8W_XI];
+#pragma unroll
+    for (int i = 0; i < C8W_XI; ++i) { const int s = 64 * i + lane; xrow[i] = s / LW - 1; xcol[i] = s % LW - 1; }
+    const int zrow = lane / TW, zcol = lane % TW;          // instruction i adds 2 rows
+    auto issue = [&](int tile) {
+        int t = tile;
+        const int tx = t % p.tiles_x; t /= p.tiles_x;
+        const int ty = t % p.tiles_y; t /= p.tiles_y;
+        const int n = t, x0 = tx * TW, y0 = ty * C8W_TH;
+        const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(xgrp + (size_t)n * xbs), 0, xg_ok ? HW * 16 : 0, 0x00020000);
+        const __amdgpu_buffer_rsrc_t zr = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(zgrp + (size_t)n * p.Cout * HW), 0, zg_ok ? HW * 16 : 0, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < C8W_XI; ++i) {
+            const int y = y0 + xrow[i], x = x0 + xcol[i];
+            const bool ok = y >= 0 && y < p.H && x >= 0 && x < p.W;
+            const unsigned voff = ok ? 16u * (unsigned)(y * p.W + x) : 0xfffffff0u;
+            if (64 * i + lane < XG)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_ptr_t)(smemc8 + (wv * XG + 64 * i) * 8), 16, voff, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int y = y0 + zrow + 2 * i, x = x0 + zcol;
+            const unsigned voff = (y < p.H && x < p.W) ? 16u * (unsigned)(y * p.W + x) : 0xfffffff0u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(zr, (lds_ptr_t)(smemc8 + ZBASE + (wv * ZG + 64 * i) * 8), 16, voff, 0, 0, 0);
+        }
+    };
+
+    const int j = lane & 15, kg = lane >> 4, q = j >> 2, pp = j & 3;
+    const int it = wv & 1, kh = wv >> 1;
+    // transposed-read addresses: lane 4q+pp of a 16-lane group supplies row q (a pixel) and columns 4pp..4pp+3 (channels;
+    // columns 0-7 from the first 8-channel group of the tile, 8-15 from the second) of the 4x16 block
+    const int zoff = ZBASE + ((pp >> 1) * ZG + 8 * kg + q) * 8 + 4 * (pp & 1);      // + c*2*ZG*8 + (row*32 + 4*blk)*8
+    const int xoff = ((2 * it + (pp >> 1)) * XG + 8 * kg + q) * 8 + 4 * (pp & 1);   // + ((row+r)*LW + 4*blk)*8
+    const bool do_bias = p.dbias_partial != nullptr && cib == 0 && it == 0;         // wave-uniform
+
+    f32x4 acc[2][9], accb[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        accb[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 9; ++i) acc[c][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    typename T::frag ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = 1.0f;
+
+    for (int tile = t_begin; tile < t_end; ++tile) {
+        lds_barrier();                         // everyone is done reading the previous tile
+        issue(tile);
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll
+        for (int ksl = 0; ksl < 2; ++ksl) {
+            const int row = 2 * kh + ksl;      // 32 pixels of one tile row per step
+            typename T::frag a[2];
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(smemc8 + zoff + c * 2 * ZG * 8 + (row * TW) * 8));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(smemc8 + zoff + c * 2 * ZG * 8 + (row * TW + 4) * 8));
+                const short e[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                a[c] = __builtin_bit_cast(typename T::frag, e);
+            }
+            if (do_bias) {
+#pragma unroll
+                for (int c = 0; c < 2; ++c) accb[c] = T::mfma(a[c], ones, accb[c]);
+            }
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                unsigned d[6];
+#pragma unroll
+                for (int b = 0; b < 3; ++b) {
+                    const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(smemc8 + xoff + ((row + r) * LW + 4 * b) * 8));
+                    const uint2 u = __builtin_bit_cast(uint2, v);
+                    d[2 * b] = u.x; d[2 * b + 1] = u.y;
+                }
+                u32x4 w0, w1, w2;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    w0[k] = d[k];
+                    w1[k] = __builtin_amdgcn_alignbit(d[k + 1], d[k], 16);
+                    w2[k] = d[k + 1];
+                }
+                const typename T::frag b0 = __builtin_bit_cast(typename T::frag, w0);
+                const typename T::frag b1 = __builtin_bit_cast(typename T::frag, w1);
+                const typename T::frag b2 = __builtin_bit_cast(typename T::frag, w2);
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    acc[c][r * 3 + 0] = T::mfma(a[c], b0, acc[c][r * 3 + 0]);
+                    acc[c][r * 3 + 1] = T::mfma(a[c], b1, acc[c][r * 3 + 1]);
+                    acc[c][r * 3 + 2] = T::mfma(a[c], b2, acc[c][r * 3 + 2]);
+                }
+            }
+        }
+    }
+    // sum the two row halves (waves 2,3 -> waves 0,1) through LDS, then one partial per block
+    __syncthreads();
+    f32x4* red = reinterpret_cast<f32x4*>(smemc8);        // [it][18][64] + [2][64] f32x4
+    if (kh == 1) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int i = 0; i < 9; ++i) red[(it * 18 + c * 9 + i) * 64 + lane] = acc[c][i];
+        if (do_bias) { red[(36 + 0) * 64 + lane] = accb[0]; red[(36 + 1) * 64 + lane] = accb[1]; }
+    }
+    __syncthreads();
+    if (kh == 1) return;
+    if (do_bias && j == 0) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = co0 + c * 16 + kg * 4 + r;
+                if (co < p.Cout) p.dbias_partial[(size_t)split * p.Cout + co] = accb[c][r] + red[(36 + c) * 64 + lane][r];
+            }
+    }
+    const int ci = ci0 + it * 16 + j;
+    if (ci >= p.Cin) return;
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int co = co0 + c * 16 + kg * 4 + r;
+            if (co >= p.Cout) continue;
+            float* dst = p.partial + (((size_t)split * p.Cout + co) * p.Cin + ci) * 9;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) dst[tap] = acc[c][tap][r] + red[(it * 18 + c * 9 + tap) * 64 + lane][r];
+        }
+}
+
+// fp32 planar (N,C,H,W) <-> 16-bit channel-blocked [N][C/8][H*W][8]; one thread = one 16-byte piece
+template <bool F16>
+__global__ void c8_pack_kernel(const float* __restrict__ x, long long xbs, unsigned short* __restrict__ y, int C, int HW, long long total) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;          // (n, grp, px)
+    if (idx >= total) return;
+    const int px = (int)(idx % HW); const long long t = idx / HW;
+    const int grp = (int)(t % (C / 8)); const long long n = t / (C / 8);
+    float f[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] = x[n * xbs + (size_t)(grp * 8 + e) * HW + px];
+    *reinterpret_cast<typename LP<F16>::frag*>(y + idx * 8) = LP<F16>::pack(f);
+}
+template <bool F16>
+__global__ void c8_unpack_kernel(const unsigned short* __restrict__ x, float* __restrict__ y, int C, int HW, long long total) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int px = (int)(idx % HW); const long long t = idx / HW;
+    const int grp = (int)(t % (C / 8)); const long long n = t / (C / 8);
+    const typename LP<F16>::frag v = *reinterpret_cast<const typename LP<F16>::frag*>(x + idx * 8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) y[(n * C + grp * 8 + e) * HW + px] = (float)v[e];
+}
+
 // ------------------------------------------------------------------ direct (VALU) fallbacks
 // One thread = one pixel x 8 output channels.  mode 0: fwd  (w[co][ci][tap])
 //                                              mode 1: dgrad (w[ci_in][co_out][8-tap], in = dz)
@@ -1646,9 +2011,37 @@ int launch_igemm_lp_mt(int MT, const ConvP& p, int mblocks, bool f16, hipStream_
     }
 }
 
-// shared by fwd and dgrad: `rows` = channels written, `red` = channels read; compute: 0 fp32, 1 bf16, 2 fp16 operands
+template <int MT, int GEO>
+int launch_igemm_c8(const ConvP& p, int mblocks, bool f16, hipStream_t st) {
+    using G = GeoLP<GEO>;
+    constexpr int HP = G::IMG * (G::TH + 2) * (G::TW + 2), HPP = (HP + 31) / 32 * 32;
+    const size_t lds = ((size_t)4 * HPP * 8 + (size_t)MT * 9 * 16 * LPROW) * 2 + (SEGL_FLOATS + MT * 16) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_igemm_c8_kernel<MT, GEO, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_igemm_c8_kernel<MT, GEO, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    const int per_cu = lds * 3 <= 160 * 1024 ? 3 : 2;      // one wave of resident blocks
+    int gx = (256 * per_cu / mblocks) / 8 * 8;
+    if (gx < 8) gx = 8;
+    if (gx > p.ntiles) gx = p.ntiles;
+    const dim3 grid(gx, mblocks);
+    if (f16) hipLaunchKernelGGL((conv3x3_igemm_c8_kernel<MT, GEO, true>), grid, dim3(256), lds, st, p);
+    else hipLaunchKernelGGL((conv3x3_igemm_c8_kernel<MT, GEO, false>), grid, dim3(256), lds, st, p);
+    MTBC_CHECK_LAUNCH();
+    return MTBC_OK;
+}
+template <int GEO>
+int launch_igemm_c8_mt(int MT, const ConvP& p, int mblocks, bool f16, hipStream_t st) {
+    if (MT == 1) return launch_igemm_c8<1, GEO>(p, mblocks, f16, st);
+    return launch_igemm_c8<2, GEO>(p, mblocks, f16, st);
+}
+
+// shared by fwd and dgrad: `rows` = channels written, `red` = channels read; compute: 0 fp32, 1 bf16, 2 fp16 operands;
+// c8: the tensor read is 16-bit channel-blocked (MTBC_LAYOUT_C8)
 int run_igemm(int N, int H, int W, int red, int rows, const SegTable& in, const SegTable& out, const float* wp,
-              const float* bias, int compute, hipStream_t st) {
+              const float* bias, int compute, hipStream_t st, bool c8 = false) {
     ConvP p;
     p.N = N; p.H = H; p.W = W; p.Cin = red; p.Cout = rows; p.in = in; p.out = out; p.wp = wp; p.bias = bias;
     static const int dbg = getenv("MTBC_DBG") ? atoi(getenv("MTBC_DBG")) : 0;
@@ -1671,6 +2064,11 @@ int run_igemm(int N, int H, int W, int red, int rows, const SegTable& in, const 
         mblocks = cdiv(p.mtiles, MT);
     }
     MT = cdiv(p.mtiles, mblocks);
+    if (c8) {
+        if (geo == 0) return launch_igemm_c8_mt<0>(MT, p, mblocks, compute == 2, st);
+        if (geo == 1) return launch_igemm_c8_mt<1>(MT, p, mblocks, compute == 2, st);
+        return launch_igemm_c8_mt<2>(MT, p, mblocks, compute == 2, st);
+    }
     if (compute != 0) {
         if (geo == 0) return launch_igemm_lp_mt<0>(MT, p, mblocks, compute == 2, st);
         if (geo == 1) return launch_igemm_lp_mt<1>(MT, p, mblocks, compute == 2, st);
@@ -1682,8 +2080,28 @@ int run_igemm(int N, int H, int W, int red, int rows, const SegTable& in, const 
 }
 
 struct WgPlan { bool mfma; bool smallcin; int cot; int geo, tiles_x, tiles_y, total_tiles, nsplit, tiles_per_split, coblocks, ciblocks; size_t partial_elems, dbias_elems; };
+// operand_layout = MTBC_LAYOUT_C8: are the 16-bit channel-blocked operands well-formed?
+bool c8_segs_ok(const mtbc_seg* segs, int nseg) {
+    for (int i = 0; i < nseg; ++i)
+        if (!segs[i].ptr || segs[i].channels % 8 || segs[i].batch_stride % 8 || (reinterpret_cast<uintptr_t>(segs[i].ptr) & 15)) return false;
+    return true;
+}
 WgPlan plan_wgrad(const mtbc_conv3x3_args* a) {
     WgPlan w{};
+    if (a->operand_layout == MTBC_LAYOUT_C8) {      // conv3x3_wgrad_c8_kernel: 32 x 32 channel blocks, 4 x 32 pixel tiles, 4 blocks per CU
+        w.mfma = true; w.geo = 0; w.cot = 2;
+        w.tiles_x = cdiv(a->W, C8W_TW); w.tiles_y = cdiv(a->H, C8W_TH);
+        w.total_tiles = w.tiles_x * w.tiles_y * a->N;
+        w.coblocks = cdiv(a->Cout, 32); w.ciblocks = cdiv(a->Cin, 32);
+        int ns = 1024 / (w.coblocks * w.ciblocks);
+        if (ns > w.total_tiles) ns = w.total_tiles;
+        if (ns < 1) ns = 1;
+        w.tiles_per_split = cdiv(w.total_tiles, ns);
+        w.nsplit = cdiv(w.total_tiles, w.tiles_per_split);
+        w.partial_elems = (size_t)w.nsplit * a->Cout * a->Cin * 9;
+        w.dbias_elems = a->dbias ? (size_t)w.nsplit * a->Cout : 0;
+        return w;
+    }
     w.mfma = !a->force_direct && mfma_ok(a->in, a->n_in, a->H, a->W) && a->Cin >= 8 &&
              (reinterpret_cast<uintptr_t>(a->dout) & 15) == 0;
     const size_t wel = (size_t)a->Cout * a->Cin * 9;
@@ -1802,6 +2220,12 @@ int mtbc_conv3x3_fwd(const mtbc_conv3x3_args* a, void* stream) {
     mtbc_seg o{a->out, (int64_t)a->Cout * a->H * a->W, a->Cout, 0};
     rc = make_segtable(&o, 1, a->Cout, &out); if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
+    if (a->operand_layout == MTBC_LAYOUT_C8) {
+        if (!a->w_packed || (a->compute != 1 && a->compute != 2) || !c8_segs_ok(a->in, a->n_in)) return MTBC_E_BADARG;
+        if (a->W % 4 || a->W < 8 || a->H < 8 || (reinterpret_cast<uintptr_t>(a->out) & 15)) return MTBC_E_UNSUPPORTED;
+        return run_igemm(a->N, a->H, a->W, a->Cin, a->Cout, in, out, a->w_packed, a->bias, a->compute, st, true);
+    }
+    if (a->operand_layout != MTBC_LAYOUT_PLANAR) return MTBC_E_BADARG;
     if (a->w_packed && !a->force_direct && mfma_ok(a->in, a->n_in, a->H, a->W))
         return run_igemm(a->N, a->H, a->W, a->Cin, a->Cout, in, out, a->w_packed, a->bias, a->compute, st);
     if (!a->w) return MTBC_E_BADARG;
@@ -1827,6 +2251,12 @@ int mtbc_conv3x3_dgrad(const mtbc_conv3x3_args* a, void* stream) {
     rc = make_segtable(&g, 1, a->Cout, &in); if (rc) return rc;
     rc = make_segtable(a->in, a->n_in, a->Cin, &out); if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
+    if (a->operand_layout == MTBC_LAYOUT_C8) {
+        if (!a->w_packed || (a->compute != 1 && a->compute != 2) || !c8_segs_ok(&g, 1)) return MTBC_E_BADARG;
+        if (!mfma_ok(a->in, a->n_in, a->H, a->W)) return MTBC_E_UNSUPPORTED;      // the fp32 planar dx segments: 16-byte stores
+        return run_igemm(a->N, a->H, a->W, a->Cout, a->Cin, in, out, a->w_packed, nullptr, a->compute, st, true);
+    }
+    if (a->operand_layout != MTBC_LAYOUT_PLANAR) return MTBC_E_BADARG;
     bool ok = a->w_packed && !a->force_direct && mfma_ok(&g, 1, a->H, a->W) && a->Cout % KC == 0;
     for (int i = 0; ok && i < a->n_in; ++i) ok = a->in[i].ptr != nullptr && a->in[i].channels % 4 == 0;
     if (ok) return run_igemm(a->N, a->H, a->W, a->Cout, a->Cin, in, out, a->w_packed, nullptr, a->compute, st);
@@ -1854,6 +2284,23 @@ int mtbc_conv3x3_wgrad(const mtbc_conv3x3_args* a, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     float* partial = reinterpret_cast<float*>(a->workspace);
     const size_t wel = (size_t)a->Cout * a->Cin * 9;
+    if (a->operand_layout == MTBC_LAYOUT_C8) {
+        mtbc_seg g{const_cast<float*>(a->dout), (int64_t)a->Cout * a->H * a->W, a->Cout, 0};
+        if ((a->compute != 1 && a->compute != 2) || !c8_segs_ok(a->in, a->n_in) || !c8_segs_ok(&g, 1)) return MTBC_E_BADARG;
+        WgC8P p; p.N = a->N; p.H = a->H; p.W = a->W; p.Cin = a->Cin; p.Cout = a->Cout; p.in = in;
+        p.dz = reinterpret_cast<const unsigned short*>(a->dout); p.partial = partial;
+        p.dbias_partial = a->dbias ? partial + w.partial_elems : nullptr;
+        p.tiles_x = w.tiles_x; p.tiles_y = w.tiles_y; p.total_tiles = w.total_tiles; p.tiles_per_split = w.tiles_per_split;
+        p.ciblocks = w.ciblocks;
+        const dim3 grid(w.nsplit, w.coblocks * w.ciblocks);
+        if (a->compute == 2) hipLaunchKernelGGL((conv3x3_wgrad_c8_kernel<true>), grid, dim3(256), C8W_LDS, st, p);
+        else hipLaunchKernelGGL((conv3x3_wgrad_c8_kernel<false>), grid, dim3(256), C8W_LDS, st, p);
+        MTBC_CHECK_LAUNCH();
+        rc = mtbc_i_splitk_reduce(partial, a->dw, w.nsplit, wel, a->accumulate_dw, st); if (rc) return rc;
+        if (a->dbias) { rc = mtbc_i_splitk_reduce(p.dbias_partial, a->dbias, w.nsplit, (size_t)a->Cout, a->accumulate_dw, st); if (rc) return rc; }
+        return MTBC_OK;
+    }
+    if (a->operand_layout != MTBC_LAYOUT_PLANAR) return MTBC_E_BADARG;
     if (w.mfma) {
         WgP p; p.N = a->N; p.H = a->H; p.W = a->W; p.Cin = a->Cin; p.Cout = a->Cout; p.in = in; p.dz = a->dout;
         p.partial = partial; p.tiles_x = w.tiles_x; p.tiles_y = w.tiles_y; p.total_tiles = w.total_tiles;
@@ -1905,6 +2352,27 @@ int mtbc_conv3x3_wgrad(const mtbc_conv3x3_args* a, void* stream) {
         rc = mtbc_i_channel_sums(a->dout, partial + w.partial_elems, a->dbias, a->N, a->Cout, a->H * a->W, a->accumulate_dw, st);
         if (rc) return rc;
     }
+    return MTBC_OK;
+}
+
+int mtbc_c8_pack(const float* src, int64_t src_batch_stride, void* dst, int32_t N, int32_t C, int32_t HW, int32_t compute, void* stream) {
+    if (!src || !dst || (compute != 1 && compute != 2) || (reinterpret_cast<uintptr_t>(dst) & 15)) return MTBC_E_BADARG;
+    if (N <= 0 || C <= 0 || HW <= 0 || C % 8) return MTBC_E_BADSHAPE;
+    const long long total = (long long)N * (C / 8) * HW;
+    const dim3 grid((unsigned)cdiv64(total, 256));
+    if (compute == 2) hipLaunchKernelGGL((c8_pack_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, src, (long long)src_batch_stride, reinterpret_cast<unsigned short*>(dst), C, HW, total);
+    else hipLaunchKernelGGL((c8_pack_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, src, (long long)src_batch_stride, reinterpret_cast<unsigned short*>(dst), C, HW, total);
+    MTBC_CHECK_LAUNCH();
+    return MTBC_OK;
+}
+int mtbc_c8_unpack(const void* src, float* dst, int32_t N, int32_t C, int32_t HW, int32_t compute, void* stream) {
+    if (!src || !dst || (compute != 1 && compute != 2) || (reinterpret_cast<uintptr_t>(src) & 15)) return MTBC_E_BADARG;
+    if (N <= 0 || C <= 0 || HW <= 0 || C % 8) return MTBC_E_BADSHAPE;
+    const long long total = (long long)N * (C / 8) * HW;
+    const dim3 grid((unsigned)cdiv64(total, 256));
+    if (compute == 2) hipLaunchKernelGGL((c8_unpack_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const unsigned short*>(src), dst, C, HW, total);
+    else hipLaunchKernelGGL((c8_unpack_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const unsigned short*>(src), dst, C, HW, total);
+    MTBC_CHECK_LAUNCH();
     return MTBC_OK;
 }
 

@@ -147,6 +147,81 @@ def conv3x3_wgrad(xs: Sequence[torch.Tensor], dz: torch.Tensor, w_shape, want_bi
     return dw, db
 
 
+# ------------------------------------------------------------------ conv3x3 on 16-bit channel-blocked operands
+class C8:
+    """A tensor in MTBC_LAYOUT_C8: [N][C/8][H*W][8] in bf16 (compute 1) or fp16 (compute 2), held as int16 storage.
+    What the 3x3 convolutions' MFMAs read when `operand_layout = 1` (include/mtbc.h)."""
+
+    def __init__(self, data: torch.Tensor, shape, compute: int):
+        self.data, self.shape, self.compute = data, tuple(shape), compute
+
+    @staticmethod
+    def pack(x: torch.Tensor, compute: int) -> "C8":
+        _chk(x)
+        N, Cc, H, W = x.shape
+        d = torch.empty(N, Cc // 8, H * W, 8, dtype=torch.int16, device=x.device)
+        L.check(L.load().mtbc_c8_pack(x.data_ptr(), Cc * H * W, d.data_ptr(), N, Cc, H * W, compute, _s()), "c8_pack")
+        return C8(d, x.shape, compute)
+
+    def unpack(self) -> torch.Tensor:
+        N, Cc, H, W = self.shape
+        y = torch.empty(N, Cc, H, W, dtype=torch.float32, device=self.data.device)
+        L.check(L.load().mtbc_c8_unpack(self.data.data_ptr(), y.data_ptr(), N, Cc, H * W, self.compute, _s()), "c8_unpack")
+        return y
+
+
+def _fill_segs_c8(arr, tensors: Sequence["C8"]):
+    for i, t in enumerate(tensors):
+        arr[i].ptr = t.data.data_ptr()
+        arr[i].batch_stride = t.shape[1] * t.shape[2] * t.shape[3]      # 16-bit elements
+        arr[i].channels = t.shape[1]
+        arr[i].accumulate = 0
+
+
+def conv3x3_fwd_c8(xs: Sequence["C8"], w: torch.Tensor, bias: Optional[torch.Tensor], packed: torch.Tensor) -> torch.Tensor:
+    """z (fp32 planar) = conv3x3(concat(xs)) with the inputs already in the MFMA's 16-bit channel-blocked layout."""
+    _chk(w, bias)
+    N, _, H, W = xs[0].shape
+    a = L.Conv3x3Args()
+    a.N, a.H, a.W, a.Cin, a.Cout, a.n_in = N, H, W, sum(x.shape[1] for x in xs), w.shape[0], len(xs)
+    _fill_segs_c8(a.in_, xs)
+    out = torch.empty(N, w.shape[0], H, W, dtype=torch.float32, device=w.device)
+    a.w, a.w_packed, a.bias, a.out = w.data_ptr(), packed.data_ptr(), _p(bias), out.data_ptr()
+    a.compute, a.operand_layout = xs[0].compute, L.LAYOUT_C8
+    L.check(L.load().mtbc_conv3x3_fwd(C.byref(a), _s()), "conv3x3_fwd(c8)")
+    return out
+
+
+def conv3x3_dgrad_c8(dz: "C8", w: torch.Tensor, dxs: Sequence[torch.Tensor], accumulate: Sequence[int], packed: torch.Tensor) -> None:
+    """dx segments (fp32 planar, accumulate honoured) from dz in the 16-bit channel-blocked layout."""
+    _chk(w, *dxs)
+    N, _, H, W = dz.shape
+    a = _conv_args(dxs, w, N, H, W)
+    _fill_segs(a.in_, dxs, accumulate)
+    a.w_packed, a.dout = packed.data_ptr(), dz.data.data_ptr()
+    a.compute, a.operand_layout = dz.compute, L.LAYOUT_C8
+    L.check(L.load().mtbc_conv3x3_dgrad(C.byref(a), _s()), "conv3x3_dgrad(c8)")
+
+
+def conv3x3_wgrad_c8(xs: Sequence["C8"], dz: "C8", w_shape, want_bias: bool = False, dw: Optional[torch.Tensor] = None,
+                     accumulate: bool = False):
+    N, _, H, W = dz.shape
+    dev = dz.data.device
+    if dw is None:
+        dw = torch.empty(*w_shape, dtype=torch.float32, device=dev)
+    db = torch.empty(w_shape[0], dtype=torch.float32, device=dev) if want_bias else None
+    a = L.Conv3x3Args()
+    a.N, a.H, a.W, a.Cin, a.Cout, a.n_in = N, H, W, w_shape[1], w_shape[0], len(xs)
+    _fill_segs_c8(a.in_, xs)
+    a.dout, a.dw, a.dbias, a.accumulate_dw = dz.data.data_ptr(), dw.data_ptr(), _p(db), int(accumulate)
+    a.compute, a.operand_layout = dz.compute, L.LAYOUT_C8
+    nb = L.load().mtbc_conv3x3_wgrad_workspace(C.byref(a))
+    ws = _ws(nb, dev)
+    a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+    L.check(L.load().mtbc_conv3x3_wgrad(C.byref(a), _s()), "conv3x3_wgrad(c8)")
+    return dw, db
+
+
 # ------------------------------------------------------------------ instance norm + leaky relu
 def instnorm_lrelu_fwd(z, gamma=None, beta=None, eps=1e-5, slope=0.01):
     _chk(z, gamma, beta)

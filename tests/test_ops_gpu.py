@@ -414,3 +414,85 @@ def test_fused_convT_1x1_head_equals_the_two_layers(N, Cin, Cmid, R, H, W, k):
     want = [y.detach()] + [t.grad for t in leaves]
     for name, a, b in zip(("y", "dx", "dwT", "dbT", "dw1", "db1"), got, want):
         _close(a, b, 1e-4, 2e-5 * max(1.0, b.abs().max().item()), "head " + name)
+
+
+# ------------------------------------------------------------------ 16-bit channel-blocked operands (MTBC_LAYOUT_C8)
+def _round16(t, compute):
+    return (t.bfloat16() if compute == 1 else t.half()).float()
+
+
+@pytest.mark.parametrize("compute", [1, 2])
+def test_c8_pack_is_rne_and_unpack_is_exact(compute):
+    x = torch.randn(3, 24, 10, 12, generator=_g(5)) * 3
+    c8 = ops.C8.pack(x.to(DEV), compute)
+    assert c8.data.shape == (3, 3, 120, 8)
+    back = c8.unpack().cpu()
+    assert torch.equal(back, _round16(x, compute))
+    # layout: piece (n, g, px) holds channels 8g..8g+7 of pixel px
+    raw = c8.data.cpu().view(torch.bfloat16 if compute == 1 else torch.float16).float()
+    assert torch.equal(raw[1, 2, 37], _round16(x, compute)[1, 16:24].reshape(8, -1)[:, 37])
+
+
+C8_CASES = [
+    (2, [8], 16, 32, 32),
+    (1, [24, 48], 24, 40, 64),          # two segments, H not a multiple of the tile
+    (2, [24, 24, 24, 48], 24, 16, 32),  # 4 segments, 120 channels: the last 32-channel chunk is ragged
+    (3, [16], 40, 16, 16),              # 16-wide geometry, Cout not a multiple of 16
+    (5, [32], 80, 8, 8),                # 8x8 geometry: 4 images per block, ragged batch
+    (1, [8], 8, 24, 48),                # width not a multiple of 32
+    (2, [144], 24, 36, 64),             # >1 chunk, rows not a multiple of 4
+    (2, [96, 96], 96, 16, 16),
+    (2, [48], 48, 32, 32),
+]
+
+
+@pytest.mark.parametrize("compute", [1, 2])
+@pytest.mark.parametrize("N,segs,Cout,H,W", C8_CASES)
+def test_conv3x3_c8_operands(N, segs, Cout, H, W, compute):
+    """fwd / dgrad read the SAME rounded values in the SAME MFMA order as the planar 16-bit path -> bit-identical;
+    wgrad (another split and tile order) and dbias are checked against fp64 on the rounded operands."""
+    g = _g(N * 77 + Cout + H + compute)
+    Cin = sum(segs)
+    xs = [torch.randn(N, c, H, W, generator=g) for c in segs]
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (9 * Cin)) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    dz = torch.randn(N, Cout, H, W, generator=g)
+    xd = [x.to(DEV) for x in xs]
+    wd, bd, dzd = w.to(DEV), b.to(DEV), dz.to(DEV)
+    pf, pd = ops.conv3x3_pack_lp(wd, compute)
+    x8 = [ops.C8.pack(x, compute) for x in xd]
+    dz8 = ops.C8.pack(dzd, compute)
+
+    z_planar = ops.conv3x3_fwd(xd, wd, bd, packed=pf, compute=compute)
+    z_c8 = ops.conv3x3_fwd_c8(x8, wd, bd, pf)
+    assert torch.equal(z_c8, z_planar), f"fwd differs: {(z_c8 - z_planar).abs().max().item():.3e}"
+
+    pre = [torch.randn(N, c, H, W, generator=g) for c in segs]
+    acc = [0] + [1] * (len(segs) - 1)
+    d_planar = [p.to(DEV).clone() for p in pre]
+    d_c8 = [p.to(DEV).clone() for p in pre]
+    ops.conv3x3_dgrad(dzd, wd, d_planar, acc, packed=pd, compute=compute)
+    ops.conv3x3_dgrad_c8(dz8, wd, d_c8, acc, pd)
+    for i in range(len(segs)):
+        assert torch.equal(d_c8[i], d_planar[i]), f"dgrad seg {i} differs"
+
+    xr = _round16(torch.cat(xs, 1), compute).double().requires_grad_(False)
+    dzr = _round16(dz, compute).double()
+    wref = torch.zeros(Cout, Cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(xr, wref, padding=1).backward(dzr)
+    dw, db = ops.conv3x3_wgrad_c8(x8, dz8, tuple(w.shape), want_bias=True)
+    scale = max(1.0, wref.grad.abs().max().item())
+    _close(dw, wref.grad.float(), 1e-5, 2e-5 * scale, "wgrad c8")
+    dbr = dzr.sum((0, 2, 3)).float()
+    _close(db, dbr, 1e-5, 2e-5 * max(1.0, dbr.abs().max().item()), "dbias c8")
+    dw2, db2 = ops.conv3x3_wgrad_c8(x8, dz8, tuple(w.shape), want_bias=False, dw=dw.clone(), accumulate=True)
+    _close(dw2, 2 * wref.grad.float(), 1e-5, 4e-5 * scale, "wgrad c8 accumulate")
+
+
+def test_conv3x3_c8_rejects_what_it_cannot_run():
+    from multi_task_breast_cancer_amd import _lib as L
+    x = torch.randn(1, 8, 8, 10, generator=_g(1)).to(DEV)      # W % 4 != 0: the fp32 output needs 16-byte rows
+    w = torch.randn(8, 8, 3, 3, generator=_g(2)).to(DEV)
+    pf, _ = ops.conv3x3_pack_lp(w, 1)
+    with pytest.raises(L.MtbcError):
+        ops.conv3x3_fwd_c8([ops.C8.pack(x, 1)], w, None, pf)
