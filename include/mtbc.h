@@ -314,7 +314,8 @@ enum {
     MTBC_OP_CONV1_FWD, MTBC_OP_CONV1_DGRAD, MTBC_OP_CONV1_WGRAD,
     MTBC_OP_GAP_FWD, MTBC_OP_GAP_BWD, MTBC_OP_LINEAR_FWD, MTBC_OP_LINEAR_BWD,
     MTBC_OP_DICE_FWD, MTBC_OP_DICE_BWD, MTBC_OP_FOCAL, MTBC_OP_LOSS_MIX, MTBC_OP_ADAM,
-    MTBC_OP_MEMSET, MTBC_OP_DICE_COUNTS, MTBC_OP_CONV3_PACK_LP, MTBC_OP_HEAD_COMBINE, MTBC_OP_HEAD_EXPAND
+    MTBC_OP_MEMSET, MTBC_OP_DICE_COUNTS, MTBC_OP_CONV3_PACK_LP, MTBC_OP_HEAD_COMBINE, MTBC_OP_HEAD_EXPAND,
+    MTBC_OP_C8_PACK
 };
 
 /* ---- deep-supervision head of MTnnUNet: ConvTranspose2d(Cin->Cmid, k=s) followed by Conv2d(Cmid->R, 1x1)
@@ -364,6 +365,7 @@ typedef struct {
         struct { void* ptr; size_t bytes; } memset0;
         struct { const float* logits; const float* target; int64_t n; double* out3; } counts;
         mtbc_head_fuse_args head;
+        struct { const float* src; int64_t src_batch_stride; void* dst; int32_t N, C, HW, compute; } c8pack;
     } u;
 } mtbc_op;
 

@@ -130,6 +130,11 @@ class _CountsArgs(C.Structure):
     _fields_ = [("logits", C.c_void_p), ("target", C.c_void_p), ("n", C.c_int64), ("out3", C.c_void_p)]
 
 
+class _C8PackArgs(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("src_batch_stride", C.c_int64), ("dst", C.c_void_p),
+                ("N", C.c_int32), ("C", C.c_int32), ("HW", C.c_int32), ("compute", C.c_int32)]
+
+
 class HeadFuseArgs(C.Structure):
     """mtbc_head_fuse_args (include/mtbc.h)."""
     _fields_ = [("Cin", C.c_int32), ("Cmid", C.c_int32), ("R", C.c_int32), ("k", C.c_int32),
@@ -143,7 +148,7 @@ class _OpUnion(C.Union):
     _fields_ = [("conv3", Conv3x3Args), ("inorm", InstNormArgs), ("pool", MaxPoolArgs), ("convT", ConvTArgs),
                 ("conv1", Conv1x1Args), ("gap", GapArgs), ("linear", LinearArgs), ("dice", DiceArgs),
                 ("focal", FocalArgs), ("adam", AdamArgs), ("pack", _PackArgs), ("mix", _MixArgs),
-                ("memset0", _MemsetArgs), ("counts", _CountsArgs), ("head", HeadFuseArgs)]
+                ("memset0", _MemsetArgs), ("counts", _CountsArgs), ("head", HeadFuseArgs), ("c8pack", _C8PackArgs)]
 
 
 class Op(C.Structure):
@@ -155,7 +160,7 @@ class Op(C.Structure):
  OP_IN_FWD, OP_IN_BWD, OP_POOL_FWD, OP_POOL_BWD, OP_CONVT_FWD, OP_CONVT_DGRAD, OP_CONVT_WGRAD,
  OP_CONV1_FWD, OP_CONV1_DGRAD, OP_CONV1_WGRAD, OP_GAP_FWD, OP_GAP_BWD, OP_LINEAR_FWD, OP_LINEAR_BWD,
  OP_DICE_FWD, OP_DICE_BWD, OP_FOCAL, OP_LOSS_MIX, OP_ADAM, OP_MEMSET, OP_DICE_COUNTS, OP_CONV3_PACK_LP,
- OP_HEAD_COMBINE, OP_HEAD_EXPAND) = range(1, 30)
+ OP_HEAD_COMBINE, OP_HEAD_EXPAND, OP_C8_PACK) = range(1, 31)
 
 OP_UNION_FIELD = {
     OP_CONV3_FWD: "conv3", OP_CONV3_DGRAD: "conv3", OP_CONV3_WGRAD: "conv3",
@@ -166,7 +171,7 @@ OP_UNION_FIELD = {
     OP_GAP_FWD: "gap", OP_GAP_BWD: "gap", OP_LINEAR_FWD: "linear", OP_LINEAR_BWD: "linear",
     OP_DICE_FWD: "dice", OP_DICE_BWD: "dice", OP_FOCAL: "focal", OP_LOSS_MIX: "mix", OP_ADAM: "adam",
     OP_MEMSET: "memset0", OP_DICE_COUNTS: "counts", OP_CONV3_PACK_LP: "pack",
-    OP_HEAD_COMBINE: "head", OP_HEAD_EXPAND: "head",
+    OP_HEAD_COMBINE: "head", OP_HEAD_EXPAND: "head", OP_C8_PACK: "c8pack",
 }
 
 # every symbol include/mtbc.h declares (tests check the library exports all of them)

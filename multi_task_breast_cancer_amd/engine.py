@@ -19,6 +19,7 @@ from . import _lib as L
 
 import os as _os
 _NOACC = _os.environ.get('MTBC_NOACC') == '1'     # timing probe only: results are wrong when set
+_NO_C8 = _os.environ.get('MTBC_NO_C8') == '1'     # A/B: 16-bit modes stage fp32 planar operands as before
 
 
 def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
@@ -35,6 +36,7 @@ class Act:
     grad_written: bool = False         # has any backward op produced (part of) this grad yet?
     fanin_separate: bool = False       # conv-cell outputs: every further consumer writes its own buffer (plain
     extra_grads: List[torch.Tensor] = field(default_factory=list)   # stores); IN-backward sums them on the fly
+    c8: Optional[torch.Tensor] = None  # 16-bit channel-blocked copy [N][C/8][H*W][8] read by the 3x3 convs' MFMAs
 
     @property
     def N(self): return self.data.shape[0]
@@ -152,6 +154,28 @@ class StepPlan:
             return t, 0
         return self.grad_of(a), (0 if _NOACC else 1)
 
+    def _c8_pack_op(self, src: torch.Tensor, dst: torch.Tensor, C_: int, HW: int) -> L.Op:
+        op = _mk(L.OP_C8_PACK)
+        a = op.u.c8pack
+        a.src, a.src_batch_stride, a.dst = src.data_ptr(), C_ * HW, dst.data_ptr()
+        a.N, a.C, a.HW, a.compute = self.N, C_, HW, self.compute
+        return op
+
+    def c8_of(self, a: Act) -> torch.Tensor:
+        """The 16-bit channel-blocked copy of an activation (MTBC_LAYOUT_C8), converted ONCE -- by an op placed right
+        behind the ops emitted so far, i.e. after its producer -- and then read by every 3x3 conv and weight gradient
+        that consumes it (X0_0 of the U-Net++ feeds 4 convs and 4 wgrads): their staging becomes LDS-DMA."""
+        if a.c8 is None:
+            a.c8 = self.alloc(self.N, a.C // 8, a.H * a.W, 8, dtype=torch.int16)
+            self.fwd_ops.append(self._c8_pack_op(a.data, a.c8, a.C, a.H * a.W))
+        return a.c8
+
+    def _dz8(self, numel: int) -> torch.Tensor:
+        """One scratch for the 16-bit copy of dz: IN-backward -> pack -> wgrad -> dgrad run back to back on one stream."""
+        if getattr(self, "_dz8_buf", None) is None or self._dz8_buf.numel() < numel:
+            self._dz8_buf = self.alloc(numel, dtype=torch.int16)
+        return self._dz8_buf
+
     def _need_ws(self, op: L.Op, fieldname: str, nbytes: int) -> None:
         self.ws_bytes = max(self.ws_bytes, int(nbytes))
         self.ws_users.append((op, fieldname))
@@ -229,9 +253,23 @@ class StepPlan:
             a.compute = self.compute if use_packed else 0
             return op
 
+        # 16-bit modes: the MFMA operands are converted once per tensor into the channel-blocked 16-bit layout instead
+        # of once per consumer inside the staging (same RNE, same MFMA order: bit-identical forward / dgrad)
+        c8 = (not _NO_C8) and use_packed and self.compute != 0 and not self.force_direct and W % 4 == 0 and H >= 8 and W >= 8
+        c8_bwd = c8 and cout % 8 == 0
+
+        def segs_c8(arr) -> None:
+            for i, a_ in enumerate(inputs):
+                arr[i].ptr = self.c8_of(a_).data_ptr()
+                arr[i].batch_stride, arr[i].channels, arr[i].accumulate = a_.bstride, a_.C, 0
+
         op = base_conv()
         op.kind = L.OP_CONV3_FWD
-        self._segs(op.u.conv3.in_, inputs)
+        if c8:
+            segs_c8(op.u.conv3.in_)
+            op.u.conv3.operand_layout = L.LAYOUT_C8
+        else:
+            self._segs(op.u.conv3.in_, inputs)
         op.u.conv3.w_packed = _ptr(wp_f)
         op.u.conv3.bias = _ptr(self.pv(bname)) if bname else None
         op.u.conv3.out = z.data_ptr()
@@ -281,12 +319,20 @@ class StepPlan:
                 a.accumulate_dparams = acc
                 self._need_ws(op, "inorm", N * cout * 3 * 4)
             self.bwd_ops.append(op)
+            dz8 = None
+            if c8_bwd:
+                dz8 = self._dz8(N * cout * H * W)
+                self.bwd_ops.append(self._c8_pack_op(dy, dz8, cout, H * W))
             # wgrad
             op = base_conv()
             op.kind = L.OP_CONV3_WGRAD
             a = op.u.conv3
-            self._segs(a.in_, inputs)
-            a.dout = dy.data_ptr()
+            if c8_bwd:
+                segs_c8(a.in_)
+                a.dout, a.operand_layout = dz8.data_ptr(), L.LAYOUT_C8
+            else:
+                self._segs(a.in_, inputs)
+                a.dout = dy.data_ptr()
             a.accumulate_dw = self._mark_param(wname)
             a.dw = self.gv(wname).data_ptr()
             self._need_ws(op, "conv3", self.lib.mtbc_conv3x3_wgrad_workspace(C.byref(a)))
@@ -301,6 +347,8 @@ class StepPlan:
                 a = op.u.conv3
                 self._segs(a.in_, inputs, grads=True)
                 a.dout = dy.data_ptr()
+                if c8_bwd and wp_d is not None:
+                    a.dout, a.operand_layout = dz8.data_ptr(), L.LAYOUT_C8
                 a.w_packed = _ptr(wp_d)
                 self.bwd_ops.append(op)
 

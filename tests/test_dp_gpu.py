@@ -39,7 +39,8 @@ def _worker(rank, world, port, q):
         torch.cuda.synchronize()
         assert step.opt.grad_scale == 1.0 / world and len(step._buckets) >= 2
         if rank == 0:
-            q.put((m.flat_p.cpu(), m.flat_g.cpu(), losses.cpu()))
+            # numpy arrays travel by value; CPU tensors would travel as shared-memory handles that die with this process
+            q.put((m.flat_p.cpu().numpy(), m.flat_g.cpu().numpy(), losses.cpu().numpy()))
         dist.barrier()
     finally:
         dist.destroy_process_group()
@@ -58,7 +59,7 @@ def test_two_rank_step_equals_single_rank_global_batch():
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    p2, g2, l2 = q.get(timeout=300)
+    p2, g2, l2 = (torch.from_numpy(a) for a in q.get(timeout=300))
     for p in procs:
         p.join(120)
         assert p.exitcode == 0
