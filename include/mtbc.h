@@ -189,7 +189,15 @@ typedef struct {
     int32_t accumulate_dw;
     void* workspace; size_t workspace_bytes;
     int32_t compute;                 /* k == 2 backward only: 0 = fp32 MFMA (exact), 1 = bf16, 2 = fp16 operands */
+    int32_t y_layout;                /* fwd: 0 = fp32 planar y; MTBC_LAYOUT_C8 = y is written as 16-bit channel-blocked
+                                        [N][Cout/8][k*H*k*W][8] (what a 3x3 conv with operand_layout C8 reads; batch
+                                        stride in 16-bit elements) -- same fp32 arithmetic, one RNE at the store, i.e.
+                                        bit-identical to the planar forward followed by mtbc_c8_pack                */
+    int32_t y_type;                  /* with y_layout C8: 1 = bf16, 2 = fp16                                        */
 } mtbc_convT_args;
+/* 1 if mtbc_convT_fwd takes these arguments with y_layout = MTBC_LAYOUT_C8 (k == 2, Cin <= 64, Cout <= 48, Cout % 8 == 0,
+ * H*W % 32 == 0), else 0: the caller then keeps the planar forward and converts with mtbc_c8_pack.              */
+int mtbc_convT_fwd_c8_supported(const mtbc_convT_args* a);
 
 size_t mtbc_convT_wgrad_workspace(const mtbc_convT_args* a);
 int mtbc_convT_fwd(const mtbc_convT_args* a, void* stream);

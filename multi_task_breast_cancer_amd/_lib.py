@@ -69,7 +69,8 @@ class ConvTArgs(C.Structure):
                 ("dx", C.c_void_p), ("dx_batch_stride", C.c_int64),
                 ("accumulate_dx", C.c_int32),
                 ("dw", C.c_void_p), ("dbias", C.c_void_p), ("accumulate_dw", C.c_int32),
-                ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("compute", C.c_int32)]
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("compute", C.c_int32),
+                ("y_layout", C.c_int32), ("y_type", C.c_int32)]
 
 
 class Conv1x1Args(C.Structure):
@@ -186,7 +187,7 @@ EXPORTS = [
     "mtbc_conv3x3_packed_elems", "mtbc_conv3x3_packed_dgrad_elems", "mtbc_conv3x3_pack_fwd",
     "mtbc_conv3x3_pack_dgrad", "mtbc_conv3x3_packed_lp_elems", "mtbc_conv3x3_pack_lp", "mtbc_conv3x3_pack_many", "mtbc_c8_pack", "mtbc_c8_unpack", "mtbc_augment_flip_rotate", "mtbc_convT_head_combine", "mtbc_convT_head_expand", "mtbc_conv3x3_wgrad_workspace", "mtbc_conv3x3_fwd", "mtbc_conv3x3_dgrad",
     "mtbc_conv3x3_wgrad", "mtbc_instnorm_fwd_workspace", "mtbc_instnorm_lrelu_fwd", "mtbc_instnorm_lrelu_bwd", "mtbc_maxpool2_fwd",
-    "mtbc_maxpool2_bwd", "mtbc_convT_wgrad_workspace", "mtbc_convT_fwd", "mtbc_convT_dgrad", "mtbc_convT_wgrad",
+    "mtbc_maxpool2_bwd", "mtbc_convT_wgrad_workspace", "mtbc_convT_fwd_c8_supported", "mtbc_convT_fwd", "mtbc_convT_dgrad", "mtbc_convT_wgrad",
     "mtbc_conv1x1_wgrad_workspace", "mtbc_conv1x1_fwd", "mtbc_conv1x1_dgrad", "mtbc_conv1x1_wgrad",
     "mtbc_gap_fwd", "mtbc_gap_bwd", "mtbc_linear_fwd", "mtbc_linear_bwd", "mtbc_dice_fwd", "mtbc_dice_bwd",
     "mtbc_focal_fwd_bwd", "mtbc_loss_mix", "mtbc_adam_step", "mtbc_dice_counts", "mtbc_program_run",
@@ -248,6 +249,8 @@ def load() -> C.CDLL:
                       ("mtbc_adam_step", AdamArgs)):
         getattr(lib, name).restype = C.c_int
         getattr(lib, name).argtypes = [C.POINTER(typ), C.c_void_p]
+    lib.mtbc_convT_fwd_c8_supported.restype = C.c_int
+    lib.mtbc_convT_fwd_c8_supported.argtypes = [C.POINTER(ConvTArgs)]
     lib.mtbc_loss_mix.restype = C.c_int
     lib.mtbc_loss_mix.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]
     lib.mtbc_dice_counts.restype = C.c_int

@@ -358,6 +358,103 @@ __global__ __launch_bounds__(256, 2) void convT2_fwd_lds_kernel(const Ct2P p, co
     }
 }
 
+// The same forward with the OUTPUT written straight into the 16-bit channel-blocked layout the 3x3 convs read
+// (MTBC_LAYOUT_C8: [n][Cout/8][4*H*W][8]) instead of fp32 planes that a pack pass would convert: the up-sampled tensor is
+// 4x the input and is consumed by 3x3 convs only, so the fp32 copy (write 4 B + read 4 B per element) disappears.
+// Arithmetic is unchanged (fp32 MFMA over the same k order, bias, then ONE round-to-nearest-even) -> bit-identical to
+// convT2_fwd_lds_kernel followed by mtbc_c8_pack.  Only the weight image differs: columns are (position, channel)
+// instead of (channel, position), so a lane's four accumulator rows are four consecutive CHANNELS of one output
+// pixel = one 8-byte store (the lane pair kg, kg^1 completes the 16-byte piece).
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+template <bool F16> __device__ __forceinline__ unsigned cvt_pk16(float a, float b) {
+    if constexpr (F16) return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){a, b}, f16x2_t));
+    else return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){a, b}, bf16x2_t));
+}
+template <int KI, bool F16>
+__global__ __launch_bounds__(256, 2) void convT2_fwd_c8_kernel(const Ct2P p, const float* __restrict__ bias, unsigned short* __restrict__ y8,
+                                                               long long ybs, int wstride, int cp) {
+    extern __shared__ float Wsm[];                  // [Cin][wstride], column = pos*cp + co ; then bias[cp]
+    float* bias_s = Wsm + p.Cin * wstride;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int j = lane & 15, kg = lane >> 4;
+    const int HW = p.H * p.W, oW = 2 * p.W, oHW = 4 * HW;
+    for (int idx = tid; idx < p.Cin * cp * 4; idx += 256) {
+        const int pos = idx & 3, co = (idx >> 2) % cp, ci = (idx >> 2) / cp;
+        Wsm[ci * wstride + pos * cp + co] = co < p.Cout ? p.w[((size_t)ci * p.Cout + co) * 4 + pos] : 0.f;
+    }
+    for (int c = tid; c < cp; c += 256) bias_s[c] = (bias && c < p.Cout) ? bias[c] : 0.f;
+    __syncthreads();
+    const int ct = cp / 16, nmt = 4 * ct;                               // uniform, nmt <= FMT
+    const int groups = HW / 32;
+    const long long ngroups = (long long)p.N * groups;
+    const long long gstride = (long long)gridDim.x * 4;
+    long long gi = (long long)blockIdx.x * 4 + wv;
+    float xv[2][KI][2];
+    auto loadx = [&](long long g, auto SL) {
+        constexpr int sl = decltype(SL)::value;
+        const int n = (int)(g / groups), gg = (int)(g % groups);
+        const float* xn = p.x + (size_t)n * p.xbs + gg * 32 + j + (size_t)kg * HW;
+#pragma unroll
+        for (int i = 0; i < KI; ++i) {
+            const float* q = xn + (size_t)(4 * i < p.Cin ? 4 * i : 0) * HW;
+            xv[sl][i][0] = q[0]; xv[sl][i][1] = q[16];
+        }
+    };
+    auto compute = [&](long long g, auto SL) {
+        constexpr int sl = decltype(SL)::value;
+        f32x4 acc[FMT][2];
+#pragma unroll
+        for (int m = 0; m < FMT; ++m) { acc[m][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[m][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int i = 0; i < KI; ++i) {
+            if (4 * i < p.Cin) {                                         // uniform
+                const float* wr = Wsm + (4 * i + kg) * wstride + j;
+#pragma unroll
+                for (int m = 0; m < FMT; ++m) {
+                    if (m < nmt) {
+                        const float a = wr[16 * m];
+                        acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, xv[sl][i][0], acc[m][0], 0, 0, 0);
+                        acc[m][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, xv[sl][i][1], acc[m][1], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        const int n = (int)(g / groups), gg = (int)(g % groups);
+        unsigned short* yn = y8 + (size_t)n * ybs + 4 * (kg & 1);
+        int obase[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int pix = gg * 32 + 16 * h + j;
+            obase[h] = (2 * (pix / p.W)) * oW + 2 * (pix % p.W);
+        }
+#pragma unroll
+        for (int m = 0; m < FMT; ++m) {
+            if (m >= nmt) continue;
+            const int pos = m / ct, cb = m - pos * ct;                   // uniform
+            const int c4 = 16 * cb + 4 * kg;
+            if (c4 >= p.Cout) continue;
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(bias_s + c4);
+            unsigned short* d = yn + ((size_t)(c4 >> 3) * oHW + (pos >> 1) * oW + (pos & 1)) * 8;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const f32x4 v = acc[m][h] + bv;
+                *reinterpret_cast<uint2*>(d + (size_t)obase[h] * 8) = make_uint2(cvt_pk16<F16>(v[0], v[1]), cvt_pk16<F16>(v[2], v[3]));
+            }
+        }
+    };
+    if (gi < ngroups) loadx(gi, S0{});
+    for (; gi < ngroups; gi += 2 * gstride) {
+        if (gi + gstride < ngroups) loadx(gi + gstride, S1{});
+        compute(gi, S0{});
+        if (gi + gstride < ngroups) {
+            if (gi + 2 * gstride < ngroups) loadx(gi + 2 * gstride, S0{});
+            compute(gi + gstride, S1{});
+        }
+    }
+}
+
 bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
 
 void fill(const mtbc_convT_args* a, Ct2P* p) {
@@ -416,6 +513,36 @@ int mtbc_i_convT2_fwd(const mtbc_convT_args* a, hipStream_t st) {
     } while (0)
     if (ki <= 8) MTBC_CT2F(8); else if (ki <= 12) MTBC_CT2F(12); else MTBC_CT2F(16);
 #undef MTBC_CT2F
+    MTBC_CHECK_LAUNCH();
+    return MTBC_OK;
+}
+
+// forward into a 16-bit channel-blocked output (y_layout = MTBC_LAYOUT_C8)
+bool mtbc_i_convT2_fwd_c8_ok(const mtbc_convT_args* a) {
+    const int HW = a->H * a->W, cp = (a->Cout + 15) / 16 * 16;
+    return a->k == 2 && HW % 32 == 0 && a->Cin % 4 == 0 && a->Cin <= 4 * FKI && 4 * cp <= 16 * FMT && a->Cout % 8 == 0 &&
+           (a->y_type == 1 || a->y_type == 2) && al16(a->y) && a->y_batch_stride % 8 == 0;
+}
+int mtbc_i_convT2_fwd_c8(const mtbc_convT_args* a, hipStream_t st) {
+    Ct2P p; fill(a, &p);
+    const int cp = (a->Cout + 15) / 16 * 16;
+    const int wstride = (4 * cp + 31) / 32 * 32 + 16;                  // == 16 mod 32
+    const size_t lds = ((size_t)a->Cin * wstride + cp) * sizeof(float);
+    const long long groups = (long long)a->N * (a->H * a->W / 32);
+    int blocks = (int)(groups < 4 * 512 ? cdiv64(groups, 4) : 512);      // 2 resident blocks per CU (register-limited)
+    const int ki = cdiv(a->Cin, 4);
+    unsigned short* y8 = reinterpret_cast<unsigned short*>(a->y);
+#define MTBC_CT2F8(KI_, F16_)                                                                                              \
+    do {                                                                                                                   \
+        static bool attr = false;                                                                                          \
+        if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&convT2_fwd_c8_kernel<KI_, F16_>),            \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); attr = true; }     \
+        hipLaunchKernelGGL((convT2_fwd_c8_kernel<KI_, F16_>), dim3(blocks), dim3(256), lds, st, p, a->bias, y8,            \
+                           (long long)a->y_batch_stride, wstride, cp);                                                     \
+    } while (0)
+    if (a->y_type == 2) { if (ki <= 8) MTBC_CT2F8(8, true); else if (ki <= 12) MTBC_CT2F8(12, true); else MTBC_CT2F8(16, true); }
+    else { if (ki <= 8) MTBC_CT2F8(8, false); else if (ki <= 12) MTBC_CT2F8(12, false); else MTBC_CT2F8(16, false); }
+#undef MTBC_CT2F8
     MTBC_CHECK_LAUNCH();
     return MTBC_OK;
 }

@@ -330,6 +330,9 @@ extern "C" {
 int mtbc_convT_fwd(const mtbc_convT_args* a, void* stream) {
     CtP p; int rc = fill_ct(a, &p); if (rc) return rc;
     if (!p.x || !p.w || !p.y) return MTBC_E_BADARG;
+    if (a->y_layout == MTBC_LAYOUT_C8)          // 16-bit channel-blocked output: the direct-to-fragment kernel or nothing
+        return mtbc_i_convT2_fwd_c8_ok(a) ? mtbc_i_convT2_fwd_c8(a, (hipStream_t)stream) : MTBC_E_UNSUPPORTED;
+    if (a->y_layout != MTBC_LAYOUT_PLANAR) return MTBC_E_BADARG;
     if (!al16(p.y) || (p.ybs & 3) || ((a->W * a->k) & 3)) return MTBC_E_UNSUPPORTED;
     static const bool generic_f = getenv("MTBC_CONVT_GENERIC") != nullptr;      // A/B switch
     if (!generic_f && mtbc_i_convT2_fwd_ok(a)) return mtbc_i_convT2_fwd(a, (hipStream_t)stream);
@@ -340,6 +343,11 @@ int mtbc_convT_fwd(const mtbc_convT_args* a, void* stream) {
     else hipLaunchKernelGGL(convT_fwd_kernel<8>, grid, dim3(256), 0, st, p);
     MTBC_CHECK_LAUNCH();
     return MTBC_OK;
+}
+int mtbc_convT_fwd_c8_supported(const mtbc_convT_args* a) {
+    CtP p;
+    if (!a || fill_ct(a, &p)) return 0;
+    return mtbc_i_convT2_fwd_c8_ok(a) ? 1 : 0;
 }
 int mtbc_convT_dgrad(const mtbc_convT_args* a, void* stream) {
     CtP p; int rc = fill_ct(a, &p); if (rc) return rc;

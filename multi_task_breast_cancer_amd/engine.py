@@ -37,6 +37,7 @@ class Act:
     fanin_separate: bool = False       # conv-cell outputs: every further consumer writes its own buffer (plain
     extra_grads: List[torch.Tensor] = field(default_factory=list)   # stores); IN-backward sums them on the fly
     c8: Optional[torch.Tensor] = None  # 16-bit channel-blocked copy [N][C/8][H*W][8] read by the 3x3 convs' MFMAs
+    planar_valid: bool = True          # False: the producer wrote only `c8` (ConvT forward in the 16-bit modes)
 
     @property
     def N(self): return self.data.shape[0]
@@ -257,6 +258,8 @@ class StepPlan:
         # of once per consumer inside the staging (same RNE, same MFMA order: bit-identical forward / dgrad)
         c8 = (not _NO_C8) and use_packed and self.compute != 0 and not self.force_direct and W % 4 == 0 and H >= 8 and W >= 8
         c8_bwd = c8 and cout % 8 == 0
+        if not c8 and not all(a_.planar_valid for a_ in inputs):
+            raise NotImplementedError(f"{out_name}: an input exists only in the channel-blocked 16-bit layout")
 
         def segs_c8(arr) -> None:
             for i, a_ in enumerate(inputs):
@@ -401,6 +404,17 @@ class StepPlan:
 
         op = base()
         op.kind = L.OP_CONVT_FWD
+        if self.compute and not _NO_C8 and cout % 8 == 0:
+            # 16-bit modes: the up-sampled tensor feeds 3x3 convs only -- write it straight into their channel-blocked
+            # 16-bit layout (same fp32 arithmetic, one RNE: bit-identical to planar forward + pack) when the kernel
+            # takes the shape; y.data then stays unwritten
+            a = op.u.convT
+            y.c8 = self.alloc(self.N, cout // 8, y.H * y.W, 8, dtype=torch.int16)
+            a.y, a.y_batch_stride, a.y_layout, a.y_type = y.c8.data_ptr(), y.bstride, L.LAYOUT_C8, self.compute
+            if not self.lib.mtbc_convT_fwd_c8_supported(C.byref(a)):
+                y.c8 = None
+                a.y, a.y_layout, a.y_type = y.data.data_ptr(), L.LAYOUT_PLANAR, 0
+            y.planar_valid = y.c8 is None
         self.fwd_ops.append(op)
 
         def emit_bwd() -> None:

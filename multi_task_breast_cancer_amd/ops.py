@@ -307,6 +307,21 @@ def convT_fwd(x, w, bias, k):
     return y
 
 
+def convT_fwd_c8(x, w, bias, k, compute: int) -> "C8":
+    """ConvTranspose2d(k = s) forward written straight into the 16-bit channel-blocked layout (y_layout = C8)."""
+    _chk(x, w, bias)
+    a = _ct_args(x, w, k)
+    N, _, H, W = x.shape
+    cout = w.shape[1]
+    y = torch.empty(N, cout // 8, H * k * W * k, 8, dtype=torch.int16, device=x.device)
+    a.bias, a.y, a.y_batch_stride = _p(bias), y.data_ptr(), cout * H * k * W * k
+    a.y_layout, a.y_type = L.LAYOUT_C8, compute
+    if not L.load().mtbc_convT_fwd_c8_supported(C.byref(a)):
+        raise L.MtbcError("convT_fwd: shape not supported with a channel-blocked output")
+    L.check(L.load().mtbc_convT_fwd(C.byref(a), _s()), "convT_fwd(c8)")
+    return C8(y, (N, cout, H * k, W * k), compute)
+
+
 def convT_dgrad(x, w, dy, k, dx=None, accumulate=False, compute=0):
     _chk(x, w, dy, dx)
     if dx is None:

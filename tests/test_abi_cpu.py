@@ -44,6 +44,7 @@ def test_ctypes_layout_matches_header(tmp_path):
             ("mtbc_instnorm_args", "dgamma", L.InstNormArgs.dgamma.offset),
             ("mtbc_convT_args", "accumulate_dw", L.ConvTArgs.accumulate_dw.offset),
             ("mtbc_convT_args", "compute", L.ConvTArgs.compute.offset),
+            ("mtbc_convT_args", "y_type", L.ConvTArgs.y_type.offset),
             ("mtbc_conv3x3_args", "compute", L.Conv3x3Args.compute.offset),
             ("mtbc_conv3x3_args", "operand_layout", L.Conv3x3Args.operand_layout.offset),
             ("mtbc_pack_desc", "kind", L.PackDesc.kind.offset),

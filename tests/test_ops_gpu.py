@@ -496,3 +496,15 @@ def test_conv3x3_c8_rejects_what_it_cannot_run():
     pf, _ = ops.conv3x3_pack_lp(w, 1)
     with pytest.raises(L.MtbcError):
         ops.conv3x3_fwd_c8([ops.C8.pack(x, 1)], w, None, pf)
+
+
+@pytest.mark.parametrize("compute", [1, 2])
+@pytest.mark.parametrize("N,Cin,Cout,H,W", [(2, 48, 48, 16, 16), (3, 24, 24, 8, 12), (1, 64, 40, 16, 8), (2, 16, 8, 4, 8)])
+def test_convT_forward_into_channel_blocked_output_equals_planar_then_pack(N, Cin, Cout, H, W, compute):
+    g = _g(N + Cin + Cout + H)
+    x = torch.randn(N, Cin, H, W, generator=g).to(DEV)
+    w = (torch.randn(Cin, Cout, 2, 2, generator=g) * 0.2).to(DEV)
+    b = torch.randn(Cout, generator=g).to(DEV)
+    want = ops.C8.pack(ops.convT_fwd(x, w, b, 2), compute)
+    got = ops.convT_fwd_c8(x, w, b, 2, compute)
+    assert got.shape == want.shape and torch.equal(got.data, want.data)
