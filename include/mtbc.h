@@ -94,6 +94,9 @@ typedef struct {
  * InstanceNorm+LeakyReLU, pooling, ConvTranspose) make the 3x3 convolutions' staging pure LDS-DMA.           */
 int mtbc_c8_pack(const float* src, int64_t src_batch_stride, void* dst, int32_t N, int32_t C, int32_t HW, int32_t compute, void* stream);
 int mtbc_c8_unpack(const void* src, float* dst, int32_t N, int32_t C, int32_t HW, int32_t compute, void* stream);
+/* 16-bit planar (N,C,H,W; batch stride in 16-bit elements) -> the same values channel-blocked [N][C/8][H*W][8].
+ * Type-agnostic (moves 16-bit words).  C % 8 == 0, HW % 4 == 0, src 8-byte and dst 16-byte aligned.             */
+int mtbc_c8_pack16(const void* src, int64_t src_batch_stride, void* dst, int32_t N, int32_t C, int32_t HW, void* stream);
 
 size_t mtbc_conv3x3_packed_elems(int32_t Cin, int32_t Cout);          /* fwd image size      */
 size_t mtbc_conv3x3_packed_dgrad_elems(int32_t Cin, int32_t Cout);    /* dgrad image size    */
@@ -149,6 +152,14 @@ typedef struct {
     int32_t accumulate_dparams;
     void* workspace;         /* bwd with any of the three: N*C*3 floats                      */
     size_t workspace_bytes;
+    /* 16-bit planar outputs (the 16-bit compute modes): when y16 / dz16 is set, the forward activation / the
+       backward dz is written ONLY as a 16-bit (N,C,H,W) tensor of type out16_type (1 = bf16, 2 = fp16; round to
+       nearest even of the fp32 value) and y / dz is not touched -- for tensors that nothing but the 3x3 convs' MFMAs
+       read (mtbc_c8_pack16 then brings them into MTBC_LAYOUT_C8): 2 instead of 4 bytes written and re-read.
+       Register-resident planes only (H*W % 4 == 0, H*W <= 65536), else MTBC_E_UNSUPPORTED.            */
+    void* y16;
+    void* dz16;
+    int32_t out16_type;
 } mtbc_instnorm_args;
 
 /* workspace bytes the forward can use for planes > 64K elements (chunked statistics: 2 reads + 1 write instead of the
@@ -323,7 +334,7 @@ enum {
     MTBC_OP_GAP_FWD, MTBC_OP_GAP_BWD, MTBC_OP_LINEAR_FWD, MTBC_OP_LINEAR_BWD,
     MTBC_OP_DICE_FWD, MTBC_OP_DICE_BWD, MTBC_OP_FOCAL, MTBC_OP_LOSS_MIX, MTBC_OP_ADAM,
     MTBC_OP_MEMSET, MTBC_OP_DICE_COUNTS, MTBC_OP_CONV3_PACK_LP, MTBC_OP_HEAD_COMBINE, MTBC_OP_HEAD_EXPAND,
-    MTBC_OP_C8_PACK
+    MTBC_OP_C8_PACK, MTBC_OP_C8_PACK16
 };
 
 /* ---- deep-supervision head of MTnnUNet: ConvTranspose2d(Cin->Cmid, k=s) followed by Conv2d(Cmid->R, 1x1)
@@ -373,7 +384,7 @@ typedef struct {
         struct { void* ptr; size_t bytes; } memset0;
         struct { const float* logits; const float* target; int64_t n; double* out3; } counts;
         mtbc_head_fuse_args head;
-        struct { const float* src; int64_t src_batch_stride; void* dst; int32_t N, C, HW, compute; } c8pack;
+        struct { const float* src; int64_t src_batch_stride; void* dst; int32_t N, C, HW, compute; } c8pack;   /* C8_PACK and C8_PACK16 (src = 16-bit planar, `compute` unused) */
     } u;
 } mtbc_op;
 

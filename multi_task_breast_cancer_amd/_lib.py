@@ -47,7 +47,8 @@ class InstNormArgs(C.Structure):
                 ("n_dy_extra", C.c_int32), ("dy_extra", C.c_void_p * 4),
                 ("dz", C.c_void_p), ("dgamma", C.c_void_p), ("dbeta", C.c_void_p), ("dbias_pre", C.c_void_p),
                 ("accumulate_dparams", C.c_int32),
-                ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+                ("y16", C.c_void_p), ("dz16", C.c_void_p), ("out16_type", C.c_int32)]
 
 
 class MaxPoolArgs(C.Structure):
@@ -161,7 +162,7 @@ class Op(C.Structure):
  OP_IN_FWD, OP_IN_BWD, OP_POOL_FWD, OP_POOL_BWD, OP_CONVT_FWD, OP_CONVT_DGRAD, OP_CONVT_WGRAD,
  OP_CONV1_FWD, OP_CONV1_DGRAD, OP_CONV1_WGRAD, OP_GAP_FWD, OP_GAP_BWD, OP_LINEAR_FWD, OP_LINEAR_BWD,
  OP_DICE_FWD, OP_DICE_BWD, OP_FOCAL, OP_LOSS_MIX, OP_ADAM, OP_MEMSET, OP_DICE_COUNTS, OP_CONV3_PACK_LP,
- OP_HEAD_COMBINE, OP_HEAD_EXPAND, OP_C8_PACK) = range(1, 31)
+ OP_HEAD_COMBINE, OP_HEAD_EXPAND, OP_C8_PACK, OP_C8_PACK16) = range(1, 32)
 
 OP_UNION_FIELD = {
     OP_CONV3_FWD: "conv3", OP_CONV3_DGRAD: "conv3", OP_CONV3_WGRAD: "conv3",
@@ -172,7 +173,7 @@ OP_UNION_FIELD = {
     OP_GAP_FWD: "gap", OP_GAP_BWD: "gap", OP_LINEAR_FWD: "linear", OP_LINEAR_BWD: "linear",
     OP_DICE_FWD: "dice", OP_DICE_BWD: "dice", OP_FOCAL: "focal", OP_LOSS_MIX: "mix", OP_ADAM: "adam",
     OP_MEMSET: "memset0", OP_DICE_COUNTS: "counts", OP_CONV3_PACK_LP: "pack",
-    OP_HEAD_COMBINE: "head", OP_HEAD_EXPAND: "head", OP_C8_PACK: "c8pack",
+    OP_HEAD_COMBINE: "head", OP_HEAD_EXPAND: "head", OP_C8_PACK: "c8pack", OP_C8_PACK16: "c8pack",
 }
 
 # every symbol include/mtbc.h declares (tests check the library exports all of them)
@@ -185,7 +186,7 @@ class PackDesc(C.Structure):
 EXPORTS = [
     "mtbc_version", "mtbc_strerror", "mtbc_arch",
     "mtbc_conv3x3_packed_elems", "mtbc_conv3x3_packed_dgrad_elems", "mtbc_conv3x3_pack_fwd",
-    "mtbc_conv3x3_pack_dgrad", "mtbc_conv3x3_packed_lp_elems", "mtbc_conv3x3_pack_lp", "mtbc_conv3x3_pack_many", "mtbc_c8_pack", "mtbc_c8_unpack", "mtbc_augment_flip_rotate", "mtbc_convT_head_combine", "mtbc_convT_head_expand", "mtbc_conv3x3_wgrad_workspace", "mtbc_conv3x3_fwd", "mtbc_conv3x3_dgrad",
+    "mtbc_conv3x3_pack_dgrad", "mtbc_conv3x3_packed_lp_elems", "mtbc_conv3x3_pack_lp", "mtbc_conv3x3_pack_many", "mtbc_c8_pack", "mtbc_c8_unpack", "mtbc_c8_pack16", "mtbc_augment_flip_rotate", "mtbc_convT_head_combine", "mtbc_convT_head_expand", "mtbc_conv3x3_wgrad_workspace", "mtbc_conv3x3_fwd", "mtbc_conv3x3_dgrad",
     "mtbc_conv3x3_wgrad", "mtbc_instnorm_fwd_workspace", "mtbc_instnorm_lrelu_fwd", "mtbc_instnorm_lrelu_bwd", "mtbc_maxpool2_fwd",
     "mtbc_maxpool2_bwd", "mtbc_convT_wgrad_workspace", "mtbc_convT_fwd_c8_supported", "mtbc_convT_fwd", "mtbc_convT_dgrad", "mtbc_convT_wgrad",
     "mtbc_conv1x1_wgrad_workspace", "mtbc_conv1x1_fwd", "mtbc_conv1x1_dgrad", "mtbc_conv1x1_wgrad",
@@ -226,6 +227,8 @@ def load() -> C.CDLL:
     lib.mtbc_conv3x3_pack_many.argtypes = [C.POINTER(PackDesc), C.c_int32, C.c_void_p]
     lib.mtbc_c8_pack.restype = C.c_int
     lib.mtbc_c8_pack.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
+    lib.mtbc_c8_pack16.restype = C.c_int
+    lib.mtbc_c8_pack16.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
     lib.mtbc_c8_unpack.restype = C.c_int
     lib.mtbc_c8_unpack.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
     lib.mtbc_conv3x3_pack_lp.restype = C.c_int

@@ -1745,6 +1745,31 @@ __global__ void c8_unpack_kernel(const unsigned short* __restrict__ x, float* __
     for (int e = 0; e < 8; ++e) y[(n * C + grp * 8 + e) * HW + px] = (float)v[e];
 }
 
+// 16-bit planar -> 16-bit channel-blocked: one thread = 4 pixels x 8 channels (8 loads of 8 bytes, 4 stores of 16)
+__global__ void c8_pack16_kernel(const unsigned short* __restrict__ x, long long xbs, unsigned short* __restrict__ y, int C, int HW, long long total) {
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;          // (n, grp, px/4)
+    if (idx >= total) return;
+    const int hw4 = HW >> 2;
+    const int q = (int)(idx % hw4); const long long t = idx / hw4;
+    const int grp = (int)(t % (C / 8)); const long long n = t / (C / 8);
+    const unsigned short* src = x + n * xbs + (size_t)(grp * 8) * HW + 4 * q;
+    uint2 v[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) v[c] = *reinterpret_cast<const uint2*>(src + (size_t)c * HW);
+    u32x4* dst = reinterpret_cast<u32x4*>(y + ((n * (C / 8) + grp) * HW + 4 * q) * 8);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        u32x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const unsigned a = e < 2 ? v[2 * k].x : v[2 * k].y, b = e < 2 ? v[2 * k + 1].x : v[2 * k + 1].y;
+            o[k] = (e & 1) ? ((a >> 16) | (b & 0xffff0000u)) : ((a & 0xffffu) | (b << 16));
+        }
+        dst[e] = o;
+    }
+}
+
 // ------------------------------------------------------------------ direct (VALU) fallbacks
 // One thread = one pixel x 8 output channels.  mode 0: fwd  (w[co][ci][tap])
 //                                              mode 1: dgrad (w[ci_in][co_out][8-tap], in = dz)
@@ -2372,6 +2397,16 @@ int mtbc_c8_unpack(const void* src, float* dst, int32_t N, int32_t C, int32_t HW
     const dim3 grid((unsigned)cdiv64(total, 256));
     if (compute == 2) hipLaunchKernelGGL((c8_unpack_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const unsigned short*>(src), dst, C, HW, total);
     else hipLaunchKernelGGL((c8_unpack_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const unsigned short*>(src), dst, C, HW, total);
+    MTBC_CHECK_LAUNCH();
+    return MTBC_OK;
+}
+
+int mtbc_c8_pack16(const void* src, int64_t src_batch_stride, void* dst, int32_t N, int32_t C, int32_t HW, void* stream) {
+    if (!src || !dst || (reinterpret_cast<uintptr_t>(dst) & 15) || (reinterpret_cast<uintptr_t>(src) & 7) || src_batch_stride % 4) return MTBC_E_BADARG;
+    if (N <= 0 || C <= 0 || HW <= 0 || C % 8 || HW % 4) return MTBC_E_BADSHAPE;
+    const long long total = (long long)N * (C / 8) * (HW / 4);
+    hipLaunchKernelGGL(c8_pack16_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const unsigned short*>(src), (long long)src_batch_stride, reinterpret_cast<unsigned short*>(dst), C, HW, total);
     MTBC_CHECK_LAUNCH();
     return MTBC_OK;
 }

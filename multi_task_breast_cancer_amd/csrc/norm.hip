@@ -18,7 +18,17 @@ struct InP {
     const float* dyx[4]; int nx;     // extra gradient contributions (fan-in), summed on the fly
     float* dz;
     float* part;       // bwd: [N*C][3] = {sum g, sum g*xh, sum dz}
+    unsigned short* y16; unsigned short* dz16; int f16;      // 16-bit planar outputs instead of y / dz
 };
+typedef float in_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 in_bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 in_f16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint2 in_cvt4(const float4& o, int f16) {      // 4 floats -> 4 x 16 bit, RNE
+    if (f16) return make_uint2(__builtin_bit_cast(unsigned, __builtin_convertvector((in_f32x2){o.x, o.y}, in_f16x2)),
+                               __builtin_bit_cast(unsigned, __builtin_convertvector((in_f32x2){o.z, o.w}, in_f16x2)));
+    return make_uint2(__builtin_bit_cast(unsigned, __builtin_convertvector((in_f32x2){o.x, o.y}, in_bf16x2)),
+                      __builtin_bit_cast(unsigned, __builtin_convertvector((in_f32x2){o.z, o.w}, in_bf16x2)));
+}
 
 // ---- forward, register-resident plane: HW % 4 == 0 and HW/4 <= VPT * blockDim
 template <int VPT>
@@ -60,7 +70,8 @@ __global__ void in_fwd_reg_kernel(const InP p) {
             t = (v[i].y - mean) * rstd * g + b; o.y = t > 0.f ? t : t * p.slope;
             t = (v[i].z - mean) * rstd * g + b; o.z = t > 0.f ? t : t * p.slope;
             t = (v[i].w - mean) * rstd * g + b; o.w = t > 0.f ? t : t * p.slope;
-            dst[idx] = o;
+            if (p.y16) reinterpret_cast<uint2*>(p.y16 + (size_t)plane * p.HW)[idx] = in_cvt4(o, p.f16);
+            else dst[idx] = o;
         }
     }
 }
@@ -286,7 +297,8 @@ __global__ void in_bwd_reg_kernel(const InP p) {
             float4 o;
             o.x = k * (y.x - m1 - x.x * m2); o.y = k * (y.y - m1 - x.y * m2);
             o.z = k * (y.z - m1 - x.z * m2); o.w = k * (y.w - m1 - x.w * m2);
-            d4[idx] = o;
+            if (p.dz16) reinterpret_cast<uint2*>(p.dz16 + (size_t)plane * p.HW)[idx] = in_cvt4(o, p.f16);
+            else d4[idx] = o;
             s3 += (o.x + o.y) + (o.z + o.w);
         }
     }
@@ -321,6 +333,9 @@ int fill(const mtbc_instnorm_args* a, InP* p) {
     p->mean = a->mean; p->rstd = a->rstd; p->dy = a->dy; p->dybs = a->dy_batch_stride; p->dz = a->dz; p->part = nullptr;
     p->nx = a->n_dy_extra;
     for (int k = 0; k < 4; ++k) p->dyx[k] = a->dy_extra[k];
+    p->y16 = reinterpret_cast<unsigned short*>(a->y16); p->dz16 = reinterpret_cast<unsigned short*>(a->dz16);
+    p->f16 = a->out16_type == 2;
+    if ((a->y16 || a->dz16) && a->out16_type != 1 && a->out16_type != 2) return MTBC_E_BADARG;
     return MTBC_OK;
 }
 bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
@@ -339,10 +354,11 @@ size_t mtbc_instnorm_fwd_workspace(const mtbc_instnorm_args* a) {
 
 int mtbc_instnorm_lrelu_fwd(const mtbc_instnorm_args* a, void* stream) {
     InP p; int rc = fill(a, &p); if (rc) return rc;
-    if (!p.z || !p.y || !p.mean || !p.rstd) return MTBC_E_BADARG;
+    if (!p.z || (!p.y && !p.y16) || !p.mean || !p.rstd) return MTBC_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
     const int planes = a->N * a->C, HW = p.HW, n4 = HW / 4;
-    const bool vec = HW % 4 == 0 && al16(p.z) && al16(p.y) && p.ybs % 4 == 0;
+    const bool vec = HW % 4 == 0 && al16(p.z) && (p.y16 ? (reinterpret_cast<uintptr_t>(p.y16) & 7) == 0 : al16(p.y) && p.ybs % 4 == 0);
+    if (p.y16 && !(vec && n4 <= 16 * 1024)) return MTBC_E_UNSUPPORTED;
     if (vec && n4 <= 16 * 1024) {
         if (n4 <= 64) hipLaunchKernelGGL(in_fwd_reg_kernel<1>, dim3(planes), dim3(64), 0, st, p);
         else if (n4 <= 4 * 64) hipLaunchKernelGGL(in_fwd_reg_kernel<4>, dim3(planes), dim3(64), 0, st, p);
@@ -364,7 +380,7 @@ int mtbc_instnorm_lrelu_fwd(const mtbc_instnorm_args* a, void* stream) {
 
 int mtbc_instnorm_lrelu_bwd(const mtbc_instnorm_args* a, void* stream) {
     InP p; int rc = fill(a, &p); if (rc) return rc;
-    if (!p.z || !p.dy || !p.dz || !p.mean || !p.rstd) return MTBC_E_BADARG;
+    if (!p.z || !p.dy || (!p.dz && !p.dz16) || !p.mean || !p.rstd) return MTBC_E_BADARG;
     if (p.nx < 0 || p.nx > 4) return MTBC_E_BADARG;
     for (int k = 0; k < p.nx; ++k) if (!p.dyx[k] || !al16(p.dyx[k])) return MTBC_E_BADARG;
     const bool want = a->dgamma || a->dbeta || a->dbias_pre;
@@ -374,10 +390,12 @@ int mtbc_instnorm_lrelu_bwd(const mtbc_instnorm_args* a, void* stream) {
         p.part = reinterpret_cast<float*>(a->workspace);
     }
     hipStream_t st = (hipStream_t)stream;
-    const bool vec = p.HW % 4 == 0 && al16(p.z) && al16(p.dy) && al16(p.dz) && p.dybs % 4 == 0;
+    const bool vec = p.HW % 4 == 0 && al16(p.z) && al16(p.dy) && p.dybs % 4 == 0 &&
+                     (p.dz16 ? (reinterpret_cast<uintptr_t>(p.dz16) & 7) == 0 : al16(p.dz));
     const int threads = p.HW >= 16384 ? 1024 : (p.HW >= 1024 ? 256 : 64);
     static const bool stream_only = getenv("MTBC_IN_BWD_STREAM") != nullptr;      // A/B switch
     const int vpt = vec ? cdiv(p.HW / 4, threads) : 0;
+    if (p.dz16 && !(vec && !stream_only && vpt <= 16)) return MTBC_E_UNSUPPORTED;
     if (vec && !stream_only && vpt <= 16) {
         const dim3 g(planes), b(threads);
         if (vpt <= 1) hipLaunchKernelGGL((in_bwd_reg_kernel<1, true>), g, b, 0, st, p);

@@ -20,6 +20,7 @@ from . import _lib as L
 import os as _os
 _NOACC = _os.environ.get('MTBC_NOACC') == '1'     # timing probe only: results are wrong when set
 _NO_C8 = _os.environ.get('MTBC_NO_C8') == '1'     # A/B: 16-bit modes stage fp32 planar operands as before
+_NO_P16 = _os.environ.get('MTBC_NO_P16') == '1'   # A/B / activation probes: InstanceNorm keeps writing fp32 y and dz
 
 
 def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
@@ -38,6 +39,9 @@ class Act:
     extra_grads: List[torch.Tensor] = field(default_factory=list)   # stores); IN-backward sums them on the fly
     c8: Optional[torch.Tensor] = None  # 16-bit channel-blocked copy [N][C/8][H*W][8] read by the 3x3 convs' MFMAs
     planar_valid: bool = True          # False: the producer wrote only `c8` (ConvT forward in the 16-bit modes)
+    planar_used: bool = False          # some op reads `data` (pool, ConvT, 1x1 heads, GAP, a planar-staged conv)
+    in_op: Optional[object] = None     # the InstanceNorm forward op that writes this activation (conv cells)
+    pack_op: Optional[object] = None   # the op that fills `c8` from `data`
 
     @property
     def N(self): return self.data.shape[0]
@@ -155,6 +159,13 @@ class StepPlan:
             return t, 0
         return self.grad_of(a), (0 if _NOACC else 1)
 
+    def _rd(self, a: Act) -> int:
+        """Pointer to the fp32 planar values of an activation, for an op that reads them."""
+        if not a.planar_valid:
+            raise NotImplementedError(f"{a.name} exists only in the channel-blocked 16-bit layout")
+        a.planar_used = True
+        return a.data.data_ptr()
+
     def _c8_pack_op(self, src: torch.Tensor, dst: torch.Tensor, C_: int, HW: int) -> L.Op:
         op = _mk(L.OP_C8_PACK)
         a = op.u.c8pack
@@ -168,14 +179,18 @@ class StepPlan:
         that consumes it (X0_0 of the U-Net++ feeds 4 convs and 4 wgrads): their staging becomes LDS-DMA."""
         if a.c8 is None:
             a.c8 = self.alloc(self.N, a.C // 8, a.H * a.W, 8, dtype=torch.int16)
-            self.fwd_ops.append(self._c8_pack_op(a.data, a.c8, a.C, a.H * a.W))
+            a.pack_op = self._c8_pack_op(a.data, a.c8, a.C, a.H * a.W)
+            self.fwd_ops.append(a.pack_op)
         return a.c8
 
-    def _dz8(self, numel: int) -> torch.Tensor:
-        """One scratch for the 16-bit copy of dz: IN-backward -> pack -> wgrad -> dgrad run back to back on one stream."""
-        if getattr(self, "_dz8_buf", None) is None or self._dz8_buf.numel() < numel:
-            self._dz8_buf = self.alloc(numel, dtype=torch.int16)
-        return self._dz8_buf
+    def _scratch16(self, attr: str, numel: int) -> torch.Tensor:
+        """Shared 16-bit scratch of the backward pass (IN-backward -> pack -> wgrad -> dgrad run back to back on one
+        stream): grows to the largest user, earlier ops keep the smaller buffer they were built with."""
+        buf = getattr(self, attr, None)
+        if buf is None or buf.numel() < numel:
+            buf = self.alloc(numel, dtype=torch.int16)
+            setattr(self, attr, buf)
+        return buf
 
     def _need_ws(self, op: L.Op, fieldname: str, nbytes: int) -> None:
         self.ws_bytes = max(self.ws_bytes, int(nbytes))
@@ -196,7 +211,7 @@ class StepPlan:
                 arr[i].ptr = g.data_ptr()
                 arr[i].accumulate = acc
             else:
-                arr[i].ptr = a.data.data_ptr()
+                arr[i].ptr = self._rd(a)
                 arr[i].accumulate = 0
             arr[i].batch_stride = a.bstride
             arr[i].channels = a.C
@@ -291,6 +306,7 @@ class StepPlan:
         op = base_in()
         op.kind = L.OP_IN_FWD
         op.u.inorm.y, op.u.inorm.y_batch_stride = y.data.data_ptr(), y.bstride
+        y.in_op = op
         nb = self.lib.mtbc_instnorm_fwd_workspace(C.byref(op.u.inorm))      # > 0 only for planes larger than 64K elements
         if nb:
             self._need_ws(op, "inorm", nb)
@@ -305,6 +321,10 @@ class StepPlan:
             op.kind = L.OP_IN_BWD
             a = op.u.inorm
             a.dy, a.dy_batch_stride, a.dz = dy.data_ptr(), y.bstride, dy.data_ptr()
+            p16 = c8_bwd and not _NO_P16 and (H * W) % 4 == 0 and H * W <= 65536
+            if p16:         # dz feeds MFMAs only: 16-bit planar here, channel-blocked by the pack below
+                dz16 = self._scratch16("_dz16_buf", N * cout * H * W)
+                a.dz16, a.out16_type = dz16.data_ptr(), self.compute
             a.n_dy_extra = len(y.extra_grads)
             for k_, t_ in enumerate(y.extra_grads):
                 a.dy_extra[k_] = t_.data_ptr()
@@ -324,8 +344,11 @@ class StepPlan:
             self.bwd_ops.append(op)
             dz8 = None
             if c8_bwd:
-                dz8 = self._dz8(N * cout * H * W)
-                self.bwd_ops.append(self._c8_pack_op(dy, dz8, cout, H * W))
+                dz8 = self._scratch16("_dz8_buf", N * cout * H * W)
+                pk = self._c8_pack_op(dz16 if p16 else dy, dz8, cout, H * W)
+                if p16:
+                    pk.kind = L.OP_C8_PACK16
+                self.bwd_ops.append(pk)
             # wgrad
             op = base_conv()
             op.kind = L.OP_CONV3_WGRAD
@@ -365,7 +388,7 @@ class StepPlan:
             op = _mk(0)
             a = op.u.pool
             a.N, a.C, a.H, a.W = self.N, x.C, x.H, x.W
-            a.x, a.x_batch_stride = x.data.data_ptr(), x.bstride
+            a.x, a.x_batch_stride = self._rd(x), x.bstride
             a.y, a.y_batch_stride = y.data.data_ptr(), y.bstride
             return op
 
@@ -396,7 +419,7 @@ class StepPlan:
             op = _mk(0)
             a = op.u.convT
             a.N, a.H, a.W, a.Cin, a.Cout, a.k = self.N, x.H, x.W, x.C, cout, k
-            a.x, a.x_batch_stride = x.data.data_ptr(), x.bstride
+            a.x, a.x_batch_stride = self._rd(x), x.bstride
             a.w = w.data_ptr()
             a.bias = _ptr(self.pv(bname)) if bname else None
             a.y, a.y_batch_stride = y.data.data_ptr(), y.bstride
@@ -467,7 +490,7 @@ class StepPlan:
             op = _mk(0)
             a = op.u.convT
             a.N, a.H, a.W, a.Cin, a.Cout, a.k = self.N, x.H, x.W, x.C, R, k
-            a.x, a.x_batch_stride = x.data.data_ptr(), x.bstride
+            a.x, a.x_batch_stride = self._rd(x), x.bstride
             a.w, a.bias = Wc.data_ptr(), bc.data_ptr()
             a.y, a.y_batch_stride = y.data.data_ptr(), y.bstride
             return op
@@ -519,7 +542,7 @@ class StepPlan:
             op = _mk(0)
             a = op.u.conv1
             a.N, a.H, a.W, a.Cin, a.Cout = self.N, x.H, x.W, x.C, cout
-            a.x, a.x_batch_stride = x.data.data_ptr(), x.bstride
+            a.x, a.x_batch_stride = self._rd(x), x.bstride
             a.w, a.bias, a.y = w.data_ptr(), _ptr(self.pv(bname)), y.data.data_ptr()
             return op
 
@@ -559,7 +582,7 @@ class StepPlan:
             op = _mk(0)
             a = op.u.gap
             a.N, a.C, a.H, a.W = self.N, x.C, x.H, x.W
-            a.x, a.y = x.data.data_ptr(), y.data.data_ptr()
+            a.x, a.y = self._rd(x), y.data.data_ptr()
             return op
 
         op = base()
@@ -590,7 +613,7 @@ class StepPlan:
             op = _mk(0)
             a = op.u.linear
             a.N, a.In, a.Out, a.relu = self.N, in_f, out_f, 1 if relu else 0
-            a.x, a.w, a.bias, a.y = x.data.data_ptr(), w.data_ptr(), _ptr(self.pv(bname)), y.data.data_ptr()
+            a.x, a.w, a.bias, a.y = self._rd(x), w.data_ptr(), _ptr(self.pv(bname)), y.data.data_ptr()
             return op
 
         op = base()
@@ -668,7 +691,24 @@ class StepPlan:
         for em in reversed(self.bwd_emitters):
             em()
 
+    def _narrow_activations(self) -> None:
+        """Conv-cell outputs that ONLY 3x3 convs read (the first conv of every double-conv block): InstanceNorm writes
+        them as 16-bit planes instead of fp32 and the pack re-blocks 16-bit words -- 4 + 2 + 2 + 2 instead of
+        4 + 4 + 4 + 2 bytes per element, same values (one RNE either way)."""
+        if _NO_P16 or not self.compute:
+            return
+        for a in self.acts.values():
+            hw = a.H * a.W
+            if a.in_op is None or a.pack_op is None or a.planar_used or hw % 4 or hw > 65536:
+                continue
+            y16 = self.alloc(a.N, a.C, a.H, a.W, dtype=torch.int16)
+            a.in_op.u.inorm.y16, a.in_op.u.inorm.out16_type = y16.data_ptr(), self.compute
+            a.pack_op.kind = L.OP_C8_PACK16
+            a.pack_op.u.c8pack.src = y16.data_ptr()
+            a.planar_valid = False
+
     def finalize(self) -> Dict[str, Program]:
+        self._narrow_activations()
         ws = self.alloc(max(16, (self.ws_bytes + 15) // 16 * 4)) if self.ws_bytes else None
         for op, fieldname in self.ws_users:
             a = getattr(op.u, fieldname)

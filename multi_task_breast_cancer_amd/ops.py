@@ -163,6 +163,14 @@ class C8:
         L.check(L.load().mtbc_c8_pack(x.data_ptr(), Cc * H * W, d.data_ptr(), N, Cc, H * W, compute, _s()), "c8_pack")
         return C8(d, x.shape, compute)
 
+    @staticmethod
+    def pack16(x16: torch.Tensor, compute: int) -> "C8":
+        """From 16-bit planes (N,C,H,W as int16 storage), mtbc_c8_pack16."""
+        N, Cc, H, W = x16.shape
+        d = torch.empty(N, Cc // 8, H * W, 8, dtype=torch.int16, device=x16.device)
+        L.check(L.load().mtbc_c8_pack16(x16.data_ptr(), Cc * H * W, d.data_ptr(), N, Cc, H * W, _s()), "c8_pack16")
+        return C8(d, x16.shape, compute)
+
     def unpack(self) -> torch.Tensor:
         N, Cc, H, W = self.shape
         y = torch.empty(N, Cc, H, W, dtype=torch.float32, device=self.data.device)
@@ -223,16 +231,19 @@ def conv3x3_wgrad_c8(xs: Sequence["C8"], dz: "C8", w_shape, want_bias: bool = Fa
 
 
 # ------------------------------------------------------------------ instance norm + leaky relu
-def instnorm_lrelu_fwd(z, gamma=None, beta=None, eps=1e-5, slope=0.01):
+def instnorm_lrelu_fwd(z, gamma=None, beta=None, eps=1e-5, slope=0.01, out16: int = 0):
+    """out16 = 1 (bf16) / 2 (fp16): the activation comes back as 16-bit planes (int16 storage), y16 of the C-ABI."""
     _chk(z, gamma, beta)
     N, Cc, H, W = z.shape
-    y = torch.empty_like(z)
+    y = torch.empty_like(z, dtype=torch.int16 if out16 else torch.float32)
     mean = torch.empty(N * Cc, dtype=torch.float32, device=z.device)
     rstd = torch.empty_like(mean)
     a = L.InstNormArgs()
     a.N, a.C, a.H, a.W, a.eps, a.slope = N, Cc, H, W, eps, slope
     a.z, a.gamma, a.beta, a.y, a.y_batch_stride = z.data_ptr(), _p(gamma), _p(beta), y.data_ptr(), Cc * H * W
     a.mean, a.rstd = mean.data_ptr(), rstd.data_ptr()
+    if out16:
+        a.y, a.y16, a.out16_type = None, y.data_ptr(), out16
     nb = L.load().mtbc_instnorm_fwd_workspace(C.byref(a))
     if nb:
         ws = _ws(nb, z.device)
@@ -242,10 +253,10 @@ def instnorm_lrelu_fwd(z, gamma=None, beta=None, eps=1e-5, slope=0.01):
 
 
 def instnorm_lrelu_bwd(z, dy, mean, rstd, gamma=None, beta=None, eps=1e-5, slope=0.01, inplace=False,
-                       dbias_pre=None, dy_extra=()):
+                       dbias_pre=None, dy_extra=(), out16: int = 0):
     _chk(z, dy, mean, rstd, gamma, beta, dbias_pre, *dy_extra)
     N, Cc, H, W = z.shape
-    dz = dy if inplace else torch.empty_like(z)
+    dz = torch.empty_like(z, dtype=torch.int16) if out16 else (dy if inplace else torch.empty_like(z))
     dg = torch.empty(Cc, dtype=torch.float32, device=z.device) if gamma is not None else None
     db = torch.empty(Cc, dtype=torch.float32, device=z.device) if gamma is not None else None
     ws = _ws(N * Cc * 12, z.device)
@@ -254,6 +265,8 @@ def instnorm_lrelu_bwd(z, dy, mean, rstd, gamma=None, beta=None, eps=1e-5, slope
     a.z, a.gamma, a.beta, a.mean, a.rstd = z.data_ptr(), _p(gamma), _p(beta), mean.data_ptr(), rstd.data_ptr()
     a.dy, a.dy_batch_stride, a.dz, a.dgamma, a.dbeta = dy.data_ptr(), Cc * H * W, dz.data_ptr(), _p(dg), _p(db)
     a.dbias_pre = _p(dbias_pre)
+    if out16:
+        a.dz, a.dz16, a.out16_type = None, dz.data_ptr(), out16
     a.n_dy_extra = len(dy_extra)
     for k_, t_ in enumerate(dy_extra):
         a.dy_extra[k_] = t_.data_ptr()

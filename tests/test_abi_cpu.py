@@ -76,7 +76,7 @@ def test_op_kind_enum_in_sync():
     want = ["CONV3_FWD", "CONV3_DGRAD", "CONV3_WGRAD", "CONV3_PACK_FWD", "CONV3_PACK_DGRAD", "IN_FWD", "IN_BWD",
             "POOL_FWD", "POOL_BWD", "CONVT_FWD", "CONVT_DGRAD", "CONVT_WGRAD", "CONV1_FWD", "CONV1_DGRAD", "CONV1_WGRAD",
             "GAP_FWD", "GAP_BWD", "LINEAR_FWD", "LINEAR_BWD", "DICE_FWD", "DICE_BWD", "FOCAL", "LOSS_MIX", "ADAM",
-            "MEMSET", "DICE_COUNTS", "CONV3_PACK_LP", "HEAD_COMBINE", "HEAD_EXPAND", "C8_PACK"]
+            "MEMSET", "DICE_COUNTS", "CONV3_PACK_LP", "HEAD_COMBINE", "HEAD_EXPAND", "C8_PACK", "C8_PACK16"]
     assert names == ["MTBC_OP_" + w for w in want]
     for i, w in enumerate(want, start=1):
         assert getattr(L, "OP_" + w) == i

@@ -508,3 +508,27 @@ def test_convT_forward_into_channel_blocked_output_equals_planar_then_pack(N, Ci
     want = ops.C8.pack(ops.convT_fwd(x, w, b, 2), compute)
     got = ops.convT_fwd_c8(x, w, b, 2, compute)
     assert got.shape == want.shape and torch.equal(got.data, want.data)
+
+
+@pytest.mark.parametrize("compute", [1, 2])
+@pytest.mark.parametrize("N,C,H,W,affine", [(2, 24, 256, 256, True), (3, 8, 64, 64, False), (2, 16, 12, 20, True), (1, 48, 128, 128, True)])
+def test_instnorm_16bit_planar_outputs_are_the_rounded_fp32_outputs(N, C, H, W, affine, compute):
+    """y16 / dz16 = RNE of the fp32 y / dz bit for bit, the fp32 side results (statistics, parameter gradients) do not
+    change, and pack16 of the planes equals pack of the fp32 tensor."""
+    g = _g(N + C + H + compute)
+    z = (torch.randn(N, C, H, W, generator=g) * 2 + 0.5).to(DEV)
+    dy = torch.randn(N, C, H, W, generator=g).to(DEV)
+    gamma = (torch.rand(C, generator=g) + 0.5).to(DEV) if affine else None
+    beta = (torch.randn(C, generator=g) * 0.1).to(DEV) if affine else None
+    dt = torch.bfloat16 if compute == 1 else torch.float16
+    y, mean, rstd = ops.instnorm_lrelu_fwd(z, gamma, beta, slope=0.1)
+    y16, mean2, rstd2 = ops.instnorm_lrelu_fwd(z, gamma, beta, slope=0.1, out16=compute)
+    assert torch.equal(y16.view(dt), y.to(dt)) and torch.equal(mean, mean2) and torch.equal(rstd, rstd2)
+    db1, db2 = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    dz, dg, dbt = ops.instnorm_lrelu_bwd(z, dy, mean, rstd, gamma, beta, slope=0.1, dbias_pre=db1)
+    dz16, dg2, dbt2 = ops.instnorm_lrelu_bwd(z, dy, mean, rstd, gamma, beta, slope=0.1, dbias_pre=db2, out16=compute)
+    assert torch.equal(dz16.view(dt), dz.to(dt)) and torch.equal(db1, db2)
+    if affine:
+        assert torch.equal(dg, dg2) and torch.equal(dbt, dbt2)
+    if C % 8 == 0:
+        assert torch.equal(ops.C8.pack16(y16, compute).data, ops.C8.pack(y, compute).data)

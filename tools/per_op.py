@@ -46,6 +46,9 @@ for pname in ("pack", "fwd", "loss", "bwd"):
         elif op.kind in (L.OP_IN_FWD, L.OP_IN_BWD):
             a = op.u.inorm
             desc = f"C{a.C} @{a.H}x{a.W} bytes {a.N*a.C*a.H*a.W*4/1e6:.1f}MB"
+        elif op.kind == L.OP_C8_PACK:
+            a = op.u.c8pack
+            desc = f"C{a.C} HW{a.HW} {a.N*a.C*a.HW*6/1e6:.0f}MB"
         rows.append((pname, i, names[op.kind], desc, t, fl))
 tot = sum(r[4] for r in rows)
 agg = {}
@@ -55,7 +58,8 @@ for r in rows:
 print(f"{arch} B={B} {S}x{S}: sum of per-op times {tot:.2f} ms")
 for k, (n, ms, fl) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
     print(f"  {k:22s} n={n:3d} {ms:8.3f} ms {100*ms/tot:5.1f}%  {fl/ms/1e9 if fl else 0:7.1f} TF")
-print("--- per op (>= 0.15 ms)")
+MINMS = float(os.environ.get("PEROP_MIN", "0.15"))
+print(f"--- per op (>= {MINMS} ms)")
 for r in rows:
-    if r[4] >= 0.15:
+    if r[4] >= MINMS:
         print(f"  {r[0]:4s} #{r[1]:3d} {r[2]:18s} {r[3]:44s} {r[4]:7.3f} ms {r[5]/r[4]/1e9 if r[5] else 0:7.1f} TF")
