@@ -20,6 +20,7 @@ from . import _lib as L
 import os as _os
 _NOACC = _os.environ.get('MTBC_NOACC') == '1'     # timing probe only: results are wrong when set
 _NO_C8 = _os.environ.get('MTBC_NO_C8') == '1'     # A/B: 16-bit modes stage fp32 planar operands as before
+_NO_CT_LP = _os.environ.get('MTBC_NO_CT_LP') == '1'  # A/B: ConvT backward keeps fp32 MFMA operands in the 16-bit modes
 _NO_P16 = _os.environ.get('MTBC_NO_P16') == '1'   # A/B / activation probes: InstanceNorm keeps writing fp32 y and dz
 
 
@@ -444,9 +445,13 @@ class StepPlan:
             if not y.grad_written:
                 return
             dy = self.grad_of(y)
+            # 16-bit modes: the backward MFMAs of the k = 2 up-convolutions take rounded operands too (they are fp32-MFMA
+            # bound otherwise); only where BOTH direct-to-fragment kernels of convt2.hip take the shape
+            lp = self.compute if (k == 2 and not _NO_CT_LP and (x.H * x.W) % 32 == 0 and x.W % 8 == 0 and cout % 2 == 0) else 0
             op = base()
             op.kind = L.OP_CONVT_WGRAD
             a = op.u.convT
+            a.compute = lp
             a.dy, a.dy_batch_stride = dy.data_ptr(), y.bstride
             a.accumulate_dw = self._mark_param(wname)
             a.dw = self.gv(wname).data_ptr()
@@ -459,6 +464,7 @@ class StepPlan:
                 op = base()
                 op.kind = L.OP_CONVT_DGRAD
                 a = op.u.convT
+                a.compute = lp
                 a.dy, a.dy_batch_stride = dy.data_ptr(), y.bstride
                 gx, acc = self.grad_slot(x)
                 a.dx, a.dx_batch_stride, a.accumulate_dx = gx.data_ptr(), x.bstride, acc

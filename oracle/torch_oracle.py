@@ -376,16 +376,60 @@ class _LowpConv3x3(torch.autograd.Function):
         return dx, dw, db, None
 
 
+class _LowpConvT2Bwd(torch.autograd.Function):
+    """ConvTranspose2d(k = s = 2) of the 16-bit modes: exact forward (the product's forward is an fp32 MFMA), backward
+    MFMAs on rounded operands (dgrad: dy, w; wgrad: x, dy), bias gradient from the unrounded dy -- convt2.hip."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, lp):
+        ctx.save_for_backward(x, w)
+        ctx.lp, ctx.has_b = lp, b is not None
+        return torch.conv_transpose2d(x, w, b, 2)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        r = lambda t: t.to(ctx.lp).to(t.dtype)
+        dyr = r(dy)
+        dx = torch.conv2d(dyr, r(w), None, 2)
+        with torch.enable_grad():
+            wz = torch.zeros_like(w, requires_grad=True)
+            (dw,) = torch.autograd.grad(torch.conv_transpose2d(r(x).detach(), wz, None, 2), wz, dyr)
+        db = dy.sum(dim=(0, 2, 3)) if ctx.has_b else None
+        return dx, dw, db, None
+
+
 class lowp_conv3x3:
     """Context manager: inside it every 3x3 / padding-1 F.conv2d (hence every nn.Conv2d of the oracle nets) runs
-    through _LowpConv3x3 with operands rounded to `mode` ('bf16' | 'f16')."""
+    through _LowpConv3x3 with operands rounded to `mode` ('bf16' | 'f16'), and the backward of every k = s = 2
+    F.conv_transpose2d through _LowpConvT2Bwd.  `model`: its ConvTranspose2d -> 1x1 Conv2d heads stay exact (the
+    product fuses them into one fp32 transposed conv, engine.convT_head)."""
 
-    def __init__(self, mode: str):
+    def __init__(self, mode: str, model=None):
         self.lp = {"bf16": torch.bfloat16, "f16": torch.float16}[mode]
+        self.exempt = set()
+        models = [] if model is None else (list(model) if isinstance(model, (list, tuple)) else [model])
+        for mod in models:
+            for m in mod.modules():
+                if (isinstance(m, torch.nn.Sequential) and len(m) >= 2 and isinstance(m[0], torch.nn.ConvTranspose2d)
+                            and isinstance(m[1], torch.nn.Conv2d) and tuple(m[1].kernel_size) == (1, 1)):
+                        self.exempt.add(id(m[0].weight))
 
     def __enter__(self):
         self._orig = F.conv2d
+        self._orig_t = F.conv_transpose2d
         orig, lp = self._orig, self.lp
+        orig_t, exempt = self._orig_t, self.exempt
+
+        def conv_transpose2d(input, weight, bias=None, stride=1, padding=0, output_padding=0, groups=1, dilation=1):
+            # same eligibility as the product (engine.convT): the direct-to-fragment backward kernels of convt2.hip
+            H, W = input.shape[-2:]
+            if (tuple(weight.shape[-2:]) == (2, 2) and stride in (2, (2, 2)) and padding in (0, (0, 0)) and groups == 1
+                    and (H * W) % 32 == 0 and W % 8 == 0 and id(weight) not in exempt):
+                return _LowpConvT2Bwd.apply(input, weight, bias, lp)
+            return orig_t(input, weight, bias, stride, padding, output_padding, groups, dilation)
+
+        F.conv_transpose2d = conv_transpose2d
 
         def conv2d(input, weight, bias=None, stride=1, padding=0, dilation=1, groups=1):
             # same eligibility as the product's MFMA path (conv3x3.hip mfma_ok): maps >= 8x8 with W % 4 == 0 and
@@ -401,6 +445,7 @@ class lowp_conv3x3:
 
     def __exit__(self, *exc):
         F.conv2d = self._orig
+        F.conv_transpose2d = self._orig_t
         return False
 
 

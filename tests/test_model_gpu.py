@@ -247,7 +247,7 @@ def test_16bit_mfma_modes_match_their_emulation(dtype):
     st = step.load_batch(img.to(DEV), mask.to(DEV), label.to(DEV))
     losses = step.run(st).cpu()
     ls = prod.loss_scale                      # 4096 in fp16 mode (dz would underflow fp16 otherwise), 1 in bf16
-    with O.lowp_conv3x3(dtype):
+    with O.lowp_conv3x3(dtype, model=[ref, ref64]):
         t32 = O.train_step(ref, O.make_adam(ref, 1e-4), img, mask, label, 0.5, True, 3, loss_scale=ls)
         t64 = O.train_step(ref64, O.make_adam(ref64, 1e-4), img.double(), mask.double(), label, 0.5, True, 3, loss_scale=ls)
     assert losses[3].item() == 0.0

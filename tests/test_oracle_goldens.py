@@ -173,3 +173,42 @@ def test_oversampling_edge_cases():
     assert list(scaling_factors(cl).keys()) == ["x", "y"]
     assert deterministic_oversampling_positions(cl) == [0, 1, 2, 3, 0, 3, 1, 2]
     assert deterministic_oversampling_positions([]) == []
+
+
+def test_16bit_emulation_contexts_are_transparent_without_rounding():
+    """oracle.lowp_conv3x3 restates where the 16-bit modes round (3x3 conv operands, k=2 ConvT backward operands): with a
+    'rounding' type that does not round (float64) its custom backward passes must reproduce autograd exactly, and the
+    ConvT -> 1x1 heads named by `model` must stay untouched."""
+    import torch
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from oracle import torch_oracle as O
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 8, 8, 8, generator=g, dtype=torch.float64, requires_grad=True)
+    up = nn.ConvTranspose2d(8, 8, 2, 2).double()
+    conv = nn.Conv2d(8, 8, 3, padding=1).double()
+    head = nn.Sequential(nn.ConvTranspose2d(8, 8, 2, 2), nn.Conv2d(8, 1, 1)).double()
+    net = nn.ModuleList([up, conv, head])
+
+    def run():
+        for p in list(net.parameters()) + [x]:
+            p.grad = None
+        y = conv(up(x))
+        (y.square().sum() + head(x).square().sum()).backward()
+        return [x.grad.clone()] + [p.grad.clone() for p in net.parameters()]
+
+    want = run()
+    ctx = O.lowp_conv3x3("bf16", model=net)
+    ctx.lp = torch.float64
+    with ctx:
+        assert F.conv2d is not ctx._orig and F.conv_transpose2d is not ctx._orig_t
+        got = run()
+    assert F.conv2d is ctx._orig and id(head[0].weight) in ctx.exempt and id(up.weight) not in ctx.exempt
+    for a, b in zip(got, want):
+        assert torch.allclose(a, b, rtol=1e-12, atol=1e-12)
+    # and with real rounding the up-conv's backward differs while its forward does not
+    with O.lowp_conv3x3("bf16", model=net):
+        y = up(x)
+        assert torch.equal(y, F.conv_transpose2d(x, up.weight, up.bias, 2))
+        got_r = run()
+    assert not torch.equal(got_r[1], want[1])
