@@ -7,8 +7,10 @@
 
 One "step" = one optimisation step (pack -> fwd -> Dice+Focal -> bwd -> [all-reduce] -> Adam) on a per-GPU batch
 of 32 synthetic images already resident in HBM (BASELINE.json configs[1]; weak scaling: global batch = 32*N).
-Default compute mode is the one configs[1] names: bf16 MFMA operands in the 3x3 convs (fp32 storage / accumulation
-/ norm statistics / losses / Adam); at N=1 the same step is also timed in the fp32 parity mode (`fp32_parity_mode`).
+Default compute mode is the one configs[1] names: bf16 MFMA operands (3x3 convs, k=2 ConvT backward), everything an
+MFMA does not read -- conv outputs, gradient sums, norm statistics, accumulators, losses, Adam -- in fp32; the operand
+tensors are stored once in the MFMA's 16-bit channel-blocked layout.  At N=1 the same step is also timed in the fp32
+parity mode (`fp32_parity_mode`).
 Rank 0 prints ONE JSON line; `roofline` is measured live with HIP events around the dominant kernel family (the
 implicit-GEMM conv3x3, forward + dgrad launches) and priced against the roof the kernel's arithmetic intensity puts it
 under (fp32: MFMA; bf16: HBM); `cpu_baseline` times the CPU oracle on the host cores.
@@ -63,16 +65,18 @@ def note(msg: str) -> None:
 
 
 def conv_bytes(op, kind, L) -> float:
-    """Algorithmic HBM bytes of one conv3x3 launch: every operand plane once, fp32 storage."""
+    """Algorithmic HBM bytes of one conv3x3 launch: every operand plane once, in the storage the launch is
+    handed -- fp32 planes, or 2-byte elements for the tensors an operand_layout = C8 launch reads."""
     a = op.u.conv3
-    plane = a.N * a.H * a.W * 4.0
-    w = 9.0 * a.Cin * a.Cout * 4
+    px = float(a.N * a.H * a.W)
+    rd = 2.0 if a.operand_layout == L.LAYOUT_C8 else 4.0
+    w = 9.0 * a.Cin * a.Cout * (2.0 if a.compute else 4.0)
     if kind == L.OP_CONV3_FWD:
-        return (a.Cin + a.Cout) * plane + w
+        return (a.Cin * rd + a.Cout * 4.0) * px + w
     if kind == L.OP_CONV3_WGRAD:
-        return (a.Cin + a.Cout) * plane + w
+        return (a.Cin + a.Cout) * rd * px + 9.0 * a.Cin * a.Cout * 4.0
     acc = sum(a.in_[i].channels for i in range(a.n_in) if a.in_[i].accumulate)      # fan-in sums re-read dx
-    return (a.Cin + a.Cout + acc) * plane + w
+    return (a.Cout * rd + (a.Cin + acc) * 4.0) * px + w
 
 
 def time_op(prog, i, reps=3) -> float:
@@ -151,8 +155,8 @@ def run_mode(args, dtype, dev, rank, world, dist, want_roofline):
     balance = peak * 1e12 / PEAK_HBM_BYTES                       # FLOP per byte at which the two roofs cross
     bound = "mfma" if fl / by > balance else "hbm"
     names = {"f32": ("conv3x3_igemm_dma_kernel", "conv3x3_wgrad_mfma_kernel"),
-             "bf16": ("conv3x3_igemm_lp_kernel", "conv3x3_wgrad_lp_kernel"),
-             "f16": ("conv3x3_igemm_lp_kernel", "conv3x3_wgrad_lp_kernel")}[dtype]
+             "bf16": ("conv3x3_igemm_c8_kernel", "conv3x3_wgrad_c8_kernel"),
+             "f16": ("conv3x3_igemm_c8_kernel", "conv3x3_wgrad_c8_kernel")}[dtype]
     traffic = None
     tpath = os.path.join(ROOT, "profiles", f"r01_hbm_traffic_{dtype}.json")
     if os.path.exists(tpath):
@@ -185,21 +189,25 @@ def run_mode(args, dtype, dev, rank, world, dist, want_roofline):
     res["roofline"] = roof
     # ---- HBM-bound kernels named by north_star (norm / upsample): algorithmic bytes / HIP-event time
     hb = {"in_fwd": [0.0, 0.0, 0], "in_bwd": [0.0, 0.0, 0], "convT_fwd": [0.0, 0.0, 0], "convT_dgrad": [0.0, 0.0, 0],
-          "convT_wgrad": [0.0, 0.0, 0]}
+          "convT_wgrad": [0.0, 0.0, 0], "c8_pack": [0.0, 0.0, 0]}
     for pname in ("fwd", "bwd"):
         prog = st.programs[pname]
         for i in range(prog.n):
             op = prog.array[i]
             if op.kind == L.OP_IN_FWD:
-                a = op.u.inorm; e = a.N * a.C * a.H * a.W * 4
-                h = hb["in_fwd"]; h[0] += 2 * e; h[1] += time_op(prog, i); h[2] += 1       # read z, write y
+                a = op.u.inorm; e = a.N * a.C * a.H * a.W
+                h = hb["in_fwd"]; h[0] += e * (4 + (2 if a.y16 else 4)); h[1] += time_op(prog, i); h[2] += 1      # read z, write y
             elif op.kind == L.OP_IN_BWD:
-                a = op.u.inorm; e = a.N * a.C * a.H * a.W * 4
-                h = hb["in_bwd"]; h[0] += 3 * e; h[1] += time_op(prog, i); h[2] += 1       # read z, dy; write dz
+                a = op.u.inorm; e = a.N * a.C * a.H * a.W
+                h = hb["in_bwd"]; h[0] += e * (8 + (2 if a.dz16 else 4)); h[1] += time_op(prog, i); h[2] += 1     # read z, dy; write dz
             elif op.kind in (L.OP_CONVT_FWD, L.OP_CONVT_DGRAD, L.OP_CONVT_WGRAD):
-                a = op.u.convT; px = a.N * a.H * a.W * 4
+                a = op.u.convT; px = a.N * a.H * a.W
+                ob = 2 if (op.kind == L.OP_CONVT_FWD and a.y_layout == L.LAYOUT_C8) else 4
                 h = hb[{L.OP_CONVT_FWD: "convT_fwd", L.OP_CONVT_DGRAD: "convT_dgrad", L.OP_CONVT_WGRAD: "convT_wgrad"}[op.kind]]
-                h[0] += px * (a.Cin + a.Cout * a.k * a.k); h[1] += time_op(prog, i); h[2] += 1
+                h[0] += px * (a.Cin * 4 + a.Cout * a.k * a.k * ob); h[1] += time_op(prog, i); h[2] += 1
+            elif op.kind in (L.OP_C8_PACK, L.OP_C8_PACK16):                               # fp32 / 16-bit planes -> channel-blocked 16-bit
+                a = op.u.c8pack; e = a.N * a.C * a.HW
+                h = hb["c8_pack"]; h[0] += e * (6 if op.kind == L.OP_C8_PACK else 4); h[1] += time_op(prog, i); h[2] += 1
     res["roofline_hbm"] = {k: {"bound": "hbm", "achieved": round(v[0] / v[1] / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
                                "frac": round(v[0] / v[1] / 8e12, 4), "launches_per_step": v[2],
                                "algorithmic_MB_per_launch": round(v[0] / max(1, v[2]) / 1e6, 1)}
@@ -248,8 +256,11 @@ def main() -> None:
         "ms_per_step": main_res["ms_per_step"], "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": args.dtype, "data": "synthetic" + (" (pinned host batches, H2D inside the step)" if args.host_input else ""),
         "config": {"workload": f"{args.arch} seg+cls deep-supervision step (Dice+Focal, alpha=0.5, Adam eps 1e-4), "
-                               f"per-GPU batch {args.batch}, 1x{args.size}x{args.size}, {args.dtype} MFMA operands in the 3x3 convs / "
-                               f"fp32 storage+accumulation, random-init weights (BASELINE.json configs[1])",
+                               f"per-GPU batch {args.batch}, 1x{args.size}x{args.size}, "
+                               + ("fp32 MFMA (parity mode)" if args.dtype == "f32" else
+                                  f"{args.dtype} MFMA operands (3x3 convs, ConvT backward) / fp32 conv outputs, gradient sums, "
+                                  f"statistics, accumulation and optimizer") +
+                               ", random-init weights (BASELINE.json configs[1])",
                    "global_batch": args.batch * world, "parallelism": f"dp{world}"},
         "final_loss": main_res["final_loss"],
     }
