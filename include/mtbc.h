@@ -160,7 +160,18 @@ typedef struct {
     void* y16;
     void* dz16;
     int32_t out16_type;
+    /* 16-bit CHANNEL-BLOCKED outputs (MTBC_LAYOUT_C8, [N][C/8][H*W][8] of type out16_type): the forward activation
+       goes to y8 (and, if y != NULL, also to y as fp32 planes), the backward dz to dz8 only.  One HBM pass by a
+       cooperative kernel (csrc/norm_coop.hip: teams of resident workgroups exchange per-channel partials through
+       coop_state).  coop_state: mtbc_instnorm_coop_state_bytes() of device memory, ZEROED once by the caller, kept
+       for the lifetime of the stream's launches and never used from two streams at once.  C % 8 == 0, no dy_extra;
+       shapes: ask mtbc_instnorm_c8_supported.  Statistics are combined with Chan's formula (fixed order).        */
+    void* y8;
+    void* dz8;
+    void* coop_state;
 } mtbc_instnorm_args;
+size_t mtbc_instnorm_coop_state_bytes(void);
+int mtbc_instnorm_c8_supported(const mtbc_instnorm_args* a, int32_t backward);
 
 /* workspace bytes the forward can use for planes > 64K elements (chunked statistics: 2 reads + 1 write instead of the
  * streaming kernel's 3 + 1); 0 for smaller planes.  Passing no workspace is valid (streaming kernel). */

@@ -48,7 +48,8 @@ class InstNormArgs(C.Structure):
                 ("dz", C.c_void_p), ("dgamma", C.c_void_p), ("dbeta", C.c_void_p), ("dbias_pre", C.c_void_p),
                 ("accumulate_dparams", C.c_int32),
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
-                ("y16", C.c_void_p), ("dz16", C.c_void_p), ("out16_type", C.c_int32)]
+                ("y16", C.c_void_p), ("dz16", C.c_void_p), ("out16_type", C.c_int32),
+                ("y8", C.c_void_p), ("dz8", C.c_void_p), ("coop_state", C.c_void_p)]
 
 
 class MaxPoolArgs(C.Structure):
@@ -187,7 +188,7 @@ EXPORTS = [
     "mtbc_version", "mtbc_strerror", "mtbc_arch",
     "mtbc_conv3x3_packed_elems", "mtbc_conv3x3_packed_dgrad_elems", "mtbc_conv3x3_pack_fwd",
     "mtbc_conv3x3_pack_dgrad", "mtbc_conv3x3_packed_lp_elems", "mtbc_conv3x3_pack_lp", "mtbc_conv3x3_pack_many", "mtbc_c8_pack", "mtbc_c8_unpack", "mtbc_c8_pack16", "mtbc_augment_flip_rotate", "mtbc_convT_head_combine", "mtbc_convT_head_expand", "mtbc_conv3x3_wgrad_workspace", "mtbc_conv3x3_fwd", "mtbc_conv3x3_dgrad",
-    "mtbc_conv3x3_wgrad", "mtbc_instnorm_fwd_workspace", "mtbc_instnorm_lrelu_fwd", "mtbc_instnorm_lrelu_bwd", "mtbc_maxpool2_fwd",
+    "mtbc_conv3x3_wgrad", "mtbc_instnorm_fwd_workspace", "mtbc_instnorm_coop_state_bytes", "mtbc_instnorm_c8_supported", "mtbc_instnorm_lrelu_fwd", "mtbc_instnorm_lrelu_bwd", "mtbc_maxpool2_fwd",
     "mtbc_maxpool2_bwd", "mtbc_convT_wgrad_workspace", "mtbc_convT_fwd_c8_supported", "mtbc_convT_fwd", "mtbc_convT_dgrad", "mtbc_convT_wgrad",
     "mtbc_conv1x1_wgrad_workspace", "mtbc_conv1x1_fwd", "mtbc_conv1x1_dgrad", "mtbc_conv1x1_wgrad",
     "mtbc_gap_fwd", "mtbc_gap_bwd", "mtbc_linear_fwd", "mtbc_linear_bwd", "mtbc_dice_fwd", "mtbc_dice_bwd",
@@ -252,6 +253,10 @@ def load() -> C.CDLL:
                       ("mtbc_adam_step", AdamArgs)):
         getattr(lib, name).restype = C.c_int
         getattr(lib, name).argtypes = [C.POINTER(typ), C.c_void_p]
+    lib.mtbc_instnorm_coop_state_bytes.restype = C.c_size_t
+    lib.mtbc_instnorm_coop_state_bytes.argtypes = []
+    lib.mtbc_instnorm_c8_supported.restype = C.c_int
+    lib.mtbc_instnorm_c8_supported.argtypes = [C.POINTER(InstNormArgs), C.c_int32]
     lib.mtbc_convT_fwd_c8_supported.restype = C.c_int
     lib.mtbc_convT_fwd_c8_supported.argtypes = [C.POINTER(ConvTArgs)]
     lib.mtbc_loss_mix.restype = C.c_int

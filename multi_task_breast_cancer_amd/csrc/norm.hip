@@ -353,6 +353,7 @@ size_t mtbc_instnorm_fwd_workspace(const mtbc_instnorm_args* a) {
 }
 
 int mtbc_instnorm_lrelu_fwd(const mtbc_instnorm_args* a, void* stream) {
+    if (a && a->y8) return mtbc_i_instnorm_fwd_c8(a, (hipStream_t)stream);
     InP p; int rc = fill(a, &p); if (rc) return rc;
     if (!p.z || (!p.y && !p.y16) || !p.mean || !p.rstd) return MTBC_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
@@ -380,7 +381,7 @@ int mtbc_instnorm_lrelu_fwd(const mtbc_instnorm_args* a, void* stream) {
 
 int mtbc_instnorm_lrelu_bwd(const mtbc_instnorm_args* a, void* stream) {
     InP p; int rc = fill(a, &p); if (rc) return rc;
-    if (!p.z || !p.dy || (!p.dz && !p.dz16) || !p.mean || !p.rstd) return MTBC_E_BADARG;
+    if (!p.z || !p.dy || (!p.dz && !p.dz16 && !a->dz8) || !p.mean || !p.rstd) return MTBC_E_BADARG;
     if (p.nx < 0 || p.nx > 4) return MTBC_E_BADARG;
     for (int k = 0; k < p.nx; ++k) if (!p.dyx[k] || !al16(p.dyx[k])) return MTBC_E_BADARG;
     const bool want = a->dgamma || a->dbeta || a->dbias_pre;
@@ -390,6 +391,15 @@ int mtbc_instnorm_lrelu_bwd(const mtbc_instnorm_args* a, void* stream) {
         p.part = reinterpret_cast<float*>(a->workspace);
     }
     hipStream_t st = (hipStream_t)stream;
+    if (a->dz8) {
+        rc = mtbc_i_instnorm_bwd_c8(a, p.part, st); if (rc) return rc;
+        if (want) {
+            hipLaunchKernelGGL(in_dparam_kernel, dim3(a->C), dim3(64), 0, st, p.part, a->dgamma, a->dbeta,
+                               a->dbias_pre, a->N, a->C, a->accumulate_dparams);
+            MTBC_CHECK_LAUNCH();
+        }
+        return MTBC_OK;
+    }
     const bool vec = p.HW % 4 == 0 && al16(p.z) && al16(p.dy) && p.dybs % 4 == 0 &&
                      (p.dz16 ? (reinterpret_cast<uintptr_t>(p.dz16) & 7) == 0 : al16(p.dz));
     const int threads = p.HW >= 16384 ? 1024 : (p.HW >= 1024 ? 256 : 64);

@@ -275,6 +275,61 @@ def instnorm_lrelu_bwd(z, dy, mean, rstd, gamma=None, beta=None, eps=1e-5, slope
     return dz, dg, db
 
 
+_coop_states = {}
+
+
+def coop_state(dev) -> torch.Tensor:
+    """The persistent, zero-initialised mailbox block of the cooperative InstanceNorm kernels (one per device here;
+    the C-ABI wants one per stream that launches them)."""
+    key = str(dev)
+    if key not in _coop_states:
+        _coop_states[key] = torch.zeros(L.load().mtbc_instnorm_coop_state_bytes() // 4, dtype=torch.int32, device=dev)
+    return _coop_states[key]
+
+
+def instnorm_lrelu_fwd_c8(z, gamma=None, beta=None, eps=1e-5, slope=0.01, compute: int = 1, want_planar: bool = False):
+    """InstanceNorm + LeakyReLU straight into the 16-bit channel-blocked layout (y8 of the C-ABI)."""
+    _chk(z, gamma, beta)
+    N, Cc, H, W = z.shape
+    y8 = torch.empty(N, Cc // 8, H * W, 8, dtype=torch.int16, device=z.device)
+    y = torch.empty_like(z) if want_planar else None
+    mean = torch.empty(N * Cc, dtype=torch.float32, device=z.device)
+    rstd = torch.empty_like(mean)
+    a = L.InstNormArgs()
+    a.N, a.C, a.H, a.W, a.eps, a.slope = N, Cc, H, W, eps, slope
+    a.z, a.gamma, a.beta, a.y, a.y_batch_stride = z.data_ptr(), _p(gamma), _p(beta), _p(y), Cc * H * W
+    a.mean, a.rstd = mean.data_ptr(), rstd.data_ptr()
+    a.y8, a.out16_type, a.coop_state = y8.data_ptr(), compute, coop_state(z.device).data_ptr()
+    if not L.load().mtbc_instnorm_c8_supported(C.byref(a), 0):
+        raise L.MtbcError("instnorm_fwd: shape not supported with a channel-blocked output")
+    L.check(L.load().mtbc_instnorm_lrelu_fwd(C.byref(a), _s()), "instnorm_fwd(c8)")
+    return C8(y8, z.shape, compute), mean, rstd, y
+
+
+def instnorm_lrelu_bwd_c8(z, dy, mean, rstd, gamma=None, beta=None, eps=1e-5, slope=0.01, dbias_pre=None, compute: int = 1):
+    _chk(z, dy, mean, rstd, gamma, beta, dbias_pre)
+    N, Cc, H, W = z.shape
+    dz8 = torch.empty(N, Cc // 8, H * W, 8, dtype=torch.int16, device=z.device)
+    dg = torch.empty(Cc, dtype=torch.float32, device=z.device) if gamma is not None else None
+    db = torch.empty(Cc, dtype=torch.float32, device=z.device) if gamma is not None else None
+    ws = _ws(N * Cc * 12, z.device)
+    a = L.InstNormArgs()
+    a.N, a.C, a.H, a.W, a.eps, a.slope = N, Cc, H, W, eps, slope
+    a.z, a.gamma, a.beta, a.mean, a.rstd = z.data_ptr(), _p(gamma), _p(beta), mean.data_ptr(), rstd.data_ptr()
+    a.dy, a.dy_batch_stride, a.dgamma, a.dbeta, a.dbias_pre = dy.data_ptr(), Cc * H * W, _p(dg), _p(db), _p(dbias_pre)
+    a.dz8, a.out16_type, a.coop_state = dz8.data_ptr(), compute, coop_state(z.device).data_ptr()
+    a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+    if not L.load().mtbc_instnorm_c8_supported(C.byref(a), 1):
+        raise L.MtbcError("instnorm_bwd: shape not supported with a channel-blocked output")
+    L.check(L.load().mtbc_instnorm_lrelu_bwd(C.byref(a), _s()), "instnorm_bwd(c8)")
+    return C8(dz8, z.shape, compute), dg, db
+
+
+def coop_error(dev) -> int:
+    """1 if a cooperative kernel ever gave up polling its mailbox (protocol failure; results are then garbage)."""
+    return int(coop_state(dev)[2].item())
+
+
 # ------------------------------------------------------------------ maxpool
 def maxpool2_fwd(x):
     _chk(x)

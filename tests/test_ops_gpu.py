@@ -532,3 +532,37 @@ def test_instnorm_16bit_planar_outputs_are_the_rounded_fp32_outputs(N, C, H, W, 
         assert torch.equal(dg, dg2) and torch.equal(dbt, dbt2)
     if C % 8 == 0:
         assert torch.equal(ops.C8.pack16(y16, compute).data, ops.C8.pack(y, compute).data)
+
+
+@pytest.mark.parametrize("compute", [1, 2])
+@pytest.mark.parametrize("N,C,H,W,affine", [(2, 24, 256, 256, True), (3, 48, 128, 128, True), (2, 96, 64, 64, False),
+                                            (5, 16, 32, 32, True), (2, 8, 16, 16, True), (3, 8, 8, 8, False), (32, 24, 256, 256, True)])
+def test_cooperative_instnorm_into_channel_blocked_layout(N, C, H, W, affine, compute):
+    """The split-plane cooperative kernels (teams of workgroups exchanging partial statistics through a mailbox) against
+    the one-plane-per-workgroup kernels: statistics to fp32 re-association, outputs to one 16-bit ulp of the rounded
+    fp32 result, parameter gradients to fp32 re-association; launched repeatedly (mailbox epochs) and never giving up
+    a poll."""
+    g = _g(N + C + H + compute)
+    z = (torch.randn(N, C, H, W, generator=g) * 2 + 0.5).to(DEV)
+    dy = torch.randn(N, C, H, W, generator=g).to(DEV)
+    gamma = (torch.rand(C, generator=g) + 0.5).to(DEV) if affine else None
+    beta = (torch.randn(C, generator=g) * 0.1).to(DEV) if affine else None
+    ulp = 2.0 ** -7 if compute == 1 else 2.0 ** -10
+    y, mean, rstd = ops.instnorm_lrelu_fwd(z, gamma, beta, slope=0.1)
+    for rep in range(3):
+        y8, mean2, rstd2, yp = ops.instnorm_lrelu_fwd_c8(z, gamma, beta, slope=0.1, compute=compute, want_planar=rep == 1)
+    assert torch.allclose(mean2, mean, rtol=1e-5, atol=1e-6) and torch.allclose(rstd2, rstd, rtol=1e-5, atol=1e-6)
+    got = y8.unpack()
+    assert bool(((got - y).abs() <= ulp * y.abs() + 1e-5).all()), (got - y).abs().max().item()
+    db1, db2 = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    dz, dg, dbt = ops.instnorm_lrelu_bwd(z, dy, mean, rstd, gamma, beta, slope=0.1, dbias_pre=db1)
+    for rep in range(2):
+        dz8, dg2, dbt2 = ops.instnorm_lrelu_bwd_c8(z, dy, mean, rstd, gamma, beta, slope=0.1, dbias_pre=db2, compute=compute)
+    gotz = dz8.unpack()
+    scale = dz.abs().max().item()
+    assert bool(((gotz - dz).abs() <= ulp * dz.abs() + 2e-6 * scale).all()), (gotz - dz).abs().max().item()
+    assert torch.allclose(db2, db1, rtol=1e-4, atol=1e-3)
+    if affine:
+        assert torch.allclose(dg2, dg, rtol=1e-4, atol=1e-3 * max(1.0, dg.abs().max().item()))
+        assert torch.allclose(dbt2, dbt, rtol=1e-4, atol=1e-3 * max(1.0, dbt.abs().max().item()))
+    assert ops.coop_error(DEV) == 0
