@@ -96,6 +96,7 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
 // norm_coop.hip: InstanceNorm straight into the 16-bit channel-blocked layout
 extern "C" int mtbc_i_instnorm_fwd_c8(const mtbc_instnorm_args* a, hipStream_t st);
 extern "C" int mtbc_i_instnorm_bwd_c8(const mtbc_instnorm_args* a, float* part, hipStream_t st);
+extern "C" int mtbc_i_instnorm_bwd_c8_team(const mtbc_instnorm_args* a);
 // internal (C++) helpers implemented in reduce.hip
 int mtbc_i_splitk_reduce(const float* partial, float* out, int nsplit, size_t elems, int accumulate, hipStream_t st);
 // convt2.hip: ConvTranspose k == s == 2 backward, operands straight from HBM into MFMA fragments

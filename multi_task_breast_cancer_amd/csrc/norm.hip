@@ -312,12 +312,16 @@ __global__ void in_bwd_reg_kernel(const InP p) {
 // one wave per channel, lanes over the images (fixed butterfly -> deterministic); a serial loop over N in one thread
 // per channel was pure latency: 9 us per launch, 36 launches per step
 __global__ void in_dparam_kernel(const float* __restrict__ part, float* dgamma, float* dbeta, float* dbias_pre, int N,
-                                 int C, int accumulate) {
+                                 int C, int accumulate, const float* __restrict__ part3 = nullptr, int T = 0) {
     const int c = blockIdx.x, lane = threadIdx.x;
     float sb = 0.f, sg = 0.f, sz = 0.f;
     for (int n = lane; n < N; n += 64) {
         const float* q = part + 3 * ((size_t)n * C + c);
         sb += q[0]; sg += q[1]; sz += q[2];
+        if (part3) {                                  // cooperative backward: every team member's share of sum dz
+            const float* r = part3 + ((size_t)n * C + c) * T;
+            for (int m = 0; m < T; ++m) sz += r[m];
+        }
     }
     sb = wave_sum(sb); sg = wave_sum(sg); sz = wave_sum(sz);
     if (lane != 0) return;
@@ -392,10 +396,13 @@ int mtbc_instnorm_lrelu_bwd(const mtbc_instnorm_args* a, void* stream) {
     }
     hipStream_t st = (hipStream_t)stream;
     if (a->dz8) {
+        const int T = mtbc_i_instnorm_bwd_c8_team(a);
+        if (T < 1) return MTBC_E_UNSUPPORTED;
+        if (want && a->workspace_bytes < (size_t)planes * (3 + T) * sizeof(float)) return MTBC_E_WORKSPACE;
         rc = mtbc_i_instnorm_bwd_c8(a, p.part, st); if (rc) return rc;
         if (want) {
             hipLaunchKernelGGL(in_dparam_kernel, dim3(a->C), dim3(64), 0, st, p.part, a->dgamma, a->dbeta,
-                               a->dbias_pre, a->N, a->C, a->accumulate_dparams);
+                               a->dbias_pre, a->N, a->C, a->accumulate_dparams, p.part + (size_t)3 * planes, T);
             MTBC_CHECK_LAUNCH();
         }
         return MTBC_OK;

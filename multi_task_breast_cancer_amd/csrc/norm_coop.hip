@@ -38,7 +38,8 @@ struct CoP {
     float* mean; float* rstd;
     const float* dy; long long dybs;
     unsigned short* dz8;                     // backward output
-    float* part;                             // backward: [N*C][3] = {sum g, sum g*xh, sum dz} or nullptr
+    float* part;                             // backward: [N*C][3] = {sum g, sum g*xh, 0} or nullptr
+    float* part3;                            // backward: [N*C][T] per-member sums of dz
     void* state;
 };
 
@@ -78,24 +79,37 @@ __device__ __forceinline__ void team_exchange(float mine, unsigned long long* mb
     ++seq;
     __syncthreads();
 }
-// sums of 8 per-thread values over the workgroup, result in every thread (fixed order: deterministic)
-__device__ __forceinline__ void block_reduce8(float (&s)[8], float (*red)[8]) {
+// Sums of NV per-thread values over the workgroup -> tot[0..NV) in LDS (fixed order: deterministic).  The per-channel
+// quantities stay in LDS and are read back (broadcast) where they are used: 8 channels x {pivot, sums, mean, scale,
+// shift, ...} as registers cost 60+ VGPRs (or as many spilled SGPRs) and with them the second resident workgroup.
+template <int NV>
+__device__ __forceinline__ void block_reduce_lds(float (&a)[NV], float (*red)[16], float* tot) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
-    for (int c = 0; c < 8; ++c) s[c] = wave_sum(s[c]);
+    for (int i = 0; i < NV; ++i) a[i] = wave_sum(a[i]);
     __syncthreads();
     if (lane == 0) {
 #pragma unroll
-        for (int c = 0; c < 8; ++c) red[wv][c] = s[c];
+        for (int i = 0; i < NV; ++i) red[wv][i] = a[i];
     }
     __syncthreads();
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
+    if (threadIdx.x < NV) {
         float t = 0.f;
 #pragma unroll
-        for (int w = 0; w < CO_WAVES; ++w) t += red[w][c];
-        s[c] = t;
+        for (int w = 0; w < CO_WAVES; ++w) t += red[w][threadIdx.x];
+        tot[threadIdx.x] = t;
     }
+    __syncthreads();
+}
+// tot[0..NV) of every member -> their sum in tot[0..NV) (member order: deterministic)
+template <int NV>
+__device__ __forceinline__ void team_sum(float* tot, unsigned long long* mb, int member, int T, unsigned& seq, unsigned epoch,
+                                         CoopHdr* hdr, float (*xch)[CO_NV]) {
+    if (T == 1) return;
+    const float mine = threadIdx.x < NV ? tot[threadIdx.x] : 0.f;
+    team_exchange<NV>(mine, mb, member, T, seq, epoch, hdr, xch);
+    if (threadIdx.x < NV) { float t = 0.f; for (int m = 0; m < T; ++m) t += xch[m][threadIdx.x]; tot[threadIdx.x] = t; }
+    __syncthreads();
 }
 __device__ __forceinline__ void coop_finish(CoopHdr* hdr, unsigned epoch) {
     __syncthreads();
@@ -109,89 +123,74 @@ __device__ __forceinline__ void coop_finish(CoopHdr* hdr, unsigned epoch) {
 }
 
 template <int PPT, bool F16>
-__global__ __launch_bounds__(CO_THREADS, 2) void in_fwd_coop_kernel(const CoP p) {
-    __shared__ float red[CO_WAVES][8];
+__global__ __launch_bounds__(CO_THREADS, 4) void in_fwd_coop_kernel(const CoP p) {
+    __shared__ float red[CO_WAVES][16];
     __shared__ float xch[CO_MAXT][CO_NV];
-    __shared__ float stat[16];
+    __shared__ float tot[16];
+    __shared__ float cst[3][8];              // mean, scale = gamma * rstd, shift = beta
     const int tid = threadIdx.x;
     CoopHdr* hdr = reinterpret_cast<CoopHdr*>(p.state);
     const unsigned epoch = __hip_atomic_load(&hdr->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int team = blockIdx.x / p.T, member = blockIdx.x % p.T;
     unsigned long long* mb = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(p.state) + CO_MAILBOX_OFF) + (size_t)team * CO_TEAM_WORDS;
     const int slab = p.HW / p.T;
+    const float inv = 1.0f / (float)p.HW;
     unsigned seq = 0;
     for (int item = team; item < p.items; item += p.nteams) {
         const int n = item / p.G8, g = item % p.G8;
-        const float* zb = p.z + ((size_t)n * p.C + 8 * g) * p.HW + (size_t)member * slab;
+        const float* zp = p.z + ((size_t)n * p.C + 8 * g) * p.HW;         // the 8 planes of the group
+        // raw buffer loads over the group's 8 planes: the plane stride rides in the scalar offset, so a load costs one
+        // 32-bit VGPR offset instead of a 64-bit address (the 32 addresses of a slab were half of the kernel's VGPRs)
+        const __amdgpu_buffer_rsrc_t zr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(zp), 0, 8 * p.HW * 4, 0x00020000);
+        const int plane_b = p.HW * 4;
         float v[8][PPT];
-        float s[8];
-#pragma unroll
-        for (int c = 0; c < 8; ++c) s[c] = 0.f;
 #pragma unroll
         for (int k = 0; k < PPT; ++k) {
             const int px = tid + CO_THREADS * k;
-            const bool ok = px < slab;
+            const int off = px < slab ? (member * slab + px) * 4 : 0;       // padding lanes read the pivot
 #pragma unroll
-            for (int c = 0; c < 8; ++c) { v[c][k] = ok ? zb[(size_t)c * p.HW + px] : 0.f; s[c] += v[c][k]; }
+            for (int c = 0; c < 8; ++c) v[c][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(zr, off, c * plane_b, 0));
         }
-        block_reduce8(s, red);
-        float lm[8], q[8];
-        const float cnt = (float)slab;
+        // One pass: sums of (x - pivot) and (x - pivot)^2 with the plane's first pixel as the pivot (the same for every
+        // member; a sample of the plane, so var = Q/HW - (S/HW)^2 cancels a few bits at most; padding lanes hold the pivot)
+        float sq[16];
 #pragma unroll
-        for (int c = 0; c < 8; ++c) { lm[c] = s[c] / cnt; q[c] = 0.f; }
+        for (int c = 0; c < 8; ++c) {
+            const float pv = zp[(size_t)c * p.HW];
+            float s = 0.f, q = 0.f;
 #pragma unroll
-        for (int k = 0; k < PPT; ++k) {
-            const bool ok = tid + CO_THREADS * k < slab;
-#pragma unroll
-            for (int c = 0; c < 8; ++c) { const float d = v[c][k] - lm[c]; q[c] += ok ? d * d : 0.f; }
+            for (int k = 0; k < PPT; ++k) { const float d = v[c][k] - pv; s += d; q += d * d; }
+            sq[c] = s; sq[8 + c] = q;
         }
-        block_reduce8(q, red);
-        float mean[8], rstd[8];
-        if (p.T == 1) {
-#pragma unroll
-            for (int c = 0; c < 8; ++c) { mean[c] = lm[c]; rstd[c] = 1.0f / sqrtf(q[c] / (float)p.HW + p.eps); }
-        } else {
-            float mine = 0.f;
-#pragma unroll
-            for (int c = 0; c < 8; ++c) { if (tid == c) mine = lm[c]; if (tid == 8 + c) mine = q[c]; }
-            team_exchange<16>(mine, mb, member, p.T, seq, epoch, hdr, xch);
-            if (tid < 8) {                       // Chan's combination of the members' (count, mean, M2), fixed order
-                float nt = 0.f, mu = 0.f, m2 = 0.f;
-                for (int m = 0; m < p.T; ++m) {
-                    const float d = xch[m][tid] - mu, nn = nt + cnt;
-                    mu += d * (cnt / nn);
-                    m2 += xch[m][8 + tid] + d * d * (nt * cnt / nn);
-                    nt = nn;
-                }
-                stat[tid] = mu; stat[8 + tid] = 1.0f / sqrtf(m2 / (float)p.HW + p.eps);
-            }
-            __syncthreads();
-#pragma unroll
-            for (int c = 0; c < 8; ++c) { mean[c] = stat[c]; rstd[c] = stat[8 + c]; }
+        block_reduce_lds<16>(sq, red, tot);
+        team_sum<16>(tot, mb, member, p.T, seq, epoch, hdr, xch);
+        if (tid < 8) {
+            const float ms = tot[tid] * inv;
+            const float mean = zp[(size_t)tid * p.HW] + ms;
+            const float rstd = 1.0f / sqrtf(fmaxf(tot[8 + tid] * inv - ms * ms, 0.f) + p.eps);
+            cst[0][tid] = mean; cst[1][tid] = (p.gamma ? p.gamma[8 * g + tid] : 1.f) * rstd; cst[2][tid] = p.beta ? p.beta[8 * g + tid] : 0.f;
+            if (member == 0) { p.mean[(size_t)n * p.C + 8 * g + tid] = mean; p.rstd[(size_t)n * p.C + 8 * g + tid] = rstd; }
         }
-        if (member == 0 && tid < 8) {
+        __syncthreads();
 #pragma unroll
-            for (int c = 0; c < 8; ++c) if (tid == c) { p.mean[(size_t)n * p.C + 8 * g + c] = mean[c]; p.rstd[(size_t)n * p.C + 8 * g + c] = rstd[c]; }
+        for (int c = 0; c < 8; ++c) {
+            const float mean = cst[0][c], ga = cst[1][c], be = cst[2][c];
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) { const float t = (v[c][k] - mean) * ga + be; v[c][k] = t > 0.f ? t : t * p.slope; }
         }
-        float ga[8], be[8];
-#pragma unroll
-        for (int c = 0; c < 8; ++c) { ga[c] = (p.gamma ? p.gamma[8 * g + c] : 1.f) * rstd[c]; be[c] = p.beta ? p.beta[8 * g + c] : 0.f; }
         unsigned short* ob = p.y8 + (((size_t)n * p.G8 + g) * p.HW + (size_t)member * slab) * 8;
         float* yb = p.y ? p.y + (size_t)n * p.ybs + (size_t)(8 * g) * p.HW + (size_t)member * slab : nullptr;
 #pragma unroll
         for (int k = 0; k < PPT; ++k) {
             const int px = tid + CO_THREADS * k;
             if (px < slab) {
-                float o[8];
-#pragma unroll
-                for (int c = 0; c < 8; ++c) { const float t = (v[c][k] - mean[c]) * ga[c] + be[c]; o[c] = t > 0.f ? t : t * p.slope; }
                 co_u32x4 w;
 #pragma unroll
-                for (int h = 0; h < 4; ++h) w[h] = co_pk<F16>(o[2 * h], o[2 * h + 1]);
+                for (int h = 0; h < 4; ++h) w[h] = co_pk<F16>(v[2 * h][k], v[2 * h + 1][k]);
                 *reinterpret_cast<co_u32x4*>(ob + (size_t)px * 8) = w;
                 if (yb) {
 #pragma unroll
-                    for (int c = 0; c < 8; ++c) yb[(size_t)c * p.HW + px] = o[c];
+                    for (int c = 0; c < 8; ++c) yb[(size_t)c * p.HW + px] = v[c][k];
                 }
             }
         }
@@ -200,103 +199,86 @@ __global__ __launch_bounds__(CO_THREADS, 2) void in_fwd_coop_kernel(const CoP p)
 }
 
 template <int PPT, bool F16>
-__global__ __launch_bounds__(CO_THREADS, 2) void in_bwd_coop_kernel(const CoP p) {
-    __shared__ float red[CO_WAVES][8];
+__global__ __launch_bounds__(CO_THREADS, 4) void in_bwd_coop_kernel(const CoP p) {
+    __shared__ float red[CO_WAVES][16];
     __shared__ float xch[CO_MAXT][CO_NV];
-    __shared__ float stat[16];
+    __shared__ float tot[16];
+    __shared__ float cst[3][8];              // k = rstd * gamma, m1 = S1 / HW, m2 = S2 / HW
     const int tid = threadIdx.x;
     CoopHdr* hdr = reinterpret_cast<CoopHdr*>(p.state);
     const unsigned epoch = __hip_atomic_load(&hdr->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int team = blockIdx.x / p.T, member = blockIdx.x % p.T;
     unsigned long long* mb = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(p.state) + CO_MAILBOX_OFF) + (size_t)team * CO_TEAM_WORDS;
     const int slab = p.HW / p.T;
+    const float inv = 1.0f / (float)p.HW;
     unsigned seq = 0;
     for (int item = team; item < p.items; item += p.nteams) {
         const int n = item / p.G8, g = item % p.G8;
         const size_t plane0 = (size_t)n * p.C + 8 * g;
-        const float* zb = p.z + plane0 * p.HW + (size_t)member * slab;
-        const float* gb = p.dy + (size_t)n * p.dybs + (size_t)(8 * g) * p.HW + (size_t)member * slab;
-        float mean[8], rstd[8], ga[8], be[8];
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            mean[c] = p.mean[plane0 + c]; rstd[c] = p.rstd[plane0 + c];
-            ga[c] = p.gamma ? p.gamma[8 * g + c] : 1.f; be[c] = p.beta ? p.beta[8 * g + c] : 0.f;
-        }
+        const __amdgpu_buffer_rsrc_t zr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.z + plane0 * p.HW), 0, 8 * p.HW * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dy + (size_t)n * p.dybs + (size_t)(8 * g) * p.HW), 0, 8 * p.HW * 4, 0x00020000);
+        const int plane_b = p.HW * 4;
         float xh[8][PPT], gy[8][PPT];
-        float s1[8], s2[8];
-#pragma unroll
-        for (int c = 0; c < 8; ++c) { s1[c] = 0.f; s2[c] = 0.f; }
 #pragma unroll
         for (int k = 0; k < PPT; ++k) {
             const int px = tid + CO_THREADS * k;
-            const bool ok = px < slab;
+            const int off = px < slab ? (member * slab + px) * 4 : 0x7ffffff0;      // out of range: the bounds check returns 0
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
-                const float zv = ok ? zb[(size_t)c * p.HW + px] : mean[c], dv = ok ? gb[(size_t)c * p.HW + px] : 0.f;
-                const float x = (zv - mean[c]) * rstd[c];
-                const float y = dv * ((x * ga[c] + be[c]) > 0.f ? 1.f : p.slope);
-                xh[c][k] = x; gy[c][k] = y;
-                s1[c] += y; s2[c] += y * x;
+                xh[c][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(zr, off, c * plane_b, 0));
+                gy[c][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(gr, off, c * plane_b, 0));
             }
         }
-        block_reduce8(s1, red);
-        block_reduce8(s2, red);
-        float S1[8], S2[8];
-        if (p.T == 1) {
+        float ss[16];
 #pragma unroll
-            for (int c = 0; c < 8; ++c) { S1[c] = s1[c]; S2[c] = s2[c]; }
-        } else {
-            float mine = 0.f;
+        for (int c = 0; c < 8; ++c) {
+            const float mean = p.mean[plane0 + c], rstd = p.rstd[plane0 + c];
+            const float ga = p.gamma ? p.gamma[8 * g + c] : 1.f, be = p.beta ? p.beta[8 * g + c] : 0.f;
+            float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-            for (int c = 0; c < 8; ++c) { if (tid == c) mine = s1[c]; if (tid == 8 + c) mine = s2[c]; }
-            team_exchange<16>(mine, mb, member, p.T, seq, epoch, hdr, xch);
-            if (tid < 16) { float t = 0.f; for (int m = 0; m < p.T; ++m) t += xch[m][tid]; stat[tid] = t; }
-            __syncthreads();
-#pragma unroll
-            for (int c = 0; c < 8; ++c) { S1[c] = stat[c]; S2[c] = stat[8 + c]; }
+            for (int k = 0; k < PPT; ++k) {
+                const bool ok = tid + CO_THREADS * k < slab;
+                const float x = ok ? (xh[c][k] - mean) * rstd : 0.f;
+                const float y = gy[c][k] * ((x * ga + be) > 0.f ? 1.f : p.slope);
+                xh[c][k] = x; gy[c][k] = y;
+                s1 += y; s2 += y * x;
+            }
+            ss[c] = s1; ss[8 + c] = s2;
         }
-        unsigned short* ob = p.dz8 + (((size_t)n * p.G8 + g) * p.HW + (size_t)member * slab) * 8;
+        block_reduce_lds<16>(ss, red, tot);
+        team_sum<16>(tot, mb, member, p.T, seq, epoch, hdr, xch);
+        if (tid < 8) {
+            cst[0][tid] = p.rstd[plane0 + tid] * (p.gamma ? p.gamma[8 * g + tid] : 1.f);
+            cst[1][tid] = tot[tid] * inv; cst[2][tid] = tot[8 + tid] * inv;
+            if (p.part && member == 0) { float* q = p.part + 3 * (plane0 + tid); q[0] = tot[tid]; q[1] = tot[8 + tid]; q[2] = 0.f; }
+        }
+        __syncthreads();
         float s3[8];
 #pragma unroll
-        for (int c = 0; c < 8; ++c) s3[c] = 0.f;
-        const float inv = 1.0f / (float)p.HW;
+        for (int c = 0; c < 8; ++c) {
+            const float kk = cst[0][c], m1 = cst[1][c], m2 = cst[2][c];
+            float t = 0.f;
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) {
+                const float o = (tid + CO_THREADS * k < slab) ? kk * (gy[c][k] - m1 - xh[c][k] * m2) : 0.f;
+                gy[c][k] = o; t += o;
+            }
+            s3[c] = t;
+        }
+        unsigned short* ob = p.dz8 + (((size_t)n * p.G8 + g) * p.HW + (size_t)member * slab) * 8;
 #pragma unroll
         for (int k = 0; k < PPT; ++k) {
             const int px = tid + CO_THREADS * k;
             if (px < slab) {
-                float o[8];
-#pragma unroll
-                for (int c = 0; c < 8; ++c) {
-                    o[c] = rstd[c] * ga[c] * (gy[c][k] - S1[c] * inv - xh[c][k] * (S2[c] * inv));
-                    s3[c] += o[c];
-                }
                 co_u32x4 w;
 #pragma unroll
-                for (int h = 0; h < 4; ++h) w[h] = co_pk<F16>(o[2 * h], o[2 * h + 1]);
+                for (int h = 0; h < 4; ++h) w[h] = co_pk<F16>(gy[2 * h][k], gy[2 * h + 1][k]);
                 *reinterpret_cast<co_u32x4*>(ob + (size_t)px * 8) = w;
             }
         }
-        if (p.part) {                            // {sum g, sum g*xh, sum dz} per plane for the parameter gradients
-            block_reduce8(s3, red);
-            float S3[8];
-            if (p.T == 1) {
-#pragma unroll
-                for (int c = 0; c < 8; ++c) S3[c] = s3[c];
-            } else {
-                float mine = 0.f;
-#pragma unroll
-                for (int c = 0; c < 8; ++c) if (tid == c) mine = s3[c];
-                team_exchange<8>(mine, mb, member, p.T, seq, epoch, hdr, xch);
-                if (tid < 8) { float t = 0.f; for (int m = 0; m < p.T; ++m) t += xch[m][tid]; stat[tid] = t; }
-                __syncthreads();
-#pragma unroll
-                for (int c = 0; c < 8; ++c) S3[c] = stat[c];
-            }
-            if (member == 0 && tid < 8) {
-#pragma unroll
-                for (int c = 0; c < 8; ++c)
-                    if (tid == c) { float* q = p.part + 3 * (plane0 + c); q[0] = S1[c]; q[1] = S2[c]; q[2] = S3[c]; }
-            }
+        if (p.part) {       // every member's share of sum dz; in_dparam_kernel adds them up (no second exchange)
+            block_reduce_lds<8>(s3, red, tot);
+            if (tid < 8) p.part3[(plane0 + tid) * p.T + member] = tot[tid];
         }
     }
     coop_finish(hdr, epoch);
@@ -337,17 +319,17 @@ int fill_coop(const mtbc_instnorm_args* a, CoP* p) {
     p->N = a->N; p->C = a->C; p->HW = a->H * a->W; p->G8 = a->C / 8; p->items = a->N * p->G8; p->f16 = a->out16_type == 2;
     p->eps = a->eps; p->slope = a->slope; p->z = a->z; p->gamma = a->gamma; p->beta = a->beta; p->y = a->y; p->ybs = a->y_batch_stride;
     p->y8 = reinterpret_cast<unsigned short*>(a->y8); p->mean = a->mean; p->rstd = a->rstd; p->dy = a->dy; p->dybs = a->dy_batch_stride;
-    p->dz8 = reinterpret_cast<unsigned short*>(a->dz8); p->part = nullptr; p->state = a->coop_state;
+    p->dz8 = reinterpret_cast<unsigned short*>(a->dz8); p->part = nullptr; p->part3 = nullptr; p->state = a->coop_state;
     return MTBC_OK;
 }
 CoPlan plan_fwd(int items, int HW) {
     static int cap[9] = {-1};
     if (cap[0] < 0) {
         cap[1] = resident_blocks(in_fwd_coop_kernel<1, false>); cap[2] = resident_blocks(in_fwd_coop_kernel<2, false>);
-        cap[4] = resident_blocks(in_fwd_coop_kernel<4, false>); cap[8] = resident_blocks(in_fwd_coop_kernel<8, false>);
+        cap[4] = resident_blocks(in_fwd_coop_kernel<4, false>); cap[8] = 0;      // 8 pixels per thread spill at 4 waves/SIMD
         cap[0] = 0;
     }
-    return plan_coop(items, HW, 8, cap);
+    return plan_coop(items, HW, 4, cap);
 }
 CoPlan plan_bwd(int items, int HW) {
     static int cap[9] = {-1};
@@ -382,18 +364,24 @@ int mtbc_i_instnorm_fwd_c8(const mtbc_instnorm_args* a, hipStream_t st) {
 #define MTBC_CO_F(PPT_)                                                                                  \
     do { if (p.f16) hipLaunchKernelGGL((in_fwd_coop_kernel<PPT_, true>), g, b, 0, st, p);                \
          else hipLaunchKernelGGL((in_fwd_coop_kernel<PPT_, false>), g, b, 0, st, p); } while (0)
-    if (pl.ppt == 8) MTBC_CO_F(8); else if (pl.ppt == 4) MTBC_CO_F(4); else if (pl.ppt == 2) MTBC_CO_F(2); else MTBC_CO_F(1);
+    if (pl.ppt == 4) MTBC_CO_F(4); else if (pl.ppt == 2) MTBC_CO_F(2); else MTBC_CO_F(1);
 #undef MTBC_CO_F
     MTBC_CHECK_LAUNCH();
     return MTBC_OK;
 }
 
+// members per team of the backward launch (the parameter-gradient partials are [N*C][3] + [N*C][T] floats)
+int mtbc_i_instnorm_bwd_c8_team(const mtbc_instnorm_args* a) {
+    if (!a || a->N <= 0 || a->C <= 0 || a->C % 8) return 0;
+    const CoPlan pl = plan_bwd(a->N * (a->C / 8), a->H * a->W);
+    return pl.ok ? pl.T : 0;
+}
 int mtbc_i_instnorm_bwd_c8(const mtbc_instnorm_args* a, float* part, hipStream_t st) {
     CoP p; int rc = fill_coop(a, &p); if (rc) return rc;
     if (!p.z || !p.dy || !p.dz8 || !p.mean || !p.rstd || (reinterpret_cast<uintptr_t>(p.dz8) & 15) || a->n_dy_extra != 0) return MTBC_E_BADARG;
     const CoPlan pl = plan_bwd(p.items, p.HW);
     if (!pl.ok) return MTBC_E_UNSUPPORTED;
-    p.T = pl.T; p.nteams = pl.nteams; p.part = part;
+    p.T = pl.T; p.nteams = pl.nteams; p.part = part; p.part3 = part ? part + (size_t)3 * a->N * a->C : nullptr;
     const dim3 g(pl.grid), b(CO_THREADS);
 #define MTBC_CO_B(PPT_)                                                                                  \
     do { if (p.f16) hipLaunchKernelGGL((in_bwd_coop_kernel<PPT_, true>), g, b, 0, st, p);                \

@@ -21,6 +21,9 @@ import os as _os
 _NOACC = _os.environ.get('MTBC_NOACC') == '1'     # timing probe only: results are wrong when set
 _NO_C8 = _os.environ.get('MTBC_NO_C8') == '1'     # A/B: 16-bit modes stage fp32 planar operands as before
 _NO_CT_LP = _os.environ.get('MTBC_NO_CT_LP') == '1'  # A/B: ConvT backward keeps fp32 MFMA operands in the 16-bit modes
+_NO_COOP = _os.environ.get('MTBC_NO_COOP') == '1'    # A/B: InstanceNorm by one-plane workgroups + pack instead of the cooperative kernels
+_COOP_MIN_FWD = int(_os.environ.get('MTBC_COOP_MIN_FWD', 16384))    # smallest plane (pixels) handed to the cooperative kernels
+_COOP_MIN_BWD = int(_os.environ.get('MTBC_COOP_MIN_BWD', 65536))
 _NO_P16 = _os.environ.get('MTBC_NO_P16') == '1'   # A/B / activation probes: InstanceNorm keeps writing fp32 y and dz
 
 
@@ -41,6 +44,7 @@ class Act:
     c8: Optional[torch.Tensor] = None  # 16-bit channel-blocked copy [N][C/8][H*W][8] read by the 3x3 convs' MFMAs
     planar_valid: bool = True          # False: the producer wrote only `c8` (ConvT forward in the 16-bit modes)
     planar_used: bool = False          # some op reads `data` (pool, ConvT, 1x1 heads, GAP, a planar-staged conv)
+    c8_used: bool = False              # some 3x3 conv reads `c8`
     in_op: Optional[object] = None     # the InstanceNorm forward op that writes this activation (conv cells)
     pack_op: Optional[object] = None   # the op that fills `c8` from `data`
 
@@ -178,11 +182,19 @@ class StepPlan:
         """The 16-bit channel-blocked copy of an activation (MTBC_LAYOUT_C8), converted ONCE -- by an op placed right
         behind the ops emitted so far, i.e. after its producer -- and then read by every 3x3 conv and weight gradient
         that consumes it (X0_0 of the U-Net++ feeds 4 convs and 4 wgrads): their staging becomes LDS-DMA."""
+        a.c8_used = True
         if a.c8 is None:
             a.c8 = self.alloc(self.N, a.C // 8, a.H * a.W, 8, dtype=torch.int16)
             a.pack_op = self._c8_pack_op(a.data, a.c8, a.C, a.H * a.W)
             self.fwd_ops.append(a.pack_op)
         return a.c8
+
+    def _coop_state(self) -> int:
+        """The zeroed mailbox block of the cooperative InstanceNorm kernels (one per plan: its programs share a stream)."""
+        if getattr(self, "_coop_buf", None) is None:
+            self._coop_buf = torch.zeros(self.lib.mtbc_instnorm_coop_state_bytes() // 4, dtype=torch.int32, device=self.dev)
+            self.keep.append(self._coop_buf)
+        return self._coop_buf.data_ptr()
 
     def _scratch16(self, attr: str, numel: int) -> torch.Tensor:
         """Shared 16-bit scratch of the backward pass (IN-backward -> pack -> wgrad -> dgrad run back to back on one
@@ -308,6 +320,14 @@ class StepPlan:
         op.kind = L.OP_IN_FWD
         op.u.inorm.y, op.u.inorm.y_batch_stride = y.data.data_ptr(), y.bstride
         y.in_op = op
+        # (measured: the cooperative kernels win on planes >= 128x128 forward / 256x256 backward; on small planes their
+        # barriers and 512-thread workgroups lose to the one-plane kernels + pack)
+        if self.compute and not _NO_C8 and not _NO_COOP and not self.force_direct and cout % 8 == 0 and H * W >= _COOP_MIN_FWD \
+                and self.lib.mtbc_instnorm_c8_supported(C.byref(op.u.inorm), 0):
+            # 16-bit modes: the cooperative kernel writes the channel-blocked operand tensor itself (and fp32 planes only
+            # if something reads them -- decided in finalize(), when all consumers are known)
+            y.c8 = self.alloc(N, cout // 8, H * W, 8, dtype=torch.int16)
+            op.u.inorm.y8, op.u.inorm.out16_type, op.u.inorm.coop_state = y.c8.data_ptr(), self.compute, self._coop_state()
         nb = self.lib.mtbc_instnorm_fwd_workspace(C.byref(op.u.inorm))      # > 0 only for planes larger than 64K elements
         if nb:
             self._need_ws(op, "inorm", nb)
@@ -322,7 +342,12 @@ class StepPlan:
             op.kind = L.OP_IN_BWD
             a = op.u.inorm
             a.dy, a.dy_batch_stride, a.dz = dy.data_ptr(), y.bstride, dy.data_ptr()
-            p16 = c8_bwd and not _NO_P16 and (H * W) % 4 == 0 and H * W <= 65536
+            a.n_dy_extra = len(y.extra_grads)
+            coop = c8_bwd and not _NO_COOP and H * W >= _COOP_MIN_BWD and self.lib.mtbc_instnorm_c8_supported(C.byref(a), 1)
+            if coop:        # one pass straight into the channel-blocked dz the wgrad / dgrad MFMAs read
+                dz8 = self._scratch16("_dz8_buf", N * cout * H * W)
+                a.dz8, a.out16_type, a.coop_state = dz8.data_ptr(), self.compute, self._coop_state()
+            p16 = c8_bwd and not coop and not _NO_P16 and (H * W) % 4 == 0 and H * W <= 65536
             if p16:         # dz feeds MFMAs only: 16-bit planar here, channel-blocked by the pack below
                 dz16 = self._scratch16("_dz16_buf", N * cout * H * W)
                 a.dz16, a.out16_type = dz16.data_ptr(), self.compute
@@ -341,10 +366,9 @@ class StepPlan:
                     assert acc == accb
                     a.dbias_pre = self.gv(bname).data_ptr()
                 a.accumulate_dparams = acc
-                self._need_ws(op, "inorm", N * cout * 3 * 4)
+                self._need_ws(op, "inorm", N * cout * (35 if coop else 3) * 4)
             self.bwd_ops.append(op)
-            dz8 = None
-            if c8_bwd:
+            if c8_bwd and not coop:
                 dz8 = self._scratch16("_dz8_buf", N * cout * H * W)
                 pk = self._c8_pack_op(dz16 if p16 else dy, dz8, cout, H * W)
                 if p16:
@@ -701,11 +725,18 @@ class StepPlan:
         """Conv-cell outputs that ONLY 3x3 convs read (the first conv of every double-conv block): InstanceNorm writes
         them as 16-bit planes instead of fp32 and the pack re-blocks 16-bit words -- 4 + 2 + 2 + 2 instead of
         4 + 4 + 4 + 2 bytes per element, same values (one RNE either way)."""
-        if _NO_P16 or not self.compute:
+        if not self.compute:
             return
         for a in self.acts.values():
             hw = a.H * a.W
-            if a.in_op is None or a.pack_op is None or a.planar_used or hw % 4 or hw > 65536:
+            if a.in_op is not None and a.in_op.u.inorm.y8:          # cooperative kernel: drop the output nobody reads
+                if not a.c8_used:
+                    a.in_op.u.inorm.y8 = None
+                elif not a.planar_used:
+                    a.in_op.u.inorm.y = None
+                    a.planar_valid = False
+                continue
+            if _NO_P16 or a.in_op is None or a.pack_op is None or a.planar_used or hw % 4 or hw > 65536:
                 continue
             y16 = self.alloc(a.N, a.C, a.H, a.W, dtype=torch.int16)
             a.in_op.u.inorm.y16, a.in_op.u.inorm.out16_type = y16.data_ptr(), self.compute
