@@ -216,9 +216,13 @@ typedef struct {
                                         stride in 16-bit elements) -- same fp32 arithmetic, one RNE at the store, i.e.
                                         bit-identical to the planar forward followed by mtbc_c8_pack                */
     int32_t y_type;                  /* with y_layout C8: 1 = bf16, 2 = fp16                                        */
+    int32_t x_layout;                /* fwd: MTBC_LAYOUT_C8 = x is ALSO 16-bit channel-blocked (type y_type, batch stride in
+                                        16-bit elements; needs y_layout C8): the forward then runs on the 16-bit MFMA
+                                        with rounded x and w (fp32 accumulate, bias, one RNE) -- k == 2, Cin % 8 == 0  */
 } mtbc_convT_args;
-/* 1 if mtbc_convT_fwd takes these arguments with y_layout = MTBC_LAYOUT_C8 (k == 2, Cin <= 64, Cout <= 48, Cout % 8 == 0,
- * H*W % 32 == 0), else 0: the caller then keeps the planar forward and converts with mtbc_c8_pack.              */
+/* 1 if mtbc_convT_fwd takes these arguments with y_layout = MTBC_LAYOUT_C8 (fp32 x: k == 2, Cin <= 64, Cout <= 48,
+ * Cout % 8 == 0, H*W % 32 == 0; x_layout C8: k == 2, channel counts % 8 == 0, H*W % 32 == 0), else 0: the caller then
+ * keeps the planar forward and converts with mtbc_c8_pack.                                                     */
 int mtbc_convT_fwd_c8_supported(const mtbc_convT_args* a);
 
 size_t mtbc_convT_wgrad_workspace(const mtbc_convT_args* a);

@@ -104,6 +104,8 @@ bool mtbc_i_convT2_fwd_ok(const mtbc_convT_args* a);
 int mtbc_i_convT2_fwd(const mtbc_convT_args* a, hipStream_t st);
 bool mtbc_i_convT2_fwd_c8_ok(const mtbc_convT_args* a);
 int mtbc_i_convT2_fwd_c8(const mtbc_convT_args* a, hipStream_t st);
+bool mtbc_i_convT2_fwd_lp_c8_ok(const mtbc_convT_args* a);
+int mtbc_i_convT2_fwd_lp_c8(const mtbc_convT_args* a, hipStream_t st);
 bool mtbc_i_convT2_dgrad_ok(const mtbc_convT_args* a);
 bool mtbc_i_convT2_wgrad_ok(const mtbc_convT_args* a);
 void mtbc_i_convT2_wgrad_plan(const mtbc_convT_args* a, int* steps_per_split, int* nsplit);

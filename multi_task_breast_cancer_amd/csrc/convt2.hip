@@ -455,6 +455,106 @@ __global__ __launch_bounds__(256, 2) void convT2_fwd_c8_kernel(const Ct2P p, con
     }
 }
 
+// Forward on the 16-bit MFMA with BOTH tensors channel-blocked (x_layout = y_layout = MTBC_LAYOUT_C8): a stored piece of x
+// (8 channels of one pixel) IS a lane's share of the B fragment of v_mfma_f32_16x16x32, so x goes straight from HBM into
+// fragments (16-byte loads, 256 contiguous bytes per 16 lanes); the weights of the block's channel slice sit in LDS as
+// 16-bit rows [(position, channel)][ci] (80-byte-style padded stride), read as A fragments with ds_read_b128.  A wave =
+// 32 input pixels x (4 positions x 16*MTC channels); fp32 accumulate, bias, one RNE, 8-byte stores into the output pieces.
+// The level-0 up-convolution (48 -> 48 @128x128, 9.7 GFLOP) was fp32-MFMA-bound at 0.12 ms; wider ones took the generic
+// fp32 GEMM + a pack pass.
+template <int MTC, bool F16>
+__global__ __launch_bounds__(256, 2) void convT2_fwd_lp_c8_kernel(const Ct2P p, const float* __restrict__ bias, const unsigned short* __restrict__ x8,
+                                                                  long long xbs, unsigned short* __restrict__ y8, long long ybs, int kpad, int wrow) {
+    typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+    typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+    typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+    extern __shared__ __attribute__((aligned(16))) unsigned short Wl[];          // [4 * 16*MTC rows][wrow], then bias[16*MTC] (fp32)
+    constexpr int CB = 16 * MTC;
+    float* bias_s = reinterpret_cast<float*>(Wl + 4 * CB * wrow);
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int j = lane & 15, kg = lane >> 4;
+    const int HW = p.H * p.W, oW = 2 * p.W, oHW = 4 * HW;
+    const int cb0 = blockIdx.y * CB;
+    for (int idx = tid; idx < 4 * CB * kpad; idx += 256) {
+        const int ci = idx % kpad, row = idx / kpad, pos = row / CB, co = cb0 + row % CB;
+        const float w = (ci < p.Cin && co < p.Cout) ? p.w[((size_t)ci * p.Cout + co) * 4 + pos] : 0.f;
+        unsigned short h;
+        if constexpr (F16) h = __builtin_bit_cast(unsigned short, (_Float16)w); else h = __builtin_bit_cast(unsigned short, (__bf16)w);
+        Wl[row * wrow + ci] = h;
+    }
+    for (int c = tid; c < CB; c += 256) bias_s[c] = (bias && cb0 + c < p.Cout) ? bias[cb0 + c] : 0.f;
+    __syncthreads();
+    const int nchunks = kpad / 32, groups8 = p.Cin / 8;
+    const int pgroups = HW / 32;
+    const long long ntasks = (long long)p.N * pgroups;
+    for (long long gi = (long long)blockIdx.x * 4 + wv; gi < ntasks; gi += (long long)gridDim.x * 4) {
+        const int n = (int)(gi / pgroups), gg = (int)(gi % pgroups);
+        const unsigned short* xn = x8 + (size_t)n * xbs + (size_t)(gg * 32 + j) * 8;
+        f32x4 acc[4][MTC][2];
+#pragma unroll
+        for (int pos = 0; pos < 4; ++pos)
+#pragma unroll
+            for (int m = 0; m < MTC; ++m) { acc[pos][m][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[pos][m][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+        u32x4_t b[2][2];
+        auto loadb = [&](int ch, auto SL) {          // register-set index is a compile-time constant (S0 / S1)
+            constexpr int slot = decltype(SL)::value;
+            const int grp = ch * 4 + kg;
+            const unsigned short* q = xn + (size_t)(grp < groups8 ? grp : 0) * HW * 8;
+#pragma unroll
+            for (int g = 0; g < 2; ++g) b[slot][g] = *reinterpret_cast<const u32x4_t*>(q + g * 16 * 8);
+        };
+        auto compute = [&](int ch, auto SL) {
+            constexpr int cur = decltype(SL)::value;
+            const bool live = ch * 4 + kg < groups8;                    // a ragged last chunk: absent groups contribute zeros
+            u32x4_t bz[2];
+#pragma unroll
+            for (int g = 0; g < 2; ++g) bz[g] = live ? b[cur][g] : (u32x4_t){0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int pos = 0; pos < 4; ++pos)
+#pragma unroll
+                for (int m = 0; m < MTC; ++m) {
+                    const u32x4_t a = *reinterpret_cast<const u32x4_t*>(Wl + ((pos * CB + m * 16 + j) * wrow + ch * 32 + 8 * kg));
+#pragma unroll
+                    for (int g = 0; g < 2; ++g) {
+                        if constexpr (F16) acc[pos][m][g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, bz[g]), acc[pos][m][g], 0, 0, 0);
+                        else acc[pos][m][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, bz[g]), acc[pos][m][g], 0, 0, 0);
+                    }
+                }
+        };
+        loadb(0, S0{});
+        for (int ch = 0; ch < nchunks; ch += 2) {
+            if (ch + 1 < nchunks) loadb(ch + 1, S1{});
+            compute(ch, S0{});
+            if (ch + 1 < nchunks) {
+                if (ch + 2 < nchunks) loadb(ch + 2, S0{});
+                compute(ch + 1, S1{});
+            }
+        }
+        unsigned short* yn = y8 + (size_t)n * ybs + 4 * (kg & 1);
+        int obase[2];
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const int pix = gg * 32 + 16 * g + j;
+            obase[g] = (2 * (pix / p.W)) * oW + 2 * (pix % p.W);
+        }
+#pragma unroll
+        for (int m = 0; m < MTC; ++m) {
+            const int c4 = cb0 + 16 * m + 4 * kg;
+            if (c4 >= p.Cout) continue;
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(bias_s + 16 * m + 4 * kg);
+#pragma unroll
+            for (int pos = 0; pos < 4; ++pos) {
+                unsigned short* d = yn + ((size_t)(c4 >> 3) * oHW + (pos >> 1) * oW + (pos & 1)) * 8;
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    const f32x4 v = acc[pos][m][g] + bv;
+                    *reinterpret_cast<uint2*>(d + (size_t)obase[g] * 8) = make_uint2(cvt_pk16<F16>(v[0], v[1]), cvt_pk16<F16>(v[2], v[3]));
+                }
+            }
+        }
+    }
+}
+
 bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
 
 void fill(const mtbc_convT_args* a, Ct2P* p) {
@@ -543,6 +643,47 @@ int mtbc_i_convT2_fwd_c8(const mtbc_convT_args* a, hipStream_t st) {
     if (a->y_type == 2) { if (ki <= 8) MTBC_CT2F8(8, true); else if (ki <= 12) MTBC_CT2F8(12, true); else MTBC_CT2F8(16, true); }
     else { if (ki <= 8) MTBC_CT2F8(8, false); else if (ki <= 12) MTBC_CT2F8(12, false); else MTBC_CT2F8(16, false); }
 #undef MTBC_CT2F8
+    MTBC_CHECK_LAUNCH();
+    return MTBC_OK;
+}
+
+// forward with channel-blocked 16-bit input AND output (x_layout = y_layout = MTBC_LAYOUT_C8): the 16-bit MFMA kernel
+static int lp_c8_mtc(const mtbc_convT_args* a, int* kpad, int* wrow, size_t* lds) {
+    *kpad = (a->Cin + 31) / 32 * 32; *wrow = *kpad + 8;
+    const int cp16 = (a->Cout + 15) / 16;
+    for (int mtc = cp16 < 3 ? cp16 : 3; mtc >= 1; --mtc) {
+        *lds = (size_t)4 * 16 * mtc * *wrow * 2 + 16 * mtc * sizeof(float);
+        if (*lds <= 72 * 1024) return mtc;
+    }
+    return 0;
+}
+bool mtbc_i_convT2_fwd_lp_c8_ok(const mtbc_convT_args* a) {
+    int kpad, wrow; size_t lds;
+    return a->k == 2 && (a->H * a->W) % 32 == 0 && a->Cin % 8 == 0 && a->Cout % 8 == 0 && (a->y_type == 1 || a->y_type == 2) &&
+           al16(a->y) && al16(a->x) && a->y_batch_stride % 8 == 0 && a->x_batch_stride % 8 == 0 && lp_c8_mtc(a, &kpad, &wrow, &lds) > 0;
+}
+int mtbc_i_convT2_fwd_lp_c8(const mtbc_convT_args* a, hipStream_t st) {
+    Ct2P p; fill(a, &p);
+    int kpad, wrow; size_t lds;
+    const int mtc = lp_c8_mtc(a, &kpad, &wrow, &lds);
+    const long long tasks = (long long)a->N * (a->H * a->W / 32);
+    const int yb = cdiv(a->Cout, 16 * mtc);
+    int gx = 512 / yb; if (gx < 1) gx = 1;
+    if ((long long)gx * 4 > tasks) gx = (int)cdiv64(tasks, 4);
+    const dim3 grid(gx, yb);
+    const unsigned short* x8 = reinterpret_cast<const unsigned short*>(a->x);
+    unsigned short* y8 = reinterpret_cast<unsigned short*>(a->y);
+#define MTBC_CT2LP(MTC_, F16_)                                                                                             \
+    do {                                                                                                                   \
+        static bool attr = false;                                                                                          \
+        if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&convT2_fwd_lp_c8_kernel<MTC_, F16_>),        \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); attr = true; }     \
+        hipLaunchKernelGGL((convT2_fwd_lp_c8_kernel<MTC_, F16_>), grid, dim3(256), lds, st, p, a->bias, x8,                \
+                           (long long)a->x_batch_stride, y8, (long long)a->y_batch_stride, kpad, wrow);                    \
+    } while (0)
+    if (a->y_type == 2) { if (mtc == 3) MTBC_CT2LP(3, true); else if (mtc == 2) MTBC_CT2LP(2, true); else MTBC_CT2LP(1, true); }
+    else { if (mtc == 3) MTBC_CT2LP(3, false); else if (mtc == 2) MTBC_CT2LP(2, false); else MTBC_CT2LP(1, false); }
+#undef MTBC_CT2LP
     MTBC_CHECK_LAUNCH();
     return MTBC_OK;
 }

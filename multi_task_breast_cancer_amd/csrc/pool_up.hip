@@ -330,6 +330,11 @@ extern "C" {
 int mtbc_convT_fwd(const mtbc_convT_args* a, void* stream) {
     CtP p; int rc = fill_ct(a, &p); if (rc) return rc;
     if (!p.x || !p.w || !p.y) return MTBC_E_BADARG;
+    if (a->x_layout == MTBC_LAYOUT_C8) {        // both tensors 16-bit channel-blocked: the 16-bit MFMA kernel or nothing
+        if (a->y_layout != MTBC_LAYOUT_C8) return MTBC_E_BADARG;
+        return mtbc_i_convT2_fwd_lp_c8_ok(a) ? mtbc_i_convT2_fwd_lp_c8(a, (hipStream_t)stream) : MTBC_E_UNSUPPORTED;
+    }
+    if (a->x_layout != MTBC_LAYOUT_PLANAR) return MTBC_E_BADARG;
     if (a->y_layout == MTBC_LAYOUT_C8)          // 16-bit channel-blocked output: the direct-to-fragment kernel or nothing
         return mtbc_i_convT2_fwd_c8_ok(a) ? mtbc_i_convT2_fwd_c8(a, (hipStream_t)stream) : MTBC_E_UNSUPPORTED;
     if (a->y_layout != MTBC_LAYOUT_PLANAR) return MTBC_E_BADARG;
@@ -347,6 +352,7 @@ int mtbc_convT_fwd(const mtbc_convT_args* a, void* stream) {
 int mtbc_convT_fwd_c8_supported(const mtbc_convT_args* a) {
     CtP p;
     if (!a || fill_ct(a, &p)) return 0;
+    if (a->x_layout == MTBC_LAYOUT_C8) return a->y_layout == MTBC_LAYOUT_C8 && mtbc_i_convT2_fwd_lp_c8_ok(a) ? 1 : 0;
     return mtbc_i_convT2_fwd_c8_ok(a) ? 1 : 0;
 }
 int mtbc_convT_dgrad(const mtbc_convT_args* a, void* stream) {

@@ -454,14 +454,20 @@ class StepPlan:
         op.kind = L.OP_CONVT_FWD
         if self.compute and not _NO_C8 and cout % 8 == 0:
             # 16-bit modes: the up-sampled tensor feeds 3x3 convs only -- write it straight into their channel-blocked
-            # 16-bit layout (same fp32 arithmetic, one RNE: bit-identical to planar forward + pack) when the kernel
-            # takes the shape; y.data then stays unwritten
+            # 16-bit layout; y.data then stays unwritten.  First choice: the 16-bit MFMA forward that also READS the
+            # channel-blocked copy of x (the same one the 3x3 convs read); else the fp32-MFMA forward on fp32 x (same
+            # arithmetic as planar forward + pack); else planar output + pack.
             a = op.u.convT
             y.c8 = self.alloc(self.N, cout // 8, y.H * y.W, 8, dtype=torch.int16)
             a.y, a.y_batch_stride, a.y_layout, a.y_type = y.c8.data_ptr(), y.bstride, L.LAYOUT_C8, self.compute
-            if not self.lib.mtbc_convT_fwd_c8_supported(C.byref(a)):
-                y.c8 = None
-                a.y, a.y_layout, a.y_type = y.data.data_ptr(), L.LAYOUT_PLANAR, 0
+            a.x_layout = L.LAYOUT_C8
+            if k == 2 and x.C % 8 == 0 and not _NO_CT_LP and self.lib.mtbc_convT_fwd_c8_supported(C.byref(a)):
+                a.x = self.c8_of(x).data_ptr()
+            else:
+                a.x_layout = L.LAYOUT_PLANAR
+                if not self.lib.mtbc_convT_fwd_c8_supported(C.byref(a)):
+                    y.c8 = None
+                    a.y, a.y_layout, a.y_type = y.data.data_ptr(), L.LAYOUT_PLANAR, 0
             y.planar_valid = y.c8 is None
         self.fwd_ops.append(op)
 

@@ -390,6 +390,23 @@ def convT_fwd_c8(x, w, bias, k, compute: int) -> "C8":
     return C8(y, (N, cout, H * k, W * k), compute)
 
 
+def convT_fwd_c8_lp(x8: "C8", w, bias, k) -> "C8":
+    """ConvTranspose2d(k = s = 2) forward on the 16-bit MFMA, input and output channel-blocked (x_layout = y_layout = C8)."""
+    _chk(w, bias)
+    N, Cin, H, W = x8.shape
+    cout = w.shape[1]
+    a = L.ConvTArgs()
+    a.N, a.H, a.W, a.Cin, a.Cout, a.k = N, H, W, Cin, cout, k
+    a.x, a.x_batch_stride, a.w = x8.data.data_ptr(), Cin * H * W, w.data_ptr()
+    y = torch.empty(N, cout // 8, H * k * W * k, 8, dtype=torch.int16, device=w.device)
+    a.bias, a.y, a.y_batch_stride = _p(bias), y.data_ptr(), cout * H * k * W * k
+    a.y_layout, a.y_type, a.x_layout = L.LAYOUT_C8, x8.compute, L.LAYOUT_C8
+    if not L.load().mtbc_convT_fwd_c8_supported(C.byref(a)):
+        raise L.MtbcError("convT_fwd: shape not supported with channel-blocked input and output")
+    L.check(L.load().mtbc_convT_fwd(C.byref(a), _s()), "convT_fwd(c8 -> c8)")
+    return C8(y, (N, cout, H * k, W * k), x8.compute)
+
+
 def convT_dgrad(x, w, dy, k, dx=None, accumulate=False, compute=0):
     _chk(x, w, dy, dx)
     if dx is None:

@@ -377,26 +377,27 @@ class _LowpConv3x3(torch.autograd.Function):
 
 
 class _LowpConvT2Bwd(torch.autograd.Function):
-    """ConvTranspose2d(k = s = 2) of the 16-bit modes: exact forward (the product's forward is an fp32 MFMA), backward
+    """ConvTranspose2d(k = s = 2) of the 16-bit modes: forward MFMA on rounded x, w (fp32 accumulate + bias), backward
     MFMAs on rounded operands (dgrad: dy, w; wgrad: x, dy), bias gradient from the unrounded dy -- convt2.hip."""
 
     @staticmethod
-    def forward(ctx, x, w, b, lp):
+    def forward(ctx, x, w, b, lp, fwd_lp, bwd_lp):
         ctx.save_for_backward(x, w)
-        ctx.lp, ctx.has_b = lp, b is not None
-        return torch.conv_transpose2d(x, w, b, 2)
+        ctx.lp, ctx.has_b, ctx.bwd_lp = lp, b is not None, bwd_lp
+        r = (lambda t: t.to(lp).to(t.dtype)) if fwd_lp else (lambda t: t)
+        return torch.conv_transpose2d(r(x), r(w), b, 2)
 
     @staticmethod
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
-        r = lambda t: t.to(ctx.lp).to(t.dtype)
+        r = (lambda t: t.to(ctx.lp).to(t.dtype)) if ctx.bwd_lp else (lambda t: t)
         dyr = r(dy)
         dx = torch.conv2d(dyr, r(w), None, 2)
         with torch.enable_grad():
             wz = torch.zeros_like(w, requires_grad=True)
             (dw,) = torch.autograd.grad(torch.conv_transpose2d(r(x).detach(), wz, None, 2), wz, dyr)
         db = dy.sum(dim=(0, 2, 3)) if ctx.has_b else None
-        return dx, dw, db, None
+        return dx, dw, db, None, None, None
 
 
 class lowp_conv3x3:
@@ -425,8 +426,11 @@ class lowp_conv3x3:
             # same eligibility as the product (engine.convT): the direct-to-fragment backward kernels of convt2.hip
             H, W = input.shape[-2:]
             if (tuple(weight.shape[-2:]) == (2, 2) and stride in (2, (2, 2)) and padding in (0, (0, 0)) and groups == 1
-                    and (H * W) % 32 == 0 and W % 8 == 0 and id(weight) not in exempt):
-                return _LowpConvT2Bwd.apply(input, weight, bias, lp)
+                    and (H * W) % 32 == 0 and id(weight) not in exempt):
+                fwd_lp = weight.shape[0] % 8 == 0 and weight.shape[1] % 8 == 0      # forward: 16-bit MFMA on channel-blocked x
+                bwd_lp = W % 8 == 0 and weight.shape[1] % 2 == 0
+                if fwd_lp or bwd_lp:
+                    return _LowpConvT2Bwd.apply(input, weight, bias, lp, fwd_lp, bwd_lp)
             return orig_t(input, weight, bias, stride, padding, output_padding, groups, dilation)
 
         F.conv_transpose2d = conv_transpose2d

@@ -566,3 +566,19 @@ def test_cooperative_instnorm_into_channel_blocked_layout(N, C, H, W, affine, co
         assert torch.allclose(dg2, dg, rtol=1e-4, atol=1e-3 * max(1.0, dg.abs().max().item()))
         assert torch.allclose(dbt2, dbt, rtol=1e-4, atol=1e-3 * max(1.0, dbt.abs().max().item()))
     assert ops.coop_error(DEV) == 0
+
+
+@pytest.mark.parametrize("compute", [1, 2])
+@pytest.mark.parametrize("N,Cin,Cout,H,W", [(2, 48, 48, 16, 16), (3, 24, 24, 8, 12), (1, 64, 40, 16, 8), (2, 96, 48, 8, 8),
+                                            (2, 384, 192, 4, 8), (1, 512, 512, 8, 4), (2, 16, 8, 4, 8)])
+def test_convT_forward_on_the_16bit_mfma_with_channel_blocked_tensors(N, Cin, Cout, H, W, compute):
+    """x and w rounded to the 16-bit type, fp32 accumulation, bias, ONE rounding of the result: against fp64 on the
+    rounded operands, to one 16-bit ulp."""
+    g = _g(N + Cin + Cout + H + compute)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cin, Cout, 2, 2, generator=g) * (1.0 / Cin) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    want = F.conv_transpose2d(_round16(x, compute).double(), _round16(w, compute).double(), b.double(), stride=2).float()
+    got = ops.convT_fwd_c8_lp(ops.C8.pack(x.to(DEV), compute), w.to(DEV), b.to(DEV), 2).unpack().cpu()
+    ulp = 2.0 ** -7 if compute == 1 else 2.0 ** -10
+    assert bool(((got - want).abs() <= ulp * want.abs() + 1e-5).all()), (got - want).abs().max().item()
