@@ -1557,13 +1557,16 @@ constexpr size_t W2_LDS = 2 * 18 * 64 * sizeof(f32x4);      // the end-of-block 
 // (32 co x 32 ci, 4x32-pixel tiles, waves = ci-tile x row-half); no staging registers -> 4 blocks per CU.
 // dbias rides along on the matrix pipe: dz x ones on the ci-block-0 / ci-tile-0 waves.
 // Measured stand-alone (tools/experiments/c8_wgrad_probe.hip): 144->24 @256x256 N=32 0.30 ms against 0.65 ms.
-constexpr int C8W_TH = 4, C8W_TW = 32, C8W_HR = 6, C8W_LW = 34;
-constexpr int C8W_XG = C8W_HR * C8W_LW;          // 204 pieces per input-channel group
-constexpr int C8W_ZG = C8W_TH * C8W_TW + 4;      // 132 pieces per output-channel group
-constexpr int C8W_XI = (C8W_XG + 63) / 64;       // 4 DMA instructions per group (the last one 12 lanes wide)
-constexpr int C8W_BUF16 = (4 * C8W_XG + 16 + 4 * C8W_ZG) * 8;      // 16-bit elements of the stage buffer
+// Tile geometries (128 pixels either way = 4 K-steps of 32 pixels): GEO 0 = 4 rows x 32 columns, a K-step is one tile row
+// and lane group kg owns columns 8kg..8kg+7; GEO 1 (maps <= 16 wide) = 8 rows x 16 columns, a K-step is two tile rows and
+// kg owns row kg>>1, columns 8(kg&1)..+7 -- the 4x32 tile wasted half of every MFMA on the 16x16 levels.
+template <int GEO> struct C8WGeo;
+template <> struct C8WGeo<0> { static constexpr int TH = 4, TW = 32, HR = 6, LW = 34; };
+template <> struct C8WGeo<1> { static constexpr int TH = 8, TW = 16, HR = 10, LW = 18; };
+constexpr int C8W_ZG = 128 + 4;                  // 132 pieces per output-channel group (2112 B = 64 mod 256)
 constexpr size_t C8W_LDS = (2 * 18 + 2) * 64 * sizeof(f32x4);      // the end-of-block reduction is the larger user (38 KB)
-static_assert(C8W_BUF16 * 2 <= (int)C8W_LDS, "stage buffer must fit the reduction area");
+static_assert((4 * C8WGeo<0>::HR * C8WGeo<0>::LW + 16 + 4 * C8W_ZG) * 16 <= (int)C8W_LDS, "stage buffer must fit the reduction area");
+static_assert((C8WGeo<0>::HR * C8WGeo<0>::LW * 16) % 256 == 192 && (C8WGeo<1>::HR * C8WGeo<1>::LW * 16) % 256 == 64, "group strides: 64/192 mod 256 B");
 struct WgC8P {
     int N, H, W, Cin, Cout;
     SegTable in;                       // ptr = 16-bit base, bstride in 16-bit elements, channels % 8 == 0
@@ -1572,13 +1575,15 @@ struct WgC8P {
     float* dbias_partial;              // [nsplit][Cout] or nullptr
     int tiles_x, tiles_y, total_tiles, tiles_per_split, ciblocks;
 };
-template <bool F16>
+template <bool F16, int GEO>
 __global__ __launch_bounds__(256, 4) void conv3x3_wgrad_c8_kernel(const WgC8P p) {
+    using G = C8WGeo<GEO>;
     using T = LP<F16>;
     typedef short s16x4 __attribute__((ext_vector_type(4)));
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     typedef __attribute__((address_space(3))) s16x4* lds_s16x4_t;
-    constexpr int TW = C8W_TW, LW = C8W_LW, XG = C8W_XG, ZG = C8W_ZG, ZBASE = (4 * XG + 16) * 8;
+    constexpr int TW = G::TW, LW = G::LW, XG = G::HR * G::LW, ZG = C8W_ZG, ZBASE = (4 * XG + 16) * 8;
+    constexpr int XI = (XG + 63) / 64;                  // DMA instructions per input-channel group (the last one partly masked)
     extern __shared__ __attribute__((aligned(16))) unsigned short smemc8[];
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int HW = p.H * p.W;
@@ -1594,19 +1599,19 @@ __global__ __launch_bounds__(256, 4) void conv3x3_wgrad_c8_kernel(const WgC8P p)
     const long long xbs = sr.bs;
     const unsigned short* xgrp = reinterpret_cast<const unsigned short*>(sr.ptr) + (size_t)((xg_ok ? cx : 0) - sr.cb) * HW;
     const unsigned short* zgrp = p.dz + (size_t)(zg_ok ? cz : 0) * HW;
-    int xrow[C8W_XI], xcol[C8W_XI];
+    int xrow[XI], xcol[XI];
 #pragma unroll
-    for (int i = 0; i < C8W_XI; ++i) { const int s = 64 * i + lane; xrow[i] = s / LW - 1; xcol[i] = s % LW - 1; }
-    const int zrow = lane / TW, zcol = lane % TW;          // instruction i adds 2 rows
+    for (int i = 0; i < XI; ++i) { const int s = 64 * i + lane; xrow[i] = s / LW - 1; xcol[i] = s % LW - 1; }
+    const int zrow = lane / TW, zcol = lane % TW;          // instruction i adds 64 / TW rows
     auto issue = [&](int tile) {
         int t = tile;
         const int tx = t % p.tiles_x; t /= p.tiles_x;
         const int ty = t % p.tiles_y; t /= p.tiles_y;
-        const int n = t, x0 = tx * TW, y0 = ty * C8W_TH;
+        const int n = t, x0 = tx * TW, y0 = ty * G::TH;
         const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(xgrp + (size_t)n * xbs), 0, xg_ok ? HW * 16 : 0, 0x00020000);
         const __amdgpu_buffer_rsrc_t zr = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(zgrp + (size_t)n * p.Cout * HW), 0, zg_ok ? HW * 16 : 0, 0x00020000);
 #pragma unroll
-        for (int i = 0; i < C8W_XI; ++i) {
+        for (int i = 0; i < XI; ++i) {
             const int y = y0 + xrow[i], x = x0 + xcol[i];
             const bool ok = y >= 0 && y < p.H && x >= 0 && x < p.W;
             const unsigned voff = ok ? 16u * (unsigned)(y * p.W + x) : 0xfffffff0u;
@@ -1615,7 +1620,7 @@ __global__ __launch_bounds__(256, 4) void conv3x3_wgrad_c8_kernel(const WgC8P p)
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int y = y0 + zrow + 2 * i, x = x0 + zcol;
+            const int y = y0 + zrow + (64 / TW) * i, x = x0 + zcol;
             const unsigned voff = (y < p.H && x < p.W) ? 16u * (unsigned)(y * p.W + x) : 0xfffffff0u;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(zr, (lds_ptr_t)(smemc8 + ZBASE + (wv * ZG + 64 * i) * 8), 16, voff, 0, 0, 0);
         }
@@ -1625,8 +1630,9 @@ __global__ __launch_bounds__(256, 4) void conv3x3_wgrad_c8_kernel(const WgC8P p)
     const int it = wv & 1, kh = wv >> 1;
     // transposed-read addresses: lane 4q+pp of a 16-lane group supplies row q (a pixel) and columns 4pp..4pp+3 (channels;
     // columns 0-7 from the first 8-channel group of the tile, 8-15 from the second) of the 4x16 block
-    const int zoff = ZBASE + ((pp >> 1) * ZG + 8 * kg + q) * 8 + 4 * (pp & 1);      // + c*2*ZG*8 + (row*32 + 4*blk)*8
-    const int xoff = ((2 * it + (pp >> 1)) * XG + 8 * kg + q) * 8 + 4 * (pp & 1);   // + ((row+r)*LW + 4*blk)*8
+    const int lrow = GEO == 0 ? 0 : (kg >> 1), lcol = GEO == 0 ? 8 * kg : 8 * (kg & 1);      // this lane group's place in a K-step
+    const int zoff = ZBASE + ((pp >> 1) * ZG + lrow * TW + lcol + q) * 8 + 4 * (pp & 1);     // + c*2*ZG*8 + (step*32 + 4*blk)*8
+    const int xoff = ((2 * it + (pp >> 1)) * XG + lrow * LW + lcol + q) * 8 + 4 * (pp & 1);  // + ((row0+r)*LW + 4*blk)*8
     const bool do_bias = p.dbias_partial != nullptr && cib == 0 && it == 0;         // wave-uniform
 
     f32x4 acc[2][9], accb[2];
@@ -1646,12 +1652,13 @@ __global__ __launch_bounds__(256, 4) void conv3x3_wgrad_c8_kernel(const WgC8P p)
         asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
 #pragma unroll
         for (int ksl = 0; ksl < 2; ++ksl) {
-            const int row = 2 * kh + ksl;      // 32 pixels of one tile row per step
+            const int step = 2 * kh + ksl;     // 32 pixels per step: one tile row (GEO 0) or two (GEO 1)
+            const int row = GEO == 0 ? step : 2 * step;
             typename T::frag a[2];
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
-                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(smemc8 + zoff + c * 2 * ZG * 8 + (row * TW) * 8));
-                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(smemc8 + zoff + c * 2 * ZG * 8 + (row * TW + 4) * 8));
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(smemc8 + zoff + c * 2 * ZG * 8 + (step * 32) * 8));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(smemc8 + zoff + c * 2 * ZG * 8 + (step * 32 + 4) * 8));
                 const short e[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                 a[c] = __builtin_bit_cast(typename T::frag, e);
             }
@@ -2114,8 +2121,8 @@ bool c8_segs_ok(const mtbc_seg* segs, int nseg) {
 WgPlan plan_wgrad(const mtbc_conv3x3_args* a) {
     WgPlan w{};
     if (a->operand_layout == MTBC_LAYOUT_C8) {      // conv3x3_wgrad_c8_kernel: 32 x 32 channel blocks, 4 x 32 pixel tiles, 4 blocks per CU
-        w.mfma = true; w.geo = 0; w.cot = 2;
-        w.tiles_x = cdiv(a->W, C8W_TW); w.tiles_y = cdiv(a->H, C8W_TH);
+        w.mfma = true; w.geo = a->W <= 16 ? 1 : 0; w.cot = 2;
+        w.tiles_x = cdiv(a->W, w.geo ? C8WGeo<1>::TW : C8WGeo<0>::TW); w.tiles_y = cdiv(a->H, w.geo ? C8WGeo<1>::TH : C8WGeo<0>::TH);
         w.total_tiles = w.tiles_x * w.tiles_y * a->N;
         w.coblocks = cdiv(a->Cout, 32); w.ciblocks = cdiv(a->Cin, 32);
         int ns = 1024 / (w.coblocks * w.ciblocks);
@@ -2318,8 +2325,13 @@ int mtbc_conv3x3_wgrad(const mtbc_conv3x3_args* a, void* stream) {
         p.tiles_x = w.tiles_x; p.tiles_y = w.tiles_y; p.total_tiles = w.total_tiles; p.tiles_per_split = w.tiles_per_split;
         p.ciblocks = w.ciblocks;
         const dim3 grid(w.nsplit, w.coblocks * w.ciblocks);
-        if (a->compute == 2) hipLaunchKernelGGL((conv3x3_wgrad_c8_kernel<true>), grid, dim3(256), C8W_LDS, st, p);
-        else hipLaunchKernelGGL((conv3x3_wgrad_c8_kernel<false>), grid, dim3(256), C8W_LDS, st, p);
+        if (w.geo == 1) {
+            if (a->compute == 2) hipLaunchKernelGGL((conv3x3_wgrad_c8_kernel<true, 1>), grid, dim3(256), C8W_LDS, st, p);
+            else hipLaunchKernelGGL((conv3x3_wgrad_c8_kernel<false, 1>), grid, dim3(256), C8W_LDS, st, p);
+        } else {
+            if (a->compute == 2) hipLaunchKernelGGL((conv3x3_wgrad_c8_kernel<true, 0>), grid, dim3(256), C8W_LDS, st, p);
+            else hipLaunchKernelGGL((conv3x3_wgrad_c8_kernel<false, 0>), grid, dim3(256), C8W_LDS, st, p);
+        }
         MTBC_CHECK_LAUNCH();
         rc = mtbc_i_splitk_reduce(partial, a->dw, w.nsplit, wel, a->accumulate_dw, st); if (rc) return rc;
         if (a->dbias) { rc = mtbc_i_splitk_reduce(p.dbias_partial, a->dbias, w.nsplit, (size_t)a->Cout, a->accumulate_dw, st); if (rc) return rc; }
