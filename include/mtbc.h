@@ -171,6 +171,10 @@ typedef struct {
     void* coop_state;
 } mtbc_instnorm_args;
 size_t mtbc_instnorm_coop_state_bytes(void);
+/* Leave `compute_units` CUs out of the cooperative kernels' grids (process-wide, takes effect for launches planned
+ * afterwards; default 0).  Their teams need every member resident at once; kernels of OTHER streams that hold CUs while
+ * they run (RCCL collectives overlapping the backward pass) would otherwise make members wait for a slot.          */
+void mtbc_instnorm_coop_reserve(int32_t compute_units);
 int mtbc_instnorm_c8_supported(const mtbc_instnorm_args* a, int32_t backward);
 
 /* workspace bytes the forward can use for planes > 64K elements (chunked statistics: 2 reads + 1 write instead of the

@@ -188,7 +188,7 @@ EXPORTS = [
     "mtbc_version", "mtbc_strerror", "mtbc_arch",
     "mtbc_conv3x3_packed_elems", "mtbc_conv3x3_packed_dgrad_elems", "mtbc_conv3x3_pack_fwd",
     "mtbc_conv3x3_pack_dgrad", "mtbc_conv3x3_packed_lp_elems", "mtbc_conv3x3_pack_lp", "mtbc_conv3x3_pack_many", "mtbc_c8_pack", "mtbc_c8_unpack", "mtbc_c8_pack16", "mtbc_augment_flip_rotate", "mtbc_convT_head_combine", "mtbc_convT_head_expand", "mtbc_conv3x3_wgrad_workspace", "mtbc_conv3x3_fwd", "mtbc_conv3x3_dgrad",
-    "mtbc_conv3x3_wgrad", "mtbc_instnorm_fwd_workspace", "mtbc_instnorm_coop_state_bytes", "mtbc_instnorm_c8_supported", "mtbc_instnorm_lrelu_fwd", "mtbc_instnorm_lrelu_bwd", "mtbc_maxpool2_fwd",
+    "mtbc_conv3x3_wgrad", "mtbc_instnorm_fwd_workspace", "mtbc_instnorm_coop_state_bytes", "mtbc_instnorm_coop_reserve", "mtbc_instnorm_c8_supported", "mtbc_instnorm_lrelu_fwd", "mtbc_instnorm_lrelu_bwd", "mtbc_maxpool2_fwd",
     "mtbc_maxpool2_bwd", "mtbc_convT_wgrad_workspace", "mtbc_convT_fwd_c8_supported", "mtbc_convT_fwd", "mtbc_convT_dgrad", "mtbc_convT_wgrad",
     "mtbc_conv1x1_wgrad_workspace", "mtbc_conv1x1_fwd", "mtbc_conv1x1_dgrad", "mtbc_conv1x1_wgrad",
     "mtbc_gap_fwd", "mtbc_gap_bwd", "mtbc_linear_fwd", "mtbc_linear_bwd", "mtbc_dice_fwd", "mtbc_dice_bwd",
@@ -255,6 +255,8 @@ def load() -> C.CDLL:
         getattr(lib, name).argtypes = [C.POINTER(typ), C.c_void_p]
     lib.mtbc_instnorm_coop_state_bytes.restype = C.c_size_t
     lib.mtbc_instnorm_coop_state_bytes.argtypes = []
+    lib.mtbc_instnorm_coop_reserve.restype = None
+    lib.mtbc_instnorm_coop_reserve.argtypes = [C.c_int32]
     lib.mtbc_instnorm_c8_supported.restype = C.c_int
     lib.mtbc_instnorm_c8_supported.argtypes = [C.POINTER(InstNormArgs), C.c_int32]
     lib.mtbc_convT_fwd_c8_supported.restype = C.c_int

@@ -285,12 +285,19 @@ __global__ __launch_bounds__(CO_THREADS, 4) void in_bwd_coop_kernel(const CoP p)
 }
 
 struct CoPlan { bool ok; int ppt, T, grid, nteams; };
+int g_reserved_cus = 0;                       // CUs left to kernels of other streams (collectives), mtbc_instnorm_coop_reserve
 template <typename K> int resident_blocks(K kernel) {
     int per_cu = 0, dev = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, CO_THREADS, 0) != hipSuccess || per_cu < 1) return 0;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
     return per_cu * prop.multiProcessorCount;
+}
+int usable(int cap_all_cus) {                 // capacity with g_reserved_cus of the device's CUs left out
+    int dev = 0; hipDeviceProp_t prop;
+    if (g_reserved_cus <= 0 || hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return cap_all_cus;
+    const int cus = prop.multiProcessorCount, keep = cus - g_reserved_cus;
+    return keep < 8 ? cap_all_cus / cus * 8 : cap_all_cus / cus * keep;
 }
 // team size / pixels per thread: the most even split of `items` over the resident teams, larger slabs on ties
 CoPlan plan_coop(int items, int HW, int max_ppt, const int* cap_by_ppt) {
@@ -301,7 +308,7 @@ CoPlan plan_coop(int items, int HW, int max_ppt, const int* cap_by_ppt) {
         if (HW <= CO_THREADS * ppt) { if (ppt > 1 && HW <= CO_THREADS * (ppt / 2)) continue; T = 1; }
         else { if (HW % (CO_THREADS * ppt)) continue; T = HW / (CO_THREADS * ppt); }
         if (T > CO_MAXT) continue;
-        const int cap = cap_by_ppt[ppt];
+        const int cap = usable(cap_by_ppt[ppt]);
         if (cap < T) continue;
         int teams = cap / T;
         if (teams > items) teams = items;
@@ -344,6 +351,8 @@ CoPlan plan_bwd(int items, int HW) {
 }  // namespace
 
 extern "C" {
+
+void mtbc_instnorm_coop_reserve(int32_t compute_units) { g_reserved_cus = compute_units < 0 ? 0 : compute_units; }
 
 size_t mtbc_instnorm_coop_state_bytes(void) { return CO_MAILBOX_OFF + (size_t)CO_MAX_TEAMS * CO_TEAM_WORDS * sizeof(unsigned long long); }
 

@@ -13,6 +13,8 @@ from __future__ import annotations
 from dataclasses import dataclass
 from typing import List, Optional, Sequence, Tuple
 
+import os
+
 import numpy as np
 import torch
 
@@ -100,6 +102,10 @@ class FusedTrainStep:
             self.world = dist.get_world_size()
             self.comm_stream = torch.cuda.Stream()
             optimizer.grad_scale = 1.0 / self.world
+            # the bucket all-reduces run on their own stream under the backward pass: keep CUs free for RCCL's resident
+            # kernels so that the cooperative InstanceNorm teams (which need every member resident) never queue behind them
+            if self.world > 1 and torch.cuda.is_available():
+                L.load().mtbc_instnorm_coop_reserve(int(os.environ.get("MTBC_COOP_RESERVE_CUS", "32")))
         self._st = None
         self._buckets: List[Bucket] = []
         self.losses: Optional[torch.Tensor] = None      # device: [total, seg, cls, nan_flag]

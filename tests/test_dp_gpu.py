@@ -53,16 +53,29 @@ def test_two_rank_step_equals_single_rank_global_batch():
     from multi_task_breast_cancer_amd.optim import FusedAdam
     from multi_task_breast_cancer_amd.trainer import FusedTrainStep
     from oracle import torch_oracle as O
-    world, port = 2, _free_port()
+    import queue as _queue
+    world = 2
     ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    p2, g2, l2 = (torch.from_numpy(a) for a in q.get(timeout=300))
-    for p in procs:
-        p.join(120)
-        assert p.exitcode == 0
+    got = None
+    for attempt in range(2):          # a 2-process gloo rendezvous on one box has been seen to stall once; a run takes ~6 s
+        q, port = ctx.Queue(), _free_port()
+        procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        try:
+            got = q.get(timeout=120)
+        except _queue.Empty:
+            got = None
+        for p in procs:
+            p.join(60 if got is not None else 1)
+            if p.is_alive():
+                p.kill()              # exactly the processes this test started
+                p.join(10)
+        if got is not None:
+            assert all(p.exitcode == 0 for p in procs)
+            break
+    assert got is not None, "the two-rank run produced no result in two attempts"
+    p2, g2, l2 = (torch.from_numpy(a) for a in got)
     dev = torch.device("cuda:0")
     seed_everything(1993)
     m = MTUNetPlusPlus(in_channels=1, out_channels=1, n_classes=3, deep_supervision=True).to(dev)
