@@ -226,8 +226,9 @@ def test_distributed_step_single_rank_rccl_equals_local_step():
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("dtype", ["bf16", "f16"])
-def test_16bit_mfma_modes_match_their_emulation(dtype):
+@pytest.mark.parametrize("arch,dtype,size", [("MTUNetPlusPlus", "bf16", 64), ("MTUNetPlusPlus", "f16", 64), ("MTnnUNet", "bf16", 128),
+                                             ("MTUNetPlusPlus", "bf16", 128)])
+def test_16bit_mfma_modes_match_their_emulation(arch, dtype, size):
     """Optional compute modes: conv3x3 MFMA operands rounded to bf16 / fp16 (fp32 storage + accumulation).  Not the
     reference-parity path (that is fp32); the oracle for it is oracle.lowp_conv3x3, which rounds the same operands
     at the same places on the CPU (fwd: x, w; dgrad: dy, w; wgrad: x, dy; RNE).  Rounding to 16 bits is itself
@@ -238,8 +239,8 @@ def test_16bit_mfma_modes_match_their_emulation(dtype):
     fp32-accumulating CPU emulation has from it (and a small floor).  A wrong operand / rounding place shows up in
     the forward as >= 3e-2.  fp16 runs with the static loss scale 4096 on both sides (unscaled, dz underflows fp16)."""
     import copy
-    N, size = 4, 64
-    prod, ref = _oracle_and_product("MTUNetPlusPlus", 1993)
+    N = 4 if size == 64 else 2          # 128x128: level 0 takes the cooperative InstanceNorm forward (planes >= 128x128)
+    prod, ref = _oracle_and_product(arch, 1993)
     prod.set_compute(dtype)
     ref64 = copy.deepcopy(ref).double()
     img, mask, label = O.synthetic_batch(N, size, size, seed=21)
