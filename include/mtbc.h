@@ -84,9 +84,21 @@ typedef struct {
                                               16-byte aligned.  What the kernels WRITE (z, dx segments, dw, dbias)
                                               stays fp32 planar.  No fallback: shapes the MFMA kernels do not take
                                               (W % 4 != 0, H or W < 8) return MTBC_E_UNSUPPORTED.                 */
+    int32_t out_accumulate;          /* fwd with operand_layout C8 only: 1 = add the result to `out` instead of overwriting
+                                        it.  A forward launch over the dz of ALL 3x3 consumers of a tensor, with
+                                        mtbc_conv3x3_weight_view(mode 1) weights, is that tensor's gathered dgrad.  */
 } mtbc_conv3x3_args;
 #define MTBC_LAYOUT_PLANAR 0
 #define MTBC_LAYOUT_C8 1
+
+/* Views of a (Cout,Cin,3,3) weight for backward launches that cover only part of a conv's input channels:
+ *   mode 0: dst (Cout, ci_cnt, 3, 3)  = w[:, ci_off : ci_off + ci_cnt]                 -- dgrad into a suffix of the segments
+ *   mode 1: dst (ci_cnt, K, 3, 3)[:, k_off : k_off + Cout] = that slice transposed with flipped taps, i.e. the weight of
+ *           the FORWARD conv over dz that computes the slice's input gradient; several convs fill one dst side by side
+ *           (K = sum of their Cout): one launch then produces the gradient of a tensor from all its consumers
+ *           (no read-modify-write fan-in).  Rebuilt every step like the packed images.                              */
+int mtbc_conv3x3_weight_view(const float* w, float* dst, int32_t Cout, int32_t Cin, int32_t ci_off, int32_t ci_cnt, int32_t mode,
+                             int32_t k_off, int32_t K, void* stream);
 
 /* fp32 planar (N,C,H,W; batch stride in elements) -> 16-bit channel-blocked [N][C/8][H*W][8] in the type of
  * `compute` (1 = bf16, 2 = fp16; round to nearest even -- the same conversion the staging of operand_layout 0 does),
@@ -353,7 +365,7 @@ enum {
     MTBC_OP_GAP_FWD, MTBC_OP_GAP_BWD, MTBC_OP_LINEAR_FWD, MTBC_OP_LINEAR_BWD,
     MTBC_OP_DICE_FWD, MTBC_OP_DICE_BWD, MTBC_OP_FOCAL, MTBC_OP_LOSS_MIX, MTBC_OP_ADAM,
     MTBC_OP_MEMSET, MTBC_OP_DICE_COUNTS, MTBC_OP_CONV3_PACK_LP, MTBC_OP_HEAD_COMBINE, MTBC_OP_HEAD_EXPAND,
-    MTBC_OP_C8_PACK, MTBC_OP_C8_PACK16
+    MTBC_OP_C8_PACK, MTBC_OP_C8_PACK16, MTBC_OP_CONV3_WVIEW
 };
 
 /* ---- deep-supervision head of MTnnUNet: ConvTranspose2d(Cin->Cmid, k=s) followed by Conv2d(Cmid->R, 1x1)
@@ -403,6 +415,7 @@ typedef struct {
         struct { void* ptr; size_t bytes; } memset0;
         struct { const float* logits; const float* target; int64_t n; double* out3; } counts;
         mtbc_head_fuse_args head;
+        struct { const float* w; float* dst; int32_t Cout, Cin, ci_off, ci_cnt, mode, k_off, K; } wview;
         struct { const float* src; int64_t src_batch_stride; void* dst; int32_t N, C, HW, compute; } c8pack;   /* C8_PACK and C8_PACK16 (src = 16-bit planar, `compute` unused) */
     } u;
 } mtbc_op;

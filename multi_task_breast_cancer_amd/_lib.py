@@ -34,7 +34,7 @@ class Conv3x3Args(C.Structure):
                 ("out", C.c_void_p), ("dout", C.c_void_p), ("dw", C.c_void_p), ("dbias", C.c_void_p),
                 ("accumulate_dw", C.c_int32), ("force_direct", C.c_int32),
                 ("stats_partial", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
-                ("compute", C.c_int32), ("operand_layout", C.c_int32)]
+                ("compute", C.c_int32), ("operand_layout", C.c_int32), ("out_accumulate", C.c_int32)]
 
 
 class InstNormArgs(C.Structure):
@@ -138,6 +138,11 @@ class _C8PackArgs(C.Structure):
                 ("N", C.c_int32), ("C", C.c_int32), ("HW", C.c_int32), ("compute", C.c_int32)]
 
 
+class _WViewArgs(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("dst", C.c_void_p), ("Cout", C.c_int32), ("Cin", C.c_int32), ("ci_off", C.c_int32),
+                ("ci_cnt", C.c_int32), ("mode", C.c_int32), ("k_off", C.c_int32), ("K", C.c_int32)]
+
+
 class HeadFuseArgs(C.Structure):
     """mtbc_head_fuse_args (include/mtbc.h)."""
     _fields_ = [("Cin", C.c_int32), ("Cmid", C.c_int32), ("R", C.c_int32), ("k", C.c_int32),
@@ -151,7 +156,7 @@ class _OpUnion(C.Union):
     _fields_ = [("conv3", Conv3x3Args), ("inorm", InstNormArgs), ("pool", MaxPoolArgs), ("convT", ConvTArgs),
                 ("conv1", Conv1x1Args), ("gap", GapArgs), ("linear", LinearArgs), ("dice", DiceArgs),
                 ("focal", FocalArgs), ("adam", AdamArgs), ("pack", _PackArgs), ("mix", _MixArgs),
-                ("memset0", _MemsetArgs), ("counts", _CountsArgs), ("head", HeadFuseArgs), ("c8pack", _C8PackArgs)]
+                ("memset0", _MemsetArgs), ("counts", _CountsArgs), ("head", HeadFuseArgs), ("c8pack", _C8PackArgs), ("wview", _WViewArgs)]
 
 
 class Op(C.Structure):
@@ -163,7 +168,7 @@ class Op(C.Structure):
  OP_IN_FWD, OP_IN_BWD, OP_POOL_FWD, OP_POOL_BWD, OP_CONVT_FWD, OP_CONVT_DGRAD, OP_CONVT_WGRAD,
  OP_CONV1_FWD, OP_CONV1_DGRAD, OP_CONV1_WGRAD, OP_GAP_FWD, OP_GAP_BWD, OP_LINEAR_FWD, OP_LINEAR_BWD,
  OP_DICE_FWD, OP_DICE_BWD, OP_FOCAL, OP_LOSS_MIX, OP_ADAM, OP_MEMSET, OP_DICE_COUNTS, OP_CONV3_PACK_LP,
- OP_HEAD_COMBINE, OP_HEAD_EXPAND, OP_C8_PACK, OP_C8_PACK16) = range(1, 32)
+ OP_HEAD_COMBINE, OP_HEAD_EXPAND, OP_C8_PACK, OP_C8_PACK16, OP_CONV3_WVIEW) = range(1, 33)
 
 OP_UNION_FIELD = {
     OP_CONV3_FWD: "conv3", OP_CONV3_DGRAD: "conv3", OP_CONV3_WGRAD: "conv3",
@@ -174,7 +179,7 @@ OP_UNION_FIELD = {
     OP_GAP_FWD: "gap", OP_GAP_BWD: "gap", OP_LINEAR_FWD: "linear", OP_LINEAR_BWD: "linear",
     OP_DICE_FWD: "dice", OP_DICE_BWD: "dice", OP_FOCAL: "focal", OP_LOSS_MIX: "mix", OP_ADAM: "adam",
     OP_MEMSET: "memset0", OP_DICE_COUNTS: "counts", OP_CONV3_PACK_LP: "pack",
-    OP_HEAD_COMBINE: "head", OP_HEAD_EXPAND: "head", OP_C8_PACK: "c8pack", OP_C8_PACK16: "c8pack",
+    OP_HEAD_COMBINE: "head", OP_HEAD_EXPAND: "head", OP_C8_PACK: "c8pack", OP_C8_PACK16: "c8pack", OP_CONV3_WVIEW: "wview",
 }
 
 # every symbol include/mtbc.h declares (tests check the library exports all of them)
@@ -187,7 +192,7 @@ class PackDesc(C.Structure):
 EXPORTS = [
     "mtbc_version", "mtbc_strerror", "mtbc_arch",
     "mtbc_conv3x3_packed_elems", "mtbc_conv3x3_packed_dgrad_elems", "mtbc_conv3x3_pack_fwd",
-    "mtbc_conv3x3_pack_dgrad", "mtbc_conv3x3_packed_lp_elems", "mtbc_conv3x3_pack_lp", "mtbc_conv3x3_pack_many", "mtbc_c8_pack", "mtbc_c8_unpack", "mtbc_c8_pack16", "mtbc_augment_flip_rotate", "mtbc_convT_head_combine", "mtbc_convT_head_expand", "mtbc_conv3x3_wgrad_workspace", "mtbc_conv3x3_fwd", "mtbc_conv3x3_dgrad",
+    "mtbc_conv3x3_pack_dgrad", "mtbc_conv3x3_packed_lp_elems", "mtbc_conv3x3_pack_lp", "mtbc_conv3x3_pack_many", "mtbc_c8_pack", "mtbc_c8_unpack", "mtbc_c8_pack16", "mtbc_conv3x3_weight_view", "mtbc_augment_flip_rotate", "mtbc_convT_head_combine", "mtbc_convT_head_expand", "mtbc_conv3x3_wgrad_workspace", "mtbc_conv3x3_fwd", "mtbc_conv3x3_dgrad",
     "mtbc_conv3x3_wgrad", "mtbc_instnorm_fwd_workspace", "mtbc_instnorm_coop_state_bytes", "mtbc_instnorm_coop_reserve", "mtbc_instnorm_c8_supported", "mtbc_instnorm_lrelu_fwd", "mtbc_instnorm_lrelu_bwd", "mtbc_maxpool2_fwd",
     "mtbc_maxpool2_bwd", "mtbc_convT_wgrad_workspace", "mtbc_convT_fwd_c8_supported", "mtbc_convT_fwd", "mtbc_convT_dgrad", "mtbc_convT_wgrad",
     "mtbc_conv1x1_wgrad_workspace", "mtbc_conv1x1_fwd", "mtbc_conv1x1_dgrad", "mtbc_conv1x1_wgrad",
@@ -228,6 +233,8 @@ def load() -> C.CDLL:
     lib.mtbc_conv3x3_pack_many.argtypes = [C.POINTER(PackDesc), C.c_int32, C.c_void_p]
     lib.mtbc_c8_pack.restype = C.c_int
     lib.mtbc_c8_pack.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
+    lib.mtbc_conv3x3_weight_view.restype = C.c_int
+    lib.mtbc_conv3x3_weight_view.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int32] * 7 + [C.c_void_p]
     lib.mtbc_c8_pack16.restype = C.c_int
     lib.mtbc_c8_pack16.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
     lib.mtbc_c8_unpack.restype = C.c_int

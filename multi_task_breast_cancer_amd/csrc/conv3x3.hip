@@ -1777,6 +1777,19 @@ __global__ void c8_pack16_kernel(const unsigned short* __restrict__ x, long long
     }
 }
 
+// Weight views for the gathered backward (engine: one dgrad launch per INPUT tensor over the dz of all its 3x3
+// consumers).  mode 0: channel slice  dst[co][ci][t] = w[co][off + ci][t]                    (Cout, cnt, 3, 3)
+//              mode 1: the slice as the weight of the equivalent FORWARD conv over dz, placed at K offset koff of a
+//                      (cnt, K, 3, 3) tensor:  dst[ci][koff + co][t] = w[co][off + ci][8 - t]
+__global__ void wview_kernel(const float* __restrict__ w, float* __restrict__ dst, int Cout, int Cin, int off, int cnt, int mode, int koff, int K) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= Cout * cnt * 9) return;
+    const int t = idx % 9, ci = (idx / 9) % cnt, co = idx / (9 * cnt);
+    const float v = w[((size_t)co * Cin + off + ci) * 9 + (mode ? 8 - t : t)];
+    if (mode) dst[((size_t)ci * K + koff + co) * 9 + t] = v;
+    else dst[((size_t)co * cnt + ci) * 9 + t] = v;
+}
+
 // ------------------------------------------------------------------ direct (VALU) fallbacks
 // One thread = one pixel x 8 output channels.  mode 0: fwd  (w[co][ci][tap])
 //                                              mode 1: dgrad (w[ci_in][co_out][8-tap], in = dz)
@@ -2249,9 +2262,10 @@ int mtbc_conv3x3_fwd(const mtbc_conv3x3_args* a, void* stream) {
     if (!a->out || (!a->w && !a->w_packed)) return MTBC_E_BADARG;
     SegTable in, out;
     rc = make_segtable(a->in, a->n_in, a->Cin, &in); if (rc) return rc;
-    mtbc_seg o{a->out, (int64_t)a->Cout * a->H * a->W, a->Cout, 0};
+    mtbc_seg o{a->out, (int64_t)a->Cout * a->H * a->W, a->Cout, a->out_accumulate ? 1 : 0};
     rc = make_segtable(&o, 1, a->Cout, &out); if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
+    if (a->out_accumulate && a->operand_layout != MTBC_LAYOUT_C8) return MTBC_E_UNSUPPORTED;
     if (a->operand_layout == MTBC_LAYOUT_C8) {
         if (!a->w_packed || (a->compute != 1 && a->compute != 2) || !c8_segs_ok(a->in, a->n_in)) return MTBC_E_BADARG;
         if (a->W % 4 || a->W < 8 || a->H < 8 || (reinterpret_cast<uintptr_t>(a->out) & 15)) return MTBC_E_UNSUPPORTED;
@@ -2409,6 +2423,16 @@ int mtbc_c8_unpack(const void* src, float* dst, int32_t N, int32_t C, int32_t HW
     const dim3 grid((unsigned)cdiv64(total, 256));
     if (compute == 2) hipLaunchKernelGGL((c8_unpack_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const unsigned short*>(src), dst, C, HW, total);
     else hipLaunchKernelGGL((c8_unpack_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const unsigned short*>(src), dst, C, HW, total);
+    MTBC_CHECK_LAUNCH();
+    return MTBC_OK;
+}
+
+int mtbc_conv3x3_weight_view(const float* w, float* dst, int32_t Cout, int32_t Cin, int32_t ci_off, int32_t ci_cnt, int32_t mode,
+                             int32_t k_off, int32_t K, void* stream) {
+    if (!w || !dst || Cout <= 0 || Cin <= 0 || ci_off < 0 || ci_cnt <= 0 || ci_off + ci_cnt > Cin || (mode != 0 && mode != 1)) return MTBC_E_BADARG;
+    if (mode == 1 && (k_off < 0 || k_off + Cout > K)) return MTBC_E_BADARG;
+    const int total = Cout * ci_cnt * 9;
+    hipLaunchKernelGGL(wview_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, w, dst, Cout, Cin, ci_off, ci_cnt, mode, k_off, K);
     MTBC_CHECK_LAUNCH();
     return MTBC_OK;
 }

@@ -52,6 +52,7 @@ int mtbc_program_run(const mtbc_op* ops, int32_t first, int32_t count, void* str
             case MTBC_OP_CONV3_PACK_DGRAD: rc = mtbc_conv3x3_pack_dgrad(o->u.pack.w, o->u.pack.packed, o->u.pack.Cin, o->u.pack.Cout, stream); break;
             case MTBC_OP_HEAD_COMBINE: rc = mtbc_convT_head_combine(&o->u.head, stream); break;
             case MTBC_OP_HEAD_EXPAND: rc = mtbc_convT_head_expand(&o->u.head, stream); break;
+            case MTBC_OP_CONV3_WVIEW: rc = mtbc_conv3x3_weight_view(o->u.wview.w, o->u.wview.dst, o->u.wview.Cout, o->u.wview.Cin, o->u.wview.ci_off, o->u.wview.ci_cnt, o->u.wview.mode, o->u.wview.k_off, o->u.wview.K, stream); break;
             case MTBC_OP_C8_PACK16: rc = mtbc_c8_pack16(o->u.c8pack.src, o->u.c8pack.src_batch_stride, o->u.c8pack.dst, o->u.c8pack.N, o->u.c8pack.C, o->u.c8pack.HW, stream); break;
             case MTBC_OP_C8_PACK: rc = mtbc_c8_pack(o->u.c8pack.src, o->u.c8pack.src_batch_stride, o->u.c8pack.dst, o->u.c8pack.N, o->u.c8pack.C, o->u.c8pack.HW, o->u.c8pack.compute, stream); break;
             case MTBC_OP_CONV3_PACK_LP: rc = mtbc_conv3x3_pack_lp(o->u.pack.w, o->u.pack.packed, o->u.pack.Cin, o->u.pack.Cout, o->u.pack.dgrad, o->u.pack.compute, stream); break;

@@ -24,6 +24,7 @@ _NO_CT_LP = _os.environ.get('MTBC_NO_CT_LP') == '1'  # A/B: ConvT backward keeps
 _NO_COOP = _os.environ.get('MTBC_NO_COOP') == '1'    # A/B: InstanceNorm by one-plane workgroups + pack instead of the cooperative kernels
 _COOP_MIN_FWD = int(_os.environ.get('MTBC_COOP_MIN_FWD', 16384))    # smallest plane (pixels) handed to the cooperative kernels
 _COOP_MIN_BWD = int(_os.environ.get('MTBC_COOP_MIN_BWD', 65536))
+_NO_GATHER = _os.environ.get('MTBC_NO_GATHER') == '1'  # A/B: every 3x3 conv back-propagates into all its inputs (fan-in by read-modify-write)
 _NO_P16 = _os.environ.get('MTBC_NO_P16') == '1'   # A/B / activation probes: InstanceNorm keeps writing fp32 y and dz
 
 
@@ -45,6 +46,9 @@ class Act:
     planar_valid: bool = True          # False: the producer wrote only `c8` (ConvT forward in the 16-bit modes)
     planar_used: bool = False          # some op reads `data` (pool, ConvT, 1x1 heads, GAP, a planar-staged conv)
     c8_used: bool = False              # some 3x3 conv reads `c8`
+    conv_consumers: int = 0            # 3x3 conv cells (16-bit, channel-blocked backward) that read this activation
+    no_gather: bool = False            # ... and one that cannot take part in a gathered dgrad
+    pending: List[tuple] = field(default_factory=list)   # gathered dgrad: (dz8, weight, channel offset, consumer Cin, consumer Cout)
     in_op: Optional[object] = None     # the InstanceNorm forward op that writes this activation (conv cells)
     pack_op: Optional[object] = None   # the op that fills `c8` from `data`
 
@@ -121,6 +125,7 @@ class StepPlan:
         self.keep: list = []
         self.fwd_ops: List[L.Op] = []
         self.pack_ops: List[L.Op] = []
+        self.wview_ops: List[L.Op] = []      # weight views of the gathered backward: run ahead of the pack ops
         self.bwd_emitters: List[Callable[[], None]] = []
         self.bwd_ops: List[L.Op] = []
         self.loss_ops: List[L.Op] = []
@@ -239,7 +244,7 @@ class StepPlan:
         w = self.pv(wname)
         assert tuple(w.shape) == (cout, cin, 3, 3), (wname, tuple(w.shape), cout, cin)
         use_packed = cin % 8 == 0 and all(a.C % 8 == 0 for a in inputs)
-        wp_f = wp_d = None
+        wp_f = wp_d = wp_d_op = None
         if use_packed and self.compute:
             # 16-bit operand images, re-converted from the fp32 master weights every step
             for dg in (0, 1):
@@ -253,7 +258,7 @@ class StepPlan:
                 if dg == 0:
                     wp_f = t
                 else:
-                    wp_d = t
+                    wp_d, wp_d_op = t, op
         elif use_packed:
             wp_f = self.alloc(self.lib.mtbc_conv3x3_packed_elems(cin, cout))
             op = _mk(L.OP_CONV3_PACK_FWD)
@@ -288,6 +293,11 @@ class StepPlan:
         c8_bwd = c8 and cout % 8 == 0
         if not c8 and not all(a_.planar_valid for a_ in inputs):
             raise NotImplementedError(f"{out_name}: an input exists only in the channel-blocked 16-bit layout")
+        for a_ in inputs:
+            if c8_bwd and wp_d is not None:
+                a_.conv_consumers += 1
+            else:
+                a_.no_gather = True
 
         def segs_c8(arr) -> None:
             for i, a_ in enumerate(inputs):
@@ -333,9 +343,43 @@ class StepPlan:
             self._need_ws(op, "inorm", nb)
         self.fwd_ops.append(op)
 
+        def wview(wsrc, dst, co, ci_total, off, cnt, mode, koff, K) -> None:
+            op = _mk(L.OP_CONV3_WVIEW)
+            v = op.u.wview
+            v.w, v.dst, v.Cout, v.Cin, v.ci_off, v.ci_cnt, v.mode, v.k_off, v.K = wsrc.data_ptr(), dst.data_ptr(), co, ci_total, off, cnt, mode, koff, K
+            self.wview_ops.append(op)
+
+        def pack_lp(wsrc, ci, co, dg) -> torch.Tensor:
+            t = self.alloc(self.lib.mtbc_conv3x3_packed_lp_elems(ci, co, dg), dtype=torch.int16)
+            op = _mk(L.OP_CONV3_PACK_LP)
+            op.u.pack.w, op.u.pack.packed, op.u.pack.Cin, op.u.pack.Cout = wsrc.data_ptr(), t.data_ptr(), ci, co
+            op.u.pack.dgrad, op.u.pack.compute = dg, self.compute
+            self.pack_ops.append(op)
+            return t
+
         def emit_bwd() -> None:
-            if not y.grad_written:
+            if not y.grad_written and not y.pending:
                 return
+            if y.pending:
+                # Gathered dgrad: the gradient of y with respect to ALL its 3x3 consumers in ONE forward-type launch over
+                # their channel-blocked dz (K = sum of their Cout), instead of one read-modify-write of y's fp32 gradient
+                # per consumer.  Weights: the consumers' slices for y's channels, transposed / tap-flipped, side by side.
+                K = sum(pj[4] for pj in y.pending)
+                wg = self.alloc(cout, K, 3, 3)
+                koff = 0
+                for (dzj, wj, offj, cinj, coutj) in y.pending:
+                    wview(wj, wg, coutj, cinj, offj, cout, 1, koff, K)
+                    koff += coutj
+                wpg = pack_lp(wg, K, cout, 0)
+                gbuf, acc = self.grad_slot(y)
+                op = _mk(L.OP_CONV3_FWD, tag)
+                a = op.u.conv3
+                a.N, a.H, a.W, a.Cin, a.Cout, a.n_in = N, H, W, K, cout, len(y.pending)
+                for i_, (dzj, wj, offj, cinj, coutj) in enumerate(y.pending):
+                    a.in_[i_].ptr, a.in_[i_].batch_stride, a.in_[i_].channels, a.in_[i_].accumulate = dzj.data_ptr(), coutj * H * W, coutj, 0
+                a.w, a.w_packed, a.out = wg.data_ptr(), wpg.data_ptr(), gbuf.data_ptr()
+                a.compute, a.operand_layout, a.out_accumulate = self.compute, L.LAYOUT_C8, acc
+                self.bwd_ops.append(op)
             dy = self.grad_of(y)
             # IN+LReLU backward, dz written in place over dy (each element is read before it is written)
             op = base_in()
@@ -343,9 +387,22 @@ class StepPlan:
             a = op.u.inorm
             a.dy, a.dy_batch_stride, a.dz = dy.data_ptr(), y.bstride, dy.data_ptr()
             a.n_dy_extra = len(y.extra_grads)
+            # inputs whose gradient is gathered later (by THEIR backward) from all their 3x3 consumers: a prefix of the
+            # segment list, so that this conv's own dgrad covers a contiguous suffix of its input channels
+            defer: List[Act] = []
+            if c8_bwd and wp_d is not None and not _NO_GATHER:
+                for a_ in inputs:
+                    if a_.in_op is not None and a_.needs_grad and a_.conv_consumers >= 2 and not a_.no_gather and a_.C % 8 == 0:
+                        defer.append(a_)
+                    else:
+                        break
+
+            def dz8_buffer() -> torch.Tensor:      # the gathered launches read it later: it cannot be the shared scratch
+                return self.alloc(N * cout * H * W, dtype=torch.int16) if defer else self._scratch16("_dz8_buf", N * cout * H * W)
+
             coop = c8_bwd and not _NO_COOP and H * W >= _COOP_MIN_BWD and self.lib.mtbc_instnorm_c8_supported(C.byref(a), 1)
             if coop:        # one pass straight into the channel-blocked dz the wgrad / dgrad MFMAs read
-                dz8 = self._scratch16("_dz8_buf", N * cout * H * W)
+                dz8 = dz8_buffer()
                 a.dz8, a.out16_type, a.coop_state = dz8.data_ptr(), self.compute, self._coop_state()
             p16 = c8_bwd and not coop and not _NO_P16 and (H * W) % 4 == 0 and H * W <= 65536
             if p16:         # dz feeds MFMAs only: 16-bit planar here, channel-blocked by the pack below
@@ -369,7 +426,7 @@ class StepPlan:
                 self._need_ws(op, "inorm", N * cout * (35 if coop else 3) * 4)
             self.bwd_ops.append(op)
             if c8_bwd and not coop:
-                dz8 = self._scratch16("_dz8_buf", N * cout * H * W)
+                dz8 = dz8_buffer()
                 pk = self._c8_pack_op(dz16 if p16 else dy, dz8, cout, H * W)
                 if p16:
                     pk.kind = L.OP_C8_PACK16
@@ -390,7 +447,26 @@ class StepPlan:
             self.bwd_ops.append(op)
             # dgrad into every input that needs one
             need = [a_ for a_ in inputs if a_.needs_grad]
-            if need:
+            if need and defer:
+                off = 0
+                for a_ in defer:
+                    a_.pending.append((dz8, w, off, cin, cout))
+                    off += a_.C
+                self.pack_ops.remove(wp_d_op)          # the full dgrad image is not needed
+                rest = inputs[len(defer):]
+                if rest:
+                    crest = cin - off
+                    ws = self.alloc(cout, crest, 3, 3)
+                    wview(w, ws, cout, cin, off, crest, 0, 0, 0)
+                    wps = pack_lp(ws, crest, cout, 1)
+                    op = base_conv()
+                    op.kind = L.OP_CONV3_DGRAD
+                    a = op.u.conv3
+                    a.Cin, a.n_in, a.w = crest, len(rest), ws.data_ptr()
+                    self._segs(a.in_, rest, grads=True)
+                    a.dout, a.operand_layout, a.w_packed = dz8.data_ptr(), L.LAYOUT_C8, wps.data_ptr()
+                    self.bwd_ops.append(op)
+            elif need:
                 if len(need) != len(inputs):
                     raise NotImplementedError("mixed grad / no-grad concat inputs")
                 op = base_conv()
@@ -757,7 +833,7 @@ class StepPlan:
             a = getattr(op.u, fieldname)
             a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel() * 4
         return {
-            "pack": Program(self.pack_ops, self.keep),
+            "pack": Program(self.wview_ops + self.pack_ops, self.keep),
             "fwd": Program(self.fwd_ops, self.keep),
             "loss": Program(self.loss_ops, self.keep),
             "bwd": Program(self.bwd_ops, self.keep),

@@ -47,6 +47,7 @@ def test_ctypes_layout_matches_header(tmp_path):
             ("mtbc_convT_args", "y_type", L.ConvTArgs.y_type.offset),
             ("mtbc_conv3x3_args", "compute", L.Conv3x3Args.compute.offset),
             ("mtbc_conv3x3_args", "operand_layout", L.Conv3x3Args.operand_layout.offset),
+            ("mtbc_conv3x3_args", "out_accumulate", L.Conv3x3Args.out_accumulate.offset),
             ("mtbc_pack_desc", "kind", L.PackDesc.kind.offset),
             ("mtbc_dice_args", "gscale_dev", L.DiceArgs.gscale_dev.offset),
             ("mtbc_adam_args", "zero_grad", L.AdamArgs.zero_grad.offset),
@@ -76,7 +77,7 @@ def test_op_kind_enum_in_sync():
     want = ["CONV3_FWD", "CONV3_DGRAD", "CONV3_WGRAD", "CONV3_PACK_FWD", "CONV3_PACK_DGRAD", "IN_FWD", "IN_BWD",
             "POOL_FWD", "POOL_BWD", "CONVT_FWD", "CONVT_DGRAD", "CONVT_WGRAD", "CONV1_FWD", "CONV1_DGRAD", "CONV1_WGRAD",
             "GAP_FWD", "GAP_BWD", "LINEAR_FWD", "LINEAR_BWD", "DICE_FWD", "DICE_BWD", "FOCAL", "LOSS_MIX", "ADAM",
-            "MEMSET", "DICE_COUNTS", "CONV3_PACK_LP", "HEAD_COMBINE", "HEAD_EXPAND", "C8_PACK", "C8_PACK16"]
+            "MEMSET", "DICE_COUNTS", "CONV3_PACK_LP", "HEAD_COMBINE", "HEAD_EXPAND", "C8_PACK", "C8_PACK16", "CONV3_WVIEW"]
     assert names == ["MTBC_OP_" + w for w in want]
     for i, w in enumerate(want, start=1):
         assert getattr(L, "OP_" + w) == i
