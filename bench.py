@@ -71,8 +71,8 @@ def conv_bytes(op, kind, L) -> float:
     px = float(a.N * a.H * a.W)
     rd = 2.0 if a.operand_layout == L.LAYOUT_C8 else 4.0
     w = 9.0 * a.Cin * a.Cout * (2.0 if a.compute else 4.0)
-    if kind == L.OP_CONV3_FWD:
-        return (a.Cin * rd + a.Cout * 4.0) * px + w
+    if kind == L.OP_CONV3_FWD:          # (a gathered dgrad is a forward-type launch that may add to its output)
+        return (a.Cin * rd + a.Cout * (8.0 if a.out_accumulate else 4.0)) * px + w
     if kind == L.OP_CONV3_WGRAD:
         return (a.Cin + a.Cout) * rd * px + 9.0 * a.Cin * a.Cout * 4.0
     acc = sum(a.in_[i].channels for i in range(a.n_in) if a.in_[i].accumulate)      # fan-in sums re-read dx
