@@ -114,7 +114,7 @@ size_t mtbc_conv3x3_packed_elems(int32_t Cin, int32_t Cout);          /* fwd ima
 size_t mtbc_conv3x3_packed_dgrad_elems(int32_t Cin, int32_t Cout);    /* dgrad image size    */
 int mtbc_conv3x3_pack_fwd(const float* w, float* packed, int32_t Cin, int32_t Cout, void* stream);
 int mtbc_conv3x3_pack_dgrad(const float* w, float* packed, int32_t Cin, int32_t Cout, void* stream);
-/* 16-bit operand images for compute = 1 (bf16) / 2 (fp16): [mtile][chunk32][tap][16][40] 16-bit elements;
+/* 16-bit operand images for compute = 1 (bf16) / 2 (fp16): [mtile][chunk32][tap][16][32] 16-bit elements;
  * dgrad = 0 packs the forward image, 1 the flipped/transposed dgrad image.  Pass as w_packed. */
 size_t mtbc_conv3x3_packed_lp_elems(int32_t Cin, int32_t Cout, int32_t dgrad);
 int mtbc_conv3x3_pack_lp(const float* w, void* packed, int32_t Cin, int32_t Cout, int32_t dgrad, int32_t compute, void* stream);

@@ -564,11 +564,12 @@ template <> struct LP<true> {
 // consecutive K per lane, K = input channels at one tap, so the LDS image is channel-interleaved: [halo pixel][32 ch]
 // as 16-bit, 80-byte pixel stride (5*px + kg spreads the 16-B slots of a ds_read_b128).  Staging: each lane owns one
 // halo pixel and one 8-channel group, reads its 8 channels with 8 dword loads (a wave reads 256 contiguous bytes of
-// one plane per load), converts, and writes ONE ds_write_b128.  Weights come pre-converted: [mtile][chunk32][tap][16][40].
+// one plane per load), converts, and writes ONE ds_write_b128.  Weights come pre-converted: [mtile][chunk32][tap][16][32].
 // With the matrix pipe 16x faster these convs are load-bound; the structure is therefore the simple one (single LDS
 // buffer, 3 blocks per CU overlap each other).
 constexpr int LPKC = 32;                 // channels per chunk = K of one MFMA
-constexpr int LPROW = 40;                // 16-bit elements per LDS row (32 + 8 pad) = 80 bytes
+constexpr int LPROW = 40;                // 16-bit elements per X row of the planar-operand kernel's LDS image (32 + 8 pad) = 80 bytes
+constexpr int WROW = 32;                 // 16-bit elements per row of the weight images: a fragment read takes 64 consecutive 16-byte pieces (conflict-free unpadded)
 template <int GEO> struct GeoLP;
 template <> struct GeoLP<0> { static constexpr int TH = 8, TW = 32, IMG = 1; };
 template <> struct GeoLP<1> { static constexpr int TH = 16, TW = 16, IMG = 1; };
@@ -581,7 +582,7 @@ __device__ __forceinline__ void pack_lp_elem8(const float* __restrict__ w, unsig
     // dgrad: rows = ci (Cin),  K = co      value = w[co][ci][8-tap]
     const int rows = dgrad ? Cin : Cout, red = dgrad ? Cout : Cin;
     const int nch = (red + LPKC - 1) / LPKC;
-    const int kq = idx8 % (LPROW / 8); long long t = idx8 / (LPROW / 8);
+    const int kq = idx8 % (WROW / 8); long long t = idx8 / (WROW / 8);
     const int i = t % 16; t /= 16;
     const int tap = t % 9; t /= 9;
     const int cb = t % nch; const int mt = t / nch;
@@ -591,7 +592,7 @@ __device__ __forceinline__ void pack_lp_elem8(const float* __restrict__ w, unsig
     for (int e = 0; e < 8; ++e) {
         const int kk = kq * 8 + e, k = cb * LPKC + kk;
         v[e] = 0.f;
-        if (kk < LPKC && r < rows && k < red)
+        if (r < rows && k < red)
             v[e] = dgrad ? w[((size_t)k * Cin + r) * 9 + (8 - tap)] : w[((size_t)r * Cin + k) * 9 + tap];
     }
     if (f16) *reinterpret_cast<f16x8*>(p + idx8 * 8) = LP<true>::pack(v);
@@ -641,7 +642,7 @@ __global__ void pack_many_kernel(const PackManyP q) {
     } else {
         const int dg = kind == 3;
         const int rows = dg ? Cin : Cout, red = dg ? Cout : Cin;
-        const long long total8 = (long long)((rows + 15) / 16) * ((red + LPKC - 1) / LPKC) * 9 * 16 * (LPROW / 8);
+        const long long total8 = (long long)((rows + 15) / 16) * ((red + LPKC - 1) / LPKC) * 9 * 16 * (WROW / 8);
         if (idx >= total8) return;
         pack_lp_elem8(w, static_cast<unsigned short*>(q.dst[d]), Cin, Cout, dg, q.f16, idx);
     }
@@ -653,7 +654,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_igemm_lp_kernel(const ConvP p)
     using T = LP<F16>;
     constexpr int HR = G::TH + 2, HC = G::TW + 2, HP = G::IMG * HR * HC;       // halo pixels
     constexpr int XB = HP * LPROW;                                             // 16-bit elements
-    constexpr int WB = MT * 9 * 16 * LPROW;
+    constexpr int WB = MT * 9 * 16 * WROW;
     extern __shared__ __attribute__((aligned(16))) unsigned short smem16[];
     unsigned short* Xs = smem16;
     unsigned short* Ws = smem16 + XB;
@@ -743,7 +744,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_igemm_lp_kernel(const ConvP p)
     };
     int w_have = -1;                              // chunk whose weights sit in Ws (mt0 is fixed per block)
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(p.wp), 0, (int)((size_t)p.mtiles * nchunks * (9 * 16 * LPROW) * 2), 0x00020000);
+        const_cast<float*>(p.wp), 0, (int)((size_t)p.mtiles * nchunks * (9 * 16 * WROW) * 2), 0x00020000);
     // XCD-aware walk: workgroups are dealt round-robin to the 8 XCDs (linear id % 8), each with its own L2.  Every
     // XCD takes one contiguous eighth of the tile list and its blocks sweep it side by side, so the halo rows / the
     // partly used cache lines two neighbouring tiles share are fetched into ONE L2 instead of two.
@@ -776,9 +777,9 @@ __global__ __launch_bounds__(256, 3) void conv3x3_igemm_lp_kernel(const ConvP p)
                     const int inst = wvu + 4 * k;
                     if (inst < WI) {
                         const int idx = inst * 64 + lane;
-                        const int mt = idx / (9 * 16 * LPROW / 8), r = idx % (9 * 16 * LPROW / 8);
+                        const int mt = idx / (9 * 16 * WROW / 8), r = idx % (9 * 16 * WROW / 8);
                         const bool ok = idx < W16 && (mt0 + mt) < p.mtiles;
-                        const unsigned voff = ok ? (unsigned)((((mt0 + mt) * nchunks + ch) * (9 * 16 * LPROW / 8) + r) * 16) : 0xfffffff0u;
+                        const unsigned voff = ok ? (unsigned)((((mt0 + mt) * nchunks + ch) * (9 * 16 * WROW / 8) + r) * 16) : 0xfffffff0u;
                         if (idx < W16)
                             __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_ptr_t)(Ws + inst * 512), 16, voff, 0, 0, 0);
                     }
@@ -804,7 +805,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_igemm_lp_kernel(const ConvP p)
                 typename T::frag a[MT], b[4];
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
-                    a[m] = *reinterpret_cast<const typename T::frag*>(Ws + ((m * 9 + tap) * 16 + j) * LPROW + 8 * kg);
+                    a[m] = *reinterpret_cast<const typename T::frag*>(Ws + ((m * 9 + tap) * 16 + j) * WROW + 8 * kg);
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
                     b[g] = *reinterpret_cast<const typename T::frag*>(Xs + bpix[g] * LPROW + toff);
@@ -867,9 +868,9 @@ __global__ __launch_bounds__(256, 3) void conv3x3_igemm_c8_kernel(const ConvP p)
     using G = GeoLP<GEO>;
     using T = LP<F16>;
     constexpr int HR = G::TH + 2, HC = G::TW + 2, HP = G::IMG * HR * HC;       // halo pixels
-    constexpr int HPP = (HP + 31) / 32 * 32;
+    constexpr int HPP = HP;                                                    // exact halo image: 4 groups x 340 pixels x 16 B
     constexpr int XB = 4 * HPP * 8;                                            // 16-bit elements
-    constexpr int WB = MT * 9 * 16 * LPROW;
+    constexpr int WB = MT * 9 * 16 * WROW;
     constexpr int XQ = (HPP + 63) / 64;
     extern __shared__ __attribute__((aligned(16))) unsigned short smem16[];
     unsigned short* Xs = smem16;
@@ -899,7 +900,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_igemm_c8_kernel(const ConvP p)
     }
     int w_have = -1;
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(p.wp), 0, (int)((size_t)p.mtiles * nchunks * (9 * 16 * LPROW) * 2), 0x00020000);
+        const_cast<float*>(p.wp), 0, (int)((size_t)p.mtiles * nchunks * (9 * 16 * WROW) * 2), 0x00020000);
     int tile, tstep, tend;            // XCD-aware walk, as above
     if ((gridDim.x & 7) == 0 && !(p.dbg & 16)) {
         const int per = (p.ntiles + 7) >> 3, xcd = blockIdx.x & 7;
@@ -958,9 +959,9 @@ __global__ __launch_bounds__(256, 3) void conv3x3_igemm_c8_kernel(const ConvP p)
                     const int inst = wvu + 4 * k;
                     if (inst < WI) {
                         const int idx = inst * 64 + lane;
-                        const int mt = idx / (9 * 16 * LPROW / 8), r = idx % (9 * 16 * LPROW / 8);
+                        const int mt = idx / (9 * 16 * WROW / 8), r = idx % (9 * 16 * WROW / 8);
                         const bool ok = idx < W16 && (mt0 + mt) < p.mtiles;
-                        const unsigned voff = ok ? (unsigned)((((mt0 + mt) * nchunks + ch) * (9 * 16 * LPROW / 8) + r) * 16) : 0xfffffff0u;
+                        const unsigned voff = ok ? (unsigned)((((mt0 + mt) * nchunks + ch) * (9 * 16 * WROW / 8) + r) * 16) : 0xfffffff0u;
                         if (idx < W16)
                             __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_ptr_t)(Ws + inst * 512), 16, voff, 0, 0, 0);
                     }
@@ -974,7 +975,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_igemm_c8_kernel(const ConvP p)
                 typename T::frag a[MT], b[4];
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
-                    a[m] = *reinterpret_cast<const typename T::frag*>(Ws + ((m * 9 + tap) * 16 + j) * LPROW + 8 * kg);
+                    a[m] = *reinterpret_cast<const typename T::frag*>(Ws + ((m * 9 + tap) * 16 + j) * WROW + 8 * kg);
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
                     b[g] = *reinterpret_cast<const typename T::frag*>(Xs + (kg * HPP + bpix[g] + toff) * 8);
@@ -2028,7 +2029,7 @@ template <int MT, int GEO>
 int launch_igemm_lp(const ConvP& p, int mblocks, bool f16, hipStream_t st) {
     using G = GeoLP<GEO>;
     constexpr int HP = G::IMG * (G::TH + 2) * (G::TW + 2);
-    const size_t lds = ((size_t)HP * LPROW + (size_t)MT * 9 * 16 * LPROW) * 2 + (SEGL_FLOATS + MT * 16) * sizeof(float);
+    const size_t lds = ((size_t)HP * LPROW + (size_t)MT * 9 * 16 * WROW) * 2 + (SEGL_FLOATS + MT * 16) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_igemm_lp_kernel<MT, GEO, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -2059,15 +2060,18 @@ int launch_igemm_lp_mt(int MT, const ConvP& p, int mblocks, bool f16, hipStream_
 template <int MT, int GEO>
 int launch_igemm_c8(const ConvP& p, int mblocks, bool f16, hipStream_t st) {
     using G = GeoLP<GEO>;
-    constexpr int HP = G::IMG * (G::TH + 2) * (G::TW + 2), HPP = (HP + 31) / 32 * 32;
-    const size_t lds = ((size_t)4 * HPP * 8 + (size_t)MT * 9 * 16 * LPROW) * 2 + (SEGL_FLOATS + MT * 16) * sizeof(float);
+    constexpr int HP = G::IMG * (G::TH + 2) * (G::TW + 2), HPP = HP;
+    const size_t lds = ((size_t)4 * HPP * 8 + (size_t)MT * 9 * 16 * WROW) * 2 + (SEGL_FLOATS + MT * 16) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_igemm_c8_kernel<MT, GEO, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_igemm_c8_kernel<MT, GEO, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    const int per_cu = lds * 3 <= 160 * 1024 ? 3 : 2;      // one wave of resident blocks
+    static const int per_cu_env = getenv("MTBC_C8_BLOCKS_PER_CU") ? atoi(getenv("MTBC_C8_BLOCKS_PER_CU")) : 0;      // A/B
+    // one wave of resident blocks.  The image fits 4 per CU (40.6 KB) and the kernel compiles to 128 VGPRs, but measured
+    // (v9): 4 resident blocks are no faster than 3 (16.52 vs 16.49 ms per step; single launches 3-15 % slower) -> 3.
+    const int per_cu = per_cu_env ? per_cu_env : (lds * 3 <= 160 * 1024 ? 3 : 2);
     int gx = (256 * per_cu / mblocks) / 8 * 8;
     if (gx < 8) gx = 8;
     if (gx > p.ntiles) gx = p.ntiles;
@@ -2208,7 +2212,7 @@ int mtbc_conv3x3_pack_dgrad(const float* w, float* packed, int32_t Cin, int32_t 
 
 size_t mtbc_conv3x3_packed_lp_elems(int32_t Cin, int32_t Cout, int32_t dgrad) {
     const int rows = dgrad ? Cin : Cout, red = dgrad ? Cout : Cin;
-    return (size_t)cdiv(rows, 16) * cdiv(red, LPKC) * 9 * 16 * LPROW;      // 16-bit elements
+    return (size_t)cdiv(rows, 16) * cdiv(red, LPKC) * 9 * 16 * WROW;      // 16-bit elements
 }
 int mtbc_conv3x3_pack_lp(const float* w, void* packed, int32_t Cin, int32_t Cout, int32_t dgrad, int32_t compute, void* stream) {
     if (!w || !packed || Cin <= 0 || Cout <= 0 || (compute != 1 && compute != 2)) return MTBC_E_BADARG;
