@@ -174,12 +174,15 @@ def test_unetpp_without_deep_supervision_returns_tensors():
     assert _maxerr(gp[k].grad, gr[k].grad) < 5e-2 * gr[k].grad.pow(2).mean().sqrt().item()
 
 
-def test_step_is_deterministic_at_bench_shape():
-    """size-independent property at the bench resolution: same seed twice -> bit-identical parameters."""
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_step_is_deterministic_at_bench_shape(dtype):
+    """size-independent property at the bench resolution: same seed twice -> bit-identical parameters.  bf16 takes the
+    channel-blocked data path: cooperative InstanceNorm (mailbox sums in member order), gathered dgrad, split-K wgrad."""
     outs = []
     for _ in range(2):
         seed_everything(1993)
         m = MTUNetPlusPlus(in_channels=1, out_channels=1, n_classes=3, deep_supervision=True).to(DEV)
+        m.set_compute(dtype)
         opt = FusedAdam(m, lr=1e-4, eps=1e-4)
         step = FusedTrainStep(m, opt, alpha=0.5)
         img, mask, label = O.synthetic_batch(8, 256, 256, seed=2)
