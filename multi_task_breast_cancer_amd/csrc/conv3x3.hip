@@ -1921,10 +1921,15 @@ __global__ void conv3x3_wgrad_direct_kernel(const DirWgP p) {
 // wgrad for very few input channels (the Cin=1 first layer: K=9 is not a dense contraction, HBM-bound):
 // block = one (n, co) plane pair; each thread walks float4 groups of dz and the 3x6 neighbourhood of x.
 // partial[n][co][ci][9], summed over n by the split-K reduce.  Needs W % 4 == 0.
+// S row bands per plane (S = nsplit / N): a 256x256 plane per block left 3 blocks per CU walking 64 iterations each
+// (1.6 TB/s); partial[(n*S + band)][co][ci][9].
 __global__ void conv3x3_wgrad_smallcin_kernel(const DirWgP p) {
     __shared__ float red[32];
-    const int n = blockIdx.x / p.Cout, co = blockIdx.x % p.Cout;
+    const int S = p.nsplit / p.N;
+    const int band = blockIdx.x % S, plane = blockIdx.x / S;
+    const int n = plane / p.Cout, co = plane % p.Cout;
     const int HW = p.H * p.W, W4 = p.W >> 2, n4 = HW >> 2;
+    const int q_lo = (int)((long long)n4 * band / S), q_hi = (int)((long long)n4 * (band + 1) / S);
     const float* g = p.dz + ((size_t)n * p.Cout + co) * HW;
     for (int ci = 0; ci < p.Cin; ++ci) {
         const SegRef si = seg_ref(p.in, ci);
@@ -1932,7 +1937,8 @@ __global__ void conv3x3_wgrad_smallcin_kernel(const DirWgP p) {
         float acc[9];
 #pragma unroll
         for (int i = 0; i < 9; ++i) acc[i] = 0.f;
-        for (int q = threadIdx.x; q < n4; q += blockDim.x) {
+#pragma unroll 4
+        for (int q = q_lo + threadIdx.x; q < q_hi; q += blockDim.x) {      // unrolled: the loads of 4 iterations in flight
             const int y = q / W4, x4 = (q % W4) * 4;
             const float4 gv = *reinterpret_cast<const float4*>(g + (size_t)y * p.W + x4);
             const float ge[4] = {gv.x, gv.y, gv.z, gv.w};
@@ -1956,7 +1962,7 @@ __global__ void conv3x3_wgrad_smallcin_kernel(const DirWgP p) {
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const float t = block_sum(acc[tap], red);
-            if (threadIdx.x == 0) p.partial[(((size_t)n * p.Cout + co) * p.Cin + ci) * 9 + tap] = t;
+            if (threadIdx.x == 0) p.partial[((((size_t)n * S + band) * p.Cout + co) * p.Cin + ci) * 9 + tap] = t;
         }
     }
 }
@@ -2180,7 +2186,8 @@ WgPlan plan_wgrad(const mtbc_conv3x3_args* a) {
         for (int i = 0; al && i < a->n_in; ++i)
             al = (reinterpret_cast<uintptr_t>(a->in[i].ptr) & 15) == 0 && a->in[i].batch_stride % 4 == 0;
         w.smallcin = !a->force_direct && a->Cin <= 4 && al;
-        w.nsplit = w.smallcin ? a->N : (a->N < 16 ? a->N : 16);
+        const int bands = (a->H * a->W >= 16384) ? 4 : 1;
+        w.nsplit = w.smallcin ? a->N * bands : (a->N < 16 ? a->N : 16);
     }
     w.partial_elems = (size_t)w.nsplit * wel;
     w.dbias_elems = a->dbias ? (size_t)a->N * a->Cout : 0;
@@ -2397,7 +2404,7 @@ int mtbc_conv3x3_wgrad(const mtbc_conv3x3_args* a, void* stream) {
         DirWgP p; p.N = a->N; p.H = a->H; p.W = a->W; p.Cin = a->Cin; p.Cout = a->Cout; p.nsplit = w.nsplit;
         p.in = in; p.dz = a->dout; p.partial = partial;
         if (w.smallcin)
-            hipLaunchKernelGGL(conv3x3_wgrad_smallcin_kernel, dim3(a->N * a->Cout), dim3(256), 0, st, p);
+            hipLaunchKernelGGL(conv3x3_wgrad_smallcin_kernel, dim3(w.nsplit * a->Cout), dim3(256), 0, st, p);
         else
             hipLaunchKernelGGL(conv3x3_wgrad_direct_kernel, dim3(a->Cout * a->Cin, w.nsplit), dim3(256), 0, st, p);
         MTBC_CHECK_LAUNCH();
