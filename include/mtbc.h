@@ -5,7 +5,11 @@
  * The reference has no FFI of its own (it is pure Python on torch.nn); each
  * entry point below names the reference call it replaces (file:line, relative to the
  * upstream repository).  All tensors are fp32, NCHW, plane-contiguous (channel stride =
- * H*W) device pointers BORROWED from the caller until the stream operation completes.
+ * H*W) device pointers BORROWED from the caller until the stream operation completes; the
+ * 16-bit compute modes may additionally hand the MFMA kernels their operand tensors in the
+ * matrix pipe's own format (MTBC_LAYOUT_C8: bf16 / fp16, [N][C/8][H*W][8]) -- every such field
+ * says so where it is declared, and what the reference would see (parameters, gradients of
+ * parameters, losses, logits) is fp32 in every mode.
  *
  * Conventions: return 0 (MTBC_OK) or a negative MTBC_E_* code; never throws, never
  * allocates, never synchronises the device; deterministic (no float atomics); thread-safe
