@@ -569,7 +569,7 @@ template <> struct LP<true> {
 // buffer, 3 blocks per CU overlap each other).
 constexpr int LPKC = 32;                 // channels per chunk = K of one MFMA
 constexpr int LPROW = 40;                // 16-bit elements per X row of the planar-operand kernel's LDS image (32 + 8 pad) = 80 bytes
-constexpr int WROW = 32;                 // 16-bit elements per row of the weight images: a fragment read takes 64 consecutive 16-byte pieces (conflict-free unpadded)
+constexpr int WROW = 32;                 // 16-bit elements per row of the weight images (unpadded; pieces XOR-swizzled, see pack_lp_elem8)
 template <int GEO> struct GeoLP;
 template <> struct GeoLP<0> { static constexpr int TH = 8, TW = 32, IMG = 1; };
 template <> struct GeoLP<1> { static constexpr int TH = 16, TW = 16, IMG = 1; };
@@ -595,8 +595,12 @@ __device__ __forceinline__ void pack_lp_elem8(const float* __restrict__ w, unsig
         if (r < rows && k < red)
             v[e] = dgrad ? w[((size_t)k * Cin + r) * 9 + (8 - tap)] : w[((size_t)r * Cin + k) * 9 + tap];
     }
-    if (f16) *reinterpret_cast<f16x8*>(p + idx8 * 8) = LP<true>::pack(v);
-    else *reinterpret_cast<bf16x8*>(p + idx8 * 8) = LP<false>::pack(v);
+    // 64-byte rows, 16-byte piece kq of row i stored at position kq ^ ((i >> 1) & 3): with that XOR the A-fragment read of the
+    // igemm kernels (lane (j, kg) -> row j, piece kg) is conflict-free for ds_read_b128's lane groups; plain 64- or 80-byte
+    // rows are 2-way (SQ_LDS_BANK_CONFLICT / brute force over the groups of MI355X_MICROARCH.md)
+    const long long dst8 = idx8 - kq + (kq ^ ((i >> 1) & 3));
+    if (f16) *reinterpret_cast<f16x8*>(p + dst8 * 8) = LP<true>::pack(v);
+    else *reinterpret_cast<bf16x8*>(p + dst8 * 8) = LP<false>::pack(v);
 }
 __global__ void pack_lp_kernel(const float* __restrict__ w, unsigned short* __restrict__ p, int Cin, int Cout, int dgrad,
                                int f16, long long total8) {
@@ -805,7 +809,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_igemm_lp_kernel(const ConvP p)
                 typename T::frag a[MT], b[4];
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
-                    a[m] = *reinterpret_cast<const typename T::frag*>(Ws + ((m * 9 + tap) * 16 + j) * WROW + 8 * kg);
+                    a[m] = *reinterpret_cast<const typename T::frag*>(Ws + ((m * 9 + tap) * 16 + j) * WROW + 8 * (kg ^ ((j >> 1) & 3)));
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
                     b[g] = *reinterpret_cast<const typename T::frag*>(Xs + bpix[g] * LPROW + toff);
@@ -868,7 +872,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_igemm_c8_kernel(const ConvP p)
     using G = GeoLP<GEO>;
     using T = LP<F16>;
     constexpr int HR = G::TH + 2, HC = G::TW + 2, HP = G::IMG * HR * HC;       // halo pixels
-    constexpr int HPP = HP;                                                    // exact halo image: 4 groups x 340 pixels x 16 B
+    constexpr int HPP = (HP + 15) / 16 * 16;       // group stride = 0 (mod 256 B): the four 16-lane groups of a ds_read_b128 hit disjoint banks (PMC-checked)
     constexpr int XB = 4 * HPP * 8;                                            // 16-bit elements
     constexpr int WB = MT * 9 * 16 * WROW;
     constexpr int XQ = (HPP + 63) / 64;
@@ -975,7 +979,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_igemm_c8_kernel(const ConvP p)
                 typename T::frag a[MT], b[4];
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
-                    a[m] = *reinterpret_cast<const typename T::frag*>(Ws + ((m * 9 + tap) * 16 + j) * WROW + 8 * kg);
+                    a[m] = *reinterpret_cast<const typename T::frag*>(Ws + ((m * 9 + tap) * 16 + j) * WROW + 8 * (kg ^ ((j >> 1) & 3)));
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
                     b[g] = *reinterpret_cast<const typename T::frag*>(Xs + (kg * HPP + bpix[g] + toff) * 8);
@@ -2066,7 +2070,7 @@ int launch_igemm_lp_mt(int MT, const ConvP& p, int mblocks, bool f16, hipStream_
 template <int MT, int GEO>
 int launch_igemm_c8(const ConvP& p, int mblocks, bool f16, hipStream_t st) {
     using G = GeoLP<GEO>;
-    constexpr int HP = G::IMG * (G::TH + 2) * (G::TW + 2), HPP = HP;
+    constexpr int HP = G::IMG * (G::TH + 2) * (G::TW + 2), HPP = (HP + 15) / 16 * 16;
     const size_t lds = ((size_t)4 * HPP * 8 + (size_t)MT * 9 * 16 * WROW) * 2 + (SEGL_FLOATS + MT * 16) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {

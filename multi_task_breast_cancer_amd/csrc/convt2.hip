@@ -458,7 +458,7 @@ __global__ __launch_bounds__(256, 2) void convT2_fwd_c8_kernel(const Ct2P p, con
 // Forward on the 16-bit MFMA with BOTH tensors channel-blocked (x_layout = y_layout = MTBC_LAYOUT_C8): a stored piece of x
 // (8 channels of one pixel) IS a lane's share of the B fragment of v_mfma_f32_16x16x32, so x goes straight from HBM into
 // fragments (16-byte loads, 256 contiguous bytes per 16 lanes); the weights of the block's channel slice sit in LDS as
-// 16-bit rows [(position, channel)][ci] (80-byte-style padded stride), read as A fragments with ds_read_b128.  A wave =
+// 16-bit rows [(position, channel)][ci] (row stride = 2 mod 4 pieces: conflict-free), read as A fragments with ds_read_b128.  A wave =
 // 32 input pixels x (4 positions x 16*MTC channels); fp32 accumulate, bias, one RNE, 8-byte stores into the output pieces.
 // The level-0 up-convolution (48 -> 48 @128x128, 9.7 GFLOP) was fp32-MFMA-bound at 0.12 ms; wider ones took the generic
 // fp32 GEMM + a pack pass.
@@ -650,7 +650,7 @@ int mtbc_i_convT2_fwd_c8(const mtbc_convT_args* a, hipStream_t st) {
 
 // forward with channel-blocked 16-bit input AND output (x_layout = y_layout = MTBC_LAYOUT_C8): the 16-bit MFMA kernel
 static int lp_c8_mtc(const mtbc_convT_args* a, int* kpad, int* wrow, size_t* lds) {
-    *kpad = (a->Cin + 31) / 32 * 32; *wrow = *kpad + 8;
+    *kpad = (a->Cin + 31) / 32 * 32; *wrow = *kpad + 16;      // row stride = 2 (mod 4) 16-byte pieces: conflict-free ds_read_b128 A fragments
     const int cp16 = (a->Cout + 15) / 16;
     for (int mtc = cp16 < 3 ? cp16 : 3; mtc >= 1; --mtc) {
         *lds = (size_t)4 * 16 * mtc * *wrow * 2 + 16 * mtc * sizeof(float);
