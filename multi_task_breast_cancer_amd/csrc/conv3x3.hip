@@ -568,7 +568,7 @@ template <> struct LP<true> {
 // With the matrix pipe 16x faster these convs are load-bound; the structure is therefore the simple one (single LDS
 // buffer, 3 blocks per CU overlap each other).
 constexpr int LPKC = 32;                 // channels per chunk = K of one MFMA
-constexpr int LPROW = 40;                // 16-bit elements per X row of the planar-operand kernel's LDS image (32 + 8 pad) = 80 bytes
+constexpr int LPROW = 48;                // 16-bit elements per X row of the planar-operand kernel's LDS image (32 + 16 pad) = 96 bytes: row stride = 2 (mod 4) pieces, conflict-free b128 reads (80 bytes was 2-way)
 constexpr int WROW = 32;                 // 16-bit elements per row of the weight images (unpadded; pieces XOR-swizzled, see pack_lp_elem8)
 template <int GEO> struct GeoLP;
 template <> struct GeoLP<0> { static constexpr int TH = 8, TW = 32, IMG = 1; };
