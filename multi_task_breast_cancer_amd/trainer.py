@@ -104,8 +104,8 @@ class FusedTrainStep:
             optimizer.grad_scale = 1.0 / self.world
             # the bucket all-reduces run on their own stream under the backward pass: keep CUs free for RCCL's resident
             # kernels so that the cooperative InstanceNorm teams (which need every member resident) never queue behind them
-            if self.world > 1 and torch.cuda.is_available():
-                L.load().mtbc_instnorm_coop_reserve(int(os.environ.get("MTBC_COOP_RESERVE_CUS", "32")))
+            if (self.world > 1 or "MTBC_COOP_RESERVE_CUS" in os.environ) and torch.cuda.is_available():
+                L.load().mtbc_instnorm_coop_reserve(int(os.environ.get("MTBC_COOP_RESERVE_CUS", "64")))
         self._st = None
         self._buckets: List[Bucket] = []
         self.losses: Optional[torch.Tensor] = None      # device: [total, seg, cls, nan_flag]
