@@ -266,3 +266,22 @@ def test_16bit_mfma_modes_match_their_emulation(arch, dtype, size):
             continue
         e_hip, e_cpu = rel(prod._grad_view(name) / ls, g64[name].grad), rel(g32[name].grad, g64[name].grad)
         assert e_hip < max(3 * e_cpu, 5e-2), (name, e_hip, e_cpu)
+
+
+def test_512_inputs_16bit_modes_track_the_fp32_step():
+    """BASELINE config 5's 512x512 inputs: planes of 1 MB leave the register-resident / cooperative InstanceNorm paths
+    (chunked forward, streaming backward, fp32 planes + pack) -- the 16-bit modes must still follow the fp32 step."""
+    out = {}
+    for dt in ("f32", "bf16", "f16"):
+        seed_everything(5)
+        m = MTUNetPlusPlus(in_channels=1, out_channels=1, n_classes=3, deep_supervision=True).to(DEV)
+        m.set_compute(dt)
+        step = FusedTrainStep(m, FusedAdam(m, lr=1e-4, eps=1e-4), alpha=0.5)
+        for s in range(2):
+            img, mask, label = O.synthetic_batch(2, 512, 512, seed=s)
+            l = step(img.to(DEV), mask.to(DEV), label.to(DEV))
+        out[dt] = (l.cpu(), m.flat_p.clone())
+    for dt in ("bf16", "f16"):
+        assert out[dt][0][3].item() == 0.0
+        assert abs(out[dt][0][0].item() - out["f32"][0][0].item()) < 5e-3
+        assert (out[dt][1] - out["f32"][1]).abs().max().item() < 5e-4      # two Adam steps of lr 1e-4
