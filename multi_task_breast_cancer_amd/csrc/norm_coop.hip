@@ -12,7 +12,7 @@
 //
 // Mailbox protocol (no fences, no L2 write-back across XCDs): a word is {fp32 value, 32-bit tag} written and polled
 // with relaxed agent-scope 64-bit atomics -- single-copy atomic, so the value is valid whenever the tag matches.
-// tag = (epoch + 1) << 10 | exchange number; `epoch` lives in the caller's persistent state block, is read by every
+// tag = (epoch mod (2^22 - 1) + 1) << 10 | exchange number; `epoch` lives in the caller's persistent state block, is read by every
 // workgroup when it starts and advanced by the LAST workgroup to finish (which thereby knows everybody has read it).
 // Two mailbox slots by exchange parity: a member can post exchange s+2 only after all members posted s+1, i.e. after
 // they finished reading s.  Polls are bounded (CO_SPIN_MAX): a protocol failure sets state->err and produces garbage,
@@ -71,7 +71,9 @@ template <int NV>
 __device__ __forceinline__ void team_exchange(float mine, unsigned long long* mb, int member, int T, unsigned& seq, unsigned epoch,
                                               CoopHdr* hdr, float (*xch)[CO_NV]) {
     const int tid = threadIdx.x;
-    const unsigned tag = ((epoch + 1u) << 10) | (seq & 1023u);
+    // 22 bits of launch epoch (never 0: zeroed / never-written mailbox words cannot match) + 10 bits of exchange number; a word
+    // is rewritten at least once per step program, so a repeat after 4M launches cannot meet a stale twin
+    const unsigned tag = ((epoch % 4194303u + 1u) << 10) | (seq & 1023u);
     unsigned long long* base = mb + (size_t)(seq & 1u) * CO_MAXT * CO_NV;
     if (tid < NV) mb_post(base + member * CO_NV + tid, mine, tag);
     for (int idx = tid; idx < T * CO_NV; idx += CO_THREADS) {
