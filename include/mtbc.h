@@ -166,7 +166,7 @@ typedef struct {
                                 norm (the conv bias) = sum over n,h,w of dz, fused here so the
                                 conv wgrad does not re-read dz                                 */
     int32_t accumulate_dparams;
-    void* workspace;         /* bwd with any of the three: N*C*3 floats (N*C*35 with dz8)    */
+    void* workspace;         /* bwd with any of the three: N*C*3 floats (N*C*131 with dz8)    */
     size_t workspace_bytes;
     /* 16-bit planar outputs (the 16-bit compute modes): when y16 / dz16 is set, the forward activation / the
        backward dz is written ONLY as a 16-bit (N,C,H,W) tensor of type out16_type (1 = bf16, 2 = fp16; round to

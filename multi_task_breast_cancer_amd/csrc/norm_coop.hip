@@ -22,7 +22,7 @@
 namespace {
 
 constexpr int CO_THREADS = 512, CO_WAVES = CO_THREADS / 64;       // (256-thread workgroups in teams of up to 64: forward 18 % slower)
-constexpr int CO_MAXT = 32, CO_NV = 16;
+constexpr int CO_MAXT = 128, CO_NV = 16;     // 128 members = a 512x512 plane group at 4 pixels per thread
 constexpr unsigned CO_SPIN_MAX = 1u << 26;      // about a minute of polling: a member that waits for a CU held by a collective of another stream is late, not lost
 constexpr size_t CO_MAILBOX_OFF = 256;
 constexpr int CO_MAX_TEAMS = 1024;

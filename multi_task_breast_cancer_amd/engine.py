@@ -423,7 +423,7 @@ class StepPlan:
                     assert acc == accb
                     a.dbias_pre = self.gv(bname).data_ptr()
                 a.accumulate_dparams = acc
-                self._need_ws(op, "inorm", N * cout * (35 if coop else 3) * 4)
+                self._need_ws(op, "inorm", N * cout * (131 if coop else 3) * 4)
             self.bwd_ops.append(op)
             if c8_bwd and not coop:
                 dz8 = dz8_buffer()

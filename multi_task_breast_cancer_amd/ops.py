@@ -312,7 +312,7 @@ def instnorm_lrelu_bwd_c8(z, dy, mean, rstd, gamma=None, beta=None, eps=1e-5, sl
     dz8 = torch.empty(N, Cc // 8, H * W, 8, dtype=torch.int16, device=z.device)
     dg = torch.empty(Cc, dtype=torch.float32, device=z.device) if gamma is not None else None
     db = torch.empty(Cc, dtype=torch.float32, device=z.device) if gamma is not None else None
-    ws = _ws(N * Cc * 35 * 4, z.device)
+    ws = _ws(N * Cc * 131 * 4, z.device)
     a = L.InstNormArgs()
     a.N, a.C, a.H, a.W, a.eps, a.slope = N, Cc, H, W, eps, slope
     a.z, a.gamma, a.beta, a.mean, a.rstd = z.data_ptr(), _p(gamma), _p(beta), mean.data_ptr(), rstd.data_ptr()

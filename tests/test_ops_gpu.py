@@ -536,7 +536,8 @@ def test_instnorm_16bit_planar_outputs_are_the_rounded_fp32_outputs(N, C, H, W, 
 
 @pytest.mark.parametrize("compute", [1, 2])
 @pytest.mark.parametrize("N,C,H,W,affine", [(2, 24, 256, 256, True), (3, 48, 128, 128, True), (2, 96, 64, 64, False),
-                                            (5, 16, 32, 32, True), (2, 8, 16, 16, True), (3, 8, 8, 8, False), (32, 24, 256, 256, True)])
+                                            (5, 16, 32, 32, True), (2, 8, 16, 16, True), (3, 8, 8, 8, False), (32, 24, 256, 256, True),
+                                            (4, 24, 512, 512, True)])
 def test_cooperative_instnorm_into_channel_blocked_layout(N, C, H, W, affine, compute):
     """The split-plane cooperative kernels (teams of workgroups exchanging partial statistics through a mailbox) against
     the one-plane-per-workgroup kernels: statistics to fp32 re-association, outputs to one 16-bit ulp of the rounded
@@ -561,7 +562,10 @@ def test_cooperative_instnorm_into_channel_blocked_layout(N, C, H, W, affine, co
     gotz = dz8.unpack()
     scale = dz.abs().max().item()
     assert bool(((gotz - dz).abs() <= ulp * dz.abs() + 2e-6 * scale).all()), (gotz - dz).abs().max().item()
-    assert torch.allclose(db2, db1, rtol=1e-4, atol=1e-3)
+    # the bias gradient of a conv in front of InstanceNorm is mathematically zero: both kernels return the rounding noise
+    # of a sum over N*H*W terms, which scales with the sum of |dz|
+    noise = 1e-6 * dz.abs().sum((0, 2, 3)).max().item()
+    assert (db2 - db1).abs().max().item() <= max(1e-3, noise)
     if affine:
         assert torch.allclose(dg2, dg, rtol=1e-4, atol=1e-3 * max(1.0, dg.abs().max().item()))
         assert torch.allclose(dbt2, dbt, rtol=1e-4, atol=1e-3 * max(1.0, dbt.abs().max().item()))
