@@ -56,8 +56,24 @@ def cpu_baseline(arch: str, size: int, batch: int, steps: int):
     for _ in range(steps):
         O.train_step(model, opt, img, mask, label, 0.5, True, 3)
     dt = time.perf_counter() - t0
-    return {"value": round(batch * steps / dt, 3), "unit": "images/sec", "cores": threads, "kind": "port",
-            "sample": f"{steps} steps of {arch} B={batch} {size}x{size} fp32 after 1 warm-up ({dt:.1f} s)"}
+    out = {"value": round(batch * steps / dt, 3), "unit": "images/sec", "cores": threads, "kind": "port",
+           "sample": f"{steps} steps of {arch} B={batch} {size}x{size} fp32 after 1 warm-up ({dt:.1f} s)"}
+    # BASELINE.json configs[0]: the reference's own CPU-runnable case (single-task segmentation, B=4, 1x128x128,
+    # src/training_segmentation.py) on the oracle's nnUNet2021 restatement (pinned: tests/golden/seg_nnunet_step.npz) --
+    # plumbing, not a kernel target
+    O.seed_everything(1993)
+    seg = O.OracleSegNnUNet(1, 1)
+    sopt = O.make_adam(seg, 1e-4)
+    simg, smask, _ = O.synthetic_batch(4, 128, 128, seed=1)
+    O.seg_train_step(seg, sopt, simg, smask, True)
+    t0 = time.perf_counter()
+    for _ in range(5):
+        sl, _ = O.seg_train_step(seg, sopt, simg, smask, True)
+    sdt = time.perf_counter() - t0
+    out["configs0_plumbing"] = {"value": round(4 * 5 / sdt, 3), "unit": "images/sec", "cores": threads, "kind": "port",
+                                "sample": f"5 steps of single-task nnUNet2021 seg (Dice, deep supervision, Adam) B=4 128x128 fp32 "
+                                          f"after 1 warm-up ({sdt:.1f} s), loss {float(sl):.4f}"}
+    return out
 
 
 def note(msg: str) -> None:
@@ -157,14 +173,21 @@ def run_mode(args, dtype, dev, rank, world, dist, want_roofline):
     names = {"f32": ("conv3x3_igemm_dma_kernel", "conv3x3_wgrad_mfma_kernel"),
              "bf16": ("conv3x3_igemm_c8_kernel", "conv3x3_wgrad_c8_kernel"),
              "f16": ("conv3x3_igemm_c8_kernel", "conv3x3_wgrad_c8_kernel")}[dtype]
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", f"r01_hbm_traffic_{dtype}.json")
-    if os.path.exists(tpath):
+    # HBM traffic per launch comes from PMC counters, which cannot be collected inside a timed run: the figure is read
+    # from the committed summary of the separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same command
+    # (tools/profile_round.sh); `traffic_source` names the file, and the field is null when no summary fits the build
+    traffic, traffic_source = None, None
+    for tag in ("r02", "r01"):
+        tpath = os.path.join(ROOT, "profiles", f"{tag}_hbm_traffic_{dtype}.json")
+        if not os.path.exists(tpath):
+            continue
         ks = json.load(open(tpath))["kernels"]
         sel = [v for k, v in ks.items() if k.startswith(names[0])]
         if sel:
             w = sum(v["launches_in_trace"] for v in sel)
             traffic = round(sum(v["hbm_bytes_per_launch"] * v["launches_in_trace"] for v in sel) / w)
+            traffic_source = f"profiles/{tag}_hbm_traffic_{dtype}.json (separate rocprofv3 --pmc passes, FETCH_SIZE x2 + WRITE_SIZE; not measured in this run)"
+            break
     ig = fam["igemm"]
     roof = {"bound": bound, "kernel": f"{names[0]} (fwd + dgrad launches of the 3x3 convs)",
             "arithmetic_intensity_flop_per_byte": round(ig[0] / ig[1], 1), "roof_crossover_flop_per_byte": round(balance, 1)}
@@ -174,7 +197,7 @@ def run_mode(args, dtype, dev, rank, world, dist, want_roofline):
     else:
         roof.update({"achieved": round(ig[1] / ig[2] / 1e9, 1), "peak": PEAK_HBM_BYTES / 1e9, "unit": "GB/s",
                      "frac": round(ig[1] / ig[2] / PEAK_HBM_BYTES, 4)})
-    roof.update({"traffic": traffic, "launches_per_step": ig[3], "avg_launch_ms": round(ig[2] / ig[3] * 1e3, 4),
+    roof.update({"traffic": traffic, "traffic_source": traffic_source, "launches_per_step": ig[3], "avg_launch_ms": round(ig[2] / ig[3] * 1e3, 4),
                  "algorithmic_gflop_per_launch": round(ig[0] / ig[3] / 1e9, 3),
                  "algorithmic_MB_per_launch": round(ig[1] / ig[3] / 1e6, 1),
                  "tflops": round(ig[0] / ig[2] / 1e12, 2), "frac_of_mfma_peak": round(ig[0] / ig[2] / 1e12 / peak, 4),
@@ -242,6 +265,11 @@ def main() -> None:
         if args.gpus != 1 or world != 1:
             raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     from multi_task_breast_cancer_amd import _lib as L
+    from multi_task_breast_cancer_amd import switches
+    bad = switches.result_altering()
+    if bad:
+        raise SystemExit(f"bench.py refuses to run with {bad} set: those select the probes build of the library or a timing "
+                         f"hack, so the numbers would not be the product's (unset them; A/B plan switches are reported, not refused)")
     L.require_gpu()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -265,6 +293,7 @@ def main() -> None:
                                ", random-init weights (BASELINE.json configs[1])",
                    "global_batch": args.batch * world, "parallelism": f"dp{world}"},
         "final_loss": main_res["final_loss"],
+        "env": {"mtbc_variables_set": switches.active(), "library": os.path.relpath(L.LIB_PATH, ROOT)},
     }
     for k in ("roofline", "roofline_hbm"):
         if k in main_res:

@@ -13,7 +13,7 @@
  *
  * Conventions: return 0 (MTBC_OK) or a negative MTBC_E_* code; never throws, never
  * allocates, never synchronises the device; deterministic (no float atomics); thread-safe
- * for distinct streams.  `stream` is a hipStream_t passed as void*.
+ * for distinct streams (no mutable process-wide state).  `stream` is a hipStream_t passed as void*.
  */
 #ifndef MTBC_H
 #define MTBC_H
@@ -70,9 +70,6 @@ typedef struct {
     float* dbias;                    /* wgrad: (Cout) or NULL                                */
     int32_t accumulate_dw;           /* wgrad: 1 = add into dw/dbias (shared modules, F10)   */
     int32_t force_direct;            /* 1 = never use the MFMA kernels (debug / tests)       */
-    /* optional fused InstanceNorm statistics of the output (fwd only): per-(n,co) partial
-       (count, mean, M2) triples are written to stats_partial; NULL = off                    */
-    float* stats_partial;
     void* workspace;                 /* wgrad split-K partials                               */
     size_t workspace_bytes;
     int32_t compute;                 /* MFMA operand type: 0 = fp32 (exact, the parity path), 1 = bf16,
@@ -185,12 +182,16 @@ typedef struct {
     void* y8;
     void* dz8;
     void* coop_state;
+    /* CUs this launch leaves out of the cooperative grid (0 = none): the teams need every member resident at once, and
+       kernels of OTHER streams that hold CUs while it runs (RCCL collectives overlapping the backward pass) would make
+       members wait for a slot.  Per call -- the library keeps no process-wide setting.                              */
+    int32_t coop_reserve_cus;
 } mtbc_instnorm_args;
 size_t mtbc_instnorm_coop_state_bytes(void);
-/* Leave `compute_units` CUs out of the cooperative kernels' grids (process-wide, takes effect for launches planned
- * afterwards; default 0).  Their teams need every member resident at once; kernels of OTHER streams that hold CUs while
- * they run (RCCL collectives overlapping the backward pass) would otherwise make members wait for a slot.          */
-void mtbc_instnorm_coop_reserve(int32_t compute_units);
+/* Byte offset, inside a coop_state block, of the 32-bit STICKY error word: non-zero once any cooperative launch on that
+ * state gave up a bounded mailbox poll (a team member was not resident).  Every output of that launch and of the ones after
+ * it is then garbage: callers read the word when they read their losses and stop (trainer.FusedTrainStep.check_nan).   */
+size_t mtbc_instnorm_coop_error_offset(void);
 int mtbc_instnorm_c8_supported(const mtbc_instnorm_args* a, int32_t backward);
 
 /* workspace bytes the forward can use for planes > 64K elements (chunked statistics: 2 reads + 1 write instead of the

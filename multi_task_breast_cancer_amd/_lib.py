@@ -33,7 +33,7 @@ class Conv3x3Args(C.Structure):
                 ("w", C.c_void_p), ("w_packed", C.c_void_p), ("bias", C.c_void_p),
                 ("out", C.c_void_p), ("dout", C.c_void_p), ("dw", C.c_void_p), ("dbias", C.c_void_p),
                 ("accumulate_dw", C.c_int32), ("force_direct", C.c_int32),
-                ("stats_partial", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
                 ("compute", C.c_int32), ("operand_layout", C.c_int32), ("out_accumulate", C.c_int32)]
 
 
@@ -49,7 +49,7 @@ class InstNormArgs(C.Structure):
                 ("accumulate_dparams", C.c_int32),
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
                 ("y16", C.c_void_p), ("dz16", C.c_void_p), ("out16_type", C.c_int32),
-                ("y8", C.c_void_p), ("dz8", C.c_void_p), ("coop_state", C.c_void_p)]
+                ("y8", C.c_void_p), ("dz8", C.c_void_p), ("coop_state", C.c_void_p), ("coop_reserve_cus", C.c_int32)]
 
 
 class MaxPoolArgs(C.Structure):
@@ -193,7 +193,7 @@ EXPORTS = [
     "mtbc_version", "mtbc_strerror", "mtbc_arch",
     "mtbc_conv3x3_packed_elems", "mtbc_conv3x3_packed_dgrad_elems", "mtbc_conv3x3_pack_fwd",
     "mtbc_conv3x3_pack_dgrad", "mtbc_conv3x3_packed_lp_elems", "mtbc_conv3x3_pack_lp", "mtbc_conv3x3_pack_many", "mtbc_c8_pack", "mtbc_c8_unpack", "mtbc_c8_pack16", "mtbc_conv3x3_weight_view", "mtbc_augment_flip_rotate", "mtbc_convT_head_combine", "mtbc_convT_head_expand", "mtbc_conv3x3_wgrad_workspace", "mtbc_conv3x3_fwd", "mtbc_conv3x3_dgrad",
-    "mtbc_conv3x3_wgrad", "mtbc_instnorm_fwd_workspace", "mtbc_instnorm_coop_state_bytes", "mtbc_instnorm_coop_reserve", "mtbc_instnorm_c8_supported", "mtbc_instnorm_lrelu_fwd", "mtbc_instnorm_lrelu_bwd", "mtbc_maxpool2_fwd",
+    "mtbc_conv3x3_wgrad", "mtbc_instnorm_fwd_workspace", "mtbc_instnorm_coop_state_bytes", "mtbc_instnorm_coop_error_offset", "mtbc_instnorm_c8_supported", "mtbc_instnorm_lrelu_fwd", "mtbc_instnorm_lrelu_bwd", "mtbc_maxpool2_fwd",
     "mtbc_maxpool2_bwd", "mtbc_convT_wgrad_workspace", "mtbc_convT_fwd_c8_supported", "mtbc_convT_fwd", "mtbc_convT_dgrad", "mtbc_convT_wgrad",
     "mtbc_conv1x1_wgrad_workspace", "mtbc_conv1x1_fwd", "mtbc_conv1x1_dgrad", "mtbc_conv1x1_wgrad",
     "mtbc_gap_fwd", "mtbc_gap_bwd", "mtbc_linear_fwd", "mtbc_linear_bwd", "mtbc_dice_fwd", "mtbc_dice_bwd",
@@ -262,8 +262,8 @@ def load() -> C.CDLL:
         getattr(lib, name).argtypes = [C.POINTER(typ), C.c_void_p]
     lib.mtbc_instnorm_coop_state_bytes.restype = C.c_size_t
     lib.mtbc_instnorm_coop_state_bytes.argtypes = []
-    lib.mtbc_instnorm_coop_reserve.restype = None
-    lib.mtbc_instnorm_coop_reserve.argtypes = [C.c_int32]
+    lib.mtbc_instnorm_coop_error_offset.restype = C.c_size_t
+    lib.mtbc_instnorm_coop_error_offset.argtypes = []
     lib.mtbc_instnorm_c8_supported.restype = C.c_int
     lib.mtbc_instnorm_c8_supported.argtypes = [C.POINTER(InstNormArgs), C.c_int32]
     lib.mtbc_convT_fwd_c8_supported.restype = C.c_int

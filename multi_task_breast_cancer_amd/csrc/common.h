@@ -14,6 +14,20 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
         if (e__ != hipSuccess) return MTBC_E_LAUNCH;          \
     } while (0)
 
+// Timing / A-B probes (environment switches, load- / store-skipping bits inside the kernels) exist only in the `make probes`
+// build (-DMTBC_PROBES -> libmtbc_hip_probes.so).  The shipped library reads no environment variable: every switch below
+// folds to its default at compile time and the probe branches are dead code.
+#ifdef MTBC_PROBES
+#include <stdlib.h>
+static inline int mtbc_probe_int(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
+static inline bool mtbc_probe_set(const char* name) { return getenv(name) != nullptr; }
+#define MTBC_DBG_BIT(p, bit) ((p).dbg & (bit))
+#else
+#define mtbc_probe_int(name, dflt) (dflt)
+#define mtbc_probe_set(name) (false)
+#define MTBC_DBG_BIT(p, bit) (0)
+#endif
+
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 

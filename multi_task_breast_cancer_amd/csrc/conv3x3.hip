@@ -238,7 +238,7 @@ __global__ __launch_bounds__(256, MT >= 3 ? 2 : 3) void conv3x3_igemm_kernel(con
                 // next item's global loads: issued here so that their address arithmetic runs in the shadow of the
                 // MFMAs below (24 of every 32 MFMA cycles leave the vector issue port free) instead of ahead of them
                 if (last) set_tile(tile + gridDim.x);
-                if (!(p.dbg & 1)) load_chunk(last ? 0 : chunk + 1);
+                if (!MTBC_DBG_BIT(p, 1)) load_chunk(last ? 0 : chunk + 1);
             } else {
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -251,7 +251,7 @@ __global__ __launch_bounds__(256, MT >= 3 ? 2 : 3) void conv3x3_igemm_kernel(con
                         acc[m][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[q & 1][s3][m], fb[q & 1][s3][g], acc[m][g], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (more && !(p.dbg & 4)) store_chunk(((it + 1) & 1) * BUF);     // prefetch registers die here, before the epilogue
+        if (more && !MTBC_DBG_BIT(p, 4)) store_chunk(((it + 1) & 1) * BUF);     // prefetch registers die here, before the epilogue
         if (last) {
             // ---- epilogue of `tile`: D row = (lane>>4)*4 + reg (channel), col = lane&15 (pixel)
             int t = tile;
@@ -267,7 +267,7 @@ __global__ __launch_bounds__(256, MT >= 3 ? 2 : 3) void conv3x3_igemm_kernel(con
                 if (GEO == 0) { y = y0 + 2 * wv + (g >> 1); x = x0 + 16 * (g & 1) + j; }
                 else if (GEO == 1) { y = y0 + 4 * wv + g; x = x0 + j; }
                 else { y = y0 + 2 * g + (j >> 3); x = x0 + (j & 7); }
-                const bool ok = n < p.N && y < p.H && x < p.W && !(p.dbg & 2);
+                const bool ok = n < p.N && y < p.H && x < p.W && !MTBC_DBG_BIT(p, 2);
                 all_px = all_px && ok;
                 poff[g] = ok ? y * p.W + x : -1;
             }
@@ -364,7 +364,7 @@ __global__ __launch_bounds__(256, RING == 3 ? 2 : 3) void conv3x3_igemm_dma_kern
     // XCD takes one contiguous eighth of the tile list and its blocks sweep it side by side, so the halo rows / the
     // partly used cache lines two neighbouring tiles share are fetched into ONE L2 instead of two.
     int tile0, tstep, tend;
-    if ((gridDim.x & 7) == 0 && !(p.dbg & 16)) {
+    if ((gridDim.x & 7) == 0 && !MTBC_DBG_BIT(p, 16)) {
         const int per = (p.ntiles + 7) >> 3, xcd = blockIdx.x & 7;
         tile0 = xcd * per + (blockIdx.x >> 3); tstep = gridDim.x >> 3; tend = min(p.ntiles, (xcd + 1) * per);
     } else { tile0 = blockIdx.x; tstep = gridDim.x; tend = p.ntiles; }
@@ -713,7 +713,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_igemm_lp_kernel(const ConvP p)
             const int img = hp / (HR * HC), rem = hp % (HR * HC);
             const int row = rem / HC, col = rem % HC;
             const int y = y0 + row - 1, x = x0 + col - 1;
-            const bool ok = hp < HP && fn0 + img < p.N && y >= 0 && y < p.H && x >= 0 && x < p.W && !(p.dbg & 1);
+            const bool ok = hp < HP && fn0 + img < p.N && y >= 0 && y < p.H && x >= 0 && x < p.W && !MTBC_DBG_BIT(p, 1);
             pixb[q] = ok ? 4u * (unsigned)(y * p.W + x) : 0xfffffff0u;      // out of range for the buffer: reads 0
             if (G::IMG > 1) okm |= ok ? (1u << q) : 0u;
         }
@@ -753,7 +753,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_igemm_lp_kernel(const ConvP p)
     // XCD takes one contiguous eighth of the tile list and its blocks sweep it side by side, so the halo rows / the
     // partly used cache lines two neighbouring tiles share are fetched into ONE L2 instead of two.
     int tile, tstep, tend;
-    if ((gridDim.x & 7) == 0 && !(p.dbg & 16)) {
+    if ((gridDim.x & 7) == 0 && !MTBC_DBG_BIT(p, 16)) {
         const int per = (p.ntiles + 7) >> 3, xcd = blockIdx.x & 7;
         tile = xcd * per + (blockIdx.x >> 3); tstep = gridDim.x >> 3; tend = min(p.ntiles, (xcd + 1) * per);
     } else { tile = blockIdx.x; tstep = gridDim.x; tend = p.ntiles; }
@@ -772,7 +772,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_igemm_lp_kernel(const ConvP p)
             // ---- W: LDS-DMA of the pre-converted image (L2-resident, shared by every block), 1 KB per wave
             //      instruction, issued first so that waiting for it later leaves the X prefetch in flight; a
             //      single-chunk conv keeps its weights in LDS for the whole launch
-            const bool wload = w_have != ch && !(p.dbg & 8);
+            const bool wload = w_have != ch && !MTBC_DBG_BIT(p, 8);
             if (wload) {
                 constexpr int W16 = WB / 8;       // 16-byte pieces
                 constexpr int WI = (W16 + 63) / 64;
@@ -826,7 +826,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_igemm_lp_kernel(const ConvP p)
         //      16-byte read-modify-write: measured against no-return float atomics (4 per store, coalesced only with
         //      channels on the rows) it is 7 % faster over the step's dgrads even though its loads queue behind the prefetch.
         const int n = GEO == 2 ? n0 + wv : n0;
-        if (p.dbg & 2) { if (acc[0][0][0] != 12345.678f) continue; }
+        if MTBC_DBG_BIT(p, 2) { if (acc[0][0][0] != 12345.678f) continue; }
         int poff[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -906,7 +906,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_igemm_c8_kernel(const ConvP p)
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(p.wp), 0, (int)((size_t)p.mtiles * nchunks * (9 * 16 * WROW) * 2), 0x00020000);
     int tile, tstep, tend;            // XCD-aware walk, as above
-    if ((gridDim.x & 7) == 0 && !(p.dbg & 16)) {
+    if ((gridDim.x & 7) == 0 && !MTBC_DBG_BIT(p, 16)) {
         const int per = (p.ntiles + 7) >> 3, xcd = blockIdx.x & 7;
         tile = xcd * per + (blockIdx.x >> 3); tstep = gridDim.x >> 3; tend = min(p.ntiles, (xcd + 1) * per);
     } else { tile = blockIdx.x; tstep = gridDim.x; tend = p.ntiles; }
@@ -923,7 +923,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_igemm_c8_kernel(const ConvP p)
             const int img = hp / (HR * HC), rem = hp % (HR * HC);
             const int row = rem / HC, col = rem % HC;
             const int y = y0 + row - 1, x = x0 + col - 1;
-            const bool ok = hp < HP && n0 + img < p.N && y >= 0 && y < p.H && x >= 0 && x < p.W && !(p.dbg & 1);
+            const bool ok = hp < HP && n0 + img < p.N && y >= 0 && y < p.H && x >= 0 && x < p.W && !MTBC_DBG_BIT(p, 1);
             pixo[q] = ok ? 16u * (unsigned)(y * p.W + x) : 0xfffffff0u;
             pimg[q] = ok ? img : 0;
         }
@@ -956,7 +956,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_igemm_c8_kernel(const ConvP p)
                         __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_ptr_t)(Xs + (wvu * HPP + 64 * q) * 8), 16, off, 0, 0, 0);
                 }
             }
-            if (w_have != ch && !(p.dbg & 8)) {   // ---- W: a single-chunk conv keeps its weights in LDS for the whole launch
+            if (w_have != ch && !MTBC_DBG_BIT(p, 8)) {   // ---- W: a single-chunk conv keeps its weights in LDS for the whole launch
                 constexpr int W16 = WB / 8, WI = (W16 + 63) / 64;
 #pragma unroll
                 for (int k = 0; k < (WI + 3) / 4; ++k) {
@@ -991,7 +991,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_igemm_c8_kernel(const ConvP p)
         }
         // ---- epilogue: identical to conv3x3_igemm_lp_kernel (fp32 planar output, 16-byte stores / read-modify-write)
         const int n = GEO == 2 ? n0 + wv : n0;
-        if (p.dbg & 2) { if (acc[0][0][0] != 12345.678f) continue; }
+        if MTBC_DBG_BIT(p, 2) { if (acc[0][0][0] != 12345.678f) continue; }
         int poff[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -1096,7 +1096,7 @@ __global__ __launch_bounds__(128 * COT, 3) void conv3x3_wgrad_mfma_kernel(const 
         const int ty = t % p.tiles_y; t /= p.tiles_y;
         const int n0 = t * G::IMG, x0 = tx * G::TW, y0 = ty * G::TH;
         if (G::IMG == 1) {
-            const bool interior = y0 >= 1 && y0 + G::TH + 1 <= p.H && x0 >= 4 && x0 + G::TW + 4 <= p.W && !(p.dbg & 1);   // uniform
+            const bool interior = y0 >= 1 && y0 + G::TH + 1 <= p.H && x0 >= 4 && x0 + G::TW + 4 <= p.W && !MTBC_DBG_BIT(p, 1);   // uniform
             if (interior) {
                 const float* xt = xplane + ((size_t)n0 * xbs + y0 * p.W + x0);
                 const float* zt = zplane + ((size_t)n0 * p.Cout * HW + y0 * p.W + x0);
@@ -1173,12 +1173,12 @@ __global__ __launch_bounds__(128 * COT, 3) void conv3x3_wgrad_mfma_kernel(const 
     for (int s = 0; s < XSLOTS; ++s) xr[s] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int s = 0; s < 4; ++s) zr[s] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (t_begin < t_end && !(p.dbg & 1)) prefetch(t_begin);
+    if (t_begin < t_end && !MTBC_DBG_BIT(p, 1)) prefetch(t_begin);
     for (int tile = t_begin; tile < t_end; ++tile) {
         __syncthreads();                       // everyone is done reading the previous tile
-        if (!(p.dbg & 4)) commit();
+        if (!MTBC_DBG_BIT(p, 4)) commit();
         __syncthreads();
-        if (tile + 1 < t_end && !(p.dbg & 1)) prefetch(tile + 1);   // in flight under the MFMAs below
+        if (tile + 1 < t_end && !MTBC_DBG_BIT(p, 1)) prefetch(tile + 1);   // in flight under the MFMAs below
         // 32 k-steps of 4 pixels; fragments of step s+1 are read before the MFMAs of step s (bounded live ranges:
         // without the sched_barriers hipcc hoists all 320 LDS reads and needs >180 VGPRs, i.e. 2 waves/SIMD)
         float fa[2], fb[2][9];
@@ -1430,7 +1430,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_lp2_kernel(const WgP p) 
         const int n = t, x0 = tx * TW, y0 = ty * TH;
         const float* xt = xplane + ((size_t)n * xbs + y0 * p.W + x0);
         const float* zt = zplane + ((size_t)n * p.Cout * HW + y0 * p.W + x0);
-        const bool interior = y0 >= 1 && y0 + TH + 1 <= p.H && x0 >= 4 && x0 + TW + 4 <= p.W && !(p.dbg & 1);   // uniform
+        const bool interior = y0 >= 1 && y0 + TH + 1 <= p.H && x0 >= 4 && x0 + TW + 4 <= p.W && !MTBC_DBG_BIT(p, 1);   // uniform
         if (interior) {
             live = slots_ok;
 #pragma unroll
@@ -1445,7 +1445,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_lp2_kernel(const WgP p) 
             const int f = q + 8 * s;
             const int row = f / (LW / 4), c4 = f % (LW / 4);
             const int y = y0 + row - 1, x = x0 - 4 + c4 * 4;
-            const bool ok = f < XF4 && ci_ok && y >= 0 && y < p.H && x >= 0 && x < p.W && !(p.dbg & 1);
+            const bool ok = f < XF4 && ci_ok && y >= 0 && y < p.H && x >= 0 && x < p.W && !MTBC_DBG_BIT(p, 1);
             xr[s] = *reinterpret_cast<const float4*>(ok ? xt + xrel[s] : xplane);
             live |= ok ? (1u << s) : 0u;
         }
@@ -1453,7 +1453,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_lp2_kernel(const WgP p) 
         for (int s = 0; s < 4; ++s) {
             const int px = (q + 8 * s) * 4;
             const int y = y0 + px / TW, x = x0 + px % TW;
-            const bool ok = co_ok && y < p.H && x < p.W && !(p.dbg & 1);
+            const bool ok = co_ok && y < p.H && x < p.W && !MTBC_DBG_BIT(p, 1);
             zr[s] = *reinterpret_cast<const float4*>(ok ? zt + zrel[s] : zplane);
             live |= ok ? (1u << (XSLOTS + s)) : 0u;
         }
@@ -1489,7 +1489,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_lp2_kernel(const WgP p) 
     if (t_begin < t_end) prefetch(t_begin);
     for (int tile = t_begin; tile < t_end; ++tile) {
         __syncthreads();                       // everyone is done reading the previous tile
-        if (!(p.dbg & 4)) commit();
+        if (!MTBC_DBG_BIT(p, 4)) commit();
         __syncthreads();
         if (tile + 1 < t_end) prefetch(tile + 1);          // in flight under the MFMAs below
 #pragma unroll
@@ -1986,13 +1986,13 @@ int pick_geo(int H, int W) { return (W == 8 && H == 8) ? 2 : (W <= 16 ? 1 : 0); 
 template <int MT, int GEO>
 int launch_igemm(const ConvP& p, int mblocks, hipStream_t st) {
     using G = Geo<GEO>;
-    static const bool nodma = getenv("MTBC_NODMA") != nullptr;
+    static const bool nodma = mtbc_probe_set("MTBC_NODMA");
     // persistent grid: gridDim.x a multiple of 8 so that the channel blocks of one pixel tile (same blockIdx.x)
     // land on one XCD and share its L2
     if constexpr (GEO != 2) {
         if (!nodma) {
             constexpr int RING = 2;     // measured: occupancy (3 blocks/CU) beats the deeper 3-slot prefetch on every layer
-            static const int ring_env = getenv("MTBC_RING") ? atoi(getenv("MTBC_RING")) : 0;
+            static const int ring_env = mtbc_probe_int("MTBC_RING", 0);
             const int ring = ring_env ? ring_env : RING;
             const size_t lds = ((size_t)ring * (KC * G::PS + MT * KC * 144) + SEGL_FLOATS + MT * 16) * sizeof(float);
             static bool attr_set = false;
@@ -2078,7 +2078,7 @@ int launch_igemm_c8(const ConvP& p, int mblocks, bool f16, hipStream_t st) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_igemm_c8_kernel<MT, GEO, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    static const int per_cu_env = getenv("MTBC_C8_BLOCKS_PER_CU") ? atoi(getenv("MTBC_C8_BLOCKS_PER_CU")) : 0;      // A/B
+    static const int per_cu_env = mtbc_probe_int("MTBC_C8_BLOCKS_PER_CU", 0);      // A/B
     // one wave of resident blocks.  The image fits 4 per CU (40.6 KB) and the kernel compiles to 128 VGPRs, but measured
     // (v9): 4 resident blocks are no faster than 3 (16.52 vs 16.49 ms per step; single launches 3-15 % slower) -> 3.
     const int per_cu = per_cu_env ? per_cu_env : (lds * 3 <= 160 * 1024 ? 3 : 2);
@@ -2103,7 +2103,7 @@ int run_igemm(int N, int H, int W, int red, int rows, const SegTable& in, const 
               const float* bias, int compute, hipStream_t st, bool c8 = false) {
     ConvP p;
     p.N = N; p.H = H; p.W = W; p.Cin = red; p.Cout = rows; p.in = in; p.out = out; p.wp = wp; p.bias = bias;
-    static const int dbg = getenv("MTBC_DBG") ? atoi(getenv("MTBC_DBG")) : 0;
+    static const int dbg = mtbc_probe_int("MTBC_DBG", 0);
     p.dbg = dbg;
 
     const int geo = pick_geo(H, W);
@@ -2112,7 +2112,7 @@ int run_igemm(int N, int H, int W, int red, int rows, const SegTable& in, const 
     else if (geo == 1) { p.tiles_x = cdiv(W, 16); p.tiles_y = cdiv(H, 16); p.ntiles = p.tiles_x * p.tiles_y * N; }
     else { p.tiles_x = 1; p.tiles_y = 1; p.ntiles = cdiv(N, 4); }
     // channel tiles per block: up to 3 (4 spills past 256 VGPRs), fewer when the launch would not fill 256 CUs twice over
-    static const int mtmax_env = getenv("MTBC_LP_MT") ? atoi(getenv("MTBC_LP_MT")) : 0;      // A/B probe
+    static const int mtmax_env = mtbc_probe_int("MTBC_LP_MT", 0);      // A/B probe
     // 16-bit kernels: 2 tiles per block keep LDS at 51 KB = 3 blocks per CU; 3 tiles (62 KB, 2 blocks) measured slower
     // on every layer (dgrad 144->24: 0.71 -> 0.56 ms) although the pixel tile is staged once more per channel block
     const int mtmax = compute != 0 ? (mtmax_env ? mtmax_env : 2) : 3;
@@ -2371,12 +2371,12 @@ int mtbc_conv3x3_wgrad(const mtbc_conv3x3_args* a, void* stream) {
         WgP p; p.N = a->N; p.H = a->H; p.W = a->W; p.Cin = a->Cin; p.Cout = a->Cout; p.in = in; p.dz = a->dout;
         p.partial = partial; p.tiles_x = w.tiles_x; p.tiles_y = w.tiles_y; p.total_tiles = w.total_tiles;
         p.tiles_per_split = w.tiles_per_split; p.ciblocks = w.ciblocks;
-        static const int dbgw = getenv("MTBC_DBG") ? atoi(getenv("MTBC_DBG")) : 0;
+        static const int dbgw = mtbc_probe_int("MTBC_DBG", 0);
         p.dbg = dbgw;
         dim3 grid(w.nsplit, w.coblocks * w.ciblocks);
         const int zch = 16 * w.cot;
         const dim3 blk(128 * w.cot);
-        static const int lowp_env = getenv("MTBC_LOWP") ? atoi(getenv("MTBC_LOWP")) : -1;
+        static const int lowp_env = mtbc_probe_int("MTBC_LOWP", -1);
         const int lowp = lowp_env >= 0 ? lowp_env : a->compute;       // 0 fp32 (exact), 1 bf16, 2 fp16 MFMA operands
 #define MTBC_WG_LAUNCH(GEO_, COT_)                                                                                         \
         do {                                                                                                               \
@@ -2387,7 +2387,7 @@ int mtbc_conv3x3_wgrad(const mtbc_conv3x3_args* a, void* stream) {
             else hipLaunchKernelGGL((conv3x3_wgrad_mfma_kernel<GEO_, COT_>), grid, blk,                                    \
                                     (32 * WGeo<GEO_>::PSX + zch * PSZ) * sizeof(float), st, p);                            \
         } while (0)
-        static const bool lp1 = getenv("MTBC_WGRAD_LP1") != nullptr;      // A/B: first-generation 16-bit wgrad
+        static const bool lp1 = mtbc_probe_set("MTBC_WGRAD_LP1");      // A/B: first-generation 16-bit wgrad
         if (w.geo == 0 && w.cot == 2 && lowp != 0 && !lp1) {
             static bool attr2 = false;
             if (!attr2) {

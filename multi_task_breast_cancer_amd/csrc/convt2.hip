@@ -581,7 +581,7 @@ bool mtbc_i_convT2_wgrad_ok(const mtbc_convT_args* a) {
 void mtbc_i_convT2_wgrad_plan(const mtbc_convT_args* a, int* steps_per_split, int* nsplit) {
     const long long total_steps = (long long)a->N * (a->H * a->W / 32);
     const long long per_split_tasks = (long long)cdiv(a->Cin, 48) * cdiv(a->Cout, 8);
-    static const int tasks_env = getenv("MTBC_CT_WG_TASKS") ? atoi(getenv("MTBC_CT_WG_TASKS")) : 0;      // A/B
+    static const int tasks_env = mtbc_probe_int("MTBC_CT_WG_TASKS", 0);      // A/B
     long long want = cdiv64(tasks_env > 0 ? tasks_env : 4096, per_split_tasks);
     if (want < 1) want = 1;
     long long sps = cdiv64(total_steps, want);

@@ -410,7 +410,7 @@ int mtbc_instnorm_lrelu_bwd(const mtbc_instnorm_args* a, void* stream) {
     const bool vec = p.HW % 4 == 0 && al16(p.z) && al16(p.dy) && p.dybs % 4 == 0 &&
                      (p.dz16 ? (reinterpret_cast<uintptr_t>(p.dz16) & 7) == 0 : al16(p.dz));
     const int threads = p.HW >= 16384 ? 1024 : (p.HW >= 1024 ? 256 : 64);
-    static const bool stream_only = getenv("MTBC_IN_BWD_STREAM") != nullptr;      // A/B switch
+    static const bool stream_only = mtbc_probe_set("MTBC_IN_BWD_STREAM");      // A/B switch
     const int vpt = vec ? cdiv(p.HW / 4, threads) : 0;
     if (p.dz16 && !(vec && !stream_only && vpt <= 16)) return MTBC_E_UNSUPPORTED;
     if (vec && !stream_only && vpt <= 16) {

@@ -15,9 +15,12 @@
 // tag = (epoch mod (2^22 - 1) + 1) << 10 | exchange number; `epoch` lives in the caller's persistent state block, is read by every
 // workgroup when it starts and advanced by the LAST workgroup to finish (which thereby knows everybody has read it).
 // Two mailbox slots by exchange parity: a member can post exchange s+2 only after all members posted s+1, i.e. after
-// they finished reading s.  Polls are bounded (CO_SPIN_MAX): a protocol failure sets state->err and produces garbage,
-// never a hang.  Requires all workgroups of a team to be resident: the grid is sized from the occupancy query.
+// they finished reading s.  Polls are bounded (CO_SPIN_MAX) and give up together: a protocol failure sets state->err (sticky;
+// the HOST must read it -- trainer.FusedTrainStep.check_nan does -- because the outputs are then garbage), never a hang.
+// Requires all workgroups of a team to be resident: the grid is sized from the occupancy query, capped at 2 per CU, minus
+// the CUs the caller reserves per call for kernels of other streams (mtbc_instnorm_args.coop_reserve_cus).
 #include "common.h"
+#include <stddef.h>
 
 namespace {
 
@@ -55,14 +58,21 @@ template <bool F16> __device__ __forceinline__ unsigned co_pk(float a, float b) 
 __device__ __forceinline__ void mb_post(unsigned long long* slot, float v, unsigned tag) {
     __hip_atomic_store(slot, ((unsigned long long)tag << 32) | __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// A poll gives up after CO_SPIN_MAX tries (sets hdr->err) -- and as soon as ANY wave of ANY workgroup has given up: err
+// is re-read every CO_ERR_EVERY tries and before the first one, so that one timeout ends the whole launch within
+// microseconds instead of every later wait of every exchange spinning its own full budget.  The host reads the word
+// (FusedTrainStep.check_nan / FusedEvalStep.result) and raises.
+constexpr unsigned CO_ERR_EVERY = 256;
 __device__ __forceinline__ float mb_wait(unsigned long long* slot, unsigned tag, CoopHdr* hdr) {
-    unsigned long long w = 0;
+    unsigned long long w = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((unsigned)(w >> 32) == tag) return __uint_as_float((unsigned)w);
     unsigned spins = 0;
     for (;;) {
+        if ((spins & (CO_ERR_EVERY - 1)) == 0 && __hip_atomic_load(&hdr->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+        __builtin_amdgcn_s_sleep(2);
         w = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if ((unsigned)(w >> 32) == tag) break;
         if (++spins >= CO_SPIN_MAX) { __hip_atomic_store(&hdr->err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-        __builtin_amdgcn_s_sleep(2);
     }
     return __uint_as_float((unsigned)w);
 }
@@ -289,22 +299,31 @@ __global__ __launch_bounds__(CO_THREADS, 4) void in_bwd_coop_kernel(const CoP p)
 }
 
 struct CoPlan { bool ok; int ppt, T, grid, nteams; };
-int g_reserved_cus = 0;                       // CUs left to kernels of other streams (collectives), mtbc_instnorm_coop_reserve
 template <typename K> int resident_blocks(K kernel) {
     int per_cu = 0, dev = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, CO_THREADS, 0) != hipSuccess || per_cu < 1) return 0;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+    // The occupancy query is advisory: for SGPR-heavy kernels it has been seen one block per CU high where it answers the
+    // wave-slot maximum (MI355X_MICROARCH.md, Residency; 512-thread workgroups: 4 per CU).  A VGPR-limited answer (2 or 3
+    // per CU) is exact, so only the maximum is lowered by one.
+    if (per_cu > 3) per_cu = 3;
     return per_cu * prop.multiProcessorCount;
 }
-int usable(int cap_all_cus) {                 // capacity with g_reserved_cus of the device's CUs left out
-    int dev = 0; hipDeviceProp_t prop;
-    if (g_reserved_cus <= 0 || hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return cap_all_cus;
-    const int cus = prop.multiProcessorCount, keep = cus - g_reserved_cus;
+int device_cus() {
+    static int cus = -1;          // immutable after the first query (the device does not change under a process)
+    if (cus < 0) { int dev = 0; hipDeviceProp_t prop; cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 0; }
+    return cus;
+}
+// capacity with `reserve` of the device's CUs left to kernels of other streams (a per-call argument: no process state)
+int usable(int cap_all_cus, int reserve) {
+    const int cus = device_cus();
+    if (reserve <= 0 || cus <= 0) return cap_all_cus;
+    const int keep = cus - reserve;
     return keep < 8 ? cap_all_cus / cus * 8 : cap_all_cus / cus * keep;
 }
 // team size / pixels per thread: the most even split of `items` over the resident teams, larger slabs on ties
-CoPlan plan_coop(int items, int HW, int max_ppt, const int* cap_by_ppt) {
+CoPlan plan_coop(int items, int HW, int max_ppt, const int* cap_by_ppt, int reserve) {
     CoPlan best{false, 0, 0, 0, 0};
     double best_eff = -1.0;
     for (int ppt = max_ppt; ppt >= 1; ppt >>= 1) {
@@ -312,7 +331,7 @@ CoPlan plan_coop(int items, int HW, int max_ppt, const int* cap_by_ppt) {
         if (HW <= CO_THREADS * ppt) { if (ppt > 1 && HW <= CO_THREADS * (ppt / 2)) continue; T = 1; }
         else { if (HW % (CO_THREADS * ppt)) continue; T = HW / (CO_THREADS * ppt); }
         if (T > CO_MAXT) continue;
-        const int cap = usable(cap_by_ppt[ppt]);
+        const int cap = usable(cap_by_ppt[ppt], reserve);
         if (cap < T) continue;
         int teams = cap / T;
         if (teams > items) teams = items;
@@ -333,44 +352,52 @@ int fill_coop(const mtbc_instnorm_args* a, CoP* p) {
     p->dz8 = reinterpret_cast<unsigned short*>(a->dz8); p->part = nullptr; p->part3 = nullptr; p->state = a->coop_state;
     return MTBC_OK;
 }
-CoPlan plan_fwd(int items, int HW) {
-    static int cap[9] = {-1};
-    if (cap[0] < 0) {
-        cap[1] = resident_blocks(in_fwd_coop_kernel<1, false>); cap[2] = resident_blocks(in_fwd_coop_kernel<2, false>);
-        cap[4] = resident_blocks(in_fwd_coop_kernel<4, false>); cap[8] = 0;      // 8 pixels per thread spill at 4 waves/SIMD
-        cap[0] = 0;
-    }
-    return plan_coop(items, HW, 4, cap);
+// Resident capacity per (pixels per thread, output type): the bf16 and fp16 instantiations are different kernels with
+// their own register counts, so each launch is planned with the capacity of the variant it runs.  Filled once
+// (function-local statics: thread-safe initialisation, immutable afterwards).
+struct CapTable { int cap[2][9]; };
+const CapTable& caps_fwd() {
+    static const CapTable t = [] { CapTable c{};
+        c.cap[0][1] = resident_blocks(in_fwd_coop_kernel<1, false>); c.cap[0][2] = resident_blocks(in_fwd_coop_kernel<2, false>);
+        c.cap[0][4] = resident_blocks(in_fwd_coop_kernel<4, false>);
+        c.cap[1][1] = resident_blocks(in_fwd_coop_kernel<1, true>); c.cap[1][2] = resident_blocks(in_fwd_coop_kernel<2, true>);
+        c.cap[1][4] = resident_blocks(in_fwd_coop_kernel<4, true>);      // 8 pixels per thread spill at 4 waves/SIMD: not built
+        return c; }();
+    return t;
 }
-CoPlan plan_bwd(int items, int HW) {
-    static int cap[9] = {-1};
-    if (cap[0] < 0) {
-        cap[1] = resident_blocks(in_bwd_coop_kernel<1, false>); cap[2] = resident_blocks(in_bwd_coop_kernel<2, false>);
-        cap[4] = resident_blocks(in_bwd_coop_kernel<4, false>); cap[8] = 0;
-        cap[0] = 0;
-    }
-    return plan_coop(items, HW, 4, cap);
+const CapTable& caps_bwd() {
+    static const CapTable t = [] { CapTable c{};
+        c.cap[0][1] = resident_blocks(in_bwd_coop_kernel<1, false>); c.cap[0][2] = resident_blocks(in_bwd_coop_kernel<2, false>);
+        c.cap[0][4] = resident_blocks(in_bwd_coop_kernel<4, false>);
+        c.cap[1][1] = resident_blocks(in_bwd_coop_kernel<1, true>); c.cap[1][2] = resident_blocks(in_bwd_coop_kernel<2, true>);
+        c.cap[1][4] = resident_blocks(in_bwd_coop_kernel<4, true>);
+        return c; }();
+    return t;
 }
+CoPlan plan_fwd(int items, int HW, bool f16, int reserve) { return plan_coop(items, HW, 4, caps_fwd().cap[f16 ? 1 : 0], reserve); }
+CoPlan plan_bwd(int items, int HW, bool f16, int reserve) { return plan_coop(items, HW, 4, caps_bwd().cap[f16 ? 1 : 0], reserve); }
 
 }  // namespace
 
 extern "C" {
 
-void mtbc_instnorm_coop_reserve(int32_t compute_units) { g_reserved_cus = compute_units < 0 ? 0 : compute_units; }
+size_t mtbc_instnorm_coop_error_offset(void) { return offsetof(CoopHdr, err); }
 
 size_t mtbc_instnorm_coop_state_bytes(void) { return CO_MAILBOX_OFF + (size_t)CO_MAX_TEAMS * CO_TEAM_WORDS * sizeof(unsigned long long); }
 
 int mtbc_instnorm_c8_supported(const mtbc_instnorm_args* a, int32_t backward) {
     if (!a || a->N <= 0 || a->C <= 0 || a->H <= 0 || a->W <= 0 || a->C % 8) return 0;
     if (backward && a->n_dy_extra != 0) return 0;
-    const CoPlan pl = backward ? plan_bwd(a->N * (a->C / 8), a->H * a->W) : plan_fwd(a->N * (a->C / 8), a->H * a->W);
+    const bool f16 = a->out16_type == 2;
+    const CoPlan pl = backward ? plan_bwd(a->N * (a->C / 8), a->H * a->W, f16, a->coop_reserve_cus)
+                               : plan_fwd(a->N * (a->C / 8), a->H * a->W, f16, a->coop_reserve_cus);
     return pl.ok ? 1 : 0;
 }
 
 int mtbc_i_instnorm_fwd_c8(const mtbc_instnorm_args* a, hipStream_t st) {
     CoP p; int rc = fill_coop(a, &p); if (rc) return rc;
     if (!p.z || !p.y8 || !p.mean || !p.rstd || (reinterpret_cast<uintptr_t>(p.y8) & 15)) return MTBC_E_BADARG;
-    const CoPlan pl = plan_fwd(p.items, p.HW);
+    const CoPlan pl = plan_fwd(p.items, p.HW, p.f16 != 0, a->coop_reserve_cus);
     if (!pl.ok) return MTBC_E_UNSUPPORTED;
     p.T = pl.T; p.nteams = pl.nteams;
     const dim3 g(pl.grid), b(CO_THREADS);
@@ -386,13 +413,13 @@ int mtbc_i_instnorm_fwd_c8(const mtbc_instnorm_args* a, hipStream_t st) {
 // members per team of the backward launch (the parameter-gradient partials are [N*C][3] + [N*C][T] floats)
 int mtbc_i_instnorm_bwd_c8_team(const mtbc_instnorm_args* a) {
     if (!a || a->N <= 0 || a->C <= 0 || a->C % 8) return 0;
-    const CoPlan pl = plan_bwd(a->N * (a->C / 8), a->H * a->W);
+    const CoPlan pl = plan_bwd(a->N * (a->C / 8), a->H * a->W, a->out16_type == 2, a->coop_reserve_cus);
     return pl.ok ? pl.T : 0;
 }
 int mtbc_i_instnorm_bwd_c8(const mtbc_instnorm_args* a, float* part, hipStream_t st) {
     CoP p; int rc = fill_coop(a, &p); if (rc) return rc;
     if (!p.z || !p.dy || !p.dz8 || !p.mean || !p.rstd || (reinterpret_cast<uintptr_t>(p.dz8) & 15) || a->n_dy_extra != 0) return MTBC_E_BADARG;
-    const CoPlan pl = plan_bwd(p.items, p.HW);
+    const CoPlan pl = plan_bwd(p.items, p.HW, p.f16 != 0, a->coop_reserve_cus);
     if (!pl.ok) return MTBC_E_UNSUPPORTED;
     p.T = pl.T; p.nteams = pl.nteams; p.part = part; p.part3 = part ? part + (size_t)3 * a->N * a->C : nullptr;
     const dim3 g(pl.grid), b(CO_THREADS);

@@ -339,7 +339,7 @@ int mtbc_convT_fwd(const mtbc_convT_args* a, void* stream) {
         return mtbc_i_convT2_fwd_c8_ok(a) ? mtbc_i_convT2_fwd_c8(a, (hipStream_t)stream) : MTBC_E_UNSUPPORTED;
     if (a->y_layout != MTBC_LAYOUT_PLANAR) return MTBC_E_BADARG;
     if (!al16(p.y) || (p.ybs & 3) || ((a->W * a->k) & 3)) return MTBC_E_UNSUPPORTED;
-    static const bool generic_f = getenv("MTBC_CONVT_GENERIC") != nullptr;      // A/B switch
+    static const bool generic_f = mtbc_probe_set("MTBC_CONVT_GENERIC");      // A/B switch
     if (!generic_f && mtbc_i_convT2_fwd_ok(a)) return mtbc_i_convT2_fwd(a, (hipStream_t)stream);
     dim3 grid(cdiv(a->H * a->W, 64), cdiv(p.M, 64), a->N);
     hipStream_t st = (hipStream_t)stream;
@@ -359,7 +359,7 @@ int mtbc_convT_dgrad(const mtbc_convT_args* a, void* stream) {
     CtP p; int rc = fill_ct(a, &p); if (rc) return rc;
     if (!p.dy || !p.w || !p.dx) return MTBC_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
-    static const bool generic = getenv("MTBC_CONVT_GENERIC") != nullptr;      // A/B switch
+    static const bool generic = mtbc_probe_set("MTBC_CONVT_GENERIC");      // A/B switch
     if (!generic && mtbc_i_convT2_dgrad_ok(a)) return mtbc_i_convT2_dgrad(a, a->compute, st);
     dim3 grid(cdiv(a->H * a->W, 64), cdiv(a->Cin, 64), a->N);
     if (a->k == 2) hipLaunchKernelGGL(convT_dgrad_kernel<2>, grid, dim3(256), 0, st, p);
@@ -387,7 +387,7 @@ int mtbc_convT_wgrad(const mtbc_convT_args* a, void* stream) {
     p.partial = reinterpret_cast<float*>(a->workspace); p.S = S; p.cols_per_split = cols;
     int nsplit = a->N * S;
     hipStream_t st = (hipStream_t)stream;
-    static const bool generic = getenv("MTBC_CONVT_GENERIC") != nullptr;      // A/B switch
+    static const bool generic = mtbc_probe_set("MTBC_CONVT_GENERIC");      // A/B switch
     bool bias_done = false;
     if (!generic && mtbc_i_convT2_wgrad_ok(a)) {
         int sps; mtbc_i_convT2_wgrad_plan(a, &sps, &nsplit);

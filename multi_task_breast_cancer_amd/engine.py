@@ -17,15 +17,16 @@ import torch
 from . import _lib as L
 
 
-import os as _os
-_NOACC = _os.environ.get('MTBC_NOACC') == '1'     # timing probe only: results are wrong when set
-_NO_C8 = _os.environ.get('MTBC_NO_C8') == '1'     # A/B: 16-bit modes stage fp32 planar operands as before
-_NO_CT_LP = _os.environ.get('MTBC_NO_CT_LP') == '1'  # A/B: ConvT backward keeps fp32 MFMA operands in the 16-bit modes
-_NO_COOP = _os.environ.get('MTBC_NO_COOP') == '1'    # A/B: InstanceNorm by one-plane workgroups + pack instead of the cooperative kernels
-_COOP_MIN_FWD = int(_os.environ.get('MTBC_COOP_MIN_FWD', 16384))    # smallest plane (pixels) handed to the cooperative kernels
-_COOP_MIN_BWD = int(_os.environ.get('MTBC_COOP_MIN_BWD', 65536))
-_NO_GATHER = _os.environ.get('MTBC_NO_GATHER') == '1'  # A/B: every 3x3 conv back-propagates into all its inputs (fan-in by read-modify-write)
-_NO_P16 = _os.environ.get('MTBC_NO_P16') == '1'   # A/B / activation probes: InstanceNorm keeps writing fp32 y and dz
+from . import switches as _sw
+
+_NO_C8 = _sw.flag("MTBC_NO_C8")            # A/B arms of measured design decisions: see switches.py (both arms parity-tested)
+_NO_CT_LP = _sw.flag("MTBC_NO_CT_LP")
+_NO_COOP = _sw.flag("MTBC_NO_COOP")
+_COOP_MIN_FWD = int(_sw.get("MTBC_COOP_MIN_FWD"))
+_COOP_MIN_BWD = int(_sw.get("MTBC_COOP_MIN_BWD"))
+_NO_GATHER = _sw.flag("MTBC_NO_GATHER")
+_NO_P16 = _sw.flag("MTBC_NO_P16")
+_FANIN = _sw.flag("MTBC_FANIN")
 
 
 def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
@@ -116,8 +117,9 @@ class StepPlan:
 
     def __init__(self, device: torch.device, N: int, param_view: Callable[[str], torch.Tensor],
                  grad_view: Callable[[str], torch.Tensor], slots: Dict[str, ParamSlot], force_direct: bool = False,
-                 compute: int = 0):
+                 compute: int = 0, coop_reserve_cus: int = 0):
         self.dev = device
+        self.coop_reserve_cus = int(coop_reserve_cus)    # CUs the cooperative InstanceNorm grids leave to other streams (data parallel)
         self.compute = int(compute)      # MFMA operand type of the 3x3 convs: 0 fp32 (parity path), 1 bf16, 2 fp16
         self.N = N
         self.pv, self.gv, self.slots = param_view, grad_view, slots
@@ -163,11 +165,11 @@ class StepPlan:
         if not a.grad_written:
             a.grad_written = True
             return self.grad_of(a), 0
-        if a.fanin_separate and len(a.extra_grads) < 4 and not _NOACC:
+        if a.fanin_separate and len(a.extra_grads) < 4:
             t = self.alloc(*a.data.shape)
             a.extra_grads.append(t)
             return t, 0
-        return self.grad_of(a), (0 if _NOACC else 1)
+        return self.grad_of(a), 1
 
     def _rd(self, a: Act) -> int:
         """Pointer to the fp32 planar values of an activation, for an op that reads them."""
@@ -200,6 +202,15 @@ class StepPlan:
             self._coop_buf = torch.zeros(self.lib.mtbc_instnorm_coop_state_bytes() // 4, dtype=torch.int32, device=self.dev)
             self.keep.append(self._coop_buf)
         return self._coop_buf.data_ptr()
+
+    def coop_error_word(self) -> Optional[torch.Tensor]:
+        """Device view (1 x int32) of the sticky error word of this plan's cooperative kernels, or None when the plan has
+        none.  Non-zero = a team member was not resident and a mailbox poll gave up: the step's results are garbage."""
+        buf = getattr(self, "_coop_buf", None)
+        if buf is None:
+            return None
+        i = self.lib.mtbc_instnorm_coop_error_offset() // 4
+        return buf[i:i + 1]
 
     def _scratch16(self, attr: str, numel: int) -> torch.Tensor:
         """Shared 16-bit scratch of the backward pass (IN-backward -> pack -> wgrad -> dgrad run back to back on one
@@ -273,7 +284,7 @@ class StepPlan:
         y = self.new_act(out_name, cout, H, W)
         # measured: private fan-in buffers summed by IN-backward (+1.25 ms there) cost more than the read-modify-write
         # they remove from the dgrad epilogues (-0.6 ms); the capability stays behind this switch
-        y.fanin_separate = _os.environ.get('MTBC_FANIN') == '1'
+        y.fanin_separate = _FANIN
         mean, rstd = self.alloc(N * cout), self.alloc(N * cout)
         self._tag += 1
         tag = self._tag
@@ -324,6 +335,7 @@ class StepPlan:
             a.gamma = _ptr(self.pv(gname)) if gname else None
             a.beta = _ptr(self.pv(betaname)) if betaname else None
             a.mean, a.rstd = mean.data_ptr(), rstd.data_ptr()
+            a.coop_reserve_cus = self.coop_reserve_cus
             return op
 
         op = base_in()
@@ -756,7 +768,7 @@ class StepPlan:
     # ------------------------------------------------------------------ losses (fused-step path)
     def fused_losses(self, seg_heads: Sequence[Act], logits: Act, mask: torch.Tensor, onehot: torch.Tensor,
                      alpha: float, inversely_weighted: bool, focal_weight: Optional[torch.Tensor] = None,
-                     loss_scale: float = 1.0):
+                     loss_scale: float = 1.0, binary: bool = False):
         """criterions.py:52-76 + training_multitask.py:98 on device: Dice over the heads (weights 1/(j+1) from the
         LAST head backwards), Focal on the logits, alpha-mix, NaN flag.  Gradients land in the heads' grad buffers."""
         nh = len(seg_heads)
@@ -766,6 +778,10 @@ class StepPlan:
         self.dice_loss = self.alloc(nh + 1)
         self.focal_loss = self.alloc(1)
         self.loss_out = self.alloc(4)
+        # device scalar multiplied into dL/d(logits) of both losses: 1 except on a rank whose shard of the global batch
+        # is not 1/world of it (trainer.FusedTrainStep.load_batch(weight=...)); the reported losses are not scaled
+        self.grad_weight = torch.ones(1, dtype=torch.float32, device=self.dev)
+        self.keep.append(self.grad_weight)
         weights = [(1.0 / (nh - i)) if inversely_weighted else 1.0 for i in range(nh)]   # head i is reversed index nh-1-i
 
         def dice_base(kind: int) -> L.Op:
@@ -783,20 +799,30 @@ class StepPlan:
         for i, h in enumerate(seg_heads):
             op.u.dice.dx[i] = self.grad_of(h).data_ptr()
             h.grad_written = True
+        op.u.dice.gscale_dev = self.grad_weight.data_ptr()
         op.u.dice.gscale = alpha * loss_scale      # loss_scale: fp16 mode keeps dz inside the fp16 range; Adam divides it out
         self.loss_ops.append(op)
+        if binary:
+            # ONE-logit head (n_classes == 2): the reference's BCEWithLogits (experiment_init.py:242) is applied by torch on
+            # the logit (trainer.FusedEvalStep); the program holds the Dice part only.  The backward program stays
+            # well-formed for the drop-in loop: the logits' gradient buffer is written by the caller.
+            self.grad_of(logits)
+            logits.grad_written = True
+            self.keep += [mask, onehot]
+            return
         op = _mk(L.OP_FOCAL)
         a = op.u.focal
         a.N, a.C, a.alpha, a.gamma = N, logits.C, 1.0, 2.0
         a.x, a.target, a.weight = logits.data.data_ptr(), onehot.data_ptr(), _ptr(focal_weight)
         a.loss, a.dx, a.gscale = self.focal_loss.data_ptr(), self.grad_of(logits).data_ptr(), (1.0 - alpha) * loss_scale
+        a.gscale_dev = self.grad_weight.data_ptr()
         logits.grad_written = True
         self.loss_ops.append(op)
         op = _mk(L.OP_LOSS_MIX)
         op.u.mix.seg = self.dice_loss.data_ptr() + 4 * nh
         op.u.mix.cls, op.u.mix.alpha, op.u.mix.out4 = self.focal_loss.data_ptr(), alpha, self.loss_out.data_ptr()
         self.loss_ops.append(op)
-        self.keep += [mask, onehot]
+        self.keep += [mask, onehot] + ([focal_weight] if focal_weight is not None else [])
 
     # ------------------------------------------------------------------ finalisation
     def emit_backward(self) -> None:

@@ -18,6 +18,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib as L
+from . import switches as _sw
 from .engine import Act, ParamSlot, StepPlan
 
 NNUNET_WIDTHS = (32, 64, 128, 256, 320)              # MTnnUNet.py:72
@@ -174,7 +175,7 @@ def _graph_mtnnunet(plan: StepPlan, x: Act):
     regions = plan.pv("output1.weight").shape[0]
     # deep-supervision heads: ConvT(k = 8 / 4 / 2) + 1x1 conv with nothing in between -> one transposed conv with the
     # combined weights (StepPlan.convT_head); MTBC_NOFUSE_HEADS=1 keeps the reference's two layers (A/B, parity check)
-    if os.environ.get("MTBC_NOFUSE_HEADS"):
+    if _sw.flag("MTBC_NOFUSE_HEADS"):
         o4 = plan.conv1x1(plan.convT(dec[4], w[2], 8, "output4.0.weight", "output4.0.bias", "o4up"), regions,
                           "output4.1.weight", "output4.1.bias", "output4")
         o3 = plan.conv1x1(plan.convT(dec[3], w[1], 4, "output3.0.weight", "output3.0.bias", "o3up"), regions,
@@ -249,7 +250,7 @@ class CompiledStep:
         dev = net.flat_p.device
         self.N, self.H, self.W = N, H, W
         plan = StepPlan(dev, N, net._param_view, net._grad_view, net.slots, force_direct=net.force_direct,
-                        compute=net.compute)
+                        compute=net.compute, coop_reserve_cus=net.coop_reserve_cus)
         self.x = Act("input", plan.alloc(N, net.in_channels, H, W), needs_grad=False)
         self.logits, self.segs = net._graph(plan, self.x)
         self.mask = self.onehot = None
@@ -259,7 +260,9 @@ class CompiledStep:
             heads = self.segs if net.deep_supervision_outputs else self.segs[-1:]
             self.loss_scale = float(net.loss_scale)
             plan.fused_losses(heads, self.logits, self.mask, self.onehot, fused_loss["alpha"],
-                              fused_loss["inversely_weighted"], fused_loss.get("focal_weight"), loss_scale=self.loss_scale)
+                              fused_loss["inversely_weighted"], fused_loss.get("focal_weight"), loss_scale=self.loss_scale,
+                              binary=bool(fused_loss.get("binary")))
+            self.grad_weight = plan.grad_weight
         else:
             for h in (self.segs if net.deep_supervision_outputs else self.segs[-1:]):
                 plan.grad_of(h)
@@ -274,6 +277,10 @@ class CompiledStep:
         # (parameters no backward op writes -- e.g. the unused deep-supervision heads when deep_supervision is
         # off -- keep a zero gradient, which Adam turns into a zero update, same as torch skipping grad=None)
         self.ready = sorted((max(s.ready_at, 0), s.name) for s in net.slots.values())
+        # ... snapshotted per compiled step: net.slots is plan-time scratch that the NEXT StepPlan resets and rewrites
+        # (another batch size, an evaluation step), and backward op indices are shape-dependent
+        self.slot_ready = [(net.slots[n].offset, net.slots[n].numel, max(net.slots[n].ready_at, 0)) for n in net._order]
+        self.buckets = None                     # trainer.plan_buckets(...) of this step, built on first use
 
 
 class HipMultiTaskNet(nn.Module):
@@ -284,6 +291,7 @@ class HipMultiTaskNet(nn.Module):
         super().__init__()
         self.compute = 0          # 3x3-conv MFMA operand type: 0 fp32 (reference arithmetic), 1 bf16, 2 fp16; set_compute()
         self.loss_scale = 1.0     # fused step only: dL is multiplied by this, Adam's grad_scale divides it out (fp16: 4096)
+        self.coop_reserve_cus = 0  # CUs the cooperative InstanceNorm grids leave free (set by a data-parallel FusedTrainStep)
         self.in_channels = in_channels
         self.deep_supervision = deep_supervision
         self.deep_supervision_outputs = deep_supervision
@@ -368,8 +376,16 @@ class HipMultiTaskNet(nn.Module):
     # ---- compiled steps ---------------------------------------------------------------------
     def compiled(self, N: int, H: int, W: int, fused_loss: Optional[dict] = None) -> CompiledStep:
         self.ensure_flat()
-        key = (N, H, W, self.compute,
-               None if fused_loss is None else (fused_loss["alpha"], fused_loss["inversely_weighted"], self.loss_scale))
+        fkey = None
+        if fused_loss is not None:
+            fw = fused_loss.get("focal_weight")
+            if fw is not None:
+                # its raw pointer is baked into the FOCAL op: validate once, key on identity, keep it alive with the plan
+                if fw.dtype != torch.float32 or not fw.is_contiguous() or fw.device != self.flat_p.device or fw.numel() != self.n_classes:
+                    raise ValueError("focal_weight must be a contiguous float32 tensor of n_classes values on the model's device")
+            fkey = (fused_loss["alpha"], fused_loss["inversely_weighted"], self.loss_scale,
+                    None if fw is None else (fw.data_ptr(), fw._version), bool(fused_loss.get("binary")))
+        key = (N, H, W, self.compute, self.coop_reserve_cus, fkey)
         st = self._steps.get(key)
         if st is None or st.param_ptr != self.flat_p.data_ptr():
             st = CompiledStep(self, N, H, W, fused_loss)

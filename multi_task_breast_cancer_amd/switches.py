@@ -1,0 +1,53 @@
+"""Every environment variable the package reads, in one place, so that a benchmark or test can report exactly which
+ones were set (`active()`) and refuse to run with one that changes results (`result_altering()`).
+
+Plan switches select between two paths that are BOTH parity-tested (A/B arms of measured design decisions, DESIGN.md
+"What was tried"); they change which kernels a step program is built from, never what it computes beyond the documented
+16-bit operand rounding.  The shipped library itself (`libmtbc_hip.so`) reads no environment variable at all: the
+kernel-level timing probes (MTBC_DBG load / store skipping, tile-shape overrides) exist only in the separately built
+`libmtbc_hip_probes.so` (`make -C csrc probes`), which has to be selected explicitly through MTBC_LIB.
+"""
+from __future__ import annotations
+
+import os
+from typing import Dict, List
+
+# name -> (default, what the non-default arm does)
+PLAN_SWITCHES: Dict[str, tuple] = {
+    "MTBC_NO_C8": ("0", "16-bit modes stage fp32 planar operands inside every consumer instead of reading channel-blocked tensors"),
+    "MTBC_NO_CT_LP": ("0", "k=2 ConvT forward/backward keep fp32 MFMA operands in the 16-bit modes"),
+    "MTBC_NO_COOP": ("0", "InstanceNorm by one-plane workgroups + pack instead of the cooperative kernels"),
+    "MTBC_COOP_MIN_FWD": ("16384", "smallest plane (pixels) handed to the cooperative InstanceNorm forward"),
+    "MTBC_COOP_MIN_BWD": ("65536", "smallest plane (pixels) handed to the cooperative InstanceNorm backward"),
+    "MTBC_NO_GATHER": ("0", "every 3x3 conv back-propagates into all its inputs (fan-in by read-modify-write)"),
+    "MTBC_NO_P16": ("0", "InstanceNorm keeps writing fp32 y / dz planes in the 16-bit modes"),
+    "MTBC_FANIN": ("0", "private gradient fan-in buffers summed by InstanceNorm backward"),
+    "MTBC_NOFUSE_HEADS": ("0", "MTnnUNet deep-supervision heads as ConvT + 1x1 (the reference's two layers) instead of one combined ConvT"),
+    "MTBC_COOP_RESERVE_CUS": ("64", "CUs kept out of the cooperative InstanceNorm grids under data parallel"),
+}
+# variables that only the probes build of the library (or removed timing hacks) ever honoured: results are wrong or
+# timings are not the product's when one of them takes effect
+RESULT_ALTERING = ("MTBC_DBG", "MTBC_NOACC", "MTBC_LOWP", "MTBC_LP_MT", "MTBC_RING", "MTBC_NODMA", "MTBC_C8_BLOCKS_PER_CU",
+                   "MTBC_WGRAD_LP1", "MTBC_CT_WG_TASKS", "MTBC_IN_BWD_STREAM", "MTBC_CONVT_GENERIC")
+
+
+def get(name: str) -> str:
+    return os.environ.get(name, PLAN_SWITCHES[name][0])
+
+
+def flag(name: str) -> bool:
+    v = get(name)
+    return v not in ("", "0")
+
+
+def active() -> Dict[str, str]:
+    """Every MTBC_* variable present in the environment (whether or not anything reads it)."""
+    return {k: v for k, v in sorted(os.environ.items()) if k.startswith("MTBC_")}
+
+
+def result_altering() -> List[str]:
+    """Set variables under which a measurement is not the product's: probe-build switches, or MTBC_LIB itself."""
+    bad = [k for k in RESULT_ALTERING if k in os.environ]
+    if "MTBC_LIB" in os.environ:
+        bad.append("MTBC_LIB")
+    return bad

@@ -19,6 +19,7 @@ import numpy as np
 import torch
 
 from . import _lib as L
+from . import switches as _sw
 
 
 # ------------------------------------------------------------------------------------------------
@@ -33,8 +34,11 @@ class Bucket:
 
 def plan_buckets(slots: Sequence[Tuple[int, int, int]], flat_numel: int, n_buckets: int) -> List[Bucket]:
     """slots: (offset, numel, ready_at) per parameter in layout order.  Splits the flat buffer into
-    `n_buckets` contiguous ranges of roughly equal size on parameter boundaries and returns them sorted by
-    readiness (earliest first).  Ranges tile [0, flat_numel) exactly."""
+    `n_buckets` contiguous ranges of roughly equal size on parameter boundaries and returns them from the END of the
+    buffer to its start: parameters are laid out in construction (= forward) order, so that is the order in which the
+    backward pass finishes them, and -- unlike a sort by op index -- it is the same on every rank even when ranks
+    build different step programs (the short last batch of an epoch): collectives must pair up.  A bucket whose
+    `ready_op` lies behind its successor's only waits a little longer.  Ranges tile [0, flat_numel) exactly."""
     if not slots:
         return []
     n_buckets = max(1, min(n_buckets, len(slots)))
@@ -54,7 +58,7 @@ def plan_buckets(slots: Sequence[Tuple[int, int, int]], flat_numel: int, n_bucke
             continue
         ready = max((r for off, numel, r in slots if a <= off < b), default=0)
         out.append(Bucket(a, b, ready))
-    out.sort(key=lambda bk: bk.ready_op)
+    out.sort(key=lambda bk: -bk.start)
     return out
 
 
@@ -90,6 +94,11 @@ def allreduce_buckets(flat_g: torch.Tensor, buckets: Sequence[Bucket], group=Non
 class FusedTrainStep:
     def __init__(self, model, optimizer, alpha: float, inversely_weighted: bool = True, n_classes: int = 3,
                  distributed: bool = False, n_buckets: int = 4, focal_weight: Optional[torch.Tensor] = None):
+        if n_classes < 3 or getattr(model, "n_classes", n_classes) < 3:
+            # training_multitask.py:84 one-hot-encodes the label; with n_classes == 2 the head has ONE logit and the
+            # reference trains it with BCEWithLogits (experiment_init.py:241-246) -- that loss is not in the fused program
+            raise NotImplementedError("FusedTrainStep covers the multi-class head (Focal / one-hot labels); for n_classes == 2 "
+                                      "use the drop-in loop (model(x), criterions.apply_criterion_..., optimizer.step())")
         self.model, self.opt = model, optimizer
         self.alpha, self.iw, self.n_classes = float(alpha), bool(inversely_weighted), n_classes
         self.focal_weight = focal_weight
@@ -103,11 +112,14 @@ class FusedTrainStep:
             self.comm_stream = torch.cuda.Stream()
             optimizer.grad_scale = 1.0 / self.world
             # the bucket all-reduces run on their own stream under the backward pass: keep CUs free for RCCL's resident
-            # kernels so that the cooperative InstanceNorm teams (which need every member resident) never queue behind them
-            if (self.world > 1 or "MTBC_COOP_RESERVE_CUS" in os.environ) and torch.cuda.is_available():
-                L.load().mtbc_instnorm_coop_reserve(int(os.environ.get("MTBC_COOP_RESERVE_CUS", "64")))
+            # kernels so that the cooperative InstanceNorm teams (which need every member resident) never queue behind
+            # them.  A property of the step programs this trainer builds (mtbc_instnorm_args.coop_reserve_cus), not of
+            # the process.
+            if self.world > 1 or "MTBC_COOP_RESERVE_CUS" in os.environ:
+                reserve = int(_sw.get("MTBC_COOP_RESERVE_CUS"))
+                if getattr(model, "coop_reserve_cus", 0) != reserve:
+                    model.coop_reserve_cus = reserve
         self._st = None
-        self._buckets: List[Bucket] = []
         self.losses: Optional[torch.Tensor] = None      # device: [total, seg, cls, nan_flag]
 
     def _compiled(self, N: int, H: int, W: int):
@@ -115,14 +127,17 @@ class FusedTrainStep:
                                                       "focal_weight": self.focal_weight})
         if st is not self._st:
             self._st = st
-            m = self.model
-            slots = [(m.slots[n].offset, m.slots[n].numel, m.slots[n].ready_at) for n in m._order]
-            self._buckets = plan_buckets(slots, m.flat_numel, self.n_buckets)
-            m.grads_as_views()
+            self.model.grads_as_views()
+        if st.buckets is None:          # readiness snapshot of THIS step program (model.slots is plan-time scratch)
+            st.buckets = plan_buckets(st.slot_ready, self.model.flat_numel, self.n_buckets)
         return st
 
-    def load_batch(self, image: torch.Tensor, mask: torch.Tensor, label: torch.Tensor):
-        """H2D / D2D of training_multitask.py:82-84 into the plan's static buffers (one-hot on the device)."""
+    def load_batch(self, image: torch.Tensor, mask: torch.Tensor, label: torch.Tensor, weight: Optional[float] = None):
+        """H2D / D2D of training_multitask.py:82-84 into the plan's static buffers (one-hot on the device).
+        `weight` = this rank's share n_local / n_batch of the global batch (EpochIndex.weights) when shards are NOT
+        equal -- the short last batch of `DataLoader(drop_last=False)`, BUSI_dataloader.py:146: the local mean-loss
+        gradient is then scaled by weight * world on the device, so that the summed, 1/world-averaged gradient is the
+        global batch's."""
         N, _, H, W = image.shape
         st = self._compiled(N, H, W)
         st.x.data.copy_(image, non_blocking=True)
@@ -130,7 +145,12 @@ class FusedTrainStep:
         lab = label.to(st.onehot.device, non_blocking=True).flatten().to(torch.int64)
         st.onehot.zero_()
         st.onehot.scatter_(1, lab.view(-1, 1), 1.0)
+        st.grad_weight.fill_(1.0 if weight is None else float(weight) * self.world)
         return st
+
+    def _reduce_all(self) -> None:
+        allreduce_buckets(self.model.flat_g, self._st.buckets if self._st is not None and self._st.buckets else
+                          plan_buckets([(0, self.model.flat_numel, 0)], self.model.flat_numel, 1))
 
     def run(self, st) -> torch.Tensor:
         """One optimisation step on the batch already resident in the plan's buffers."""
@@ -143,7 +163,7 @@ class FusedTrainStep:
         else:
             cur = torch.cuda.current_stream()
             done = 0
-            for b in self._buckets:
+            for b in st.buckets:
                 upto = min(P["bwd"].n, b.ready_op + 1)
                 if upto > done:
                     P["bwd"].run(done, upto - done)
@@ -159,14 +179,38 @@ class FusedTrainStep:
         self.opt.grad_scale = (1.0 / self.world) / getattr(st, "loss_scale", 1.0)
         self.opt.step(grads_in_flat=True)
         self.losses = st.plan.loss_out
+        self._coop_err = st.plan.coop_error_word()
         return self.losses
 
-    def __call__(self, image, mask, label) -> torch.Tensor:
-        return self.run(self.load_batch(image, mask, label))
+    def run_empty(self) -> None:
+        """This rank's shard of the (short, last) global batch is EMPTY: contribute a zero gradient to the same
+        collectives the other ranks issue, then apply the same update.  Needs one earlier real step (bucket layout)."""
+        if not self.distributed:
+            return
+        if self._st is None:
+            raise L.MtbcError("run_empty() before any real step: the bucket layout is not known yet")
+        self.model.flat_g.zero_()
+        for b in self._st.buckets:
+            allreduce_buckets(self.model.flat_g, [b])
+        self.opt.grad_scale = (1.0 / self.world) / getattr(self._st, "loss_scale", 1.0)
+        self.opt.step(grads_in_flat=True)
+
+    def __call__(self, image, mask, label, weight: Optional[float] = None) -> torch.Tensor:
+        return self.run(self.load_batch(image, mask, label, weight))
 
     def check_nan(self) -> None:
-        """The reference's NaN guard (criterions.py:72-76), one device->host read when the caller chooses."""
-        if self.losses is not None and float(self.losses[3].item()) != 0.0:
+        """The reference's NaN guard (criterions.py:72-76) plus the device-side protocol check of the cooperative
+        InstanceNorm kernels, one device->host read when the caller chooses.  NaN -> log + exit(1) like the reference;
+        a cooperative-kernel failure (a team member was not resident: results are garbage) raises MtbcError."""
+        if self.losses is None:
+            return
+        err = getattr(self, "_coop_err", None)
+        vals = torch.cat([self.losses[3:4].double(), (err if err is not None else self.losses[3:4] * 0).double()]).cpu().tolist()
+        if vals[1] != 0.0:
+            raise L.MtbcError("cooperative InstanceNorm: a mailbox poll timed out (team members were not co-resident, e.g. "
+                              "another stream or process held the CUs): activations and gradients of this and later steps "
+                              "are invalid. Raise MTBC_COOP_RESERVE_CUS, or set MTBC_NO_COOP=1.")
+        if vals[0] != 0.0:
             import logging
             import sys
             logging.info("NaN in model loss!!")
@@ -197,49 +241,73 @@ class FusedEvalStep:
     """Forward + losses + metrics of `validate_one_epoch` (training_multitask.py:119-159) with no host round trip per
     batch: the step program runs pack -> forward -> fused Dice/Focal, `mtbc_dice_counts` gives the batch Dice of
     `process_segmentation_predicted` (:66-71: sigmoid(last head) > .5 against the mask, `dice_score_from_tensor`), and
-    the 3x3 confusion matrix of `processes_classification_predicted` (:34-63, argmax of softmax vs argmax of the
-    one-hot label) accumulates on the device.  `result()` reads everything back once and returns the reference's
-    6-tuple (avg_val_loss, avg_val_dice, val_acc, val_f1, avg_seg_val_loss, avg_cls_val_loss)."""
+    the confusion matrix of `processes_classification_predicted` (:34-63) accumulates on the device: multi-class =
+    argmax of softmax vs argmax of the one-hot label (:41-51); binary head (n_classes == 2, ONE logit) = sigmoid > .5
+    vs the {0,1} label (:53-61), classification loss BCEWithLogits (experiment_init.py:242) by torch on the HIP
+    model's logit, as the reference does.  `result()` reads everything back once and returns the reference's 6-tuple
+    (avg_val_loss, avg_val_dice, val_acc, val_f1, avg_seg_val_loss, avg_cls_val_loss)."""
 
     def __init__(self, model, alpha: float, inversely_weighted: bool = True, n_classes: int = 3,
                  focal_weight: Optional[torch.Tensor] = None):
-        if n_classes < 3:
-            raise NotImplementedError("binary head (n_classes == 2): the sigmoid > .5 branch of :53-61 is not wired yet")
         self.model, self.alpha, self.iw, self.n_classes = model, float(alpha), bool(inversely_weighted), n_classes
-        self.focal_weight = focal_weight
-        self._helper = FusedTrainStep.__new__(FusedTrainStep)        # reuse load_batch / plan cache, never its optimizer
-        self._helper.model, self._helper.alpha, self._helper.iw = model, self.alpha, self.iw
-        self._helper.focal_weight, self._helper.n_buckets, self._helper._st, self._helper._buckets = focal_weight, 4, None, []
+        self.binary = n_classes == 2
+        if self.binary != (getattr(model, "n_classes", n_classes) == 1):
+            raise ValueError("n_classes does not match the model's classification head")
+        self.focal_weight = None if self.binary else focal_weight
+        self._coop_err = None
         self.reset()
 
     def reset(self) -> None:
         self._acc = None          # device float64: [sum total, sum seg, sum cls, sum dice, batches]
-        self._conf = None         # device int64 (n_classes, n_classes): rows = ground truth, cols = prediction
+        self._conf = None         # device int64 (3, 3): rows = ground truth, cols = prediction (f1 is asked for labels 0,1,2)
 
     @torch.no_grad()
     def __call__(self, image: torch.Tensor, mask: torch.Tensor, label: torch.Tensor) -> None:
-        st = self._helper.load_batch(image, mask, label)
+        N, _, H, W = image.shape
+        st = self.model.compiled(N, H, W, fused_loss={"alpha": self.alpha, "inversely_weighted": self.iw,
+                                                      "focal_weight": self.focal_weight, "binary": self.binary})
+        st.x.data.copy_(image, non_blocking=True)
+        st.mask.copy_(mask, non_blocking=True)
+        dev = st.plan.loss_out.device
+        lab = label.to(dev, non_blocking=True).flatten()
+        if not self.binary:
+            st.onehot.zero_()
+            st.onehot.scatter_(1, lab.to(torch.int64).view(-1, 1), 1.0)
         P = st.programs
         P["pack"].run()
         P["fwd"].run()
         P["loss"].run()
-        dev = st.plan.loss_out.device
+        self._coop_err = st.plan.coop_error_word()
         if self._acc is None:
             self._acc = torch.zeros(5, dtype=torch.float64, device=dev)
-            self._conf = torch.zeros(self.n_classes, self.n_classes, dtype=torch.int64, device=dev)
+            self._conf = torch.zeros(3, 3, dtype=torch.int64, device=dev)
         counts = dice_counts(st.segs[-1].data, st.mask)                 # {tp, fp, fn} float64 on the device
         tp, fp, fn = counts[0], counts[1], counts[2]
         empty_gt = (tp + fn) == 0
         dice = torch.where(empty_gt, torch.where((tp + fp) == 0, torch.ones_like(tp), torch.zeros_like(tp)),
                            2 * tp / torch.clamp(2 * tp + fp + fn, min=1.0))          # metrics.py:255-267
-        self._acc[:3] += st.plan.loss_out[:3].double()
+        logit = st.logits.data.view(N, -1)
+        if self.binary:
+            seg = st.plan.dice_loss[-1]
+            cls = torch.nn.functional.binary_cross_entropy_with_logits(logit, lab.float().view(N, 1))
+            self._acc[0] += (self.alpha * seg + (1.0 - self.alpha) * cls).double()
+            self._acc[1] += seg.double()
+            self._acc[2] += cls.double()
+            pred = (torch.sigmoid(logit[:, 0]) > 0.5).to(torch.int64)
+            gt = lab.to(torch.int64)
+        else:
+            self._acc[:3] += st.plan.loss_out[:3].double()
+            pred = logit.argmax(dim=1)
+            gt = st.onehot.argmax(dim=1)
         self._acc[3] += dice
         self._acc[4] += 1
-        pred = st.logits.data.view(st.logits.data.shape[0], -1).argmax(dim=1)
-        gt = st.onehot.argmax(dim=1)
-        self._conf.view(-1).index_add_(0, gt * self.n_classes + pred, torch.ones_like(gt))
+        self._conf.view(-1).index_add_(0, gt * 3 + pred, torch.ones_like(gt))
 
     def result(self):
+        err = self._coop_err
+        if err is not None and int(err.item()) != 0:
+            raise L.MtbcError("cooperative InstanceNorm: a mailbox poll timed out (team members were not co-resident): the "
+                              "activations of this evaluation are invalid")
         acc = self._acc.cpu().tolist()
         conf = self._conf.cpu().numpy().astype(np.float64)
         nb = max(acc[4], 1.0)

@@ -42,9 +42,42 @@ def state_sha256(sd) -> str:
     return h.hexdigest()
 
 
+def seg_nnunet_goldens() -> None:
+    """(8) BASELINE.json configs[0], the single-task CPU plumbing case: the reference's nnUNet2021
+    (src/models/segmentation/nnUNet.py) + apply_criterion_binary_segmentation (src/utils/criterions.py:27-49) + Adam
+    (eps 1e-4, src/utils/experiment_init.py:187): seeded weights, forward, loss, weights after one step."""
+    from src.models.segmentation.nnUNet import nnUNet2021
+    from src.utils.criterions import apply_criterion_binary_segmentation
+    seed_everything(1993)
+    model = nnUNet2021(sequences=1, regions=1)
+    sha0 = state_sha256(model.state_dict())
+    torch.manual_seed(0)
+    x = torch.rand(2, 1, 64, 64) * 255
+    mask = (torch.rand(2, 1, 64, 64) > 0.7).float()
+    model.train(True)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4, eps=1e-4)
+    opt.zero_grad(set_to_none=True)
+    outs = model(x)
+    loss = apply_criterion_binary_segmentation(dice_loss_sigmoid_sq, mask, outs, True)
+    loss.backward()
+    opt.step()
+    sd = model.state_dict()
+    probe = ["encoder1.ConvInNormLRelu1.Conv.weight", "bottleneck.ConvInNormLRelu2.Conv.weight", "upsample3.weight",
+             "output4.1.weight", "output1.weight", "output1.bias"]
+    np.savez_compressed(
+        os.path.join(OUT, "seg_nnunet_step.npz"), sha256_init=np.array(sha0), x=x.numpy(), mask=mask.numpy(),
+        out_means=np.array([o.mean().item() for o in outs]), out1=outs[-1].detach().numpy(), loss=np.array(loss.item()),
+        probe_names=np.array(probe), **{f"after_{i}": sd[k].flatten()[:32].numpy() for i, k in enumerate(probe)},
+        **{f"aftersum_{i}": np.array(sd[k].double().sum().item()) for i, k in enumerate(probe)})
+    print("seg_nnunet_step.npz written; loss", loss.item())
+
+
 def main() -> None:
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
+    if "--only-seg" in sys.argv:
+        seg_nnunet_goldens()
+        return
 
     # ---- (1) MTnnUNet: seeded weights + forward ------------------------------------------
     seed_everything(1993)
@@ -154,6 +187,7 @@ def main() -> None:
     ci = header.index("class")
     classes = [r[ci] for r in body]
     np.savez_compressed(os.path.join(OUT, "curated_busi_classes.npz"), classes=np.array(classes))
+    seg_nnunet_goldens()
     print("goldens written to", OUT)
 
 

@@ -108,6 +108,74 @@ class OracleMTnnUNet(nn.Module):
         return [logits], outs
 
 
+class OracleSegNnUNet(nn.Module):
+    """Single-task segmentation net of BASELINE.json configs[0] (the CPU plumbing case): `nnUNet2021`
+    (src/models/segmentation/nnUNet.py:64-168) -- the encoder / decoder / deep-supervision heads of MTnnUNet without the
+    classification head; `weights_initialization` (:124-130) runs after every module exists, so ALL Conv2d weights
+    (1x1 heads included) are kaiming-normal and their biases zero.  Returns the list [out4, out3, out2, out1] (:163).
+    Pinned: tests/golden/seg_nnunet_step.npz (oracle/make_goldens.py imports the reference's class)."""
+
+    def __init__(self, sequences: int = 1, regions: int = 1):
+        super().__init__()
+        w = NNUNET_WIDTHS
+        enc_io = [(sequences, w[0]), (w[0], w[1]), (w[1], w[2]), (w[2], w[3]), (w[3], w[4])]
+        for i, (a, b) in enumerate(enc_io, start=1):
+            setattr(self, f"encoder{i}", _level(a, b, b))
+        self.bottleneck = _level(w[4], w[4], w[4])
+        dec_io = {5: (2 * w[4], w[3], w[3]), 4: (2 * w[3], w[2], w[2]), 3: (2 * w[2], w[1], w[1]),
+                  2: (2 * w[1], w[0], w[0]), 1: (2 * w[0], w[0], w[0] // 2)}
+        for i in (5, 4, 3, 2, 1):
+            setattr(self, f"decoder{i}", _level(*dec_io[i]))
+        for i in (5, 4, 3, 2, 1):
+            c = w[i - 1]
+            setattr(self, f"upsample{i}", nn.ConvTranspose2d(c, c, kernel_size=2, stride=2))
+        self.downsample = nn.MaxPool2d(2, 2)
+        self.output4 = nn.Sequential(nn.ConvTranspose2d(w[2], w[2], kernel_size=8, stride=8),
+                                     nn.Conv2d(w[2], regions, kernel_size=1))
+        self.output3 = nn.Sequential(nn.ConvTranspose2d(w[1], w[1], kernel_size=4, stride=4),
+                                     nn.Conv2d(w[1], regions, kernel_size=1))
+        self.output2 = nn.Sequential(nn.ConvTranspose2d(w[0], w[0], kernel_size=2, stride=2),
+                                     nn.Conv2d(w[0], regions, kernel_size=1))
+        self.output1 = nn.Conv2d(w[0] // 2, regions, kernel_size=1)
+        for m in self.modules():                                      # nnUNet.py:124-130
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, nonlinearity="leaky_relu")
+                if m.bias is not None:
+                    nn.init.constant_(m.bias, 0)
+
+    def forward(self, x):                                             # nnUNet.py:133-165
+        skips, t = [], x
+        for i in range(1, 6):
+            e = getattr(self, f"encoder{i}")(t)
+            skips.append(e)
+            t = self.downsample(e)
+        d = self.bottleneck(t)
+        dec = {}
+        for i in (5, 4, 3, 2, 1):
+            d = getattr(self, f"decoder{i}")(torch.cat([skips[i - 1], getattr(self, f"upsample{i}")(d)], dim=1))
+            dec[i] = d
+        return [self.output4(dec[4]), self.output3(dec[3]), self.output2(dec[2]), self.output1(dec[1])]
+
+
+def seg_train_step(model: nn.Module, optimizer, image: torch.Tensor, mask: torch.Tensor, inversely_weighted: bool = True):
+    """One step of src/training_segmentation.py:29-62: zero_grad -> model -> apply_criterion_binary_segmentation
+    (src/utils/criterions.py:27-49: deep-supervision heads reversed, 1/(n+1) weights when inversely_weighted) -> backward
+    -> Adam.  Returns (loss, batch Dice of sigmoid(last head) > .5)."""
+    optimizer.zero_grad(set_to_none=True)
+    outputs = model(image)
+    if isinstance(outputs, (list, tuple)):
+        terms = [dice_loss_sigmoid_sq(s, mask) / ((j + 1) if inversely_weighted else 1) for j, s in enumerate(reversed(list(outputs)))]
+        loss = torch.sum(torch.stack(terms))
+        last = outputs[-1]
+    else:
+        loss, last = dice_loss_sigmoid_sq(outputs, mask), outputs
+    if torch.isnan(loss):
+        raise SystemExit(1)
+    loss.backward()
+    optimizer.step()
+    return loss.detach(), dice_score_from_tensor(mask, torch.sigmoid(last.detach()) > .5)
+
+
 # --------------------------------------------------------------------------
 # MTUNetPlusPlus (src/models/multitask/MTUNetPlusPlus.py:12-136) on MONAI 1.3.0
 # blocks (monai/networks/nets/basic_unet.py TwoConv/Down/UpCat,

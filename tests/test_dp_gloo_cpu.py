@@ -61,3 +61,23 @@ def test_bucketed_allreduce_equals_single_rank_gradient():
         assert p.exitcode == 0
     got = sorted(q.get(timeout=5) for _ in range(world))
     assert got == [(0, "ok"), (1, "ok")]
+
+
+def test_bucket_order_is_a_function_of_the_layout_only():
+    """Ranks may build different step programs (short last batch): their collectives still pair up because the bucket
+    ranges AND their order depend on the parameter layout alone, never on the readiness indices."""
+    sizes = [1000, 24, 3000, 8, 4000, 1972, 512, 64]
+    offs = np.concatenate([[0], np.cumsum(sizes)[:-1]]).tolist()
+    total = int(sum(sizes))
+    rng = np.random.default_rng(0)
+    ref = None
+    for _ in range(5):
+        ready = rng.permutation(len(sizes)).tolist()
+        b = plan_buckets([(o, n, r) for o, n, r in zip(offs, sizes, ready)], total, 3)
+        rng_ = [(x.start, x.end) for x in b]
+        assert rng_ == sorted(rng_, reverse=True) and rng_[-1][0] == 0 and rng_[0][1] == total
+        assert sum(e - s_ for s_, e in rng_) == total
+        for x in b:     # a bucket waits for the LAST op that writes any of its parameters
+            assert x.ready_op == max(r for o, n, r in zip(offs, sizes, ready) if x.start <= o < x.end)
+        ref = ref or rng_
+        assert rng_ == ref

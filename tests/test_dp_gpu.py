@@ -17,7 +17,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, G=4, cuts=None):
     import torch.distributed as dist
     from multi_task_breast_cancer_amd.miscellany import seed_everything
     from multi_task_breast_cancer_amd.nets import MTUNetPlusPlus
@@ -32,12 +32,16 @@ def _worker(rank, world, port, q):
         seed_everything(1993)
         m = MTUNetPlusPlus(in_channels=1, out_channels=1, n_classes=3, deep_supervision=True).to(dev)
         step = FusedTrainStep(m, FusedAdam(m, lr=1e-4, eps=1e-4), alpha=0.5, distributed=True, n_buckets=4)
-        img, mask, label = O.synthetic_batch(4, 64, 64, seed=7)          # the GLOBAL batch
-        per = 4 // world
-        sl = slice(rank * per, (rank + 1) * per)                          # equal contiguous shards
-        losses = step(img[sl].to(dev), mask[sl].to(dev), label[sl].to(dev))
+        img, mask, label = O.synthetic_batch(G, 64, 64, seed=7)          # the GLOBAL batch
+        if cuts is None:
+            per = G // world
+            sl, weight = slice(rank * per, (rank + 1) * per), None        # equal contiguous shards
+        else:                                                             # the short last batch of drop_last=False: uneven shards
+            sl = slice(cuts[rank], cuts[rank + 1])
+            weight = (cuts[rank + 1] - cuts[rank]) / G                    # EpochIndex.weights
+        losses = step(img[sl].to(dev), mask[sl].to(dev), label[sl].to(dev), weight=weight)
         torch.cuda.synchronize()
-        assert step.opt.grad_scale == 1.0 / world and len(step._buckets) >= 2
+        assert len(step._st.buckets) >= 2 and [b.start for b in step._st.buckets] == sorted((b.start for b in step._st.buckets), reverse=True)
         if rank == 0:
             # numpy arrays travel by value; CPU tensors would travel as shared-memory handles that die with this process
             q.put((m.flat_p.cpu().numpy(), m.flat_g.cpu().numpy(), losses.cpu().numpy()))
@@ -46,7 +50,8 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_two_rank_step_equals_single_rank_global_batch():
+@pytest.mark.parametrize("G,cuts", [(4, None), (5, (0, 3, 5))])
+def test_two_rank_step_equals_single_rank_global_batch(G, cuts):
     import torch.multiprocessing as mp
     from multi_task_breast_cancer_amd.miscellany import seed_everything
     from multi_task_breast_cancer_amd.nets import MTUNetPlusPlus
@@ -59,7 +64,7 @@ def test_two_rank_step_equals_single_rank_global_batch():
     got = None
     for attempt in range(2):          # a 2-process gloo rendezvous on one box has been seen to stall once; a run takes ~6 s
         q, port = ctx.Queue(), _free_port()
-        procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+        procs = [ctx.Process(target=_worker, args=(r, world, port, q, G, cuts)) for r in range(world)]
         for p in procs:
             p.start()
         try:
@@ -80,10 +85,11 @@ def test_two_rank_step_equals_single_rank_global_batch():
     seed_everything(1993)
     m = MTUNetPlusPlus(in_channels=1, out_channels=1, n_classes=3, deep_supervision=True).to(dev)
     step = FusedTrainStep(m, FusedAdam(m, lr=1e-4, eps=1e-4), alpha=0.5)
-    img, mask, label = O.synthetic_batch(4, 64, 64, seed=7)
+    img, mask, label = O.synthetic_batch(G, 64, 64, seed=7)
     l1 = step(img.to(dev), mask.to(dev), label.to(dev)).cpu()
     p1, g1 = m.flat_p.cpu(), m.flat_g.cpu()
-    # rank-0 loss is the mean over ITS shard; the gradient (sum over ranks, scaled 1/world in Adam) is the global one
+    # rank-0 loss is the mean over ITS shard; the gradient (sum over ranks, scaled 1/world in Adam) is the global one --
+    # also for uneven shards, where each rank weighted its local mean-loss gradient by n_local / G on the device
     g2 = g2 / world
     rel = (g2 - g1).norm().item() / g1.norm().item()
     assert rel < 1e-5, rel

@@ -81,8 +81,9 @@ def _oracle_and_product(arch, seed):
 
 
 @pytest.mark.parametrize("arch,N,size", [("MTUNetPlusPlus", 2, 64), ("MTUNetPlusPlus", 2, 256), ("MTnnUNet", 2, 256),
-                                         ("MTUNetPlusPlus", 3, 96)])
+                                         ("MTUNetPlusPlus", 3, 96), ("MTUNetPlusPlus", 1, 512)])
 def test_fused_step_matches_oracle(arch, N, size):
+    """(The 512x512 case is BASELINE.json configs[4]'s plane size meeting the oracle once, in the parity arithmetic.)"""
     prod, ref = _oracle_and_product(arch, 11)
     start = {k: v.detach().cpu().clone() for k, v in ref.state_dict().items()}
     img, mask, label = O.synthetic_batch(N, size, size, seed=size + N)
@@ -99,18 +100,45 @@ def test_fused_step_matches_oracle(arch, N, size):
     assert abs(losses[0].item() - total.item()) < TOL
     assert abs(losses[1].item() - seg.item()) < TOL and abs(losses[2].item() - cls.item()) < TOL
     assert losses[3].item() == 0.0
-    # Gradients and the Adam update are judged against an fp64 run of the same oracle, per tensor, in relative L2:
-    # error <= max(3x the error of the fp32 CPU oracle (= the reference's arithmetic), 5e-2).  The 5e-2 floor is the
-    # price of ONE LeakyReLU / max-pool routing flip: a pre-activation of ~5e-6 (inside the 1e-5 forward rounding
-    # band) that changes sign moves every gradient upstream of the 4x4 classifier map by ~2% at N=2 (measured,
-    # DESIGN.md "Numerics"); wiring bugs show up as O(1).  Each kernel's backward is checked tightly (1e-4..1e-5)
-    # in test_ops_gpu.py, Adam bit-for-bit against torch there too; after the step every weight must sit within
-    # 2*lr of the oracle's.  Conv biases in front of InstanceNorm have a true gradient of 0 and are skipped.
+    # Gradients and the Adam update are judged against an fp64 run of the same oracle, per tensor.  Composed gradients
+    # are discontinuous in the forward rounding: ONE LeakyReLU pre-activation of ~5e-6 (inside the 1e-5 forward
+    # rounding band) that changes sign moves every gradient upstream of the 4x4 classifier map by ~2 % at N=2
+    # (DESIGN.md "Numerics").  So the sign flips are COUNTED -- every conv-cell activation of the HIP forward against
+    # the fp64 forward (LeakyReLU keeps the sign of its input) -- and the bar depends on them:
+    #   no flip anywhere        : cosine >= 0.999 and relative L2 <= max(3x the fp32 CPU oracle's own error, 5e-3);
+    #   k flips (each of them a pre-activation the fp64 run has inside the rounding band, |v| < 1e-3, and k small):
+    #                             relative L2 <= max(3x the oracle's error, 5e-2), the measured price of a flip.
+    # A wiring bug is O(1) either way.  Each kernel's backward is checked tightly (1e-4..1e-5) in test_ops_gpu.py, Adam
+    # bit-for-bit against torch there too; after the step every weight must sit within 2*lr of the oracle's.  Conv
+    # biases in front of InstanceNorm have a true gradient of 0 and are skipped.
     import copy
     ref64 = copy.deepcopy(ref).double()
     ref64.load_state_dict({k: v.double() for k, v in start.items()})
     o64 = O.make_adam(ref64, 1e-4)
+    acts64 = {}
+    hooks = [mod.register_forward_hook(lambda m, i, o, name=name: acts64.setdefault(name, []).append(o.detach()))
+             for name, mod in ref64.named_modules() if name in st.plan.acts]
     O.train_step(ref64, o64, img.double(), mask.double(), label, alpha, True, 3)
+    for h in hooks:
+        h.remove()
+    flips, compared, worst_flip = 0, 0, 0.0
+    for name, act in st.plan.acts.items():
+        if act.in_op is None or name not in acts64:
+            continue
+        got = act.data.cpu()
+        cands = [w for w in acts64[name] if tuple(w.shape) == tuple(got.shape)]
+        if not cands:
+            continue
+        # a module applied twice (shared weights, F10) fires its hook once per use: this Act is the use it agrees with
+        want = min(cands, key=lambda w: (got.double() - w).abs().max().item())
+        f = (got > 0) != (want > 0)
+        flips += int(f.sum())
+        compared += 1
+        if f.any():
+            worst_flip = max(worst_flip, want[f].abs().max().item())
+    assert compared >= 20, compared                      # the activation names do line up with the oracle's modules
+    assert flips <= 64 and worst_flip < 1e-3, (flips, worst_flip)
+    floor = 5e-3 if flips == 0 else 5e-2
     r32, r64 = dict(ref.named_parameters()), dict(ref64.named_parameters())
     for name in prod._order:
         assert _maxerr(prod._param_view(name), r32[name]) <= 2.0e-4, name    # |update| <= lr per element, both sides
@@ -120,9 +148,13 @@ def test_fused_step_matches_oracle(arch, N, size):
         gn = g64.norm().item()
         if gn / g64.numel() ** 0.5 < 1e-9:
             continue
-        e_ours = (prod._grad_view(name).cpu().double() - g64).norm().item() / gn
+        ours = prod._grad_view(name).cpu().double()
+        e_ours = (ours - g64).norm().item() / gn
         e_32 = (r32[name].grad.double() - g64).norm().item() / gn
-        assert e_ours <= max(3 * e_32, 5e-2), ("grad", name, e_ours, e_32)
+        assert e_ours <= max(3 * e_32, floor), ("grad", name, e_ours, e_32, flips)
+        if flips == 0:
+            cos = (ours * g64).sum().item() / (ours.norm().item() * gn)
+            assert cos >= 0.999, ("cosine", name, cos)
     # second step (exercises Adam state + weight re-packing)
     img2, mask2, label2 = O.synthetic_batch(N, size, size, seed=99)
     l2 = step(img2.to(DEV), mask2.to(DEV), label2.to(DEV)).cpu()
@@ -221,7 +253,7 @@ def test_distributed_step_single_rank_rccl_equals_local_step():
                 l = step(img.to(DEV), mask.to(DEV), label.to(DEV))
             torch.cuda.synchronize()
             if distributed:
-                assert len(step._buckets) >= 2
+                assert len(step._st.buckets) >= 2
                 assert sorted(b.ready_op for b in step._buckets) == [b.ready_op for b in step._buckets]
             res.append((m.flat_p.clone(), l.clone()))
         assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])

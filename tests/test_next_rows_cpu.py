@@ -7,6 +7,7 @@ import pytest
 from multi_task_breast_cancer_amd import checkpoint as CK
 from multi_task_breast_cancer_amd.dataset_index import EpochIndex, cv_fold_positions
 from multi_task_breast_cancer_amd.oversampling import oversampled_positions
+from oracle.oversampling_oracle import deterministic_oversampling_positions
 
 
 def _classes(golden_dir):
@@ -28,10 +29,28 @@ def test_cv_folds_equal_the_reference_call_sequence(golden_dir):
         train_val_mapping, test_mapping = mapping.iloc[train_ix], mapping.iloc[test_ix]
         train_mapping, val_mapping = train_test_split(train_val_mapping, train_size=train_size, random_state=int(seed),
                                                       shuffle=True, stratify=train_val_mapping["class"])
-        over = train_mapping.iloc[oversampled_positions(train_mapping["class"].tolist())]
+        # the ORACLE's restatement of deterministic_oversampling (:320-340), not the product's own function
+        over = train_mapping.iloc[deterministic_oversampling_positions(train_mapping["class"].tolist())]
         assert np.array_equal(folds[n]["test"], test_mapping["id"].to_numpy())
         assert np.array_equal(folds[n]["val"], val_mapping["id"].to_numpy())
         assert np.array_equal(folds[n]["train"], over["id"].to_numpy())
+
+
+def test_cv_folds_equal_the_committed_fixture(golden_dir):
+    """tests/golden/cv_folds_sklearn_<version>.npz (oracle/make_fold_fixture.py: the reference's call sequence + the
+    oracle's oversampling on the curated mapping).  sklearn's splitters are version-sensitive in principle, so the
+    fixture is labelled with the version that generated it and only compared under that version."""
+    import sklearn
+    path = os.path.join(golden_dir, f"cv_folds_sklearn_{sklearn.__version__}.npz")
+    if not os.path.exists(path):
+        pytest.skip(f"no fold fixture generated with sklearn {sklearn.__version__}")
+    g = np.load(path)
+    folds = cv_fold_positions(_classes(golden_dir), int(g["seed"]), int(g["n_folds"]), float(g["train_size"]), oversampling=True)
+    assert len(folds) == 5
+    for n, f in enumerate(folds):
+        for k in ("train", "val", "test"):
+            assert np.array_equal(f[k], g[f"{k}{n}"]), (n, k)
+    assert [len(g[f"train{n}"]) for n in range(5)] == [len(f["train"]) for f in folds]
 
 
 def test_cv_folds_partition_and_stratify(golden_dir):

@@ -489,6 +489,49 @@ def test_conv3x3_c8_operands(N, segs, Cout, H, W, compute):
     _close(dw2, 2 * wref.grad.float(), 1e-5, 4e-5 * scale, "wgrad c8 accumulate")
 
 
+@pytest.mark.parametrize("compute", [1, 2])
+@pytest.mark.parametrize("N,segs,Cout,H,W", C8_CASES + [(2, [24, 24, 24, 24, 24, 24], 24, 256, 256),   # 144->24 @256x256: the bench's widest level-0 node
+                                                        (1, [384, 384, 384], 512, 16, 16)])                # K = 1152 x 9: the longest accumulation of the step
+def test_conv3x3_16bit_fwd_dgrad_match_fp64_on_rounded_operands(N, segs, Cout, H, W, compute):
+    """The oracle of the 16-bit forward / dgrad kernels (channel-blocked AND planar staging): fp64 conv2d / conv2d_input
+    on operands rounded (RNE) to the MFMA's 16-bit type -- x and w forward, dz and w backward -- i.e. exact products,
+    fp32 accumulation being the only difference.  Tolerance 1e-5 relative to the output scale (fp32 accumulation over
+    K <= 10368 terms: ~ sqrt(K) * 2^-24 * |terms|), the standard wgrad_c8 already meets."""
+    g = _g(N * 131 + Cout + H + compute)
+    Cin = sum(segs)
+    xs = [torch.randn(N, c, H, W, generator=g) for c in segs]
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (9 * Cin)) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    dz = torch.randn(N, Cout, H, W, generator=g)
+    xr, wr, dzr = _round16(torch.cat(xs, 1), compute).double(), _round16(w, compute).double(), _round16(dz, compute).double()
+    z_ref = F.conv2d(xr, wr, b.double(), padding=1)
+    dx_ref = torch.nn.grad.conv2d_input(xr.shape, wr, dzr, padding=1)
+    dxs_ref = torch.split(dx_ref, segs, dim=1)
+
+    xd = [x.to(DEV) for x in xs]
+    wd, bd, dzd = w.to(DEV), b.to(DEV), dz.to(DEV)
+    pf, pd = ops.conv3x3_pack_lp(wd, compute)
+    x8 = [ops.C8.pack(x, compute) for x in xd]
+    dz8 = ops.C8.pack(dzd, compute)
+    zs = z_ref.abs().max().item()
+    for name, z in (("c8", ops.conv3x3_fwd_c8(x8, wd, bd, pf)), ("planar", ops.conv3x3_fwd(xd, wd, bd, packed=pf, compute=compute))):
+        err = (z.cpu().double() - z_ref).abs().max().item()
+        assert err <= 1e-5 * zs, f"fwd {name}: max err {err:.3e} vs scale {zs:.3e}"
+    pre = [torch.randn(N, c, H, W, generator=g) for c in segs]
+    acc = [0] + [1] * (len(segs) - 1)
+    ds = dx_ref.abs().max().item()
+    for name in ("c8", "planar"):
+        d = [p.to(DEV).clone() for p in pre]
+        if name == "c8":
+            ops.conv3x3_dgrad_c8(dz8, wd, d, acc, pd)
+        else:
+            ops.conv3x3_dgrad(dzd, wd, d, acc, packed=pd, compute=compute)
+        for i in range(len(segs)):
+            want = dxs_ref[i] + (pre[i].double() if acc[i] else 0)
+            err = (d[i].cpu().double() - want).abs().max().item()
+            assert err <= 1e-5 * max(ds, want.abs().max().item()), f"dgrad {name} seg {i}: max err {err:.3e} vs scale {ds:.3e}"
+
+
 def test_conv3x3_c8_rejects_what_it_cannot_run():
     from multi_task_breast_cancer_amd import _lib as L
     x = torch.randn(1, 8, 8, 10, generator=_g(1)).to(DEV)      # W % 4 != 0: the fp32 output needs 16-byte rows

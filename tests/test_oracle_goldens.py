@@ -213,3 +213,25 @@ def test_16bit_emulation_contexts_are_transparent_without_rounding():
         assert torch.equal(head[0](x), torch.conv_transpose2d(x, head[0].weight, head[0].bias, 2))
         got_r = run()
     assert not torch.equal(got_r[1], want[1])
+
+
+def test_single_task_seg_nnunet_step_matches_reference(golden_dir):
+    """BASELINE.json configs[0] (the CPU plumbing case): the oracle's nnUNet2021 restatement and its segmentation-only
+    step against the reference's own class / criterion glue (oracle/make_goldens.py:seg_nnunet_goldens)."""
+    g = np.load(os.path.join(golden_dir, "seg_nnunet_step.npz"))
+    O.seed_everything(1993)
+    model = O.OracleSegNnUNet(1, 1)
+    assert _sha(model.state_dict()) == str(g["sha256_init"])          # bit-exact initial weights, heads included
+    model.train(True)
+    opt = O.make_adam(model, lr=1e-4)
+    x, mask = torch.from_numpy(g["x"]), torch.from_numpy(g["mask"])
+    with torch.no_grad():
+        outs = model(x)
+    np.testing.assert_allclose([o.mean().item() for o in outs], g["out_means"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(outs[-1].numpy(), g["out1"], rtol=0, atol=2e-6)
+    loss, dice = O.seg_train_step(model, opt, x, mask, True)
+    assert abs(loss.item() - float(g["loss"])) < 1e-6 and 0.0 <= float(dice) <= 1.0
+    sd = model.state_dict()
+    for i, k in enumerate(str(n) for n in g["probe_names"]):
+        np.testing.assert_allclose(sd[k].flatten()[:32].numpy(), g[f"after_{i}"], rtol=0, atol=2e-6)
+        assert abs(sd[k].double().sum().item() - float(g[f"aftersum_{i}"])) < 1e-3
