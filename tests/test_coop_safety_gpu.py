@@ -40,11 +40,15 @@ def _model(dtype, reserve, no_coop=False):
     return m
 
 
-def _run_steps(m, batch, n_steps):
+def _run_steps(m, batch, n_steps, after_warmup=None):
     step = FusedTrainStep(m, FusedAdam(m, lr=1e-4, eps=1e-4), alpha=0.5)
+    step(*batch)                                       # builds the step programs (about a second of host work)
+    torch.cuda.current_stream().synchronize()
+    if after_warmup is not None:
+        after_warmup()
     for _ in range(n_steps):
         losses = step(*batch)
-    torch.cuda.synchronize()
+    torch.cuda.current_stream().synchronize()          # this stream only: a device-wide sync would wait for the hog
     step.check_nan()                                   # raises on the cooperative kernels' error word
     st = step._st
     n_coop = sum(1 for prog in (st.programs["fwd"], st.programs["bwd"]) for i in range(prog.n)
@@ -64,13 +68,17 @@ def test_cooperative_step_beside_a_cu_hogging_kernel(dtype, N, size, monkeypatch
 
     side = torch.cuda.Stream()
     word = torch.zeros(4, dtype=torch.int32, device=DEV)
-    m = _model(dtype, 64)
-    rc = hog.hog_launch(64, 1500.0, C.c_void_p(word.data_ptr()), C.c_void_p(side.cuda_stream))
-    assert rc == 0
-    time.sleep(0.05)                                   # the hog is running by now (1.5 s); the two steps take a fraction of that
-    t0 = time.perf_counter()
-    l_hog, p_hog, _, step = _run_steps(m, batch, 2)
-    busy = time.perf_counter() - t0
+    t0 = [0.0]
+
+    def launch_hog():
+        rc = hog.hog_launch(64, 1500.0, C.c_void_p(word.data_ptr()), C.c_void_p(side.cuda_stream))
+        assert rc == 0
+        time.sleep(0.05)                               # the hog is running by now (1.5 s); the two steps take a fraction of that
+        t0[0] = time.perf_counter()
+
+    l_hog, p_hog, _, step = _run_steps(_model(dtype, 64), batch, 2, after_warmup=launch_hog)
+    busy = time.perf_counter() - t0[0]
+    assert busy < 1.0, f"the steps took {busy:.2f} s: they did not run beside the hog but behind it"
     assert not side.query(), f"the hog finished before the steps did ({busy:.2f} s): the test did not overlap them"
     side.synchronize()
     assert int(step._st.plan.coop_error_word().item()) == 0
@@ -81,7 +89,7 @@ def test_cooperative_step_beside_a_cu_hogging_kernel(dtype, N, size, monkeypatch
     l_ref, p_ref, n_coop_ref, _ = _run_steps(_model(dtype, 0), batch, 2)
     assert n_coop_ref == 0
     assert abs(l_ref[0].item() - l_idle[0].item()) < 2e-3 * abs(l_ref[0].item())
-    assert (p_ref - p_idle).abs().max().item() < 4.1e-4          # two Adam steps of lr 1e-4 move a weight by at most 2e-4 each way
+    assert (p_ref - p_idle).abs().max().item() < 6.1e-4          # three Adam steps of lr 1e-4 move a weight by at most 3e-4 each way
 
 
 def test_cooperative_error_word_reaches_the_host():

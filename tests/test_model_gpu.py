@@ -106,7 +106,7 @@ def test_fused_step_matches_oracle(arch, N, size):
     # (DESIGN.md "Numerics").  So the sign flips are COUNTED -- every conv-cell activation of the HIP forward against
     # the fp64 forward (LeakyReLU keeps the sign of its input) -- and the bar depends on them:
     #   no flip anywhere        : cosine >= 0.999 and relative L2 <= max(3x the fp32 CPU oracle's own error, 5e-3);
-    #   k flips (each of them a pre-activation the fp64 run has inside the rounding band, |v| < 1e-3, and k small):
+    #   k flips (each of them a pre-activation the fp64 run has inside the rounding band, |v| < 1e-4, k <= 3e-6 of all):
     #                             relative L2 <= max(3x the oracle's error, 5e-2), the measured price of a flip.
     # A wiring bug is O(1) either way.  Each kernel's backward is checked tightly (1e-4..1e-5) in test_ops_gpu.py, Adam
     # bit-for-bit against torch there too; after the step every weight must sit within 2*lr of the oracle's.  Conv
@@ -121,7 +121,7 @@ def test_fused_step_matches_oracle(arch, N, size):
     O.train_step(ref64, o64, img.double(), mask.double(), label, alpha, True, 3)
     for h in hooks:
         h.remove()
-    flips, compared, worst_flip = 0, 0, 0.0
+    flips, compared, worst_flip, elements = 0, 0, 0.0, 0
     for name, act in st.plan.acts.items():
         if act.in_op is None or name not in acts64:
             continue
@@ -134,10 +134,12 @@ def test_fused_step_matches_oracle(arch, N, size):
         f = (got > 0) != (want > 0)
         flips += int(f.sum())
         compared += 1
+        elements += f.numel()
         if f.any():
             worst_flip = max(worst_flip, want[f].abs().max().item())
     assert compared >= 20, compared                      # the activation names do line up with the oracle's modules
-    assert flips <= 64 and worst_flip < 1e-3, (flips, worst_flip)
+    # measured: about 6e-7 of the (normalised, O(1)) pre-activations lie inside the band, the largest flipped one at 6e-6
+    assert flips <= max(8, 3e-6 * elements) and worst_flip < 1e-4, (flips, worst_flip, elements)
     floor = 5e-3 if flips == 0 else 5e-2
     r32, r64 = dict(ref.named_parameters()), dict(ref64.named_parameters())
     for name in prod._order:
@@ -254,7 +256,7 @@ def test_distributed_step_single_rank_rccl_equals_local_step():
             torch.cuda.synchronize()
             if distributed:
                 assert len(step._st.buckets) >= 2
-                assert sorted(b.ready_op for b in step._buckets) == [b.ready_op for b in step._buckets]
+                assert sorted((b.start for b in step._st.buckets), reverse=True) == [b.start for b in step._st.buckets]
             res.append((m.flat_p.clone(), l.clone()))
         assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
     finally:
