@@ -100,6 +100,13 @@ typedef struct {
  *           (no read-modify-write fan-in).  Rebuilt every step like the packed images.                              */
 int mtbc_conv3x3_weight_view(const float* w, float* dst, int32_t Cout, int32_t Cin, int32_t ci_off, int32_t ci_cnt, int32_t mode,
                              int32_t k_off, int32_t K, void* stream);
+/* Batched form: every weight view a step needs in one launch (they are rebuilt after each optimizer update). */
+typedef struct mtbc_wview_desc {
+    const float* w;
+    float* dst;
+    int32_t Cout, Cin, ci_off, ci_cnt, mode, k_off, K;
+} mtbc_wview_desc;
+int mtbc_conv3x3_weight_view_many(const mtbc_wview_desc* descs, int32_t n, void* stream);
 
 /* fp32 planar (N,C,H,W; batch stride in elements) -> 16-bit channel-blocked [N][C/8][H*W][8] in the type of
  * `compute` (1 = bf16, 2 = fp16; round to nearest even -- the same conversion the staging of operand_layout 0 does),
@@ -210,6 +217,12 @@ typedef struct {
     const float* dy; int64_t dy_batch_stride;
     float* dx;       int64_t dx_batch_stride;
     int32_t accumulate_dx;
+    int32_t layout;                  /* 0 = fp32 planar x / y.  MTBC_LAYOUT_C8 (the 16-bit compute modes): x and y are 16-bit
+                                        channel-blocked [N][C/8][H*W][8] of type16 (1 = bf16, 2 = fp16), batch strides in
+                                        16-bit elements, C % 8 == 0 -- forward = the fp32 pool of the stored values followed
+                                        by mtbc_c8_pack, bit for bit (max commutes with rounding); backward routes on the
+                                        stored values; dy / dx stay fp32 planar                                            */
+    int32_t type16;
 } mtbc_maxpool_args;
 
 int mtbc_maxpool2_fwd(const mtbc_maxpool_args* a, void* stream);
@@ -265,6 +278,12 @@ typedef struct {
     float* dw;       float* dbias;
     int32_t accumulate_dw;
     void* workspace; size_t workspace_bytes;
+    int32_t x_layout;                /* 0 = fp32 planar x.  MTBC_LAYOUT_C8: x is 16-bit channel-blocked [N][Cin/8][H*W][8] of
+                                        x_type (1 = bf16, 2 = fp16; batch stride in 16-bit elements; Cin % 8 == 0, Cout <= 8):
+                                        forward and weight gradient read the stored (rounded) activation with fp32 weights,
+                                        products and sums (forward = mtbc_conv1x1_fwd on the unpacked tensor, bit for bit);
+                                        y, dy, dx, dw stay fp32.  Ask mtbc_conv1x1_wgrad_workspace with the same fields set */
+    int32_t x_type;
 } mtbc_conv1x1_args;
 
 size_t mtbc_conv1x1_wgrad_workspace(const mtbc_conv1x1_args* a);

@@ -58,7 +58,7 @@ class MaxPoolArgs(C.Structure):
                 ("y", C.c_void_p), ("y_batch_stride", C.c_int64),
                 ("dy", C.c_void_p), ("dy_batch_stride", C.c_int64),
                 ("dx", C.c_void_p), ("dx_batch_stride", C.c_int64),
-                ("accumulate_dx", C.c_int32)]
+                ("accumulate_dx", C.c_int32), ("layout", C.c_int32), ("type16", C.c_int32)]
 
 
 class ConvTArgs(C.Structure):
@@ -81,7 +81,7 @@ class Conv1x1Args(C.Structure):
                 ("w", C.c_void_p), ("bias", C.c_void_p), ("y", C.c_void_p), ("dy", C.c_void_p),
                 ("dx", C.c_void_p), ("dx_batch_stride", C.c_int64), ("accumulate_dx", C.c_int32),
                 ("dw", C.c_void_p), ("dbias", C.c_void_p), ("accumulate_dw", C.c_int32),
-                ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("x_layout", C.c_int32), ("x_type", C.c_int32)]
 
 
 class GapArgs(C.Structure):
@@ -189,10 +189,16 @@ class PackDesc(C.Structure):
                 ("kind", C.c_int32), ("compute", C.c_int32)]
 
 
+class WViewDesc(C.Structure):
+    """mtbc_wview_desc (include/mtbc.h)."""
+    _fields_ = [("w", C.c_void_p), ("dst", C.c_void_p), ("Cout", C.c_int32), ("Cin", C.c_int32), ("ci_off", C.c_int32),
+                ("ci_cnt", C.c_int32), ("mode", C.c_int32), ("k_off", C.c_int32), ("K", C.c_int32)]
+
+
 EXPORTS = [
     "mtbc_version", "mtbc_strerror", "mtbc_arch",
     "mtbc_conv3x3_packed_elems", "mtbc_conv3x3_packed_dgrad_elems", "mtbc_conv3x3_pack_fwd",
-    "mtbc_conv3x3_pack_dgrad", "mtbc_conv3x3_packed_lp_elems", "mtbc_conv3x3_pack_lp", "mtbc_conv3x3_pack_many", "mtbc_c8_pack", "mtbc_c8_unpack", "mtbc_c8_pack16", "mtbc_conv3x3_weight_view", "mtbc_augment_flip_rotate", "mtbc_convT_head_combine", "mtbc_convT_head_expand", "mtbc_conv3x3_wgrad_workspace", "mtbc_conv3x3_fwd", "mtbc_conv3x3_dgrad",
+    "mtbc_conv3x3_pack_dgrad", "mtbc_conv3x3_packed_lp_elems", "mtbc_conv3x3_pack_lp", "mtbc_conv3x3_pack_many", "mtbc_c8_pack", "mtbc_c8_unpack", "mtbc_c8_pack16", "mtbc_conv3x3_weight_view", "mtbc_conv3x3_weight_view_many", "mtbc_augment_flip_rotate", "mtbc_convT_head_combine", "mtbc_convT_head_expand", "mtbc_conv3x3_wgrad_workspace", "mtbc_conv3x3_fwd", "mtbc_conv3x3_dgrad",
     "mtbc_conv3x3_wgrad", "mtbc_instnorm_fwd_workspace", "mtbc_instnorm_coop_state_bytes", "mtbc_instnorm_coop_error_offset", "mtbc_instnorm_c8_supported", "mtbc_instnorm_lrelu_fwd", "mtbc_instnorm_lrelu_bwd", "mtbc_maxpool2_fwd",
     "mtbc_maxpool2_bwd", "mtbc_convT_wgrad_workspace", "mtbc_convT_fwd_c8_supported", "mtbc_convT_fwd", "mtbc_convT_dgrad", "mtbc_convT_wgrad",
     "mtbc_conv1x1_wgrad_workspace", "mtbc_conv1x1_fwd", "mtbc_conv1x1_dgrad", "mtbc_conv1x1_wgrad",
@@ -235,6 +241,8 @@ def load() -> C.CDLL:
     lib.mtbc_c8_pack.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
     lib.mtbc_conv3x3_weight_view.restype = C.c_int
     lib.mtbc_conv3x3_weight_view.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int32] * 7 + [C.c_void_p]
+    lib.mtbc_conv3x3_weight_view_many.restype = C.c_int
+    lib.mtbc_conv3x3_weight_view_many.argtypes = [C.POINTER(WViewDesc), C.c_int32, C.c_void_p]
     lib.mtbc_c8_pack16.restype = C.c_int
     lib.mtbc_c8_pack16.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
     lib.mtbc_c8_unpack.restype = C.c_int

@@ -111,6 +111,12 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
 extern "C" int mtbc_i_instnorm_fwd_c8(const mtbc_instnorm_args* a, hipStream_t st);
 extern "C" int mtbc_i_instnorm_bwd_c8(const mtbc_instnorm_args* a, float* part, hipStream_t st);
 extern "C" int mtbc_i_instnorm_bwd_c8_team(const mtbc_instnorm_args* a);
+// c8_ops.hip: max-pool and 1x1 conv on 16-bit channel-blocked tensors
+int mtbc_i_maxpool_c8_fwd(const mtbc_maxpool_args* a, hipStream_t st);
+int mtbc_i_maxpool_c8_bwd(const mtbc_maxpool_args* a, hipStream_t st);
+int mtbc_i_conv1x1_c8_fwd(const mtbc_conv1x1_args* a, hipStream_t st);
+size_t mtbc_i_conv1x1_c8_wgrad_workspace(const mtbc_conv1x1_args* a);
+int mtbc_i_conv1x1_c8_wgrad(const mtbc_conv1x1_args* a, hipStream_t st);
 // internal (C++) helpers implemented in reduce.hip
 int mtbc_i_splitk_reduce(const float* partial, float* out, int nsplit, size_t elems, int accumulate, hipStream_t st);
 // convt2.hip: ConvTranspose k == s == 2 backward, operands straight from HBM into MFMA fragments

@@ -867,15 +867,21 @@ __global__ __launch_bounds__(256, 3) void conv3x3_igemm_lp_kernel(const ConvP p)
 // kernel above, so results are bit-identical to it on the same rounded operands.  SegL.ptr carries the 16-bit base and
 // SegL.bs the batch stride in 16-bit elements; every segment holds a multiple of 8 channels.
 // Measured stand-alone (tools/experiments/c8_igemm_probe.hip): fwd 144->24 @256x256 N=32 0.27 ms against 0.46 ms.
-template <int MT, int GEO, bool F16>
-__global__ __launch_bounds__(256, 3) void conv3x3_igemm_c8_kernel(const ConvP p) {
+// NW = waves per block: 4 (256 pixels: 8 x 32, 16 x 16 or four 8 x 8 images) or, wide maps only, 8 (512 pixels: 16 x 32 --
+// 19.5 % halo instead of 33 % and each weight chunk shared by twice the pixels; 58 KB of LDS = 2 blocks per CU.  Measured
+// (tools/experiments/c8_igemm_v2_probe.hip): 144->24 @256x256 -6..-17 %, 24->24 -3 %, 64x64 maps +15 %: chosen by run_igemm).
+template <int MT, int GEO, bool F16, int NW>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 4) void conv3x3_igemm_c8_kernel(const ConvP p) {
     using G = GeoLP<GEO>;
     using T = LP<F16>;
-    constexpr int HR = G::TH + 2, HC = G::TW + 2, HP = G::IMG * HR * HC;       // halo pixels
+    static_assert(NW == 4 || (NW == 8 && GEO == 0), "8-wave blocks: wide-map geometry only");
+    constexpr int TH = GEO == 0 ? 2 * NW : G::TH;
+    constexpr int HR = TH + 2, HC = G::TW + 2, HP = G::IMG * HR * HC;       // halo pixels
     constexpr int HPP = (HP + 15) / 16 * 16;       // group stride = 0 (mod 256 B): the four 16-lane groups of a ds_read_b128 hit disjoint banks (PMC-checked)
     constexpr int XB = 4 * HPP * 8;                                            // 16-bit elements
     constexpr int WB = MT * 9 * 16 * WROW;
-    constexpr int XQ = (HPP + 63) / 64;
+    constexpr int XQ = (HPP + 63) / 64;                                        // DMA instructions per channel group ...
+    constexpr int XPW = NW == 4 ? XQ : (XQ + 1) / 2;                           // ... per wave (8 waves: two waves share a group)
     extern __shared__ __attribute__((aligned(16))) unsigned short smem16[];
     unsigned short* Xs = smem16;
     unsigned short* Ws = smem16 + XB;
@@ -914,12 +920,13 @@ __global__ __launch_bounds__(256, 3) void conv3x3_igemm_c8_kernel(const ConvP p)
         int t = tile;
         const int tx = t % p.tiles_x; t /= p.tiles_x;
         const int ty = t % p.tiles_y; t /= p.tiles_y;
-        const int n0 = t * G::IMG, x0 = tx * G::TW, y0 = ty * G::TH;
-        unsigned pixo[XQ];            // byte offset of the halo pixel's piece inside a channel group (out of range: reads 0)
-        int pimg[XQ];
+        const int n0 = t * G::IMG, x0 = tx * G::TW, y0 = ty * TH;
+        const int xgrp_w = NW == 4 ? wvu : (wvu >> 1), xq0 = NW == 4 ? 0 : (wvu & 1) * XPW;      // this wave's channel group / first piece row
+        unsigned pixo[XPW];           // byte offset of the halo pixel's piece inside a channel group (out of range: reads 0)
+        int pimg[XPW];
 #pragma unroll
-        for (int q = 0; q < XQ; ++q) {
-            const int hp = lane + 64 * q;
+        for (int q = 0; q < XPW; ++q) {
+            const int hp = lane + 64 * (xq0 + q);
             const int img = hp / (HR * HC), rem = hp % (HR * HC);
             const int row = rem / HC, col = rem % HC;
             const int y = y0 + row - 1, x = x0 + col - 1;
@@ -935,8 +942,8 @@ __global__ __launch_bounds__(256, 3) void conv3x3_igemm_c8_kernel(const ConvP p)
 
         for (int ch = 0; ch < nchunks; ++ch) {
             lds_barrier();                        // the previous step's fragments are consumed
-            {   // ---- X: wave w brings channel group w of the chunk, XQ instructions of 64 halo pixels x 16 bytes
-                const int c0 = ch * LPKC + 8 * wvu;
+            {   // ---- X: wave w (wave pair w/2 for 8 waves) brings one channel group of the chunk, 64 halo pixels x 16 bytes per instruction
+                const int c0 = ch * LPKC + 8 * xgrp_w;
                 const bool xgrp = c0 < p.Cin;
                 const SegL sr = segl_ref(seg_in, xgrp ? c0 : 0);
                 const unsigned long long pu = reinterpret_cast<unsigned long long>(sr.ptr);
@@ -949,18 +956,18 @@ __global__ __launch_bounds__(256, 3) void conv3x3_igemm_c8_kernel(const ConvP p)
                 const unsigned span = (G::IMG > 1 ? (unsigned)((G::IMG - 1) * bs) * 2u : 0u) + (unsigned)HW * 16u;
                 const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(base, 0, xgrp ? (int)span : 0, 0x00020000);
 #pragma unroll
-                for (int q = 0; q < XQ; ++q) {
+                for (int q = 0; q < XPW; ++q) {
                     unsigned off = pixo[q];
                     if (G::IMG > 1) off += 2u * (unsigned)(pimg[q] * bs);
-                    if (lane + 64 * q < HPP)
-                        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_ptr_t)(Xs + (wvu * HPP + 64 * q) * 8), 16, off, 0, 0, 0);
+                    if (xq0 + q < XQ && lane + 64 * (xq0 + q) < HPP)
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_ptr_t)(Xs + (xgrp_w * HPP + 64 * (xq0 + q)) * 8), 16, off, 0, 0, 0);
                 }
             }
             if (w_have != ch && !MTBC_DBG_BIT(p, 8)) {   // ---- W: a single-chunk conv keeps its weights in LDS for the whole launch
                 constexpr int W16 = WB / 8, WI = (W16 + 63) / 64;
 #pragma unroll
-                for (int k = 0; k < (WI + 3) / 4; ++k) {
-                    const int inst = wvu + 4 * k;
+                for (int k = 0; k < (WI + NW - 1) / NW; ++k) {
+                    const int inst = wvu + NW * k;
                     if (inst < WI) {
                         const int idx = inst * 64 + lane;
                         const int mt = idx / (9 * 16 * WROW / 8), r = idx % (9 * 16 * WROW / 8);
@@ -1795,6 +1802,31 @@ __global__ void wview_kernel(const float* __restrict__ w, float* __restrict__ ds
     else dst[((size_t)co * cnt + ci) * 9 + t] = v;
 }
 
+// Every weight view of a step in ONE launch (a U-Net++ step rebuilds 25 of them after each optimizer update; as 25 launches
+// of a few KB each that is ~0.25 ms of launch latency).  Descriptors travel by value in the kernel arguments.
+constexpr int WVIEW_MANY = 48;
+struct WViewManyP {
+    const float* w[WVIEW_MANY];
+    float* dst[WVIEW_MANY];
+    int Cout[WVIEW_MANY], Cin[WVIEW_MANY], off[WVIEW_MANY], cnt[WVIEW_MANY], koff[WVIEW_MANY], K[WVIEW_MANY];
+    unsigned char mode[WVIEW_MANY];
+    int first_block[WVIEW_MANY + 1];
+    int n;
+};
+__global__ void wview_many_kernel(const WViewManyP q) {
+    int d = 0;
+    while (d + 1 < q.n && (int)blockIdx.x >= q.first_block[d + 1]) ++d;          // scalar, uniform
+    const int idx = ((int)blockIdx.x - q.first_block[d]) * blockDim.x + threadIdx.x;
+    const int Cout = q.Cout[d], Cin = q.Cin[d], off = q.off[d], cnt = q.cnt[d], mode = q.mode[d], koff = q.koff[d], K = q.K[d];
+    if (idx >= Cout * cnt * 9) return;
+    const float* __restrict__ w = q.w[d];
+    float* __restrict__ dst = q.dst[d];
+    const int t = idx % 9, ci = (idx / 9) % cnt, co = idx / (9 * cnt);
+    const float v = w[((size_t)co * Cin + off + ci) * 9 + (mode ? 8 - t : t)];
+    if (mode) dst[((size_t)ci * K + koff + co) * 9 + t] = v;
+    else dst[((size_t)co * cnt + ci) * 9 + t] = v;
+}
+
 // ------------------------------------------------------------------ direct (VALU) fallbacks
 // One thread = one pixel x 8 output channels.  mode 0: fwd  (w[co][ci][tap])
 //                                              mode 1: dgrad (w[ci_in][co_out][8-tap], in = dz)
@@ -2067,34 +2099,35 @@ int launch_igemm_lp_mt(int MT, const ConvP& p, int mblocks, bool f16, hipStream_
     }
 }
 
-template <int MT, int GEO>
+template <int MT, int GEO, int NW>
 int launch_igemm_c8(const ConvP& p, int mblocks, bool f16, hipStream_t st) {
     using G = GeoLP<GEO>;
-    constexpr int HP = G::IMG * (G::TH + 2) * (G::TW + 2), HPP = (HP + 15) / 16 * 16;
+    constexpr int TH = GEO == 0 ? 2 * NW : G::TH;
+    constexpr int HP = G::IMG * (TH + 2) * (G::TW + 2), HPP = (HP + 15) / 16 * 16;
     const size_t lds = ((size_t)4 * HPP * 8 + (size_t)MT * 9 * 16 * WROW) * 2 + (SEGL_FLOATS + MT * 16) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_igemm_c8_kernel<MT, GEO, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_igemm_c8_kernel<MT, GEO, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_igemm_c8_kernel<MT, GEO, false, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_igemm_c8_kernel<MT, GEO, true, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     static const int per_cu_env = mtbc_probe_int("MTBC_C8_BLOCKS_PER_CU", 0);      // A/B
-    // one wave of resident blocks.  The image fits 4 per CU (40.6 KB) and the kernel compiles to 128 VGPRs, but measured
+    // one wave of resident blocks.  The 4-wave image fits 4 per CU (40.6 KB) and the kernel compiles to 128 VGPRs, but measured
     // (v9): 4 resident blocks are no faster than 3 (16.52 vs 16.49 ms per step; single launches 3-15 % slower) -> 3.
-    const int per_cu = per_cu_env ? per_cu_env : (lds * 3 <= 160 * 1024 ? 3 : 2);
+    const int per_cu = per_cu_env ? per_cu_env : (NW == 8 ? 2 : (lds * 3 <= 160 * 1024 ? 3 : 2));
     int gx = (256 * per_cu / mblocks) / 8 * 8;
     if (gx < 8) gx = 8;
     if (gx > p.ntiles) gx = p.ntiles;
     const dim3 grid(gx, mblocks);
-    if (f16) hipLaunchKernelGGL((conv3x3_igemm_c8_kernel<MT, GEO, true>), grid, dim3(256), lds, st, p);
-    else hipLaunchKernelGGL((conv3x3_igemm_c8_kernel<MT, GEO, false>), grid, dim3(256), lds, st, p);
+    if (f16) hipLaunchKernelGGL((conv3x3_igemm_c8_kernel<MT, GEO, true, NW>), grid, dim3(64 * NW), lds, st, p);
+    else hipLaunchKernelGGL((conv3x3_igemm_c8_kernel<MT, GEO, false, NW>), grid, dim3(64 * NW), lds, st, p);
     MTBC_CHECK_LAUNCH();
     return MTBC_OK;
 }
 template <int GEO>
 int launch_igemm_c8_mt(int MT, const ConvP& p, int mblocks, bool f16, hipStream_t st) {
-    if (MT == 1) return launch_igemm_c8<1, GEO>(p, mblocks, f16, st);
-    return launch_igemm_c8<2, GEO>(p, mblocks, f16, st);
+    if (MT == 1) return launch_igemm_c8<1, GEO, 4>(p, mblocks, f16, st);
+    return launch_igemm_c8<2, GEO, 4>(p, mblocks, f16, st);
 }
 
 // shared by fwd and dgrad: `rows` = channels written, `red` = channels read; compute: 0 fp32, 1 bf16, 2 fp16 operands;
@@ -2124,6 +2157,13 @@ int run_igemm(int N, int H, int W, int red, int rows, const SegTable& in, const 
     }
     MT = cdiv(p.mtiles, mblocks);
     if (c8) {
+        // wide maps with enough tiles for two 512-pixel blocks per CU several times over: 16 x 32 tiles, 8 waves
+        static const int nw_env = mtbc_probe_int("MTBC_C8_NW", 0);      // A/B
+        const int t16 = p.tiles_x * cdiv(H, 16) * N;
+        if (geo == 0 && MT == 2 && (nw_env ? nw_env == 8 : (long long)t16 * mblocks >= 2048)) {
+            p.tiles_y = cdiv(H, 16); p.ntiles = t16;
+            return launch_igemm_c8<2, 0, 8>(p, mblocks, compute == 2, st);
+        }
         if (geo == 0) return launch_igemm_c8_mt<0>(MT, p, mblocks, compute == 2, st);
         if (geo == 1) return launch_igemm_c8_mt<1>(MT, p, mblocks, compute == 2, st);
         return launch_igemm_c8_mt<2>(MT, p, mblocks, compute == 2, st);
@@ -2449,6 +2489,29 @@ int mtbc_conv3x3_weight_view(const float* w, float* dst, int32_t Cout, int32_t C
     const int total = Cout * ci_cnt * 9;
     hipLaunchKernelGGL(wview_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, w, dst, Cout, Cin, ci_off, ci_cnt, mode, k_off, K);
     MTBC_CHECK_LAUNCH();
+    return MTBC_OK;
+}
+
+int mtbc_conv3x3_weight_view_many(const mtbc_wview_desc* descs, int32_t n, void* stream) {
+    if (!descs || n < 0) return MTBC_E_BADARG;
+    for (int32_t base = 0; base < n; base += WVIEW_MANY) {
+        const int32_t m = n - base < WVIEW_MANY ? n - base : WVIEW_MANY;
+        WViewManyP q;
+        int blocks = 0;
+        for (int32_t i = 0; i < m; ++i) {
+            const mtbc_wview_desc& d = descs[base + i];
+            if (!d.w || !d.dst || d.Cout <= 0 || d.Cin <= 0 || d.ci_off < 0 || d.ci_cnt <= 0 || d.ci_off + d.ci_cnt > d.Cin) return MTBC_E_BADSHAPE;
+            if (d.mode && (d.k_off < 0 || d.k_off + d.Cout > d.K)) return MTBC_E_BADSHAPE;
+            q.w[i] = d.w; q.dst[i] = d.dst; q.Cout[i] = d.Cout; q.Cin[i] = d.Cin; q.off[i] = d.ci_off; q.cnt[i] = d.ci_cnt;
+            q.koff[i] = d.k_off; q.K[i] = d.K; q.mode[i] = d.mode ? 1 : 0;
+            q.first_block[i] = blocks;
+            blocks += cdiv(d.Cout * d.ci_cnt * 9, 256);
+        }
+        q.first_block[m] = blocks;
+        q.n = m;
+        hipLaunchKernelGGL(wview_many_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, q);
+        MTBC_CHECK_LAUNCH();
+    }
     return MTBC_OK;
 }
 

@@ -426,6 +426,8 @@ static int fill_mp(const mtbc_maxpool_args* a, MpP* p) {
 int mtbc_maxpool2_fwd(const mtbc_maxpool_args* a, void* stream) {
     MpP p; int rc = fill_mp(a, &p); if (rc) return rc;
     if (!p.x || !p.y) return MTBC_E_BADARG;
+    if (a->layout == MTBC_LAYOUT_C8) return mtbc_i_maxpool_c8_fwd(a, (hipStream_t)stream);
+    if (a->layout != MTBC_LAYOUT_PLANAR) return MTBC_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
     if ((a->W & 3) == 0 && al16(p.x) && (p.xbs & 3) == 0 && (reinterpret_cast<uintptr_t>(p.y) & 7) == 0 && (p.ybs & 1) == 0) {
         const size_t total = (size_t)a->N * a->C * (a->H / 2) * (a->W / 4);
@@ -440,6 +442,8 @@ int mtbc_maxpool2_fwd(const mtbc_maxpool_args* a, void* stream) {
 int mtbc_maxpool2_bwd(const mtbc_maxpool_args* a, void* stream) {
     MpP p; int rc = fill_mp(a, &p); if (rc) return rc;
     if (!p.x || !p.dy || !p.dx) return MTBC_E_BADARG;
+    if (a->layout == MTBC_LAYOUT_C8) return mtbc_i_maxpool_c8_bwd(a, (hipStream_t)stream);
+    if (a->layout != MTBC_LAYOUT_PLANAR) return MTBC_E_BADARG;
     if ((reinterpret_cast<uintptr_t>(p.x) & 7) || (reinterpret_cast<uintptr_t>(p.dx) & 7) || (p.xbs & 1) || (p.dxbs & 1))
         return MTBC_E_UNSUPPORTED;
     const size_t total = (size_t)a->N * a->C * (a->H / 2) * (a->W / 2);
@@ -460,6 +464,8 @@ static int fill_c1(const mtbc_conv1x1_args* a, C1P* p) {
 int mtbc_conv1x1_fwd(const mtbc_conv1x1_args* a, void* stream) {
     C1P p; int rc = fill_c1(a, &p); if (rc) return rc;
     if (!p.x || !p.w || !p.y) return MTBC_E_BADARG;
+    if (a->x_layout == MTBC_LAYOUT_C8) return mtbc_i_conv1x1_c8_fwd(a, (hipStream_t)stream);
+    if (a->x_layout != MTBC_LAYOUT_PLANAR) return MTBC_E_BADARG;
     if (!al16(p.x) || !al16(p.y) || (p.xbs & 3)) return MTBC_E_UNSUPPORTED;
     dim3 grid(cdiv(p.HW / 4, 256), cdiv(a->Cout, 8), a->N);
     hipLaunchKernelGGL(conv1x1_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
@@ -477,11 +483,14 @@ int mtbc_conv1x1_dgrad(const mtbc_conv1x1_args* a, void* stream) {
 }
 size_t mtbc_conv1x1_wgrad_workspace(const mtbc_conv1x1_args* a) {
     if (!a) return 0;
+    if (a->x_layout == MTBC_LAYOUT_C8) return mtbc_i_conv1x1_c8_wgrad_workspace(a);
     return ((size_t)a->N * a->Cout * a->Cin + (size_t)a->N * a->Cout) * sizeof(float);
 }
 int mtbc_conv1x1_wgrad(const mtbc_conv1x1_args* a, void* stream) {
     C1P p; int rc = fill_c1(a, &p); if (rc) return rc;
     if (!p.x || !p.dy || !a->dw) return MTBC_E_BADARG;
+    if (a->x_layout == MTBC_LAYOUT_C8) return mtbc_i_conv1x1_c8_wgrad(a, (hipStream_t)stream);
+    if (a->x_layout != MTBC_LAYOUT_PLANAR) return MTBC_E_BADARG;
     if (!al16(p.x) || !al16(p.dy) || (p.xbs & 3)) return MTBC_E_UNSUPPORTED;
     if (!a->workspace || a->workspace_bytes < mtbc_conv1x1_wgrad_workspace(a)) return MTBC_E_WORKSPACE;
     p.partial = reinterpret_cast<float*>(a->workspace);

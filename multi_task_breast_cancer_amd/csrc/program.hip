@@ -44,6 +44,23 @@ int mtbc_program_run(const mtbc_op* ops, int32_t first, int32_t count, void* str
                 continue;
             }
         }
+        if (o->kind == MTBC_OP_CONV3_WVIEW) {          // ... and so does a run of weight views
+            mtbc_wview_desc d[128];
+            int32_t n = 0;
+            while (n < 128 && i + n < first + count && ops[i + n].kind == MTBC_OP_CONV3_WVIEW) {
+                const mtbc_op* q = &ops[i + n];
+                d[n].w = q->u.wview.w; d[n].dst = q->u.wview.dst; d[n].Cout = q->u.wview.Cout; d[n].Cin = q->u.wview.Cin;
+                d[n].ci_off = q->u.wview.ci_off; d[n].ci_cnt = q->u.wview.ci_cnt; d[n].mode = q->u.wview.mode;
+                d[n].k_off = q->u.wview.k_off; d[n].K = q->u.wview.K;
+                ++n;
+            }
+            if (n > 1) {
+                rc = mtbc_conv3x3_weight_view_many(d, n, stream);
+                if (rc != MTBC_OK) { if (failed_index) *failed_index = i; return rc; }
+                i += n - 1;
+                continue;
+            }
+        }
         switch (o->kind) {
             case MTBC_OP_CONV3_FWD: rc = mtbc_conv3x3_fwd(&o->u.conv3, stream); break;
             case MTBC_OP_CONV3_DGRAD: rc = mtbc_conv3x3_dgrad(&o->u.conv3, stream); break;

@@ -27,6 +27,7 @@ _COOP_MIN_BWD = int(_sw.get("MTBC_COOP_MIN_BWD"))
 _NO_GATHER = _sw.flag("MTBC_NO_GATHER")
 _NO_P16 = _sw.flag("MTBC_NO_P16")
 _FANIN = _sw.flag("MTBC_FANIN")
+_NO_C8_SMALL = _sw.flag("MTBC_NO_C8_SMALL_OPS")
 
 
 def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
@@ -494,15 +495,32 @@ class StepPlan:
         self.bwd_emitters.append(emit_bwd)
         return y
 
+    def _c8_small_ok(self, x: Act) -> bool:
+        """16-bit modes: may a small consumer (max-pool, 1x1 head) read the channel-blocked copy of x instead of fp32 planes?"""
+        return bool(self.compute) and not _NO_C8 and not _NO_C8_SMALL and not self.force_direct and x.C % 8 == 0 and (x.H * x.W) % 4 == 0
+
     def maxpool(self, x: Act, out_name: str) -> Act:
         y = self.new_act(out_name, x.C, x.H // 2, x.W // 2)
+        # 16-bit modes: pool the channel-blocked 16-bit tensor into a channel-blocked 16-bit tensor (max commutes with the
+        # rounding: bit-identical to the fp32 pool + pack) -- the pooled tensor feeds 3x3 convs only, and x then needs no
+        # fp32 planes on the pool's account.  Only when those convs can take the layout (else they need planes of y).
+        c8 = self._c8_small_ok(x) and (x.W // 2) % 4 == 0 and x.H // 2 >= 8 and x.W // 2 >= 8 and x.H % 2 == 0 and x.W % 2 == 0
+        if c8:
+            y.c8 = self.alloc(self.N, x.C // 8, y.H * y.W, 8, dtype=torch.int16)
+            y.planar_valid = False
+            x8 = self.c8_of(x)
 
         def base() -> L.Op:
             op = _mk(0)
             a = op.u.pool
             a.N, a.C, a.H, a.W = self.N, x.C, x.H, x.W
-            a.x, a.x_batch_stride = self._rd(x), x.bstride
-            a.y, a.y_batch_stride = y.data.data_ptr(), y.bstride
+            if c8:
+                a.layout, a.type16 = L.LAYOUT_C8, self.compute
+                a.x, a.x_batch_stride = x8.data_ptr(), x.bstride
+                a.y, a.y_batch_stride = y.c8.data_ptr(), y.bstride
+            else:
+                a.x, a.x_batch_stride = self._rd(x), x.bstride
+                a.y, a.y_batch_stride = y.data.data_ptr(), y.bstride
             return op
 
         op = base()
@@ -661,12 +679,19 @@ class StepPlan:
         w = self.pv(wname)
         assert tuple(w.shape) == (cout, x.C, 1, 1), (wname, tuple(w.shape))
         y = self.new_act(out_name, cout, x.H, x.W)
+        # 16-bit modes: the head reads the channel-blocked 16-bit activation the 3x3 convs read (fp32 weights, products
+        # and sums): x then needs no fp32 planes on the head's account
+        c8 = self._c8_small_ok(x) and cout <= 8
+        x8 = self.c8_of(x) if c8 else None
 
         def base() -> L.Op:
             op = _mk(0)
             a = op.u.conv1
             a.N, a.H, a.W, a.Cin, a.Cout = self.N, x.H, x.W, x.C, cout
-            a.x, a.x_batch_stride = self._rd(x), x.bstride
+            if c8:
+                a.x, a.x_batch_stride, a.x_layout, a.x_type = x8.data_ptr(), x.bstride, L.LAYOUT_C8, self.compute
+            else:
+                a.x, a.x_batch_stride = self._rd(x), x.bstride
             a.w, a.bias, a.y = w.data_ptr(), _ptr(self.pv(bname)), y.data.data_ptr()
             return op
 

@@ -356,6 +356,31 @@ def maxpool2_bwd(x, dy, dx=None, accumulate=False):
     return dx
 
 
+def maxpool2_fwd_c8(x8: "C8") -> "C8":
+    """2x2 max-pool of a channel-blocked 16-bit tensor into one (mtbc_maxpool_args.layout = MTBC_LAYOUT_C8)."""
+    N, Cc, H, W = x8.shape
+    y = torch.empty(N, Cc // 8, (H // 2) * (W // 2), 8, dtype=torch.int16, device=x8.data.device)
+    a = L.MaxPoolArgs()
+    a.N, a.C, a.H, a.W, a.layout, a.type16 = N, Cc, H, W, L.LAYOUT_C8, x8.compute
+    a.x, a.x_batch_stride, a.y, a.y_batch_stride = x8.data.data_ptr(), Cc * H * W, y.data_ptr(), Cc * H * W // 4
+    L.check(L.load().mtbc_maxpool2_fwd(C.byref(a), _s()), "maxpool_fwd c8")
+    return C8(y, (N, Cc, H // 2, W // 2), x8.compute)
+
+
+def maxpool2_bwd_c8(x8: "C8", dy, dx=None, accumulate=False):
+    _chk(dy, dx)
+    N, Cc, H, W = x8.shape
+    if dx is None:
+        dx = torch.empty(N, Cc, H, W, dtype=torch.float32, device=dy.device)
+    a = L.MaxPoolArgs()
+    a.N, a.C, a.H, a.W, a.layout, a.type16 = N, Cc, H, W, L.LAYOUT_C8, x8.compute
+    a.x, a.x_batch_stride = x8.data.data_ptr(), Cc * H * W
+    a.dy, a.dy_batch_stride, a.dx, a.dx_batch_stride = dy.data_ptr(), Cc * H * W // 4, dx.data_ptr(), Cc * H * W
+    a.accumulate_dx = int(accumulate)
+    L.check(L.load().mtbc_maxpool2_bwd(C.byref(a), _s()), "maxpool_bwd c8")
+    return dx
+
+
 # ------------------------------------------------------------------ conv transpose (k == stride)
 def _ct_args(x, w, k):
     a = L.ConvTArgs()
@@ -462,6 +487,34 @@ def conv1x1_bwd(x, w, dy):
     a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel() * 4
     L.check(L.load().mtbc_conv1x1_wgrad(C.byref(a), _s()), "conv1x1_wgrad")
     return dx, dw, db
+
+
+def conv1x1_fwd_c8(x8: "C8", w, bias):
+    """1x1 conv reading the channel-blocked 16-bit activation (mtbc_conv1x1_args.x_layout = MTBC_LAYOUT_C8)."""
+    _chk(w, bias)
+    N, Cin, H, W = x8.shape
+    y = torch.empty(N, w.shape[0], H, W, dtype=torch.float32, device=w.device)
+    a = L.Conv1x1Args()
+    a.N, a.H, a.W, a.Cin, a.Cout = N, H, W, Cin, w.shape[0]
+    a.x, a.x_batch_stride, a.w, a.x_layout, a.x_type = x8.data.data_ptr(), Cin * H * W, w.data_ptr(), L.LAYOUT_C8, x8.compute
+    a.bias, a.y = _p(bias), y.data_ptr()
+    L.check(L.load().mtbc_conv1x1_fwd(C.byref(a), _s()), "conv1x1_fwd c8")
+    return y
+
+
+def conv1x1_wgrad_c8(x8: "C8", w, dy, accumulate=False, dw=None, db=None):
+    _chk(w, dy)
+    N, Cin, H, W = x8.shape
+    dw = torch.empty_like(w) if dw is None else dw
+    db = torch.empty(w.shape[0], dtype=torch.float32, device=w.device) if db is None else db
+    a = L.Conv1x1Args()
+    a.N, a.H, a.W, a.Cin, a.Cout = N, H, W, Cin, w.shape[0]
+    a.x, a.x_batch_stride, a.w, a.x_layout, a.x_type = x8.data.data_ptr(), Cin * H * W, w.data_ptr(), L.LAYOUT_C8, x8.compute
+    a.dy, a.dw, a.dbias, a.accumulate_dw = dy.data_ptr(), dw.data_ptr(), db.data_ptr(), int(accumulate)
+    ws = _ws(L.load().mtbc_conv1x1_wgrad_workspace(C.byref(a)), w.device)
+    a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+    L.check(L.load().mtbc_conv1x1_wgrad(C.byref(a), _s()), "conv1x1_wgrad c8")
+    return dw, db
 
 
 # ------------------------------------------------------------------ head

@@ -444,6 +444,25 @@ class _LowpConv3x3(torch.autograd.Function):
         return dx, dw, db, None
 
 
+class _LowpConv1x1(torch.autograd.Function):
+    """1x1 head of the 16-bit modes (c8_ops.hip): reads the stored (rounded) activation; weights, products and sums
+    stay in the tensor dtype -- forward and weight gradient see r(x), the input gradient is exact."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, lp):
+        ctx.save_for_backward(x, w)
+        ctx.lp, ctx.has_b = lp, b is not None
+        return torch.conv2d(x.to(lp).to(x.dtype), w, b)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dx = torch.nn.grad.conv2d_input(x.shape, w, dy)
+        dw = torch.nn.grad.conv2d_weight(x.to(ctx.lp).to(x.dtype), w.shape, dy)
+        db = dy.sum(dim=(0, 2, 3)) if ctx.has_b else None
+        return dx, dw, db, None
+
+
 class _LowpConvT2Bwd(torch.autograd.Function):
     """ConvTranspose2d(k = s = 2) of the 16-bit modes: forward MFMA on rounded x, w (fp32 accumulate + bias), backward
     MFMAs on rounded operands (dgrad: dy, w; wgrad: x, dy), bias gradient from the unrounded dy -- convt2.hip."""
@@ -471,8 +490,11 @@ class _LowpConvT2Bwd(torch.autograd.Function):
 class lowp_conv3x3:
     """Context manager: inside it every 3x3 / padding-1 F.conv2d (hence every nn.Conv2d of the oracle nets) runs
     through _LowpConv3x3 with operands rounded to `mode` ('bf16' | 'f16'), and the backward of every k = s = 2
-    F.conv_transpose2d through _LowpConvT2Bwd.  `model`: its ConvTranspose2d -> 1x1 Conv2d heads stay exact (the
-    product fuses them into one fp32 transposed conv, engine.convT_head)."""
+    F.conv_transpose2d through _LowpConvT2Bwd.  The small consumers of a conv-cell activation read the stored (rounded)
+    tensor too: F.max_pool2d(2, 2) pools r(x) (forward unchanged -- max commutes with rounding -- but the backward routes
+    on the rounded values) and a 1x1 F.conv2d with <= 8 outputs runs through _LowpConv1x1.  `model`: its
+    ConvTranspose2d -> 1x1 Conv2d heads stay exact (the product fuses them into one fp32 transposed conv,
+    engine.convT_head)."""
 
     def __init__(self, mode: str, model=None):
         self.lp = {"bf16": torch.bfloat16, "f16": torch.float16}[mode]
@@ -483,12 +505,27 @@ class lowp_conv3x3:
                 if (isinstance(m, torch.nn.Sequential) and len(m) >= 2 and isinstance(m[0], torch.nn.ConvTranspose2d)
                             and isinstance(m[1], torch.nn.Conv2d) and tuple(m[1].kernel_size) == (1, 1)):
                         self.exempt.add(id(m[0].weight))
+                        self.exempt.add(id(m[1].weight))
 
     def __enter__(self):
         self._orig = F.conv2d
         self._orig_t = F.conv_transpose2d
+        self._orig_p = F.max_pool2d
         orig, lp = self._orig, self.lp
         orig_t, exempt = self._orig_t, self.exempt
+        orig_p = self._orig_p
+
+        def max_pool2d(input, kernel_size, stride=None, padding=0, dilation=1, ceil_mode=False, return_indices=False):
+            # same eligibility as the product (engine.maxpool): channel groups of 8, and a pooled map the 3x3 convs take
+            # in the channel-blocked layout
+            H, W = input.shape[-2:]
+            if (kernel_size in (2, (2, 2)) and stride in (None, 2, (2, 2)) and padding in (0, (0, 0)) and not return_indices
+                    and input.dim() == 4 and input.shape[1] % 8 == 0 and (H * W) % 4 == 0 and H % 2 == 0 and W % 2 == 0
+                    and (W // 2) % 4 == 0 and H // 2 >= 8 and W // 2 >= 8):
+                input = input.to(lp).to(input.dtype)
+            return orig_p(input, kernel_size, stride, padding, dilation, ceil_mode, return_indices)
+
+        F.max_pool2d = max_pool2d
 
         def conv_transpose2d(input, weight, bias=None, stride=1, padding=0, output_padding=0, groups=1, dilation=1):
             # same eligibility as the product (engine.convT): the direct-to-fragment backward kernels of convt2.hip
@@ -510,6 +547,9 @@ class lowp_conv3x3:
             if (tuple(weight.shape[-2:]) == (3, 3) and padding in (1, (1, 1)) and stride in (1, (1, 1)) and groups == 1
                     and H >= 8 and W >= 8 and W % 4 == 0 and weight.shape[1] % 8 == 0 and weight.shape[0] % 8 == 0):
                 return _LowpConv3x3.apply(input, weight, bias, lp)
+            if (tuple(weight.shape[-2:]) == (1, 1) and padding in (0, (0, 0)) and stride in (1, (1, 1)) and groups == 1
+                    and weight.shape[1] % 8 == 0 and weight.shape[0] <= 8 and (H * W) % 4 == 0 and id(weight) not in exempt):
+                return _LowpConv1x1.apply(input, weight, bias, lp)
             return orig(input, weight, bias, stride, padding, dilation, groups)
 
         F.conv2d = conv2d
@@ -518,6 +558,7 @@ class lowp_conv3x3:
     def __exit__(self, *exc):
         F.conv2d = self._orig
         F.conv_transpose2d = self._orig_t
+        F.max_pool2d = self._orig_p
         return False
 
 

@@ -491,7 +491,8 @@ def test_conv3x3_c8_operands(N, segs, Cout, H, W, compute):
 
 @pytest.mark.parametrize("compute", [1, 2])
 @pytest.mark.parametrize("N,segs,Cout,H,W", C8_CASES + [(2, [24, 24, 24, 24, 24, 24], 24, 256, 256),   # 144->24 @256x256: the bench's widest level-0 node
-                                                        (1, [384, 384, 384], 512, 16, 16)])                # K = 1152 x 9: the longest accumulation of the step
+                                                        (1, [384, 384, 384], 512, 16, 16),                 # K = 1152 x 9: the longest accumulation of the step
+                                                        (16, [24, 24], 24, 256, 256)])                     # enough 16 x 32 tiles for the 8-wave (512-pixel) blocks
 def test_conv3x3_16bit_fwd_dgrad_match_fp64_on_rounded_operands(N, segs, Cout, H, W, compute):
     """The oracle of the 16-bit forward / dgrad kernels (channel-blocked AND planar staging): fp64 conv2d / conv2d_input
     on operands rounded (RNE) to the MFMA's 16-bit type -- x and w forward, dz and w backward -- i.e. exact products,
@@ -629,3 +630,75 @@ def test_convT_forward_on_the_16bit_mfma_with_channel_blocked_tensors(N, Cin, Co
     got = ops.convT_fwd_c8_lp(ops.C8.pack(x.to(DEV), compute), w.to(DEV), b.to(DEV), 2).unpack().cpu()
     ulp = 2.0 ** -7 if compute == 1 else 2.0 ** -10
     assert bool(((got - want).abs() <= ulp * want.abs() + 1e-5).all()), (got - want).abs().max().item()
+
+
+@pytest.mark.parametrize("compute", [1, 2])
+@pytest.mark.parametrize("N,C,H,W", [(2, 24, 256, 256), (3, 8, 16, 24), (1, 48, 32, 32), (2, 16, 64, 16)])
+def test_maxpool_on_channel_blocked_tensors(N, C, H, W, compute):
+    """forward == fp32 pool of the stored values, re-packed, bit for bit; backward == the fp32 kernel run on the stored
+    (unpacked) values, bit for bit, overwrite and accumulate (ties of rounded values included: the test data has many)."""
+    g = _g(N + C + H + compute)
+    x = torch.randn(N, C, H, W, generator=g).to(DEV)
+    x8 = ops.C8.pack(x, compute)
+    xs = x8.unpack()                                         # the stored values
+    y8 = ops.maxpool2_fwd_c8(x8)
+    want = ops.C8.pack(ops.maxpool2_fwd(xs), compute)
+    assert y8.shape == want.shape and torch.equal(y8.data, want.data)
+    assert torch.equal(y8.data, ops.C8.pack(ops.maxpool2_fwd(x), compute).data)      # max commutes with the rounding
+    dy = torch.randn(N, C, H // 2, W // 2, generator=g).to(DEV)
+    assert torch.equal(ops.maxpool2_bwd_c8(x8, dy), ops.maxpool2_bwd(xs, dy))
+    pre = torch.randn(N, C, H, W, generator=g).to(DEV)
+    assert torch.equal(ops.maxpool2_bwd_c8(x8, dy, dx=pre.clone(), accumulate=True), ops.maxpool2_bwd(xs, dy, dx=pre.clone(), accumulate=True))
+    ties = (F.max_pool2d(xs, 2, 2).repeat_interleave(2, 2).repeat_interleave(2, 3) == xs).float().mean().item()
+    assert ties > 0.25                                       # (>= one maximal element per window; more = ties exercised)
+
+
+@pytest.mark.parametrize("compute", [1, 2])
+@pytest.mark.parametrize("N,Cin,Cout,H,W", [(2, 24, 1, 256, 256), (3, 16, 1, 32, 32), (2, 24, 3, 64, 48), (1, 64, 8, 16, 16)])
+def test_conv1x1_head_on_channel_blocked_input(N, Cin, Cout, H, W, compute):
+    """forward == the fp32 1x1 kernel on the stored values bit for bit (same fmaf chain); weight / bias gradient against
+    fp64 on the stored values (another summation order)."""
+    g = _g(N + Cin + Cout + H + compute)
+    x = torch.randn(N, Cin, H, W, generator=g).to(DEV)
+    w = (torch.randn(Cout, Cin, 1, 1, generator=g) * 0.3).to(DEV)
+    b = torch.randn(Cout, generator=g).to(DEV)
+    dy = torch.randn(N, Cout, H, W, generator=g).to(DEV)
+    x8 = ops.C8.pack(x, compute)
+    xs = x8.unpack()
+    assert torch.equal(ops.conv1x1_fwd_c8(x8, w, b), ops.conv1x1_fwd(xs, w, b))
+    dw, db = ops.conv1x1_wgrad_c8(x8, w, dy)
+    wr = torch.zeros(Cout, Cin, 1, 1, dtype=torch.float64, requires_grad=True)
+    F.conv2d(xs.cpu().double(), wr).backward(dy.cpu().double())
+    _close(dw, wr.grad.float(), 1e-5, 2e-5 * max(1.0, wr.grad.abs().max().item()), "conv1x1 c8 wgrad")
+    dbr = dy.cpu().double().sum((0, 2, 3)).float()
+    _close(db, dbr, 1e-5, 2e-5 * max(1.0, dbr.abs().max().item()), "conv1x1 c8 dbias")
+    dw2, db2 = ops.conv1x1_wgrad_c8(x8, w, dy, accumulate=True, dw=dw.clone(), db=db.clone())
+    _close(dw2, 2 * wr.grad.float(), 1e-5, 4e-5 * max(1.0, wr.grad.abs().max().item()), "conv1x1 c8 wgrad accumulate")
+    _close(db2, 2 * dbr, 1e-5, 4e-5 * max(1.0, dbr.abs().max().item()), "conv1x1 c8 dbias accumulate")
+
+
+def test_weight_view_many_equals_single_views():
+    """The batched weight-view launch (one per step) writes what the per-view entry point writes."""
+    import ctypes as C
+    from multi_task_breast_cancer_amd import _lib as L
+    g = _g(17)
+    lib = L.load()
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    descs, outs_many, outs_single = [], [], []
+    cases = [(24, 144, 24, 24, 0), (24, 144, 48, 96, 0), (48, 96, 0, 48, 1), (24, 72, 24, 24, 1), (96, 288, 96, 96, 1)] * 11      # 55 > one kernel-argument batch
+    keep = []
+    for Cout, Cin, off, cnt, mode in cases:
+        w = torch.randn(Cout, Cin, 3, 3, generator=g).to(DEV)
+        K = Cout + 8
+        shape = (cnt, K, 3, 3) if mode else (Cout, cnt, 3, 3)
+        a, b = torch.zeros(shape, device=DEV), torch.zeros(shape, device=DEV)
+        keep.append(w)
+        d = L.WViewDesc()
+        d.w, d.dst, d.Cout, d.Cin, d.ci_off, d.ci_cnt, d.mode, d.k_off, d.K = w.data_ptr(), a.data_ptr(), Cout, Cin, off, cnt, mode, 8 if mode else 0, K if mode else 0
+        descs.append(d)
+        L.check(lib.mtbc_conv3x3_weight_view(w.data_ptr(), b.data_ptr(), Cout, Cin, off, cnt, mode, 8 if mode else 0, K if mode else 0, st), "wview")
+        outs_many.append(a); outs_single.append(b)
+    arr = (L.WViewDesc * len(descs))(*descs)
+    L.check(lib.mtbc_conv3x3_weight_view_many(arr, len(descs), st), "wview_many")
+    for a, b in zip(outs_many, outs_single):
+        assert torch.equal(a, b) and a.abs().sum().item() > 0

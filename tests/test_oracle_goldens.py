@@ -235,3 +235,47 @@ def test_single_task_seg_nnunet_step_matches_reference(golden_dir):
     for i, k in enumerate(str(n) for n in g["probe_names"]):
         np.testing.assert_allclose(sd[k].flatten()[:32].numpy(), g[f"after_{i}"], rtol=0, atol=2e-6)
         assert abs(sd[k].double().sum().item() - float(g[f"aftersum_{i}"])) < 1e-3
+
+
+def test_16bit_emulation_of_pool_and_1x1_head_is_transparent_without_rounding_and_rounds_with_it():
+    """The small consumers of a conv-cell activation (max-pool, 1x1 head <= 8 outputs) read the stored (rounded) tensor in
+    the 16-bit modes: with a non-rounding type the patched functions must reproduce autograd exactly; with bf16 the pooled
+    values equal the rounded pooled values and the gradient is routed by the rounded values."""
+    import torch
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from oracle import torch_oracle as O
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(2, 8, 16, 16, generator=g, dtype=torch.float64, requires_grad=True)
+    pool, head = nn.MaxPool2d(2, 2), nn.Conv2d(8, 1, 1).double()
+
+    def run():
+        for p in list(head.parameters()) + [x]:
+            p.grad = None
+        (pool(x).square().sum() + head(x).square().sum()).backward()
+        return [x.grad.clone()] + [p.grad.clone() for p in head.parameters()]
+
+    want = run()
+    ctx = O.lowp_conv3x3("bf16")
+    ctx.lp = torch.float64
+    with ctx:
+        assert F.max_pool2d is not ctx._orig_p
+        got = run()
+    assert F.max_pool2d is ctx._orig_p
+    for a, b in zip(got, want):
+        assert torch.allclose(a, b, rtol=1e-12, atol=1e-12)
+    r = lambda t: t.bfloat16().to(t.dtype)
+    with O.lowp_conv3x3("bf16"):
+        assert torch.equal(pool(x), r(pool(x.detach())))                       # max commutes with rounding
+        assert torch.equal(head(x), torch.conv2d(r(x), head.weight, head.bias))
+        x.grad = None
+        pool(x).sum().backward()
+        # every window routes its gradient to exactly one element, a maximal one of the ROUNDED window
+        gx = x.grad
+        win = gx.view(2, 8, 8, 2, 8, 2).permute(0, 1, 2, 4, 3, 5).reshape(2, 8, 8, 8, 4)
+        assert torch.equal(win.sum(-1), torch.ones(2, 8, 8, 8, dtype=torch.float64))
+        xr = r(x.detach()).view(2, 8, 8, 2, 8, 2).permute(0, 1, 2, 4, 3, 5).reshape(2, 8, 8, 8, 4)
+        assert torch.equal((xr * win).sum(-1), xr.max(-1).values)
+    small = torch.randn(1, 8, 8, 8, dtype=torch.float64)      # pooled map 4x4: the product keeps fp32 planes there
+    with O.lowp_conv3x3("bf16"):
+        assert torch.equal(pool(small), F.max_pool2d(small, 2, 2)) and not torch.equal(pool(small), r(pool(small)))

@@ -60,7 +60,9 @@ __device__ __forceinline__ void wait_vmcnt_dyn(int n) {
 }
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-template <int MT, int NW, int VAR>
+// ABL (timing ablations, results wrong): 1 = halo pixels are not loaded (centre only), 2 = no stores, 4 = no X loads, 8 = no MFMAs,
+// 16 = W loaded once per block (not per chunk), 32 = every tile reads the pixels of tiles 0..7 (X served by L2)
+template <int MT, int NW, int VAR, int ABL = 0>
 __global__ __launch_bounds__(64 * NW, (NW == 4 ? 3 : 4)) void conv_c8_v(const P p) {
     constexpr int TH = 2 * NW, TW = 32, HR = TH + 2, HC = TW + 2, HP = HR * HC, HPP = (HP + 15) / 16 * 16;
     constexpr int XB = 4 * HPP * 8, WB = MT * 9 * 16 * WROW;           // 16-bit elements
@@ -82,7 +84,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 ? 3 : 4)) void conv_c8_v(const P 
     const int grp_w = NW == 4 ? wv : (wv >> 1), half = NW == 4 ? 0 : (wv & 1);      // which channel group / half of it this wave brings
 
     auto issue_x = [&](int tile, int ch, int slot) {
-        int t = tile; const int tx = t % p.tiles_x; t /= p.tiles_x; const int ty = t % p.tiles_y; t /= p.tiles_y;
+        int t = (ABL & 32) ? (tile & 7) : tile; const int tx = t % p.tiles_x; t /= p.tiles_x; const int ty = t % p.tiles_y; t /= p.tiles_y;
         const int n = t, x0 = tx * TW, y0 = ty * TH;
         const int g8 = ch * 4 + grp_w;
         const __bf16* base = p.x8 + ((size_t)n * (p.Cin / 8) + (g8 < p.Cin / 8 ? g8 : 0)) * HW * 8;
@@ -91,7 +93,10 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 ? 3 : 4)) void conv_c8_v(const P 
         for (int q = 0; q < XPW; ++q) {
             const int qi = half * XPW + q;
             const int hp = lane + 64 * qi, row = hp / HC, col = hp % HC, y = y0 + row - 1, x = x0 + col - 1;
-            const unsigned off = (hp < HP && y >= 0 && y < p.H && x >= 0 && x < p.W) ? 16u * (unsigned)(y * p.W + x) : 0xfffffff0u;
+            bool okx = hp < HP && y >= 0 && y < p.H && x >= 0 && x < p.W;
+            if (ABL & 1) okx = okx && row >= 1 && row <= TH && col >= 1 && col <= TW;
+            if (ABL & 4) okx = false;
+            const unsigned off = okx ? 16u * (unsigned)(y * p.W + x) : 0xfffffff0u;
             if (qi < XI && hp < HPP)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_ptr_t)(Xs + slot * XB + (grp_w * HPP + 64 * qi) * 8), 16, off, 0, 0, 0);
         }
@@ -121,7 +126,10 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 ? 3 : 4)) void conv_c8_v(const P 
 #pragma unroll
             for (int m = 0; m < MT; ++m)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) acc[m][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[g], a[m], acc[m][g], 0, 0, 0);
+                for (int g = 0; g < 4; ++g) {
+                    if (ABL & 8) { acc[m][g][0] += (float)b[g][0] * (float)a[m][0]; }
+                    else acc[m][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[g], a[m], acc[m][g], 0, 0, 0);
+                }
         }
     };
     // epilogue: fp32 planar output, one 16-byte store per accumulator tile; returns the number of store INSTRUCTIONS that had an
@@ -137,7 +145,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 ? 3 : 4)) void conv_c8_v(const P 
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int y = y0 + 2 * wv + (g >> 1), x = x0 + 16 * (g & 1) + 4 * kg;
-                const bool ok = co < p.Cout && y < p.H && x < p.W;
+                bool ok = co < p.Cout && y < p.H && x < p.W;
+                if (ABL & 2) ok = ok && acc[m][g][0] == 12345.678f;
                 nst += __ballot(ok) != 0ull ? 1 : 0;
                 if (ok) cb[(y * p.W + x) >> 2] = acc[m][g];
             }
@@ -157,7 +166,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 ? 3 : 4)) void conv_c8_v(const P 
             for (int ch = 0; ch < nchunks; ++ch) {
                 lds_barrier();
                 issue_x(tile, ch, 0);
-                if (w_have != ch) { issue_w(ch); w_have = ch; }
+                if (w_have != ch && !((ABL & 16) && w_have >= 0)) { issue_w(ch); w_have = ch; }
                 asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
                 compute(acc, 0);
             }
@@ -204,7 +213,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 ? 3 : 4)) void conv_c8_v(const P 
     }
 }
 
-template <int MT, int NW, int VAR>
+template <int MT, int NW, int VAR, int ABL = 0>
 static float run(const P& p0, int reps) {
     P p = p0;
     constexpr int TH = 2 * NW, HP = (TH + 2) * 34, HPP = (HP + 15) / 16 * 16;
@@ -214,15 +223,15 @@ static float run(const P& p0, int reps) {
     const int mblocks = (p.mtiles + MT - 1) / MT;
     int gx = (256 * per_cu / mblocks) / 8 * 8;
     if (gx > (p.ntiles + 7) / 8 * 8) gx = (p.ntiles + 7) / 8 * 8;
-    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_c8_v<MT, NW, VAR>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_c8_v<MT, NW, VAR, ABL>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int i = 0; i < 2; ++i) conv_c8_v<MT, NW, VAR><<<dim3(gx, mblocks), 64 * NW, lds>>>(p);
+    for (int i = 0; i < 2; ++i) conv_c8_v<MT, NW, VAR, ABL><<<dim3(gx, mblocks), 64 * NW, lds>>>(p);
     CK(hipDeviceSynchronize());
     CK(hipEventRecord(e0));
-    for (int i = 0; i < reps; ++i) conv_c8_v<MT, NW, VAR><<<dim3(gx, mblocks), 64 * NW, lds>>>(p);
+    for (int i = 0; i < reps; ++i) conv_c8_v<MT, NW, VAR, ABL><<<dim3(gx, mblocks), 64 * NW, lds>>>(p);
     CK(hipEventRecord(e1)); CK(hipDeviceSynchronize());
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-    printf("    [MT%d NW%d VAR%d grid %dx%d lds %zu (%d/CU)]", MT, NW, VAR, gx, mblocks, lds, per_cu);
+    printf("    [MT%d NW%d VAR%d ABL%d grid %dx%d lds %zu (%d/CU)]", MT, NW, VAR, ABL, gx, mblocks, lds, per_cu);
     return ms / reps;
 }
 
@@ -268,9 +277,15 @@ int main(int argc, char** argv) {
     printf("c8 igemm %d->%d @%dx%d N=%d  (%.1f GFLOP, %.1f MB algorithmic)\n", Cin, Cout, H, W, N, gf, gb * 1e3);
 #define RUN(MT_, NW_, VAR_) do { const float ms = run<MT_, NW_, VAR_>(p, 20); const double err = verify(); \
         printf("  %.4f ms  %.1f TF  %.2f TB/s  max|err| %.2e\n", ms, gf / ms, gb / ms, err); } while (0)
+#define RUNA(MT_, NW_, VAR_, ABL_) do { const float ms = run<MT_, NW_, VAR_, ABL_>(p, 20); CK(hipMemset(dout, 0, 16)); \
+        printf("  %.4f ms  %.2f TB/s (algorithmic bytes)\n", ms, gb / ms); } while (0)
+    if (argc > 5) {          // ablations of the production structure
+        RUN(2, 4, 0); RUNA(2, 4, 0, 1); RUNA(2, 4, 0, 2); RUNA(2, 4, 0, 4); RUNA(2, 4, 0, 8); RUNA(2, 4, 0, 3); RUNA(2, 4, 0, 6); RUNA(2, 4, 0, 10); RUNA(2, 4, 0, 12);
+        RUNA(2, 4, 0, 16); RUNA(2, 4, 0, 32); RUNA(2, 4, 0, 48); RUNA(2, 4, 0, 18); RUNA(2, 4, 0, 50);
+        RUN(2, 8, 0); RUNA(2, 8, 0, 16); RUNA(2, 8, 0, 18);
+        return 0;
+    }
     if (Cout <= 16) { RUN(1, 4, 0); RUN(1, 4, 1); RUN(1, 4, 2); RUN(1, 8, 0); RUN(1, 8, 1); RUN(1, 8, 2); }
     else { RUN(2, 4, 0); RUN(2, 4, 1); RUN(2, 4, 2); RUN(2, 8, 0); RUN(2, 8, 1); RUN(2, 8, 2); }
-    for (int r = 0; r < 2; ++r)       // interleaved rounds of the leading candidates (A/B in one process)
-        if (Cout > 16) { RUN(2, 4, 0); RUN(2, 4, 1); RUN(2, 8, 1); RUN(2, 8, 2); }
     return 0;
 }
