@@ -59,20 +59,20 @@ __device__ __forceinline__ void mb_post(unsigned long long* slot, float v, unsig
     __hip_atomic_store(slot, ((unsigned long long)tag << 32) | __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // A poll gives up after CO_SPIN_MAX tries (sets hdr->err) -- and as soon as ANY wave of ANY workgroup has given up: err
-// is re-read every CO_ERR_EVERY tries and before the first one, so that one timeout ends the whole launch within
+// is re-read every CO_ERR_EVERY failed tries, so that one timeout ends the whole launch within
 // microseconds instead of every later wait of every exchange spinning its own full budget.  The host reads the word
 // (FusedTrainStep.check_nan / FusedEvalStep.result) and raises.
 constexpr unsigned CO_ERR_EVERY = 256;
 __device__ __forceinline__ float mb_wait(unsigned long long* slot, unsigned tag, CoopHdr* hdr) {
-    unsigned long long w = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if ((unsigned)(w >> 32) == tag) return __uint_as_float((unsigned)w);
+    unsigned long long w = 0;
     unsigned spins = 0;
     for (;;) {
-        if ((spins & (CO_ERR_EVERY - 1)) == 0 && __hip_atomic_load(&hdr->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
-        __builtin_amdgcn_s_sleep(2);
         w = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if ((unsigned)(w >> 32) == tag) break;
-        if (++spins >= CO_SPIN_MAX) { __hip_atomic_store(&hdr->err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+        ++spins;        // (the error word is looked at only after CO_ERR_EVERY failed polls: never on the fast path of an exchange)
+        if ((spins & (CO_ERR_EVERY - 1)) == 0 && __hip_atomic_load(&hdr->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+        if (spins >= CO_SPIN_MAX) { __hip_atomic_store(&hdr->err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+        __builtin_amdgcn_s_sleep(2);
     }
     return __uint_as_float((unsigned)w);
 }
