@@ -256,6 +256,9 @@ def main() -> None:
     ap.add_argument("--no-parity-mode", action="store_true", help="skip the extra fp32 (parity mode) measurement at N=1")
     ap.add_argument("--host-input", action="store_true",
                     help="feed pinned HOST batches (H2D copy inside the timed step): the PCIe-inclusive rate, never the headline")
+    ap.add_argument("--allow-probes", action="store_true",
+                    help="A/B experiments only: run although probe variables / MTBC_LIB are set; the JSON line is then marked "
+                         "not_reportable and must never be quoted as a result")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -267,7 +270,7 @@ def main() -> None:
     from multi_task_breast_cancer_amd import _lib as L
     from multi_task_breast_cancer_amd import switches
     bad = switches.result_altering()
-    if bad:
+    if bad and not args.allow_probes:
         raise SystemExit(f"bench.py refuses to run with {bad} set: those select the probes build of the library or a timing "
                          f"hack, so the numbers would not be the product's (unset them; A/B plan switches are reported, not refused)")
     L.require_gpu()
@@ -293,7 +296,8 @@ def main() -> None:
                                ", random-init weights (BASELINE.json configs[1])",
                    "global_batch": args.batch * world, "parallelism": f"dp{world}"},
         "final_loss": main_res["final_loss"],
-        "env": {"mtbc_variables_set": switches.active(), "library": os.path.relpath(L.LIB_PATH, ROOT)},
+        "env": {"mtbc_variables_set": switches.active(), "library": os.path.relpath(L.LIB_PATH, ROOT),
+                **({"not_reportable": bad} if bad else {})},
     }
     for k in ("roofline", "roofline_hbm"):
         if k in main_res:

@@ -45,7 +45,11 @@ const char* mtbc_arch(void);
 /* A channel segment of a virtually concatenated NCHW tensor (replaces torch.cat(dim=1),
  * MTnnUNet.py:161-169,174; MTUNetPlusPlus.py:107-118,128).  Element (n, c, y, x) of the
  * segment lives at ptr[n*batch_stride + c*H*W + y*W + x].  `accumulate` is honoured when
- * the segment is an OUTPUT (gradient fan-in): 0 = overwrite, 1 = add to what is there. */
+ * the segment is an OUTPUT (gradient fan-in): 0 = overwrite, 1 = add to what is there;
+ * 2 (mtbc_conv3x3_dgrad with operand_layout C8 only) = overwrite a 16-BIT planar (N,C,H,W)
+ * segment of the type of `compute` (ptr 8-byte aligned, batch_stride in 16-bit elements): the
+ * fp32 result rounded to nearest even -- for a gradient whose only reader rounds it to that
+ * type anyway (the k = 2 transposed conv backward, mtbc_convT_args.dy_type16).            */
 typedef struct {
     float* ptr;
     int64_t batch_stride;   /* elements */
@@ -253,6 +257,11 @@ typedef struct {
     int32_t x_layout;                /* fwd: MTBC_LAYOUT_C8 = x is ALSO 16-bit channel-blocked (type y_type, batch stride in
                                         16-bit elements; needs y_layout C8): the forward then runs on the 16-bit MFMA
                                         with rounded x and w (fp32 accumulate, bias, one RNE) -- k == 2, Cin % 8 == 0  */
+    int32_t dy_type16;               /* dgrad / wgrad, k == 2 with compute = 1 | 2 only: non-zero (= compute) says dy is a 16-BIT
+                                        planar (N,Cout,kH,kW) tensor of that type (batch stride in 16-bit elements), as
+                                        written by mtbc_conv3x3_dgrad into a segment with accumulate = 2; the MFMAs read it
+                                        as is (what they did to an fp32 dy while loading it), the bias gradient is the
+                                        sum of the stored values.  Shapes the direct kernels do not take: MTBC_E_UNSUPPORTED */
 } mtbc_convT_args;
 /* 1 if mtbc_convT_fwd takes these arguments with y_layout = MTBC_LAYOUT_C8 (fp32 x: k == 2, Cin <= 64, Cout <= 48,
  * Cout % 8 == 0, H*W % 32 == 0; x_layout C8: k == 2, channel counts % 8 == 0, H*W % 32 == 0), else 0: the caller then

@@ -1015,7 +1015,20 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 4) void conv3x3_igemm_c8_ker
             const SegL so = segl_ref(seg_out, co);
             gfloat* cb = (gfloat*)so.ptr + (size_t)n * so.bs + (size_t)(co - so.cb) * HW;
             const float bv = bias_s[m * 16 + j];
-            if (so.acc) {
+            if (so.acc == 2) {          // 16-bit planar segment: the lane's 4 consecutive pixels of its channel = one 8-byte store
+                typedef unsigned ep_u32x2 __attribute__((ext_vector_type(2)));
+                typedef unsigned ep_u32x4 __attribute__((ext_vector_type(4)));
+                typedef __attribute__((address_space(1))) ep_u32x2 guint2;
+                gchar* c16 = (gchar*)so.ptr + 2 * ((size_t)n * so.bs + (size_t)(co - so.cb) * HW);
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    if (poff[g] >= 0) {
+                        const float q[8] = {acc[m][g][0] + bv, acc[m][g][1] + bv, acc[m][g][2] + bv, acc[m][g][3] + bv, 0.f, 0.f, 0.f, 0.f};
+                        const typename T::frag h = T::pack(q);          // RNE, the conversion every consumer's staging would apply
+                        const ep_u32x4 u = __builtin_bit_cast(ep_u32x4, h);
+                        *(guint2*)(c16 + 2 * (size_t)poff[g]) = (ep_u32x2){u[0], u[1]};
+                    }
+            } else if (so.acc) {
                 f32x4 old[4];
 #pragma unroll
                 for (int g = 0; g < 4; ++g) old[g] = poff[g] >= 0 ? *(const gf32x4*)(cb + poff[g]) : (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -2355,9 +2368,13 @@ int mtbc_conv3x3_dgrad(const mtbc_conv3x3_args* a, void* stream) {
     if (a->operand_layout == MTBC_LAYOUT_C8) {
         if (!a->w_packed || (a->compute != 1 && a->compute != 2) || !c8_segs_ok(&g, 1)) return MTBC_E_BADARG;
         if (!mfma_ok(a->in, a->n_in, a->H, a->W)) return MTBC_E_UNSUPPORTED;      // the fp32 planar dx segments: 16-byte stores
+        for (int i = 0; i < a->n_in; ++i)
+            if (a->in[i].accumulate == 2 && ((reinterpret_cast<uintptr_t>(a->in[i].ptr) & 7) || (a->in[i].batch_stride & 3))) return MTBC_E_BADARG;
         return run_igemm(a->N, a->H, a->W, a->Cout, a->Cin, in, out, a->w_packed, nullptr, a->compute, st, true);
     }
     if (a->operand_layout != MTBC_LAYOUT_PLANAR) return MTBC_E_BADARG;
+    for (int i = 0; i < a->n_in; ++i)
+        if (a->in[i].accumulate == 2) return MTBC_E_UNSUPPORTED;      // 16-bit planar dx segments: channel-blocked dgrad only
     bool ok = a->w_packed && !a->force_direct && mfma_ok(&g, 1, a->H, a->W) && a->Cout % KC == 0;
     for (int i = 0; ok && i < a->n_in; ++i) ok = a->in[i].ptr != nullptr && a->in[i].channels % 4 == 0;
     if (ok) return run_igemm(a->N, a->H, a->W, a->Cout, a->Cin, in, out, a->w_packed, nullptr, a->compute, st);

@@ -60,6 +60,17 @@ template <> struct Frag<2> {
     }
 };
 
+typedef unsigned ct_u32x4 __attribute__((ext_vector_type(4)));
+template <int LP> __device__ __forceinline__ void frag_from_words(Frag<LP>& f, unsigned w0, unsigned w1, unsigned w2, unsigned w3) {
+    static_assert(LP != 0, "16-bit operands only");
+    f.v = __builtin_bit_cast(decltype(f.v), (ct_u32x4){w0, w1, w2, w3});
+}
+// sum of the two 16-bit values of a dword, in fp32
+template <int LP> __device__ __forceinline__ float sum2_16(unsigned w) {
+    if constexpr (LP == 2) { typedef _Float16 h2 __attribute__((ext_vector_type(2))); const h2 h = __builtin_bit_cast(h2, w); return (float)h[0] + (float)h[1]; }
+    else return __uint_as_float(w << 16) + __uint_as_float(w & 0xffff0000u);
+}
+
 struct Ct2P {
     int N, H, W, Cin, Cout;            // input H x W, output 2H x 2W
     const float* x; long long xbs;
@@ -84,8 +95,12 @@ __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast
 // wave task = (48 input channels) x (32 consecutive input pixels); MFMA column j of tile E is pixel 2j, of tile O pixel
 // 2j+1, so one float4 of an output row feeds both.  Step = 8 output channels (32 k); lane group kg owns channels
 // 8s + 2kg, 8s + 2kg + 1.
-template <int LP>
+// DY16: dY is a 16-bit planar tensor of the MFMA's own type (written by the 3x3 conv's dgrad, mtbc_seg.accumulate = 2): the
+// four values of an output row that the fp32 form loads as one float4 and converts are ONE 8-byte load whose two dwords
+// are the fragment words of the even / odd pixel as they stand -- half the bytes, no conversion, same MFMA operands.
+template <int LP, bool DY16 = false>
 __global__ __launch_bounds__(256) void convT2_dgrad_kernel(const Ct2P p) {
+    static_assert(!DY16 || LP != 0, "a 16-bit dY feeds the 16-bit MFMA");
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int j = lane & 15, kg = lane >> 4;
     const long long task = (long long)blockIdx.x * 4 + wv;
@@ -98,6 +113,7 @@ __global__ __launch_bounds__(256) void convT2_dgrad_kernel(const Ct2P p) {
     const int pix = g * 32 + 2 * j;
     const int i = pix / p.W, jx = pix % p.W;
     const float* dyn = p.dy + (size_t)n * p.dybs + (size_t)(2 * i) * oW + 2 * jx;      // + co*4HW + a*oW
+    const unsigned short* dyn16 = reinterpret_cast<const unsigned short*>(p.dy) + (size_t)n * p.dybs + (size_t)(2 * i) * oW + 2 * jx;
     const float* wrow[MT];
     bool rok[MT];
 #pragma unroll
@@ -113,6 +129,7 @@ __global__ __launch_bounds__(256) void convT2_dgrad_kernel(const Ct2P p) {
     const int nsteps = (p.Cout + 7) / 8;
     // two register sets with COMPILE-TIME slot numbers (a runtime slot index would put the arrays in scratch)
     float4 ra[2][MT][2], rb[2][4];
+    uint2 rh[2][4];                          // DY16: (row a, channel c) -> {even pixel (b0,b1), odd pixel (b0,b1)}
     auto load = [&](int s, auto SL) {       // issue only; masking happens at use
         constexpr int slot = decltype(SL)::value;
         const int c0 = 8 * s + 2 * kg;
@@ -124,8 +141,13 @@ __global__ __launch_bounds__(256) void convT2_dgrad_kernel(const Ct2P p) {
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             const int co = c0 + c < p.Cout ? c0 + c : 0;
-            const float* q = dyn + (size_t)co * 4 * HW;
-            rb[slot][2 * c] = ld4(q); rb[slot][2 * c + 1] = ld4(q + oW);
+            if constexpr (DY16) {
+                const unsigned short* q = dyn16 + (size_t)co * 4 * HW;
+                rh[slot][2 * c] = *reinterpret_cast<const uint2*>(q); rh[slot][2 * c + 1] = *reinterpret_cast<const uint2*>(q + oW);
+            } else {
+                const float* q = dyn + (size_t)co * 4 * HW;
+                rb[slot][2 * c] = ld4(q); rb[slot][2 * c + 1] = ld4(q + oW);
+            }
         }
     };
     auto compute = [&](int s, auto SL) {
@@ -138,7 +160,10 @@ __global__ __launch_bounds__(256) void convT2_dgrad_kernel(const Ct2P p) {
         o[0] = ok0 ? rb[cur][0].z : 0.f; o[1] = ok0 ? rb[cur][0].w : 0.f; o[2] = ok0 ? rb[cur][1].z : 0.f; o[3] = ok0 ? rb[cur][1].w : 0.f;
         o[4] = ok1 ? rb[cur][2].z : 0.f; o[5] = ok1 ? rb[cur][2].w : 0.f; o[6] = ok1 ? rb[cur][3].z : 0.f; o[7] = ok1 ? rb[cur][3].w : 0.f;
         Frag<LP> fe, fo;
-        fe.set(e); fo.set(o);
+        if constexpr (DY16) {
+            frag_from_words<LP>(fe, ok0 ? rh[cur][0].x : 0u, ok0 ? rh[cur][1].x : 0u, ok1 ? rh[cur][2].x : 0u, ok1 ? rh[cur][3].x : 0u);
+            frag_from_words<LP>(fo, ok0 ? rh[cur][0].y : 0u, ok0 ? rh[cur][1].y : 0u, ok1 ? rh[cur][2].y : 0u, ok1 ? rh[cur][3].y : 0u);
+        } else { fe.set(e); fo.set(o); }
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
             float a[8];
@@ -179,8 +204,11 @@ __global__ __launch_bounds__(256) void convT2_dgrad_kernel(const Ct2P p) {
 // wave task = (48 input channels) x (8 output channels) x (a run of 32-pixel steps of the flattened (image, step)
 // list).  MFMA column j is (co = 8*ct + j/2, a = j%2); b = 0 and b = 1 are two accumulator tiles fed by the even /
 // odd elements of the same 64 bytes.  Lane group kg owns pixels 8kg .. 8kg+7 of the step.
-template <int LP>
+// DY16: the 16 consecutive values of an output row (8 pixels x b) are 32 bytes; fragment word m of the b = 0 tile is
+// (low half of dword 2m) | (low half of dword 2m+1) << 16, of the b = 1 tile the two high halves: two v_perm per word.
+template <int LP, bool DY16 = false>
 __global__ __launch_bounds__(256) void convT2_wgrad_kernel(const Ct2P p) {
+    static_assert(!DY16 || LP != 0, "a 16-bit dY feeds the 16-bit MFMA");
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int j = lane & 15, kg = lane >> 4;
     const long long task = (long long)blockIdx.x * 4 + wv;
@@ -204,6 +232,7 @@ __global__ __launch_bounds__(256) void convT2_wgrad_kernel(const Ct2P p) {
     const int co = ct * 8 + (j >> 1);
     const bool cok = co < p.Cout;
     const float* dcol = p.dy + (size_t)(cok ? co : 0) * 4 * HW + (size_t)(j & 1) * oW;
+    const unsigned short* dcol16 = reinterpret_cast<const unsigned short*>(p.dy) + (size_t)(cok ? co : 0) * 4 * HW + (size_t)(j & 1) * oW;
 
     f32x4 acc[MT][2];
 #pragma unroll
@@ -212,6 +241,7 @@ __global__ __launch_bounds__(256) void convT2_wgrad_kernel(const Ct2P p) {
     const bool want_bias = p.dbias_part != nullptr && mb == 0;      // uniform
     float bsum = 0.f;
     float4 ra[2][MT][2], rb[2][4];
+    ct_u32x4 rh[2][2];                       // DY16: 8 dwords = 8 pixels, each {b0, b1}
     auto load = [&](int g, auto SL) {
         constexpr int slot = decltype(SL)::value;
         const int n = g / steps_per_img, st = g % steps_per_img;
@@ -222,13 +252,35 @@ __global__ __launch_bounds__(256) void convT2_wgrad_kernel(const Ct2P p) {
             const float* q = xrow[m] + (size_t)n * p.xbs + st * 32;
             ra[slot][m][0] = ld4(q); ra[slot][m][1] = ld4(q + 4);
         }
-        const float* q = dcol + (size_t)n * p.dybs + (size_t)(2 * i) * oW + 2 * jx;
+        if constexpr (DY16) {
+            const unsigned short* q = dcol16 + (size_t)n * p.dybs + (size_t)(2 * i) * oW + 2 * jx;
+            rh[slot][0] = *reinterpret_cast<const ct_u32x4*>(q); rh[slot][1] = *reinterpret_cast<const ct_u32x4*>(q + 8);
+        } else {
+            const float* q = dcol + (size_t)n * p.dybs + (size_t)(2 * i) * oW + 2 * jx;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) rb[slot][k] = ld4(q + 4 * k);
+            for (int k = 0; k < 4; ++k) rb[slot][k] = ld4(q + 4 * k);
+        }
     };
     auto compute = [&](auto SL) {
         constexpr int cur = decltype(SL)::value;
         float b0[8], b1[8];
+        Frag<LP> f0, f1;
+        if constexpr (DY16) {
+            unsigned d[8], w0[4], w1[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { d[k] = cok ? rh[cur][0][k] : 0u; d[4 + k] = cok ? rh[cur][1][k] : 0u; }
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                w0[m] = (d[2 * m] & 0xffffu) | (d[2 * m + 1] << 16);
+                w1[m] = (d[2 * m] >> 16) | (d[2 * m + 1] & 0xffff0000u);
+            }
+            if (want_bias) {               // the bias gradient is the plain sum of the stored dY values
+#pragma unroll
+                for (int k = 0; k < 8; ++k) bsum += sum2_16<LP>(d[k]);
+            }
+            frag_from_words<LP>(f0, w0[0], w0[1], w0[2], w0[3]);
+            frag_from_words<LP>(f1, w1[0], w1[1], w1[2], w1[3]);
+        } else {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             b0[2 * k] = cok ? rb[cur][k].x : 0.f; b1[2 * k] = cok ? rb[cur][k].y : 0.f;
@@ -238,8 +290,8 @@ __global__ __launch_bounds__(256) void convT2_wgrad_kernel(const Ct2P p) {
 #pragma unroll
             for (int k = 0; k < 8; ++k) bsum += b0[k] + b1[k];
         }
-        Frag<LP> f0, f1;
         f0.set(b0); f1.set(b1);
+        }
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
             float a[8];
@@ -569,11 +621,13 @@ void fill(const mtbc_convT_args* a, Ct2P* p) {
 // eligibility of the direct-to-fragment kernels (k == 2 only); everything else takes the generic GEMM in pool_up.hip
 bool mtbc_i_convT2_dgrad_ok(const mtbc_convT_args* a) {
     const int HW = a->H * a->W;
+    if (a->dy_type16 && (a->dy_type16 != a->compute || a->dy_batch_stride % 8 != 0)) return false;
     return a->k == 2 && HW % 32 == 0 && a->W % 2 == 0 && a->Cout % 2 == 0 && al16(a->dy) && al16(a->w) && al16(a->dx) &&
            a->dy_batch_stride % 4 == 0 && a->dx_batch_stride % 2 == 0;
 }
 bool mtbc_i_convT2_wgrad_ok(const mtbc_convT_args* a) {
     const int HW = a->H * a->W;
+    if (a->dy_type16 && (a->dy_type16 != a->compute || a->dy_batch_stride % 8 != 0)) return false;
     return a->k == 2 && HW % 32 == 0 && a->W % 8 == 0 && al16(a->dy) && al16(a->x) && a->dy_batch_stride % 4 == 0 &&
            a->x_batch_stride % 4 == 0;
 }
@@ -693,7 +747,10 @@ int mtbc_i_convT2_dgrad(const mtbc_convT_args* a, int compute, hipStream_t st) {
     Ct2P p; fill(a, &p);
     p.ntasks = (long long)p.mblocks * a->N * (a->H * a->W / 32);
     const unsigned blocks = (unsigned)cdiv64(p.ntasks, 4);
-    if (compute == 1) hipLaunchKernelGGL(convT2_dgrad_kernel<1>, dim3(blocks), dim3(256), 0, st, p);
+    if (a->dy_type16) {
+        if (compute == 1) hipLaunchKernelGGL((convT2_dgrad_kernel<1, true>), dim3(blocks), dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((convT2_dgrad_kernel<2, true>), dim3(blocks), dim3(256), 0, st, p);
+    } else if (compute == 1) hipLaunchKernelGGL(convT2_dgrad_kernel<1>, dim3(blocks), dim3(256), 0, st, p);
     else if (compute == 2) hipLaunchKernelGGL(convT2_dgrad_kernel<2>, dim3(blocks), dim3(256), 0, st, p);
     else hipLaunchKernelGGL(convT2_dgrad_kernel<0>, dim3(blocks), dim3(256), 0, st, p);
     MTBC_CHECK_LAUNCH();
@@ -705,7 +762,10 @@ int mtbc_i_convT2_wgrad(const mtbc_convT_args* a, int compute, float* partial, f
     p.partial = partial; p.dbias_part = dbias_part; p.steps_per_split = steps_per_split; p.nsplit = nsplit;
     p.ntasks = (long long)p.mblocks * p.ctiles * nsplit;
     const unsigned blocks = (unsigned)cdiv64(p.ntasks, 4);
-    if (compute == 1) hipLaunchKernelGGL(convT2_wgrad_kernel<1>, dim3(blocks), dim3(256), 0, st, p);
+    if (a->dy_type16) {
+        if (compute == 1) hipLaunchKernelGGL((convT2_wgrad_kernel<1, true>), dim3(blocks), dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((convT2_wgrad_kernel<2, true>), dim3(blocks), dim3(256), 0, st, p);
+    } else if (compute == 1) hipLaunchKernelGGL(convT2_wgrad_kernel<1>, dim3(blocks), dim3(256), 0, st, p);
     else if (compute == 2) hipLaunchKernelGGL(convT2_wgrad_kernel<2>, dim3(blocks), dim3(256), 0, st, p);
     else hipLaunchKernelGGL(convT2_wgrad_kernel<0>, dim3(blocks), dim3(256), 0, st, p);
     MTBC_CHECK_LAUNCH();

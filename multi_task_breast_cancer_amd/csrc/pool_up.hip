@@ -360,7 +360,8 @@ int mtbc_convT_dgrad(const mtbc_convT_args* a, void* stream) {
     if (!p.dy || !p.w || !p.dx) return MTBC_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
     static const bool generic = mtbc_probe_set("MTBC_CONVT_GENERIC");      // A/B switch
-    if (!generic && mtbc_i_convT2_dgrad_ok(a)) return mtbc_i_convT2_dgrad(a, a->compute, st);
+    if (a->dy_type16 && !((a->compute == 1 || a->compute == 2) && mtbc_i_convT2_dgrad_ok(a))) return MTBC_E_UNSUPPORTED;      // 16-bit dY: the direct kernel or nothing
+    if ((!generic || a->dy_type16) && mtbc_i_convT2_dgrad_ok(a)) return mtbc_i_convT2_dgrad(a, a->compute, st);
     dim3 grid(cdiv(a->H * a->W, 64), cdiv(a->Cin, 64), a->N);
     if (a->k == 2) hipLaunchKernelGGL(convT_dgrad_kernel<2>, grid, dim3(256), 0, st, p);
     else if (a->k == 4) hipLaunchKernelGGL(convT_dgrad_kernel<4>, grid, dim3(256), 0, st, p);
@@ -389,7 +390,8 @@ int mtbc_convT_wgrad(const mtbc_convT_args* a, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     static const bool generic = mtbc_probe_set("MTBC_CONVT_GENERIC");      // A/B switch
     bool bias_done = false;
-    if (!generic && mtbc_i_convT2_wgrad_ok(a)) {
+    if (a->dy_type16 && !((a->compute == 1 || a->compute == 2) && mtbc_i_convT2_wgrad_ok(a))) return MTBC_E_UNSUPPORTED;      // 16-bit dY: the direct kernel or nothing
+    if ((!generic || a->dy_type16) && mtbc_i_convT2_wgrad_ok(a)) {
         int sps; mtbc_i_convT2_wgrad_plan(a, &sps, &nsplit);
         float* bpart = a->dbias ? p.partial + (size_t)nsplit * a->Cin * p.M : nullptr;
         rc = mtbc_i_convT2_wgrad(a, a->compute, p.partial, bpart, sps, nsplit, st); if (rc) return rc;

@@ -28,6 +28,7 @@ _NO_GATHER = _sw.flag("MTBC_NO_GATHER")
 _NO_P16 = _sw.flag("MTBC_NO_P16")
 _FANIN = _sw.flag("MTBC_FANIN")
 _NO_C8_SMALL = _sw.flag("MTBC_NO_C8_SMALL_OPS")
+_NO_G16 = _sw.flag("MTBC_NO_G16")
 
 
 def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
@@ -51,6 +52,9 @@ class Act:
     conv_consumers: int = 0            # 3x3 conv cells (16-bit, channel-blocked backward) that read this activation
     no_gather: bool = False            # ... and one that cannot take part in a gathered dgrad
     pending: List[tuple] = field(default_factory=list)   # gathered dgrad: (dz8, weight, channel offset, consumer Cin, consumer Cout)
+    readers: int = 0                   # ops that read this activation (any kind): 1 = its gradient has a single writer
+    grad16_ok: bool = False            # ConvT output whose backward MFMAs round dy anyway: a lone 3x3-conv reader may hand
+    grad16: Optional[torch.Tensor] = None   # them the gradient as 16-bit planes (mtbc_seg.accumulate = 2) instead of fp32
     in_op: Optional[object] = None     # the InstanceNorm forward op that writes this activation (conv cells)
     pack_op: Optional[object] = None   # the op that fills `c8` from `data`
 
@@ -234,9 +238,16 @@ class StepPlan:
         s.ready_at = len(self.bwd_ops)      # index of the op about to be appended
         return acc
 
-    def _segs(self, arr, acts: Sequence[Act], grads: bool = False) -> None:
+    def _segs(self, arr, acts: Sequence[Act], grads: bool = False, g16: bool = False) -> None:
         for i, a in enumerate(acts):
-            if grads:
+            if grads and g16 and a.grad16_ok and a.readers == 1 and not a.grad_written:
+                # the only gradient this tensor will ever get, and its reader (the ConvT backward) rounds it to 16 bits
+                # while loading: written as 16-bit planes by this dgrad launch (mtbc_seg.accumulate = 2)
+                a.grad16 = self.alloc(*a.data.shape, dtype=torch.int16)
+                a.grad_written = True
+                arr[i].ptr = a.grad16.data_ptr()
+                arr[i].accumulate = 2
+            elif grads:
                 g, acc = self.grad_slot(a)
                 arr[i].ptr = g.data_ptr()
                 arr[i].accumulate = acc
@@ -251,6 +262,8 @@ class StepPlan:
                   gname: Optional[str], betaname: Optional[str], slope: float, out_name: str) -> Act:
         """conv3x3(pad 1) -> InstanceNorm(eps 1e-5, affine optional) -> LeakyReLU(slope)."""
         inputs = list(inputs)
+        for a_ in inputs:
+            a_.readers += 1
         N, H, W = self.N, inputs[0].H, inputs[0].W
         cin = sum(a.C for a in inputs)
         w = self.pv(wname)
@@ -476,7 +489,7 @@ class StepPlan:
                     op.kind = L.OP_CONV3_DGRAD
                     a = op.u.conv3
                     a.Cin, a.n_in, a.w = crest, len(rest), ws.data_ptr()
-                    self._segs(a.in_, rest, grads=True)
+                    self._segs(a.in_, rest, grads=True, g16=True)
                     a.dout, a.operand_layout, a.w_packed = dz8.data_ptr(), L.LAYOUT_C8, wps.data_ptr()
                     self.bwd_ops.append(op)
             elif need:
@@ -485,7 +498,7 @@ class StepPlan:
                 op = base_conv()
                 op.kind = L.OP_CONV3_DGRAD
                 a = op.u.conv3
-                self._segs(a.in_, inputs, grads=True)
+                self._segs(a.in_, inputs, grads=True, g16=bool(c8_bwd and wp_d is not None))
                 a.dout = dy.data_ptr()
                 if c8_bwd and wp_d is not None:
                     a.dout, a.operand_layout = dz8.data_ptr(), L.LAYOUT_C8
@@ -500,6 +513,7 @@ class StepPlan:
         return bool(self.compute) and not _NO_C8 and not _NO_C8_SMALL and not self.force_direct and x.C % 8 == 0 and (x.H * x.W) % 4 == 0
 
     def maxpool(self, x: Act, out_name: str) -> Act:
+        x.readers += 1
         y = self.new_act(out_name, x.C, x.H // 2, x.W // 2)
         # 16-bit modes: pool the channel-blocked 16-bit tensor into a channel-blocked 16-bit tensor (max commutes with the
         # rounding: bit-identical to the fp32 pool + pack) -- the pooled tensor feeds 3x3 convs only, and x then needs no
@@ -544,6 +558,7 @@ class StepPlan:
     def convT(self, x: Act, cout: int, k: int, wname: str, bname: Optional[str], out_name: str) -> Act:
         w = self.pv(wname)
         assert tuple(w.shape) == (x.C, cout, k, k), (wname, tuple(w.shape))
+        x.readers += 1
         y = self.new_act(out_name, cout, x.H * k, x.W * k)
 
         def base() -> L.Op:
@@ -576,19 +591,23 @@ class StepPlan:
                     a.y, a.y_layout, a.y_type = y.data.data_ptr(), L.LAYOUT_PLANAR, 0
             y.planar_valid = y.c8 is None
         self.fwd_ops.append(op)
+        # 16-bit modes: the backward MFMAs of the k = 2 up-convolutions take rounded operands too (they are fp32-MFMA
+        # bound otherwise); only where BOTH direct-to-fragment kernels of convt2.hip take the shape
+        lp = self.compute if (k == 2 and not _NO_CT_LP and (x.H * x.W) % 32 == 0 and x.W % 8 == 0 and cout % 2 == 0) else 0
+        # ... and since they round dy while loading it, a dy with a single writer can arrive as 16-bit planes (half the bytes
+        # written by the 3x3 conv's dgrad and read twice here); the writer decides (conv_cell.emit_bwd)
+        y.grad16_ok = bool(lp) and not _NO_G16 and (y.bstride % 8 == 0)
 
         def emit_bwd() -> None:
             if not y.grad_written:
                 return
-            dy = self.grad_of(y)
-            # 16-bit modes: the backward MFMAs of the k = 2 up-convolutions take rounded operands too (they are fp32-MFMA
-            # bound otherwise); only where BOTH direct-to-fragment kernels of convt2.hip take the shape
-            lp = self.compute if (k == 2 and not _NO_CT_LP and (x.H * x.W) % 32 == 0 and x.W % 8 == 0 and cout % 2 == 0) else 0
+            g16 = y.grad16 is not None
+            dy = y.grad16 if g16 else self.grad_of(y)
             op = base()
             op.kind = L.OP_CONVT_WGRAD
             a = op.u.convT
             a.compute = lp
-            a.dy, a.dy_batch_stride = dy.data_ptr(), y.bstride
+            a.dy, a.dy_batch_stride, a.dy_type16 = dy.data_ptr(), y.bstride, (lp if g16 else 0)
             a.accumulate_dw = self._mark_param(wname)
             a.dw = self.gv(wname).data_ptr()
             if bname:
@@ -601,7 +620,7 @@ class StepPlan:
                 op.kind = L.OP_CONVT_DGRAD
                 a = op.u.convT
                 a.compute = lp
-                a.dy, a.dy_batch_stride = dy.data_ptr(), y.bstride
+                a.dy, a.dy_batch_stride, a.dy_type16 = dy.data_ptr(), y.bstride, (lp if g16 else 0)
                 gx, acc = self.grad_slot(x)
                 a.dx, a.dx_batch_stride, a.accumulate_dx = gx.data_ptr(), x.bstride, acc
                 self.bwd_ops.append(op)
@@ -614,6 +633,7 @@ class StepPlan:
         combined weights (mtbc_convT_head_combine / _expand, include/mtbc.h): the cmid-channel full-resolution
         intermediate is never formed."""
         wT, w1 = self.pv(wTname), self.pv(w1name)
+        x.readers += 1
         R = w1.shape[0]
         assert tuple(wT.shape) == (x.C, cmid, k, k) and tuple(w1.shape) == (R, cmid, 1, 1), (wTname, w1name)
         Wc, bc = self.alloc(x.C, R, k, k), self.alloc(R)
@@ -678,6 +698,7 @@ class StepPlan:
     def conv1x1(self, x: Act, cout: int, wname: str, bname: str, out_name: str) -> Act:
         w = self.pv(wname)
         assert tuple(w.shape) == (cout, x.C, 1, 1), (wname, tuple(w.shape))
+        x.readers += 1
         y = self.new_act(out_name, cout, x.H, x.W)
         # 16-bit modes: the head reads the channel-blocked 16-bit activation the 3x3 convs read (fp32 weights, products
         # and sums): x then needs no fp32 planes on the head's account
@@ -725,6 +746,7 @@ class StepPlan:
         return y
 
     def gap(self, x: Act, out_name: str) -> Act:
+        x.readers += 1
         y = Act(out_name, self.alloc(self.N, x.C, 1, 1))
 
         def base() -> L.Op:
@@ -754,6 +776,7 @@ class StepPlan:
 
     def linear(self, x: Act, out_f: int, wname: str, bname: str, relu: bool, out_name: str) -> Act:
         in_f = x.C * x.H * x.W
+        x.readers += 1
         w = self.pv(wname)
         assert tuple(w.shape) == (out_f, in_f), (wname, tuple(w.shape))
         y = Act(out_name, self.alloc(self.N, out_f, 1, 1))

@@ -201,8 +201,9 @@ def conv3x3_fwd_c8(xs: Sequence["C8"], w: torch.Tensor, bias: Optional[torch.Ten
 
 
 def conv3x3_dgrad_c8(dz: "C8", w: torch.Tensor, dxs: Sequence[torch.Tensor], accumulate: Sequence[int], packed: torch.Tensor) -> None:
-    """dx segments (fp32 planar, accumulate honoured) from dz in the 16-bit channel-blocked layout."""
-    _chk(w, *dxs)
+    """dx segments (fp32 planar, accumulate honoured; accumulate 2 = the segment is an int16 (N,C,H,W) tensor written as
+    16-bit planar values of dz's type) from dz in the 16-bit channel-blocked layout."""
+    _chk(w, *[d for i, d in enumerate(dxs) if not (i < len(accumulate) and accumulate[i] == 2)])
     N, _, H, W = dz.shape
     a = _conv_args(dxs, w, N, H, W)
     _fill_segs(a.in_, dxs, accumulate)
@@ -432,23 +433,26 @@ def convT_fwd_c8_lp(x8: "C8", w, bias, k) -> "C8":
     return C8(y, (N, cout, H * k, W * k), x8.compute)
 
 
-def convT_dgrad(x, w, dy, k, dx=None, accumulate=False, compute=0):
-    _chk(x, w, dy, dx)
+def convT_dgrad(x, w, dy, k, dx=None, accumulate=False, compute=0, dy16=False):
+    """dy16: dy is an int16 (N,Cout,kH,kW) tensor holding 16-bit planar values of the type of `compute`."""
+    _chk(x, w, None if dy16 else dy, dx)
     if dx is None:
         dx = torch.empty_like(x)
     a = _ct_args(x, w, k)
     a.compute = compute
+    a.dy_type16 = compute if dy16 else 0
     a.dy, a.dy_batch_stride, a.dx, a.dx_batch_stride, a.accumulate_dx = dy.data_ptr(), dy[0].numel(), dx.data_ptr(), x[0].numel(), int(accumulate)
     L.check(L.load().mtbc_convT_dgrad(C.byref(a), _s()), "convT_dgrad")
     return dx
 
 
-def convT_wgrad(x, w, dy, k, want_bias=True, compute=0):
-    _chk(x, w, dy)
+def convT_wgrad(x, w, dy, k, want_bias=True, compute=0, dy16=False):
+    _chk(x, w, None if dy16 else dy)
     dw = torch.empty_like(w)
     db = torch.empty(w.shape[1], dtype=torch.float32, device=x.device) if want_bias else None
     a = _ct_args(x, w, k)
     a.compute = compute
+    a.dy_type16 = compute if dy16 else 0
     a.dy, a.dy_batch_stride, a.dw, a.dbias = dy.data_ptr(), dy[0].numel(), dw.data_ptr(), _p(db)
     ws = _ws(L.load().mtbc_convT_wgrad_workspace(C.byref(a)), x.device)
     a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel() * 4

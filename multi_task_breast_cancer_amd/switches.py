@@ -24,6 +24,7 @@ PLAN_SWITCHES: Dict[str, tuple] = {
     "MTBC_FANIN": ("0", "private gradient fan-in buffers summed by InstanceNorm backward"),
     "MTBC_NOFUSE_HEADS": ("0", "MTnnUNet deep-supervision heads as ConvT + 1x1 (the reference's two layers) instead of one combined ConvT"),
     "MTBC_NO_C8_SMALL_OPS": ("0", "max-pool and the 1x1 heads keep reading fp32 planes in the 16-bit modes (InstanceNorm then writes them too)"),
+    "MTBC_NO_G16": ("0", "the gradient of an up-sampled (ConvT) tensor stays fp32 between the 3x3 conv's dgrad and the ConvT backward"),
     "MTBC_COOP_RESERVE_CUS": ("64", "CUs kept out of the cooperative InstanceNorm grids under data parallel"),
 }
 # variables that only the probes build of the library (or removed timing hacks) ever honoured: results are wrong or

@@ -465,7 +465,7 @@ class _LowpConv1x1(torch.autograd.Function):
 
 class _LowpConvT2Bwd(torch.autograd.Function):
     """ConvTranspose2d(k = s = 2) of the 16-bit modes: forward MFMA on rounded x, w (fp32 accumulate + bias), backward
-    MFMAs on rounded operands (dgrad: dy, w; wgrad: x, dy), bias gradient from the unrounded dy -- convt2.hip."""
+    MFMAs on rounded operands (dgrad: dy, w; wgrad: x, dy), bias gradient from the rounded dy -- convt2.hip."""
 
     @staticmethod
     def forward(ctx, x, w, b, lp, fwd_lp, bwd_lp):
@@ -483,7 +483,9 @@ class _LowpConvT2Bwd(torch.autograd.Function):
         with torch.enable_grad():
             wz = torch.zeros_like(w, requires_grad=True)
             (dw,) = torch.autograd.grad(torch.conv_transpose2d(r(x).detach(), wz, None, 2), wz, dyr)
-        db = dy.sum(dim=(0, 2, 3)) if ctx.has_b else None
+        # the bias gradient: the product hands the ConvT backward a 16-bit dy whenever the up-sampled tensor has a single
+        # reader (every UpCat of the U-Net++; all but upsample5 of MTnnUNet) -> sum of the rounded values
+        db = dyr.sum(dim=(0, 2, 3)) if ctx.has_b else None
         return dx, dw, db, None, None, None
 
 

@@ -705,3 +705,50 @@ def test_weight_view_many_equals_single_views():
     L.check(lib.mtbc_conv3x3_weight_view_many(arr, len(descs), st), "wview_many")
     for a, b in zip(outs_many, outs_single):
         assert torch.equal(a, b) and a.abs().sum().item() > 0
+
+
+@pytest.mark.parametrize("compute", [1, 2])
+@pytest.mark.parametrize("N,segs,Cout,H,W", [(2, [24, 48], 24, 40, 64), (2, [48], 24, 256, 256), (3, [16, 16], 40, 16, 16), (5, [32, 8], 80, 8, 8)])
+def test_conv3x3_dgrad_into_16bit_planar_segment(N, segs, Cout, H, W, compute):
+    """mtbc_seg.accumulate = 2: the LAST dx segment is written as 16-bit planes = the fp32 result of the same launch rounded
+    to nearest even, bit for bit; the other segments are untouched by the mode."""
+    g = _g(N + Cout + H + compute)
+    Cin = sum(segs)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (9 * Cin)) ** 0.5).to(DEV)
+    dz8 = ops.C8.pack(torch.randn(N, Cout, H, W, generator=g).to(DEV), compute)
+    _, pd = ops.conv3x3_pack_lp(w, compute)
+    ref = [torch.zeros(N, c, H, W, device=DEV) for c in segs]
+    ops.conv3x3_dgrad_c8(dz8, w, ref, [0] * len(segs), pd)
+    got = [torch.zeros(N, c, H, W, device=DEV) for c in segs[:-1]] + [torch.zeros(N, segs[-1], H, W, dtype=torch.int16, device=DEV)]
+    ops.conv3x3_dgrad_c8(dz8, w, got, [0] * (len(segs) - 1) + [2], pd)
+    dt = torch.bfloat16 if compute == 1 else torch.float16
+    for a, b in zip(got[:-1], ref[:-1]):
+        assert torch.equal(a, b)
+    assert torch.equal(got[-1].view(dt), ref[-1].to(dt))
+
+
+@pytest.mark.parametrize("compute", [1, 2])
+@pytest.mark.parametrize("N,Cin,Cout,H,W", [(2, 48, 48, 32, 32), (3, 96, 48, 8, 16), (1, 384, 192, 8, 8), (2, 48, 24, 16, 8)])
+def test_convT_backward_reads_16bit_planar_dy(N, Cin, Cout, H, W, compute):
+    """dy_type16: the k = 2 ConvT dgrad / wgrad on a 16-bit planar dy must equal the same kernels fed the fp32 tensor with
+    the same (representable) values, bit for bit -- they rounded an fp32 dy to exactly these operands while loading it."""
+    g = _g(N + Cin + Cout + H + compute)
+    dt = torch.bfloat16 if compute == 1 else torch.float16
+    x = torch.randn(N, Cin, H, W, generator=g).to(DEV)
+    w = (torch.randn(Cin, Cout, 2, 2, generator=g) * 0.1).to(DEV)
+    dy16 = torch.randn(N, Cout, 2 * H, 2 * W, generator=g).to(DEV).to(dt)
+    dy = dy16.float()
+    dy16i = dy16.view(torch.int16)
+    dx_ref = ops.convT_dgrad(x, w, dy, 2, compute=compute)
+    dx = ops.convT_dgrad(x, w, dy16i, 2, compute=compute, dy16=True)
+    assert torch.equal(dx, dx_ref)
+    pre = torch.randn(N, Cin, H, W, generator=g).to(DEV)
+    assert torch.equal(ops.convT_dgrad(x, w, dy16i, 2, dx=pre.clone(), accumulate=True, compute=compute, dy16=True),
+                       ops.convT_dgrad(x, w, dy, 2, dx=pre.clone(), accumulate=True, compute=compute))
+    dw_ref, db_ref = ops.convT_wgrad(x, w, dy, 2, compute=compute)
+    dw, db = ops.convT_wgrad(x, w, dy16i, 2, compute=compute, dy16=True)
+    assert torch.equal(dw, dw_ref) and torch.equal(db, db_ref)
+    # and against fp64 on the rounded operands (the oracle of the mode)
+    r = lambda t: t.to(dt).double()
+    want = F.conv2d(dy.cpu().double(), r(w.cpu()), stride=2)
+    assert (dx.cpu().double() - want).abs().max().item() <= 1e-5 * max(1.0, want.abs().max().item())
