@@ -398,8 +398,11 @@ enum {
     MTBC_OP_GAP_FWD, MTBC_OP_GAP_BWD, MTBC_OP_LINEAR_FWD, MTBC_OP_LINEAR_BWD,
     MTBC_OP_DICE_FWD, MTBC_OP_DICE_BWD, MTBC_OP_FOCAL, MTBC_OP_LOSS_MIX, MTBC_OP_ADAM,
     MTBC_OP_MEMSET, MTBC_OP_DICE_COUNTS, MTBC_OP_CONV3_PACK_LP, MTBC_OP_HEAD_COMBINE, MTBC_OP_HEAD_EXPAND,
-    MTBC_OP_C8_PACK, MTBC_OP_C8_PACK16, MTBC_OP_CONV3_WVIEW
+    MTBC_OP_C8_PACK, MTBC_OP_C8_PACK16, MTBC_OP_CONV3_WVIEW,
+    MTBC_OP_SET_STREAM, MTBC_OP_EVENT_RECORD, MTBC_OP_EVENT_WAIT
 };
+/* (the last three: stream control of mtbc_program_run_ms -- independent ops of a step, the weight gradient and the input
+ * gradient of one layer, overlap on two HIP streams: the small latency-bound launches of the deep levels fill the chip together) */
 
 /* ---- deep-supervision head of MTnnUNet: ConvTranspose2d(Cin->Cmid, k=s) followed by Conv2d(Cmid->R, 1x1)
  * (MTnnUNet.py:106-116: output4 k=8, output3 k=4, output2 k=2).  With no non-linearity in between the pair is ONE
@@ -450,12 +453,21 @@ typedef struct {
         mtbc_head_fuse_args head;
         struct { const float* w; float* dst; int32_t Cout, Cin, ci_off, ci_cnt, mode, k_off, K; } wview;
         struct { const float* src; int64_t src_batch_stride; void* dst; int32_t N, C, HW, compute; } c8pack;   /* C8_PACK and C8_PACK16 (src = 16-bit planar, `compute` unused) */
+        struct { void* event; int32_t index; } sync;      /* SET_STREAM: following ops go to streams[index]; EVENT_RECORD / EVENT_WAIT: on the current stream */
     } u;
 } mtbc_op;
 
 /* run ops[first .. first+count) on `stream`; returns 0 or the first failing op's error code,
  * with *failed_index (may be NULL) set to its index. */
 int mtbc_program_run(const mtbc_op* ops, int32_t first, int32_t count, void* stream, int32_t* failed_index);
+/* The same with several streams: ops run on streams[0] until a MTBC_OP_SET_STREAM op selects another; MTBC_OP_EVENT_RECORD /
+ * MTBC_OP_EVENT_WAIT order the streams (events from mtbc_event_create, reusable: a wait refers to the latest record issued
+ * before it).  A range must begin and end on streams[0] with everything joined.  With n_streams == 1 every op runs on that
+ * stream (indices are clamped): the same program, serialised.                                                            */
+int mtbc_program_run_ms(const mtbc_op* ops, int32_t first, int32_t count, void* const* streams, int32_t n_streams, int32_t* failed_index);
+/* timing-disabled HIP events for the two ops above; created when a step program is built, never inside a step */
+int mtbc_event_create(void** event);
+int mtbc_event_destroy(void* event);
 
 #ifdef __cplusplus
 }

@@ -138,6 +138,10 @@ class _C8PackArgs(C.Structure):
                 ("N", C.c_int32), ("C", C.c_int32), ("HW", C.c_int32), ("compute", C.c_int32)]
 
 
+class _SyncArgs(C.Structure):
+    _fields_ = [("event", C.c_void_p), ("index", C.c_int32)]
+
+
 class _WViewArgs(C.Structure):
     _fields_ = [("w", C.c_void_p), ("dst", C.c_void_p), ("Cout", C.c_int32), ("Cin", C.c_int32), ("ci_off", C.c_int32),
                 ("ci_cnt", C.c_int32), ("mode", C.c_int32), ("k_off", C.c_int32), ("K", C.c_int32)]
@@ -156,7 +160,7 @@ class _OpUnion(C.Union):
     _fields_ = [("conv3", Conv3x3Args), ("inorm", InstNormArgs), ("pool", MaxPoolArgs), ("convT", ConvTArgs),
                 ("conv1", Conv1x1Args), ("gap", GapArgs), ("linear", LinearArgs), ("dice", DiceArgs),
                 ("focal", FocalArgs), ("adam", AdamArgs), ("pack", _PackArgs), ("mix", _MixArgs),
-                ("memset0", _MemsetArgs), ("counts", _CountsArgs), ("head", HeadFuseArgs), ("c8pack", _C8PackArgs), ("wview", _WViewArgs)]
+                ("memset0", _MemsetArgs), ("counts", _CountsArgs), ("head", HeadFuseArgs), ("c8pack", _C8PackArgs), ("wview", _WViewArgs), ("sync", _SyncArgs)]
 
 
 class Op(C.Structure):
@@ -168,7 +172,8 @@ class Op(C.Structure):
  OP_IN_FWD, OP_IN_BWD, OP_POOL_FWD, OP_POOL_BWD, OP_CONVT_FWD, OP_CONVT_DGRAD, OP_CONVT_WGRAD,
  OP_CONV1_FWD, OP_CONV1_DGRAD, OP_CONV1_WGRAD, OP_GAP_FWD, OP_GAP_BWD, OP_LINEAR_FWD, OP_LINEAR_BWD,
  OP_DICE_FWD, OP_DICE_BWD, OP_FOCAL, OP_LOSS_MIX, OP_ADAM, OP_MEMSET, OP_DICE_COUNTS, OP_CONV3_PACK_LP,
- OP_HEAD_COMBINE, OP_HEAD_EXPAND, OP_C8_PACK, OP_C8_PACK16, OP_CONV3_WVIEW) = range(1, 33)
+ OP_HEAD_COMBINE, OP_HEAD_EXPAND, OP_C8_PACK, OP_C8_PACK16, OP_CONV3_WVIEW,
+ OP_SET_STREAM, OP_EVENT_RECORD, OP_EVENT_WAIT) = range(1, 36)
 
 OP_UNION_FIELD = {
     OP_CONV3_FWD: "conv3", OP_CONV3_DGRAD: "conv3", OP_CONV3_WGRAD: "conv3",
@@ -180,6 +185,7 @@ OP_UNION_FIELD = {
     OP_DICE_FWD: "dice", OP_DICE_BWD: "dice", OP_FOCAL: "focal", OP_LOSS_MIX: "mix", OP_ADAM: "adam",
     OP_MEMSET: "memset0", OP_DICE_COUNTS: "counts", OP_CONV3_PACK_LP: "pack",
     OP_HEAD_COMBINE: "head", OP_HEAD_EXPAND: "head", OP_C8_PACK: "c8pack", OP_C8_PACK16: "c8pack", OP_CONV3_WVIEW: "wview",
+    OP_SET_STREAM: "sync", OP_EVENT_RECORD: "sync", OP_EVENT_WAIT: "sync",
 }
 
 # every symbol include/mtbc.h declares (tests check the library exports all of them)
@@ -204,6 +210,7 @@ EXPORTS = [
     "mtbc_conv1x1_wgrad_workspace", "mtbc_conv1x1_fwd", "mtbc_conv1x1_dgrad", "mtbc_conv1x1_wgrad",
     "mtbc_gap_fwd", "mtbc_gap_bwd", "mtbc_linear_fwd", "mtbc_linear_bwd", "mtbc_dice_fwd", "mtbc_dice_bwd",
     "mtbc_focal_fwd_bwd", "mtbc_loss_mix", "mtbc_adam_step", "mtbc_dice_counts", "mtbc_program_run",
+    "mtbc_program_run_ms", "mtbc_event_create", "mtbc_event_destroy",
 ]
 
 _lib: Optional[C.CDLL] = None
@@ -282,6 +289,12 @@ def load() -> C.CDLL:
     lib.mtbc_dice_counts.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
     lib.mtbc_program_run.restype = C.c_int
     lib.mtbc_program_run.argtypes = [C.POINTER(Op), C.c_int32, C.c_int32, C.c_void_p, C.POINTER(C.c_int32)]
+    lib.mtbc_program_run_ms.restype = C.c_int
+    lib.mtbc_program_run_ms.argtypes = [C.POINTER(Op), C.c_int32, C.c_int32, C.POINTER(C.c_void_p), C.c_int32, C.POINTER(C.c_int32)]
+    lib.mtbc_event_create.restype = C.c_int
+    lib.mtbc_event_create.argtypes = [C.POINTER(C.c_void_p)]
+    lib.mtbc_event_destroy.restype = C.c_int
+    lib.mtbc_event_destroy.argtypes = [C.c_void_p]
     _lib = lib
     return lib
 

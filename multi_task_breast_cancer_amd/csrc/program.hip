@@ -22,11 +22,42 @@ const char* mtbc_strerror(int code) {
 
 static inline bool is_pack(int32_t k) { return k == MTBC_OP_CONV3_PACK_FWD || k == MTBC_OP_CONV3_PACK_DGRAD || k == MTBC_OP_CONV3_PACK_LP; }
 
+int mtbc_event_create(void** event) {
+    if (!event) return MTBC_E_BADARG;
+    hipEvent_t e;
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return MTBC_E_LAUNCH;
+    *event = e;
+    return MTBC_OK;
+}
+int mtbc_event_destroy(void* event) {
+    if (!event) return MTBC_E_BADARG;
+    return hipEventDestroy((hipEvent_t)event) == hipSuccess ? MTBC_OK : MTBC_E_LAUNCH;
+}
+
 int mtbc_program_run(const mtbc_op* ops, int32_t first, int32_t count, void* stream, int32_t* failed_index) {
-    if (!ops || first < 0 || count < 0) return MTBC_E_BADARG;
+    void* one[1] = {stream};
+    return mtbc_program_run_ms(ops, first, count, one, 1, failed_index);
+}
+
+int mtbc_program_run_ms(const mtbc_op* ops, int32_t first, int32_t count, void* const* streams, int32_t n_streams, int32_t* failed_index) {
+    if (!ops || first < 0 || count < 0 || !streams || n_streams < 1) return MTBC_E_BADARG;
+    void* stream = streams[0];
     for (int32_t i = first; i < first + count; ++i) {
         const mtbc_op* o = &ops[i];
         int rc;
+        if (o->kind == MTBC_OP_SET_STREAM) {
+            if (o->u.sync.index < 0) { if (failed_index) *failed_index = i; return MTBC_E_BADARG; }
+            stream = streams[o->u.sync.index < n_streams ? o->u.sync.index : 0];
+            continue;
+        }
+        if (o->kind == MTBC_OP_EVENT_RECORD || o->kind == MTBC_OP_EVENT_WAIT) {
+            hipError_t e = hipErrorInvalidValue;
+            if (o->u.sync.event)
+                e = o->kind == MTBC_OP_EVENT_RECORD ? hipEventRecord((hipEvent_t)o->u.sync.event, (hipStream_t)stream)
+                                                    : hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)o->u.sync.event, 0);
+            if (e != hipSuccess) { if (failed_index) *failed_index = i; return o->u.sync.event ? MTBC_E_LAUNCH : MTBC_E_BADARG; }
+            continue;
+        }
         if (is_pack(o->kind)) {               // a run of weight-image ops becomes one batched launch
             mtbc_pack_desc d[128];
             int32_t n = 0;

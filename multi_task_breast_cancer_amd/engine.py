@@ -29,6 +29,8 @@ _NO_P16 = _sw.flag("MTBC_NO_P16")
 _FANIN = _sw.flag("MTBC_FANIN")
 _NO_C8_SMALL = _sw.flag("MTBC_NO_C8_SMALL_OPS")
 _NO_G16 = _sw.flag("MTBC_NO_G16")
+_BWD_OVERLAP = _sw.flag("MTBC_BWD_OVERLAP")
+_BWD_OVERLAP_MAX_HW = int(_sw.get("MTBC_BWD_OVERLAP_MAX_HW"))
 
 
 def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
@@ -87,13 +89,17 @@ class ParamSlot:
 
 
 class Program:
-    """A contiguous ctypes array of ops + the stream-ordered runner."""
+    """A contiguous ctypes array of ops + the stream-ordered runner.  Ops run on the caller's current stream; a program
+    that contains stream-control ops (MTBC_OP_SET_STREAM / EVENT_RECORD / EVENT_WAIT) also gets ONE side stream of its own,
+    on which the ops between a fork and its join run beside the main stream (mtbc_program_run_ms)."""
 
-    def __init__(self, ops: List[L.Op], keep: list):
+    def __init__(self, ops: List[L.Op], keep: list, side_stream: Optional["torch.cuda.Stream"] = None):
         self.n = len(ops)
         self.array = (L.Op * max(1, self.n))(*ops)
         self.keep = keep                 # tensors referenced by raw pointer
         self._failed = C.c_int32(-1)
+        self.side = side_stream
+        self._streams = (C.c_void_p * 2)()
 
     def run(self, first: int = 0, count: Optional[int] = None, stream: Optional[torch.cuda.Stream] = None) -> None:
         if count is None:
@@ -101,10 +107,32 @@ class Program:
         if count <= 0:
             return
         s = (stream or torch.cuda.current_stream()).cuda_stream
-        rc = L.load().mtbc_program_run(self.array, first, count, C.c_void_p(s), C.byref(self._failed))
+        if self.side is None:
+            rc = L.load().mtbc_program_run(self.array, first, count, C.c_void_p(s), C.byref(self._failed))
+        else:
+            self._streams[0], self._streams[1] = s, self.side.cuda_stream
+            rc = L.load().mtbc_program_run_ms(self.array, first, count, self._streams, 2, C.byref(self._failed))
         if rc != 0:
             i = self._failed.value
             L.check(rc, f"program op #{i} (kind {self.array[i].kind}, tag {self.array[i].tag})")
+
+
+class _Events:
+    """The two HIP events a step program's forks / joins reuse (a wait refers to the latest record issued before it)."""
+
+    def __init__(self):
+        self.handles = []
+        for _ in range(2):
+            h = C.c_void_p()
+            L.check(L.load().mtbc_event_create(C.byref(h)), "event_create")
+            self.handles.append(h)
+
+    def __del__(self):
+        try:
+            for h in self.handles:
+                L.load().mtbc_event_destroy(h)
+        except Exception:
+            pass
 
 
 def _mk(kind: int, tag: int = 0) -> L.Op:
@@ -225,6 +253,37 @@ class StepPlan:
             buf = self.alloc(numel, dtype=torch.int16)
             setattr(self, attr, buf)
         return buf
+
+    # ------------------------------------------------------------------ two-stream backward
+    def _overlap_ok(self, hw: int) -> bool:
+        # OFF by default.  Measured (U-Net++ B=32 256x256, bf16, same box, interleaved): overlapping every layer's pair costs
+        # +1.0 ms per step (16.8 vs 15.75: on the large maps both launches are bandwidth-bound and disturb each other's L2
+        # tile walk); restricted to maps <= 32x32, where both launches are latency-bound, still +0.25 ms (15.80 vs 15.52):
+        # two event record / wait pairs per layer cost more than the side-by-side launches gain.
+        return _BWD_OVERLAP and self.dev.type == "cuda" and hw <= _BWD_OVERLAP_MAX_HW
+
+    def _sync_op(self, kind: int, event: int = 0, index: int = 0) -> L.Op:
+        op = _mk(kind)
+        op.u.sync.event, op.u.sync.index = (self._events.handles[event] if kind != L.OP_SET_STREAM else None), index
+        return op
+
+    def fork_side(self) -> None:
+        """Following backward ops go to the side stream, ordered behind everything issued so far on the main stream."""
+        if getattr(self, "_events", None) is None:
+            self._events = _Events()
+            self.keep.append(self._events)
+        self.bwd_ops += [self._sync_op(L.OP_EVENT_RECORD, 0), self._sync_op(L.OP_SET_STREAM, index=1), self._sync_op(L.OP_EVENT_WAIT, 0)]
+
+    def back_to_main(self) -> None:
+        """End of the side-stream section: mark it and continue on the main stream (which does NOT wait yet)."""
+        self.bwd_ops += [self._sync_op(L.OP_EVENT_RECORD, 1), self._sync_op(L.OP_SET_STREAM, index=0)]
+
+    def join_side(self, params: Sequence[str] = ()) -> None:
+        """The main stream waits for the side-stream section; the gradients of `params` (written there) are ready from
+        THIS op on -- what the data-parallel bucket schedule keys on."""
+        self.bwd_ops.append(self._sync_op(L.OP_EVENT_WAIT, 1))
+        for name in params:
+            self.slots[name].ready_at = len(self.bwd_ops) - 1
 
     def _need_ws(self, op: L.Op, fieldname: str, nbytes: int) -> None:
         self.ws_bytes = max(self.ws_bytes, int(nbytes))
@@ -457,7 +516,13 @@ class StepPlan:
                 if p16:
                     pk.kind = L.OP_C8_PACK16
                 self.bwd_ops.append(pk)
-            # wgrad
+            # dgrad into every input that needs one
+            need = [a_ for a_ in inputs if a_.needs_grad]
+            # wgrad -- beside the dgrad on the side stream when there is one: both only READ dz and the inputs, the weight
+            # gradient's split-K workspace is not touched by a dgrad, and on the deep levels neither fills the chip alone
+            forked = bool(need) and self._overlap_ok(H * W)
+            if forked:
+                self.fork_side()
             op = base_conv()
             op.kind = L.OP_CONV3_WGRAD
             a = op.u.conv3
@@ -471,8 +536,8 @@ class StepPlan:
             a.dw = self.gv(wname).data_ptr()
             self._need_ws(op, "conv3", self.lib.mtbc_conv3x3_wgrad_workspace(C.byref(a)))
             self.bwd_ops.append(op)
-            # dgrad into every input that needs one
-            need = [a_ for a_ in inputs if a_.needs_grad]
+            if forked:
+                self.back_to_main()
             if need and defer:
                 off = 0
                 for a_ in defer:
@@ -504,6 +569,8 @@ class StepPlan:
                     a.dout, a.operand_layout = dz8.data_ptr(), L.LAYOUT_C8
                 a.w_packed = _ptr(wp_d)
                 self.bwd_ops.append(op)
+            if forked:
+                self.join_side([wname])
 
         self.bwd_emitters.append(emit_bwd)
         return y
@@ -603,6 +670,9 @@ class StepPlan:
                 return
             g16 = y.grad16 is not None
             dy = y.grad16 if g16 else self.grad_of(y)
+            forked = x.needs_grad and self._overlap_ok(x.H * x.W)
+            if forked:
+                self.fork_side()
             op = base()
             op.kind = L.OP_CONVT_WGRAD
             a = op.u.convT
@@ -615,6 +685,8 @@ class StepPlan:
                 a.dbias = self.gv(bname).data_ptr()
             self._need_ws(op, "convT", self.lib.mtbc_convT_wgrad_workspace(C.byref(a)))
             self.bwd_ops.append(op)
+            if forked:
+                self.back_to_main()
             if x.needs_grad:
                 op = base()
                 op.kind = L.OP_CONVT_DGRAD
@@ -624,6 +696,8 @@ class StepPlan:
                 gx, acc = self.grad_slot(x)
                 a.dx, a.dx_batch_stride, a.accumulate_dx = gx.data_ptr(), x.bstride, acc
                 self.bwd_ops.append(op)
+            if forked:
+                self.join_side([wname] + ([bname] if bname else []))
 
         self.bwd_emitters.append(emit_bwd)
         return y
@@ -906,9 +980,10 @@ class StepPlan:
         for op, fieldname in self.ws_users:
             a = getattr(op.u, fieldname)
             a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+        side = torch.cuda.Stream(device=self.dev) if getattr(self, "_events", None) is not None else None
         return {
             "pack": Program(self.wview_ops + self.pack_ops, self.keep),
             "fwd": Program(self.fwd_ops, self.keep),
             "loss": Program(self.loss_ops, self.keep),
-            "bwd": Program(self.bwd_ops, self.keep),
+            "bwd": Program(self.bwd_ops, self.keep, side_stream=side),
         }

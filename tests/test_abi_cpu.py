@@ -38,7 +38,7 @@ def test_ctypes_layout_matches_header(tmp_path):
                "mtbc_maxpool_args": L.MaxPoolArgs, "mtbc_convT_args": L.ConvTArgs, "mtbc_conv1x1_args": L.Conv1x1Args,
                "mtbc_gap_args": L.GapArgs, "mtbc_linear_args": L.LinearArgs, "mtbc_dice_args": L.DiceArgs,
                "mtbc_focal_args": L.FocalArgs, "mtbc_adam_args": L.AdamArgs, "mtbc_op": L.Op,
-               "mtbc_pack_desc": L.PackDesc, "mtbc_head_fuse_args": L.HeadFuseArgs}
+               "mtbc_pack_desc": L.PackDesc, "mtbc_head_fuse_args": L.HeadFuseArgs, "mtbc_wview_desc": L.WViewDesc}
     offs = [("mtbc_conv3x3_args", "workspace_bytes", L.Conv3x3Args.workspace_bytes.offset),
             ("mtbc_conv3x3_args", "w_packed", L.Conv3x3Args.w_packed.offset),
             ("mtbc_instnorm_args", "dgamma", L.InstNormArgs.dgamma.offset),
@@ -77,7 +77,8 @@ def test_op_kind_enum_in_sync():
     want = ["CONV3_FWD", "CONV3_DGRAD", "CONV3_WGRAD", "CONV3_PACK_FWD", "CONV3_PACK_DGRAD", "IN_FWD", "IN_BWD",
             "POOL_FWD", "POOL_BWD", "CONVT_FWD", "CONVT_DGRAD", "CONVT_WGRAD", "CONV1_FWD", "CONV1_DGRAD", "CONV1_WGRAD",
             "GAP_FWD", "GAP_BWD", "LINEAR_FWD", "LINEAR_BWD", "DICE_FWD", "DICE_BWD", "FOCAL", "LOSS_MIX", "ADAM",
-            "MEMSET", "DICE_COUNTS", "CONV3_PACK_LP", "HEAD_COMBINE", "HEAD_EXPAND", "C8_PACK", "C8_PACK16", "CONV3_WVIEW"]
+            "MEMSET", "DICE_COUNTS", "CONV3_PACK_LP", "HEAD_COMBINE", "HEAD_EXPAND", "C8_PACK", "C8_PACK16", "CONV3_WVIEW",
+            "SET_STREAM", "EVENT_RECORD", "EVENT_WAIT"]
     assert names == ["MTBC_OP_" + w for w in want]
     for i, w in enumerate(want, start=1):
         assert getattr(L, "OP_" + w) == i

@@ -319,3 +319,29 @@ def test_512_inputs_16bit_modes_track_the_fp32_step():
         assert out[dt][0][3].item() == 0.0
         assert abs(out[dt][0][0].item() - out["f32"][0][0].item()) < 5e-3
         assert (out[dt][1] - out["f32"][1]).abs().max().item() < 5e-4      # two Adam steps of lr 1e-4
+
+
+def test_two_stream_backward_is_bit_identical_to_the_single_stream_one(monkeypatch):
+    """MTBC_BWD_OVERLAP (off by default: measured slower): the weight gradient of a layer on a side stream beside its input
+    gradient (mtbc_program_run_ms, MTBC_OP_SET_STREAM / EVENT_RECORD / EVENT_WAIT) must change nothing but the schedule."""
+    from multi_task_breast_cancer_amd import engine, _lib as L
+
+    def run(overlap):
+        monkeypatch.setattr(engine, "_BWD_OVERLAP", overlap)
+        monkeypatch.setattr(engine, "_BWD_OVERLAP_MAX_HW", 1 << 30)
+        seed_everything(21)
+        m = MTUNetPlusPlus(in_channels=1, out_channels=1, n_classes=3, deep_supervision=True).to(DEV)
+        m.set_compute("bf16")
+        step = FusedTrainStep(m, FusedAdam(m, lr=1e-4, eps=1e-4), alpha=0.5)
+        batch = tuple(t.to(DEV) for t in O.synthetic_batch(2, 128, 128, seed=2))
+        for _ in range(2):
+            losses = step(*batch)
+        torch.cuda.synchronize()
+        prog = step._st.programs["bwd"]
+        n_sync = sum(1 for i in range(prog.n) if prog.array[i].kind in (L.OP_SET_STREAM, L.OP_EVENT_RECORD, L.OP_EVENT_WAIT))
+        return losses.cpu(), m.flat_p.detach().cpu().clone(), m.flat_g.detach().cpu().clone(), n_sync
+
+    l0, p0, g0, s0 = run(False)
+    l1, p1, g1, s1 = run(True)
+    assert s0 == 0 and s1 > 100
+    assert torch.equal(l0, l1) and torch.equal(p0, p1) and torch.equal(g0, g1)
