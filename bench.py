@@ -91,8 +91,11 @@ def conv_bytes(op, kind, L) -> float:
         return (a.Cin * rd + a.Cout * (8.0 if a.out_accumulate else 4.0)) * px + w
     if kind == L.OP_CONV3_WGRAD:
         return (a.Cin + a.Cout) * rd * px + 9.0 * a.Cin * a.Cout * 4.0
-    acc = sum(a.in_[i].channels for i in range(a.n_in) if a.in_[i].accumulate)      # fan-in sums re-read dx
-    return (a.Cout * rd + (a.Cin + acc) * 4.0) * px + w
+    out = 0.0
+    for i in range(a.n_in):          # dx segments: fp32 written (+ re-read when accumulated), or 16-bit planes (accumulate = 2)
+        m = a.in_[i].accumulate
+        out += a.in_[i].channels * (2.0 if m == 2 else (8.0 if m == 1 else 4.0))
+    return (a.Cout * rd + out) * px + w
 
 
 def time_op(prog, i, reps=3) -> float:

@@ -2140,6 +2140,7 @@ int launch_igemm_c8(const ConvP& p, int mblocks, bool f16, hipStream_t st) {
 template <int GEO>
 int launch_igemm_c8_mt(int MT, const ConvP& p, int mblocks, bool f16, hipStream_t st) {
     if (MT == 1) return launch_igemm_c8<1, GEO, 4>(p, mblocks, f16, st);
+    if (MT == 3) return launch_igemm_c8<3, GEO, 4>(p, mblocks, f16, st);
     return launch_igemm_c8<2, GEO, 4>(p, mblocks, f16, st);
 }
 
@@ -2161,7 +2162,10 @@ int run_igemm(int N, int H, int W, int red, int rows, const SegTable& in, const 
     static const int mtmax_env = mtbc_probe_int("MTBC_LP_MT", 0);      // A/B probe
     // 16-bit kernels: 2 tiles per block keep LDS at 51 KB = 3 blocks per CU; 3 tiles (62 KB, 2 blocks) measured slower
     // on every layer (dgrad 144->24: 0.71 -> 0.56 ms) although the pixel tile is staged once more per channel block
-    const int mtmax = compute != 0 ? (mtmax_env ? mtmax_env : 2) : 3;
+    // ... except on the channel-blocked kernel when the channel tiles come in threes (48 / 96 / 192 / 384 channels): 3 tiles
+    // per block are 49 KB there (still 3 blocks per CU) and the pixel tile is staged once per 48 channels instead of once
+    // per 32 (Cout = 48: X read once instead of twice).  Not on 8x8 maps: that instantiation spills.
+    const int mtmax = compute != 0 ? (mtmax_env ? mtmax_env : ((c8 && geo != 2 && p.mtiles % 3 == 0) ? 3 : 2)) : 3;
     int mblocks = cdiv(p.mtiles, mtmax);
     int MT = cdiv(p.mtiles, mblocks);
     while (MT > 1 && (long long)p.ntiles * mblocks < 512) {
