@@ -49,7 +49,10 @@ const char* mtbc_arch(void);
  * 2 (mtbc_conv3x3_dgrad with operand_layout C8 only) = overwrite a 16-BIT planar (N,C,H,W)
  * segment of the type of `compute` (ptr 8-byte aligned, batch_stride in 16-bit elements): the
  * fp32 result rounded to nearest even -- for a gradient whose only reader rounds it to that
- * type anyway (the k = 2 transposed conv backward, mtbc_convT_args.dy_type16).            */
+ * type anyway (the k = 2 transposed conv backward, mtbc_convT_args.dy_type16);
+ * 3 (same call) = overwrite a 16-BIT CHANNEL-BLOCKED segment [N][channels/8][H*W][8] of that type (MTBC_LAYOUT_C8;
+ * ptr 16-byte aligned, batch_stride in 16-bit elements, channels % 8 == 0) -- for a gradient with this one writer
+ * whose reader takes the layout (mtbc_instnorm_args.dy_layout).  Either every segment of a launch has mode 3 or none. */
 typedef struct {
     float* ptr;
     int64_t batch_stride;   /* elements */
@@ -92,6 +95,12 @@ typedef struct {
     int32_t out_accumulate;          /* fwd with operand_layout C8 only: 1 = add the result to `out` instead of overwriting
                                         it.  A forward launch over the dz of ALL 3x3 consumers of a tensor, with
                                         mtbc_conv3x3_weight_view(mode 1) weights, is that tensor's gathered dgrad.  */
+    int32_t out_layout;              /* fwd with operand_layout C8 only: MTBC_LAYOUT_C8 = `out` is written as a 16-bit
+                                        channel-blocked tensor [N][Cout/8][H*W][8] of the type of `compute` (fp32 accumulate,
+                                        + bias, ONE round-to-nearest-even) instead of fp32 planes: the conv output of the
+                                        16-bit modes, read by mtbc_instnorm_args.z_layout = C8 (what torch.autocast stores
+                                        between a convolution and its normalisation).  Cout % 8 == 0, out 16-byte aligned,
+                                        out_accumulate = 0.                                                             */
 } mtbc_conv3x3_args;
 #define MTBC_LAYOUT_PLANAR 0
 #define MTBC_LAYOUT_C8 1
@@ -197,6 +206,15 @@ typedef struct {
        kernels of OTHER streams that hold CUs while it runs (RCCL collectives overlapping the backward pass) would make
        members wait for a slot.  Per call -- the library keeps no process-wide setting.                              */
     int32_t coop_reserve_cus;
+    /* 16-bit channel-blocked INPUTS (with y8 / dz8 outputs only; type out16_type, C % 8 == 0, 16-byte aligned):
+       z_layout  = MTBC_LAYOUT_C8: z is [N][C/8][H*W][8] as written by mtbc_conv3x3_fwd(out_layout = C8); statistics are
+                   those of the stored (rounded) values, accumulated in fp32;
+       dy_layout = MTBC_LAYOUT_C8: dy is [N][C/8][H*W][8] as written by mtbc_conv3x3_dgrad (segment mode 3) or by a
+                   gathered forward-type launch with out_layout = C8 (dy_batch_stride in 16-bit elements); with
+                   n_dy_extra = 1, dy_extra[0] is an fp32 planar (N,C,H,W) partial gradient from the tensor's other
+                   readers (batch stride C*H*W), added to it in fp32 while loading.                                     */
+    int32_t z_layout;
+    int32_t dy_layout;
 } mtbc_instnorm_args;
 size_t mtbc_instnorm_coop_state_bytes(void);
 /* Byte offset, inside a coop_state block, of the 32-bit STICKY error word: non-zero once any cooperative launch on that

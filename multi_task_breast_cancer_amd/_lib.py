@@ -34,7 +34,7 @@ class Conv3x3Args(C.Structure):
                 ("out", C.c_void_p), ("dout", C.c_void_p), ("dw", C.c_void_p), ("dbias", C.c_void_p),
                 ("accumulate_dw", C.c_int32), ("force_direct", C.c_int32),
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
-                ("compute", C.c_int32), ("operand_layout", C.c_int32), ("out_accumulate", C.c_int32)]
+                ("compute", C.c_int32), ("operand_layout", C.c_int32), ("out_accumulate", C.c_int32), ("out_layout", C.c_int32)]
 
 
 class InstNormArgs(C.Structure):
@@ -49,7 +49,8 @@ class InstNormArgs(C.Structure):
                 ("accumulate_dparams", C.c_int32),
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
                 ("y16", C.c_void_p), ("dz16", C.c_void_p), ("out16_type", C.c_int32),
-                ("y8", C.c_void_p), ("dz8", C.c_void_p), ("coop_state", C.c_void_p), ("coop_reserve_cus", C.c_int32)]
+                ("y8", C.c_void_p), ("dz8", C.c_void_p), ("coop_state", C.c_void_p), ("coop_reserve_cus", C.c_int32),
+                ("z_layout", C.c_int32), ("dy_layout", C.c_int32)]
 
 
 class MaxPoolArgs(C.Structure):

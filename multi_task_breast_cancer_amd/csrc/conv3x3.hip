@@ -870,7 +870,11 @@ __global__ __launch_bounds__(256, 3) void conv3x3_igemm_lp_kernel(const ConvP p)
 // NW = waves per block: 4 (256 pixels: 8 x 32, 16 x 16 or four 8 x 8 images) or, wide maps only, 8 (512 pixels: 16 x 32 --
 // 19.5 % halo instead of 33 % and each weight chunk shared by twice the pixels; 58 KB of LDS = 2 blocks per CU.  Measured
 // (tools/experiments/c8_igemm_v2_probe.hip): 144->24 @256x256 -6..-17 %, 24->24 -3 %, 64x64 maps +15 %: chosen by run_igemm).
-template <int MT, int GEO, bool F16, int NW>
+// O8 = the OUTPUT is 16-bit channel-blocked as well (conv outputs z / single-writer gradients of the 16-bit modes): the MFMAs
+// run as D = W X (channels on the rows), so a lane holds 4 consecutive channels of ONE pixel = half a 16-byte piece; the 16
+// lanes of a row group write 16 consecutive pixels, and the lane groups kg = 2q, 2q + 1 the two halves of the same pieces
+// (256 contiguous bytes per channel group and instruction).  fp32 accumulate + bias, one RNE.
+template <int MT, int GEO, bool F16, int NW, bool O8>
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 4) void conv3x3_igemm_c8_kernel(const ConvP p) {
     using G = GeoLP<GEO>;
     using T = LP<F16>;
@@ -993,12 +997,48 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 4) void conv3x3_igemm_c8_ker
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) acc[m][g] = T::mfma(b[g], a[m], acc[m][g]);      // rows = pixels, cols = channels
+                    for (int g = 0; g < 4; ++g) {
+                        if constexpr (O8) acc[m][g] = T::mfma(a[m], b[g], acc[m][g]);      // rows = channels, cols = pixels
+                        else acc[m][g] = T::mfma(b[g], a[m], acc[m][g]);                   // rows = pixels, cols = channels
+                    }
             }
         }
-        // ---- epilogue: identical to conv3x3_igemm_lp_kernel (fp32 planar output, 16-byte stores / read-modify-write)
         const int n = GEO == 2 ? n0 + wv : n0;
         if MTBC_DBG_BIT(p, 2) { if (acc[0][0][0] != 12345.678f) continue; }
+        if constexpr (O8) {
+            // ---- epilogue, channel-blocked 16-bit output: lane (j, kg) holds channels 16m + 4kg .. + 3 of pixel j of group g
+            typedef unsigned ep_u32x2 __attribute__((ext_vector_type(2)));
+            typedef unsigned ep_u32x4 __attribute__((ext_vector_type(4)));
+            typedef __attribute__((address_space(1))) ep_u32x2 guint2;
+            int pix[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                int y, x;
+                if (GEO == 0) { y = y0 + 2 * wv + (g >> 1); x = x0 + 16 * (g & 1) + j; }
+                else if (GEO == 1) { y = y0 + 4 * wv + g; x = x0 + j; }
+                else { y = y0 + 2 * g + (j >> 3); x = x0 + (j & 7); }
+                pix[g] = (n < p.N && y < p.H && x < p.W) ? y * p.W + x : -1;
+            }
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const int co = (mt0 + m) * 16 + 4 * kg;
+                if (co >= p.Cout) continue;
+                const SegL so = segl_ref(seg_out, co);
+                // piece (n, group, pixel) of the segment's tensor; this lane owns channels (co - cb) % 8 .. + 3 of it
+                gchar* cb = (gchar*)so.ptr + 2 * ((size_t)n * so.bs + (size_t)((co - so.cb) >> 3) * HW * 8) + 2 * ((co - so.cb) & 7);
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(bias_s + m * 16 + 4 * kg);
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    if (pix[g] >= 0) {
+                        const f32x4 r = acc[m][g] + bv;
+                        const float q[8] = {r[0], r[1], r[2], r[3], 0.f, 0.f, 0.f, 0.f};
+                        const ep_u32x4 u = __builtin_bit_cast(ep_u32x4, T::pack(q));
+                        *(guint2*)(cb + 16 * (size_t)pix[g]) = (ep_u32x2){u[0], u[1]};
+                    }
+            }
+            continue;
+        }
+        // ---- epilogue: identical to conv3x3_igemm_lp_kernel (fp32 planar output, 16-byte stores / read-modify-write)
         int poff[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -2112,7 +2152,7 @@ int launch_igemm_lp_mt(int MT, const ConvP& p, int mblocks, bool f16, hipStream_
     }
 }
 
-template <int MT, int GEO, int NW>
+template <int MT, int GEO, int NW, bool O8>
 int launch_igemm_c8(const ConvP& p, int mblocks, bool f16, hipStream_t st) {
     using G = GeoLP<GEO>;
     constexpr int TH = GEO == 0 ? 2 * NW : G::TH;
@@ -2120,8 +2160,8 @@ int launch_igemm_c8(const ConvP& p, int mblocks, bool f16, hipStream_t st) {
     const size_t lds = ((size_t)4 * HPP * 8 + (size_t)MT * 9 * 16 * WROW) * 2 + (SEGL_FLOATS + MT * 16) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_igemm_c8_kernel<MT, GEO, false, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_igemm_c8_kernel<MT, GEO, true, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_igemm_c8_kernel<MT, GEO, false, NW, O8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_igemm_c8_kernel<MT, GEO, true, NW, O8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     static const int per_cu_env = mtbc_probe_int("MTBC_C8_BLOCKS_PER_CU", 0);      // A/B
@@ -2132,22 +2172,22 @@ int launch_igemm_c8(const ConvP& p, int mblocks, bool f16, hipStream_t st) {
     if (gx < 8) gx = 8;
     if (gx > p.ntiles) gx = p.ntiles;
     const dim3 grid(gx, mblocks);
-    if (f16) hipLaunchKernelGGL((conv3x3_igemm_c8_kernel<MT, GEO, true, NW>), grid, dim3(64 * NW), lds, st, p);
-    else hipLaunchKernelGGL((conv3x3_igemm_c8_kernel<MT, GEO, false, NW>), grid, dim3(64 * NW), lds, st, p);
+    if (f16) hipLaunchKernelGGL((conv3x3_igemm_c8_kernel<MT, GEO, true, NW, O8>), grid, dim3(64 * NW), lds, st, p);
+    else hipLaunchKernelGGL((conv3x3_igemm_c8_kernel<MT, GEO, false, NW, O8>), grid, dim3(64 * NW), lds, st, p);
     MTBC_CHECK_LAUNCH();
     return MTBC_OK;
 }
-template <int GEO>
+template <int GEO, bool O8>
 int launch_igemm_c8_mt(int MT, const ConvP& p, int mblocks, bool f16, hipStream_t st) {
-    if (MT == 1) return launch_igemm_c8<1, GEO, 4>(p, mblocks, f16, st);
-    if (MT == 3) return launch_igemm_c8<3, GEO, 4>(p, mblocks, f16, st);
-    return launch_igemm_c8<2, GEO, 4>(p, mblocks, f16, st);
+    if (MT == 1) return launch_igemm_c8<1, GEO, 4, O8>(p, mblocks, f16, st);
+    if (MT == 3) return launch_igemm_c8<3, GEO, 4, O8>(p, mblocks, f16, st);
+    return launch_igemm_c8<2, GEO, 4, O8>(p, mblocks, f16, st);
 }
 
 // shared by fwd and dgrad: `rows` = channels written, `red` = channels read; compute: 0 fp32, 1 bf16, 2 fp16 operands;
 // c8: the tensor read is 16-bit channel-blocked (MTBC_LAYOUT_C8)
 int run_igemm(int N, int H, int W, int red, int rows, const SegTable& in, const SegTable& out, const float* wp,
-              const float* bias, int compute, hipStream_t st, bool c8 = false) {
+              const float* bias, int compute, hipStream_t st, bool c8 = false, bool o8 = false) {
     ConvP p;
     p.N = N; p.H = H; p.W = W; p.Cin = red; p.Cout = rows; p.in = in; p.out = out; p.wp = wp; p.bias = bias;
     static const int dbg = mtbc_probe_int("MTBC_DBG", 0);
@@ -2179,11 +2219,16 @@ int run_igemm(int N, int H, int W, int red, int rows, const SegTable& in, const 
         const int t16 = p.tiles_x * cdiv(H, 16) * N;
         if (geo == 0 && MT == 2 && (nw_env ? nw_env == 8 : (long long)t16 * mblocks >= 2048)) {
             p.tiles_y = cdiv(H, 16); p.ntiles = t16;
-            return launch_igemm_c8<2, 0, 8>(p, mblocks, compute == 2, st);
+            return o8 ? launch_igemm_c8<2, 0, 8, true>(p, mblocks, compute == 2, st) : launch_igemm_c8<2, 0, 8, false>(p, mblocks, compute == 2, st);
         }
-        if (geo == 0) return launch_igemm_c8_mt<0>(MT, p, mblocks, compute == 2, st);
-        if (geo == 1) return launch_igemm_c8_mt<1>(MT, p, mblocks, compute == 2, st);
-        return launch_igemm_c8_mt<2>(MT, p, mblocks, compute == 2, st);
+        if (o8) {
+            if (geo == 0) return launch_igemm_c8_mt<0, true>(MT, p, mblocks, compute == 2, st);
+            if (geo == 1) return launch_igemm_c8_mt<1, true>(MT, p, mblocks, compute == 2, st);
+            return launch_igemm_c8_mt<2, true>(MT, p, mblocks, compute == 2, st);
+        }
+        if (geo == 0) return launch_igemm_c8_mt<0, false>(MT, p, mblocks, compute == 2, st);
+        if (geo == 1) return launch_igemm_c8_mt<1, false>(MT, p, mblocks, compute == 2, st);
+        return launch_igemm_c8_mt<2, false>(MT, p, mblocks, compute == 2, st);
     }
     if (compute != 0) {
         if (geo == 0) return launch_igemm_lp_mt<0>(MT, p, mblocks, compute == 2, st);
@@ -2338,10 +2383,16 @@ int mtbc_conv3x3_fwd(const mtbc_conv3x3_args* a, void* stream) {
     rc = make_segtable(&o, 1, a->Cout, &out); if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
     if (a->out_accumulate && a->operand_layout != MTBC_LAYOUT_C8) return MTBC_E_UNSUPPORTED;
+    if (a->out_layout != MTBC_LAYOUT_PLANAR && (a->out_layout != MTBC_LAYOUT_C8 || a->operand_layout != MTBC_LAYOUT_C8)) return MTBC_E_UNSUPPORTED;
     if (a->operand_layout == MTBC_LAYOUT_C8) {
         if (!a->w_packed || (a->compute != 1 && a->compute != 2) || !c8_segs_ok(a->in, a->n_in)) return MTBC_E_BADARG;
         if (a->W % 4 || a->W < 8 || a->H < 8 || (reinterpret_cast<uintptr_t>(a->out) & 15)) return MTBC_E_UNSUPPORTED;
-        return run_igemm(a->N, a->H, a->W, a->Cin, a->Cout, in, out, a->w_packed, a->bias, a->compute, st, true);
+        const bool o8 = a->out_layout == MTBC_LAYOUT_C8;
+        if (o8) {
+            if (a->Cout % 8 || a->out_accumulate) return MTBC_E_BADARG;
+            out.accumulate[0] = 3;
+        }
+        return run_igemm(a->N, a->H, a->W, a->Cin, a->Cout, in, out, a->w_packed, a->bias, a->compute, st, true, o8);
     }
     if (a->operand_layout != MTBC_LAYOUT_PLANAR) return MTBC_E_BADARG;
     if (a->w_packed && !a->force_direct && mfma_ok(a->in, a->n_in, a->H, a->W))
@@ -2372,13 +2423,17 @@ int mtbc_conv3x3_dgrad(const mtbc_conv3x3_args* a, void* stream) {
     if (a->operand_layout == MTBC_LAYOUT_C8) {
         if (!a->w_packed || (a->compute != 1 && a->compute != 2) || !c8_segs_ok(&g, 1)) return MTBC_E_BADARG;
         if (!mfma_ok(a->in, a->n_in, a->H, a->W)) return MTBC_E_UNSUPPORTED;      // the fp32 planar dx segments: 16-byte stores
-        for (int i = 0; i < a->n_in; ++i)
+        int n3 = 0;
+        for (int i = 0; i < a->n_in; ++i) {
             if (a->in[i].accumulate == 2 && ((reinterpret_cast<uintptr_t>(a->in[i].ptr) & 7) || (a->in[i].batch_stride & 3))) return MTBC_E_BADARG;
-        return run_igemm(a->N, a->H, a->W, a->Cout, a->Cin, in, out, a->w_packed, nullptr, a->compute, st, true);
+            if (a->in[i].accumulate == 3) ++n3;
+        }
+        if (n3 != 0 && (n3 != a->n_in || !c8_segs_ok(a->in, a->n_in))) return MTBC_E_BADARG;      // channel-blocked dx: every segment or none
+        return run_igemm(a->N, a->H, a->W, a->Cout, a->Cin, in, out, a->w_packed, nullptr, a->compute, st, true, n3 != 0);
     }
     if (a->operand_layout != MTBC_LAYOUT_PLANAR) return MTBC_E_BADARG;
     for (int i = 0; i < a->n_in; ++i)
-        if (a->in[i].accumulate == 2) return MTBC_E_UNSUPPORTED;      // 16-bit planar dx segments: channel-blocked dgrad only
+        if (a->in[i].accumulate >= 2) return MTBC_E_UNSUPPORTED;      // 16-bit dx segments: channel-blocked dgrad only
     bool ok = a->w_packed && !a->force_direct && mfma_ok(&g, 1, a->H, a->W) && a->Cout % KC == 0;
     for (int i = 0; ok && i < a->n_in; ++i) ok = a->in[i].ptr != nullptr && a->in[i].channels % 4 == 0;
     if (ok) return run_igemm(a->N, a->H, a->W, a->Cout, a->Cin, in, out, a->w_packed, nullptr, a->compute, st);

@@ -1,6 +1,6 @@
 // InstanceNorm + LeakyReLU whose output IS the 16-bit channel-blocked layout the 3x3 convs read (MTBC_LAYOUT_C8):
-// forward  z (fp32 planes) -> a8  [n][C/8][H*W][8]   (+ fp32 planes y when something else reads them)
-// backward z, dy (fp32 planes) -> dz8 [n][C/8][H*W][8]
+// forward  z (fp32 planes, or 16-bit channel-blocked: z_layout) -> a8  [n][C/8][H*W][8]   (+ fp32 planes y when something else reads them)
+// backward z, dy (fp32 planes, or 16-bit channel-blocked [+ an fp32 planar partial]: z_layout / dy_layout) -> dz8 [n][C/8][H*W][8]
 // replaces nn.InstanceNorm2d + nn.LeakyReLU (MTnnUNet.py:35-36, MTUNetPlusPlus.py:20-22) in the 16-bit modes.
 //
 // A 16-byte piece holds 8 channels of one pixel, so a workgroup must own all 8 planes of a channel group -- 2 MB at
@@ -21,6 +21,7 @@
 // the CUs the caller reserves per call for kernels of other streams (mtbc_instnorm_args.coop_reserve_cus).
 #include "common.h"
 #include <stddef.h>
+#include <type_traits>
 
 namespace {
 
@@ -44,6 +45,9 @@ struct CoP {
     float* part;                             // backward: [N*C][3] = {sum g, sum g*xh, 0} or nullptr
     float* part3;                            // backward: [N*C][T] per-member sums of dz
     void* state;
+    const unsigned short* z8;                // z as 16-bit channel-blocked [n][C/8][HW][8] (else nullptr: fp32 planes `z`)
+    const unsigned short* dy8; long long dy8bs;   // dy as 16-bit channel-blocked (else nullptr: fp32 planes `dy`)
+    const float* dyx;                        // with dy8: optional fp32 planar partial gradient (N,C,H,W), added while loading
 };
 
 typedef float co_f32x2 __attribute__((ext_vector_type(2)));
@@ -53,6 +57,19 @@ typedef unsigned co_u32x4 __attribute__((ext_vector_type(4)));
 template <bool F16> __device__ __forceinline__ unsigned co_pk(float a, float b) {
     if constexpr (F16) return __builtin_bit_cast(unsigned, __builtin_convertvector((co_f32x2){a, b}, co_f16x2));
     else return __builtin_bit_cast(unsigned, __builtin_convertvector((co_f32x2){a, b}, co_bf16x2));
+}
+
+// the 8 channels of a stored piece as fp32 (exact)
+typedef _Float16 co_f16x8 __attribute__((ext_vector_type(8)));
+template <bool F16> __device__ __forceinline__ void co_unpk(const co_u32x4 w, float (&o)[8]) {
+    if constexpr (F16) {          // (bit-cast the WHOLE vector: __builtin_bit_cast of a subscripted element reads element 0)
+        const co_f16x8 t = __builtin_bit_cast(co_f16x8, w);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = (float)t[i];
+    } else {
+#pragma unroll
+        for (int h = 0; h < 4; ++h) { const unsigned u = w[h]; o[2 * h] = __uint_as_float(u << 16); o[2 * h + 1] = __uint_as_float(u & 0xffff0000u); }
+    }
 }
 
 __device__ __forceinline__ void mb_post(unsigned long long* slot, float v, unsigned tag) {
@@ -77,7 +94,7 @@ __device__ __forceinline__ float mb_wait(unsigned long long* slot, unsigned tag,
     return __uint_as_float((unsigned)w);
 }
 // Every member posts its NV values (thread i < NV holds value i in `mine`) and collects everybody's into xch[m][i].
-template <int NV>
+template <int NV, int THREADS>
 __device__ __forceinline__ void team_exchange(float mine, unsigned long long* mb, int member, int T, unsigned& seq, unsigned epoch,
                                               CoopHdr* hdr, float (*xch)[CO_NV]) {
     const int tid = threadIdx.x;
@@ -86,7 +103,7 @@ __device__ __forceinline__ void team_exchange(float mine, unsigned long long* mb
     const unsigned tag = ((epoch % 4194303u + 1u) << 10) | (seq & 1023u);
     unsigned long long* base = mb + (size_t)(seq & 1u) * CO_MAXT * CO_NV;
     if (tid < NV) mb_post(base + member * CO_NV + tid, mine, tag);
-    for (int idx = tid; idx < T * CO_NV; idx += CO_THREADS) {
+    for (int idx = tid; idx < T * CO_NV; idx += THREADS) {
         const int m = idx >> 4, i = idx & 15;
         if (i < NV) xch[m][i] = mb_wait(base + m * CO_NV + i, tag, hdr);
     }
@@ -96,7 +113,7 @@ __device__ __forceinline__ void team_exchange(float mine, unsigned long long* mb
 // Sums of NV per-thread values over the workgroup -> tot[0..NV) in LDS (fixed order: deterministic).  The per-channel
 // quantities stay in LDS and are read back (broadcast) where they are used: 8 channels x {pivot, sums, mean, scale,
 // shift, ...} as registers cost 60+ VGPRs (or as many spilled SGPRs) and with them the second resident workgroup.
-template <int NV>
+template <int NV, int THREADS>
 __device__ __forceinline__ void block_reduce_lds(float (&a)[NV], float (*red)[16], float* tot) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
@@ -110,18 +127,18 @@ __device__ __forceinline__ void block_reduce_lds(float (&a)[NV], float (*red)[16
     if (threadIdx.x < NV) {
         float t = 0.f;
 #pragma unroll
-        for (int w = 0; w < CO_WAVES; ++w) t += red[w][threadIdx.x];
+        for (int w = 0; w < THREADS / 64; ++w) t += red[w][threadIdx.x];
         tot[threadIdx.x] = t;
     }
     __syncthreads();
 }
 // tot[0..NV) of every member -> their sum in tot[0..NV) (member order: deterministic)
-template <int NV>
+template <int NV, int THREADS>
 __device__ __forceinline__ void team_sum(float* tot, unsigned long long* mb, int member, int T, unsigned& seq, unsigned epoch,
                                          CoopHdr* hdr, float (*xch)[CO_NV]) {
     if (T == 1) return;
     const float mine = threadIdx.x < NV ? tot[threadIdx.x] : 0.f;
-    team_exchange<NV>(mine, mb, member, T, seq, epoch, hdr, xch);
+    team_exchange<NV, THREADS>(mine, mb, member, T, seq, epoch, hdr, xch);
     if (threadIdx.x < NV) { float t = 0.f; for (int m = 0; m < T; ++m) t += xch[m][threadIdx.x]; tot[threadIdx.x] = t; }
     __syncthreads();
 }
@@ -136,51 +153,73 @@ __device__ __forceinline__ void coop_finish(CoopHdr* hdr, unsigned epoch) {
     }
 }
 
-template <int PPT, bool F16>
-__global__ __launch_bounds__(CO_THREADS, 4) void in_fwd_coop_kernel(const CoP p) {
-    __shared__ float red[CO_WAVES][16];
-    __shared__ float xch[CO_MAXT][CO_NV];
+// COOP = teams of resident workgroups per (n, channel group) (planes of 16K pixels and more); !COOP = ONE workgroup owns the
+// whole group of 8 planes (up to 64 x 64: THREADS x PPT >= H*W), grid = items, no mailbox, no state.
+// Inputs per launch (uniform branches): z / dy as fp32 planes (raw buffer loads, plane stride in the scalar offset) or as
+// 16-bit channel-blocked pieces (ONE 16-byte load per pixel = its 8 channels).
+template <int THREADS, int PPT, bool F16, bool COOP, bool ZC8>
+__global__ __launch_bounds__(THREADS, THREADS >= 512 ? 4 : 2) void in_fwd_c8_kernel(const CoP p) {
+    __shared__ float red[THREADS / 64][16];
+    __shared__ float xch[COOP ? CO_MAXT : 1][CO_NV];
     __shared__ float tot[16];
-    __shared__ float cst[3][8];              // mean, scale = gamma * rstd, shift = beta
+    __shared__ float cst[4][8];              // mean, scale = gamma * rstd, shift = beta, pivot
     const int tid = threadIdx.x;
-    CoopHdr* hdr = reinterpret_cast<CoopHdr*>(p.state);
-    const unsigned epoch = __hip_atomic_load(&hdr->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int team = blockIdx.x / p.T, member = blockIdx.x % p.T;
-    unsigned long long* mb = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(p.state) + CO_MAILBOX_OFF) + (size_t)team * CO_TEAM_WORDS;
+    CoopHdr* hdr = COOP ? reinterpret_cast<CoopHdr*>(p.state) : nullptr;
+    unsigned epoch = 0;
+    if constexpr (COOP) epoch = __hip_atomic_load(&hdr->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int team = COOP ? blockIdx.x / p.T : blockIdx.x, member = COOP ? blockIdx.x % p.T : 0;
+    unsigned long long* mb = COOP ? reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(p.state) + CO_MAILBOX_OFF) + (size_t)team * CO_TEAM_WORDS : nullptr;
     const int slab = p.HW / p.T;
     const float inv = 1.0f / (float)p.HW;
     unsigned seq = 0;
     for (int item = team; item < p.items; item += p.nteams) {
         const int n = item / p.G8, g = item % p.G8;
-        const float* zp = p.z + ((size_t)n * p.C + 8 * g) * p.HW;         // the 8 planes of the group
-        // raw buffer loads over the group's 8 planes: the plane stride rides in the scalar offset, so a load costs one
-        // 32-bit VGPR offset instead of a 64-bit address (the 32 addresses of a slab were half of the kernel's VGPRs)
-        const __amdgpu_buffer_rsrc_t zr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(zp), 0, 8 * p.HW * 4, 0x00020000);
-        const int plane_b = p.HW * 4;
         float v[8][PPT];
+        if constexpr (ZC8) {
+            // one 16-byte piece per pixel; padding lanes read the plane's first pixel (= the pivot)
+            const unsigned short* zg = p.z8 + ((size_t)n * p.G8 + g) * p.HW * 8;
 #pragma unroll
-        for (int k = 0; k < PPT; ++k) {
-            const int px = tid + CO_THREADS * k;
-            const int off = px < slab ? (member * slab + px) * 4 : 0;       // padding lanes read the pivot
+            for (int k = 0; k < PPT; ++k) {
+                const int px = tid + THREADS * k;
+                const size_t idx = px < slab ? (size_t)member * slab + px : 0;
+                float o[8];
+                co_unpk<F16>(*reinterpret_cast<const co_u32x4*>(zg + idx * 8), o);
 #pragma unroll
-            for (int c = 0; c < 8; ++c) v[c][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(zr, off, c * plane_b, 0));
+                for (int c = 0; c < 8; ++c) v[c][k] = o[c];
+            }
+            if (tid < 8) cst[3][tid] = F16 ? (float)reinterpret_cast<const _Float16*>(zg)[tid] : __uint_as_float((unsigned)zg[tid] << 16);
+        } else {
+            const float* zp = p.z + ((size_t)n * p.C + 8 * g) * p.HW;         // the 8 planes of the group
+            // raw buffer loads over the group's 8 planes: the plane stride rides in the scalar offset, so a load costs one
+            // 32-bit VGPR offset instead of a 64-bit address (the 32 addresses of a slab were half of the kernel's VGPRs)
+            const __amdgpu_buffer_rsrc_t zr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(zp), 0, 8 * p.HW * 4, 0x00020000);
+            const int plane_b = p.HW * 4;
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) {
+                const int px = tid + THREADS * k;
+                const int off = px < slab ? (member * slab + px) * 4 : 0;       // padding lanes read the pivot
+#pragma unroll
+                for (int c = 0; c < 8; ++c) v[c][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(zr, off, c * plane_b, 0));
+            }
+            if (tid < 8) cst[3][tid] = zp[(size_t)tid * p.HW];
         }
+        __syncthreads();
         // One pass: sums of (x - pivot) and (x - pivot)^2 with the plane's first pixel as the pivot (the same for every
         // member; a sample of the plane, so var = Q/HW - (S/HW)^2 cancels a few bits at most; padding lanes hold the pivot)
         float sq[16];
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
-            const float pv = zp[(size_t)c * p.HW];
+            const float pv = cst[3][c];
             float s = 0.f, q = 0.f;
 #pragma unroll
             for (int k = 0; k < PPT; ++k) { const float d = v[c][k] - pv; s += d; q += d * d; }
             sq[c] = s; sq[8 + c] = q;
         }
-        block_reduce_lds<16>(sq, red, tot);
-        team_sum<16>(tot, mb, member, p.T, seq, epoch, hdr, xch);
+        block_reduce_lds<16, THREADS>(sq, red, tot);
+        if constexpr (COOP) team_sum<16, THREADS>(tot, mb, member, p.T, seq, epoch, hdr, xch);
         if (tid < 8) {
             const float ms = tot[tid] * inv;
-            const float mean = zp[(size_t)tid * p.HW] + ms;
+            const float mean = cst[3][tid] + ms;
             const float rstd = 1.0f / sqrtf(fmaxf(tot[8 + tid] * inv - ms * ms, 0.f) + p.eps);
             cst[0][tid] = mean; cst[1][tid] = (p.gamma ? p.gamma[8 * g + tid] : 1.f) * rstd; cst[2][tid] = p.beta ? p.beta[8 * g + tid] : 0.f;
             if (member == 0) { p.mean[(size_t)n * p.C + 8 * g + tid] = mean; p.rstd[(size_t)n * p.C + 8 * g + tid] = rstd; }
@@ -196,7 +235,7 @@ __global__ __launch_bounds__(CO_THREADS, 4) void in_fwd_coop_kernel(const CoP p)
         float* yb = p.y ? p.y + (size_t)n * p.ybs + (size_t)(8 * g) * p.HW + (size_t)member * slab : nullptr;
 #pragma unroll
         for (int k = 0; k < PPT; ++k) {
-            const int px = tid + CO_THREADS * k;
+            const int px = tid + THREADS * k;
             if (px < slab) {
                 co_u32x4 w;
 #pragma unroll
@@ -208,39 +247,82 @@ __global__ __launch_bounds__(CO_THREADS, 4) void in_fwd_coop_kernel(const CoP p)
                 }
             }
         }
+        __syncthreads();                     // cst / tot are rewritten by the next item
     }
-    coop_finish(hdr, epoch);
+    if constexpr (COOP) coop_finish(hdr, epoch);
 }
 
-template <int PPT, bool F16>
-__global__ __launch_bounds__(CO_THREADS, 4) void in_bwd_coop_kernel(const CoP p) {
-    __shared__ float red[CO_WAVES][16];
-    __shared__ float xch[CO_MAXT][CO_NV];
+template <int THREADS, int PPT, bool F16, bool COOP, bool ZC8, int DY8>      // DY8: 0 = fp32 planar dy, 1 = 16-bit channel-blocked, 2 = that + an fp32 planar partial
+__global__ __launch_bounds__(THREADS, THREADS >= 512 ? 4 : 2) void in_bwd_c8_kernel(const CoP p) {
+    __shared__ float red[THREADS / 64][16];
+    __shared__ float xch[COOP ? CO_MAXT : 1][CO_NV];
     __shared__ float tot[16];
     __shared__ float cst[3][8];              // k = rstd * gamma, m1 = S1 / HW, m2 = S2 / HW
     const int tid = threadIdx.x;
-    CoopHdr* hdr = reinterpret_cast<CoopHdr*>(p.state);
-    const unsigned epoch = __hip_atomic_load(&hdr->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int team = blockIdx.x / p.T, member = blockIdx.x % p.T;
-    unsigned long long* mb = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(p.state) + CO_MAILBOX_OFF) + (size_t)team * CO_TEAM_WORDS;
+    CoopHdr* hdr = COOP ? reinterpret_cast<CoopHdr*>(p.state) : nullptr;
+    unsigned epoch = 0;
+    if constexpr (COOP) epoch = __hip_atomic_load(&hdr->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int team = COOP ? blockIdx.x / p.T : blockIdx.x, member = COOP ? blockIdx.x % p.T : 0;
+    unsigned long long* mb = COOP ? reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(p.state) + CO_MAILBOX_OFF) + (size_t)team * CO_TEAM_WORDS : nullptr;
     const int slab = p.HW / p.T;
     const float inv = 1.0f / (float)p.HW;
     unsigned seq = 0;
     for (int item = team; item < p.items; item += p.nteams) {
         const int n = item / p.G8, g = item % p.G8;
         const size_t plane0 = (size_t)n * p.C + 8 * g;
-        const __amdgpu_buffer_rsrc_t zr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.z + plane0 * p.HW), 0, 8 * p.HW * 4, 0x00020000);
-        const __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dy + (size_t)n * p.dybs + (size_t)(8 * g) * p.HW), 0, 8 * p.HW * 4, 0x00020000);
         const int plane_b = p.HW * 4;
         float xh[8][PPT], gy[8][PPT];
+        // out-of-slab lanes: offsets past the buffer, the bounds check returns 0
+        if constexpr (ZC8) {
+            const __amdgpu_buffer_rsrc_t zr = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.z8 + ((size_t)n * p.G8 + g) * p.HW * 8), 0, p.HW * 16, 0x00020000);
 #pragma unroll
-        for (int k = 0; k < PPT; ++k) {
-            const int px = tid + CO_THREADS * k;
-            const int off = px < slab ? (member * slab + px) * 4 : 0x7ffffff0;      // out of range: the bounds check returns 0
+            for (int k = 0; k < PPT; ++k) {
+                const int px = tid + THREADS * k;
+                const int off = px < slab ? (member * slab + px) * 16 : 0x7ffffff0;
+                float o[8];
+                co_unpk<F16>(__builtin_bit_cast(co_u32x4, __builtin_amdgcn_raw_buffer_load_b128(zr, off, 0, 0)), o);
 #pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                xh[c][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(zr, off, c * plane_b, 0));
-                gy[c][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(gr, off, c * plane_b, 0));
+                for (int c = 0; c < 8; ++c) xh[c][k] = o[c];
+            }
+        } else {
+            const __amdgpu_buffer_rsrc_t zr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.z + plane0 * p.HW), 0, 8 * p.HW * 4, 0x00020000);
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) {
+                const int px = tid + THREADS * k;
+                const int off = px < slab ? (member * slab + px) * 4 : 0x7ffffff0;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) xh[c][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(zr, off, c * plane_b, 0));
+            }
+        }
+        if constexpr (DY8 != 0) {
+            const __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.dy8 + (size_t)n * p.dy8bs + (size_t)g * p.HW * 8), 0, p.HW * 16, 0x00020000);
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) {
+                const int px = tid + THREADS * k;
+                const int off = px < slab ? (member * slab + px) * 16 : 0x7ffffff0;
+                float o[8];
+                co_unpk<F16>(__builtin_bit_cast(co_u32x4, __builtin_amdgcn_raw_buffer_load_b128(gr, off, 0, 0)), o);
+#pragma unroll
+                for (int c = 0; c < 8; ++c) gy[c][k] = o[c];
+            }
+            if constexpr (DY8 == 2) {        // the fp32 planar partial from the tensor's other readers (pool / ConvT / 1x1 backward)
+                const __amdgpu_buffer_rsrc_t er = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dyx + plane0 * p.HW), 0, 8 * p.HW * 4, 0x00020000);
+#pragma unroll
+                for (int k = 0; k < PPT; ++k) {
+                    const int px = tid + THREADS * k;
+                    const int off = px < slab ? (member * slab + px) * 4 : 0x7ffffff0;
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) gy[c][k] += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(er, off, c * plane_b, 0));
+                }
+            }
+        } else {
+            const __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dy + (size_t)n * p.dybs + (size_t)(8 * g) * p.HW), 0, 8 * p.HW * 4, 0x00020000);
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) {
+                const int px = tid + THREADS * k;
+                const int off = px < slab ? (member * slab + px) * 4 : 0x7ffffff0;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) gy[c][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(gr, off, c * plane_b, 0));
             }
         }
         float ss[16];
@@ -251,7 +333,7 @@ __global__ __launch_bounds__(CO_THREADS, 4) void in_bwd_coop_kernel(const CoP p)
             float s1 = 0.f, s2 = 0.f;
 #pragma unroll
             for (int k = 0; k < PPT; ++k) {
-                const bool ok = tid + CO_THREADS * k < slab;
+                const bool ok = tid + THREADS * k < slab;
                 const float x = ok ? (xh[c][k] - mean) * rstd : 0.f;
                 const float y = gy[c][k] * ((x * ga + be) > 0.f ? 1.f : p.slope);
                 xh[c][k] = x; gy[c][k] = y;
@@ -259,8 +341,8 @@ __global__ __launch_bounds__(CO_THREADS, 4) void in_bwd_coop_kernel(const CoP p)
             }
             ss[c] = s1; ss[8 + c] = s2;
         }
-        block_reduce_lds<16>(ss, red, tot);
-        team_sum<16>(tot, mb, member, p.T, seq, epoch, hdr, xch);
+        block_reduce_lds<16, THREADS>(ss, red, tot);
+        if constexpr (COOP) team_sum<16, THREADS>(tot, mb, member, p.T, seq, epoch, hdr, xch);
         if (tid < 8) {
             cst[0][tid] = p.rstd[plane0 + tid] * (p.gamma ? p.gamma[8 * g + tid] : 1.f);
             cst[1][tid] = tot[tid] * inv; cst[2][tid] = tot[8 + tid] * inv;
@@ -274,7 +356,7 @@ __global__ __launch_bounds__(CO_THREADS, 4) void in_bwd_coop_kernel(const CoP p)
             float t = 0.f;
 #pragma unroll
             for (int k = 0; k < PPT; ++k) {
-                const float o = (tid + CO_THREADS * k < slab) ? kk * (gy[c][k] - m1 - xh[c][k] * m2) : 0.f;
+                const float o = (tid + THREADS * k < slab) ? kk * (gy[c][k] - m1 - xh[c][k] * m2) : 0.f;
                 gy[c][k] = o; t += o;
             }
             s3[c] = t;
@@ -282,7 +364,7 @@ __global__ __launch_bounds__(CO_THREADS, 4) void in_bwd_coop_kernel(const CoP p)
         unsigned short* ob = p.dz8 + (((size_t)n * p.G8 + g) * p.HW + (size_t)member * slab) * 8;
 #pragma unroll
         for (int k = 0; k < PPT; ++k) {
-            const int px = tid + CO_THREADS * k;
+            const int px = tid + THREADS * k;
             if (px < slab) {
                 co_u32x4 w;
 #pragma unroll
@@ -291,11 +373,12 @@ __global__ __launch_bounds__(CO_THREADS, 4) void in_bwd_coop_kernel(const CoP p)
             }
         }
         if (p.part) {       // every member's share of sum dz; in_dparam_kernel adds them up (no second exchange)
-            block_reduce_lds<8>(s3, red, tot);
+            block_reduce_lds<8, THREADS>(s3, red, tot);
             if (tid < 8) p.part3[(plane0 + tid) * p.T + member] = tot[tid];
         }
+        __syncthreads();                     // cst / tot are rewritten by the next item
     }
-    coop_finish(hdr, epoch);
+    if constexpr (COOP) coop_finish(hdr, epoch);
 }
 
 struct CoPlan { bool ok; int ppt, T, grid, nteams; };
@@ -345,37 +428,67 @@ CoPlan plan_coop(int items, int HW, int max_ppt, const int* cap_by_ppt, int rese
 }
 int fill_coop(const mtbc_instnorm_args* a, CoP* p) {
     if (!a || a->N <= 0 || a->C <= 0 || a->H <= 0 || a->W <= 0) return MTBC_E_BADSHAPE;
-    if (a->C % 8 || (a->out16_type != 1 && a->out16_type != 2) || !a->coop_state) return MTBC_E_BADARG;
+    if (a->C % 8 || (a->out16_type != 1 && a->out16_type != 2)) return MTBC_E_BADARG;
+    if ((a->z_layout != MTBC_LAYOUT_PLANAR && a->z_layout != MTBC_LAYOUT_C8) || (a->dy_layout != MTBC_LAYOUT_PLANAR && a->dy_layout != MTBC_LAYOUT_C8)) return MTBC_E_BADARG;
     p->N = a->N; p->C = a->C; p->HW = a->H * a->W; p->G8 = a->C / 8; p->items = a->N * p->G8; p->f16 = a->out16_type == 2;
     p->eps = a->eps; p->slope = a->slope; p->z = a->z; p->gamma = a->gamma; p->beta = a->beta; p->y = a->y; p->ybs = a->y_batch_stride;
     p->y8 = reinterpret_cast<unsigned short*>(a->y8); p->mean = a->mean; p->rstd = a->rstd; p->dy = a->dy; p->dybs = a->dy_batch_stride;
     p->dz8 = reinterpret_cast<unsigned short*>(a->dz8); p->part = nullptr; p->part3 = nullptr; p->state = a->coop_state;
+    p->z8 = nullptr; p->dy8 = nullptr; p->dy8bs = 0; p->dyx = nullptr;
+    if (a->z_layout == MTBC_LAYOUT_C8) {
+        if (reinterpret_cast<uintptr_t>(a->z) & 15) return MTBC_E_BADARG;
+        p->z8 = reinterpret_cast<const unsigned short*>(a->z); p->z = nullptr;
+    }
     return MTBC_OK;
 }
-// Resident capacity per (pixels per thread, output type): the bf16 and fp16 instantiations are different kernels with
-// their own register counts, so each launch is planned with the capacity of the variant it runs.  Filled once
-// (function-local statics: thread-safe initialisation, immutable afterwards).
-struct CapTable { int cap[2][9]; };
-const CapTable& caps_fwd() {
-    static const CapTable t = [] { CapTable c{};
-        c.cap[0][1] = resident_blocks(in_fwd_coop_kernel<1, false>); c.cap[0][2] = resident_blocks(in_fwd_coop_kernel<2, false>);
-        c.cap[0][4] = resident_blocks(in_fwd_coop_kernel<4, false>);
-        c.cap[1][1] = resident_blocks(in_fwd_coop_kernel<1, true>); c.cap[1][2] = resident_blocks(in_fwd_coop_kernel<2, true>);
-        c.cap[1][4] = resident_blocks(in_fwd_coop_kernel<4, true>);      // 8 pixels per thread spill at 4 waves/SIMD: not built
-        return c; }();
-    return t;
+// One workgroup per (n, channel group): planes up to 64 x 64
+constexpr int SOLO_MAX_HW = 4096;
+// Resident capacity per kernel instantiation (the bf16 and fp16 variants have their own register counts): one occupancy
+// query each, cached in a function-local static (thread-safe initialisation, immutable afterwards).
+template <auto K> int cap_of() { static const int c = resident_blocks(K); return c; }
+// the variant a launch runs: (output type, z layout, dy layout)
+struct Var { bool f16, zc8; int dy8; };
+template <bool BWD, int THREADS, int PPT, bool COOP, bool F16, bool ZC8, int DY8> constexpr auto kernel_of() {
+    if constexpr (BWD) return &in_bwd_c8_kernel<THREADS, PPT, F16, COOP, ZC8, DY8>;
+    else return &in_fwd_c8_kernel<THREADS, PPT, F16, COOP, ZC8>;
 }
-const CapTable& caps_bwd() {
-    static const CapTable t = [] { CapTable c{};
-        c.cap[0][1] = resident_blocks(in_bwd_coop_kernel<1, false>); c.cap[0][2] = resident_blocks(in_bwd_coop_kernel<2, false>);
-        c.cap[0][4] = resident_blocks(in_bwd_coop_kernel<4, false>);
-        c.cap[1][1] = resident_blocks(in_bwd_coop_kernel<1, true>); c.cap[1][2] = resident_blocks(in_bwd_coop_kernel<2, true>);
-        c.cap[1][4] = resident_blocks(in_bwd_coop_kernel<4, true>);
-        return c; }();
-    return t;
+// calls f(kernel pointer as a compile-time constant) for the variant `v`
+template <bool BWD, int THREADS, int PPT, bool COOP, typename F> auto with_kernel(const Var& v, F&& f) {
+#define MTBC_V(F16_, Z_, D_) f(std::integral_constant<decltype(kernel_of<BWD, THREADS, PPT, COOP, F16_, Z_, D_>()), kernel_of<BWD, THREADS, PPT, COOP, F16_, Z_, D_>()>{})
+    const int d = BWD ? v.dy8 : 0;
+#define MTBC_VD(F16_, Z_) (d == 2 ? MTBC_V(F16_, Z_, 2) : d == 1 ? MTBC_V(F16_, Z_, 1) : MTBC_V(F16_, Z_, 0))
+    if (v.f16) return v.zc8 ? MTBC_VD(true, true) : MTBC_VD(true, false);
+    return v.zc8 ? MTBC_VD(false, true) : MTBC_VD(false, false);
+#undef MTBC_VD
+#undef MTBC_V
 }
-CoPlan plan_fwd(int items, int HW, bool f16, int reserve) { return plan_coop(items, HW, 4, caps_fwd().cap[f16 ? 1 : 0], reserve); }
-CoPlan plan_bwd(int items, int HW, bool f16, int reserve) { return plan_coop(items, HW, 4, caps_bwd().cap[f16 ? 1 : 0], reserve); }
+template <bool BWD, int PPT> int cap_ppt(const Var& v) { return with_kernel<BWD, CO_THREADS, PPT, true>(v, [](auto k) { return cap_of<decltype(k)::value>(); }); }
+template <bool BWD> CoPlan plan_team(int items, int HW, const Var& v, int reserve) {
+    int cap[9] = {0};
+    cap[1] = cap_ppt<BWD, 1>(v); cap[2] = cap_ppt<BWD, 2>(v); cap[4] = cap_ppt<BWD, 4>(v);      // 8 pixels per thread spill at 4 waves/SIMD: not built
+    return plan_coop(items, HW, 4, cap, reserve);
+}
+Var var_of(const mtbc_instnorm_args* a) { return Var{a->out16_type == 2, a->z_layout == MTBC_LAYOUT_C8, a->dy_layout == MTBC_LAYOUT_C8 ? (a->n_dy_extra ? 2 : 1) : 0}; }
+
+template <bool BWD, int THREADS, int PPT, bool COOP>
+void launch_c8(const CoP& p, int grid, hipStream_t st) {
+    const Var v{p.f16 != 0, p.z8 != nullptr, p.dy8 ? (p.dyx ? 2 : 1) : 0};
+    with_kernel<BWD, THREADS, PPT, COOP>(v, [&](auto k) { hipLaunchKernelGGL(decltype(k)::value, dim3(grid), dim3(THREADS), 0, st, p); return 0; });
+}
+// one workgroup per item, sized to the plane
+template <bool BWD> void launch_solo(CoP& p, hipStream_t st) {
+    p.T = 1; p.nteams = p.items;
+    if (p.HW <= 64) launch_c8<BWD, 64, 1, false>(p, p.items, st);
+    else if (p.HW <= 256) launch_c8<BWD, 256, 1, false>(p, p.items, st);
+    else if (p.HW <= 1024) launch_c8<BWD, 256, 4, false>(p, p.items, st);
+    else launch_c8<BWD, 1024, 4, false>(p, p.items, st);
+}
+template <bool BWD> void launch_team(CoP& p, const CoPlan& pl, hipStream_t st) {
+    p.T = pl.T; p.nteams = pl.nteams;
+    if (pl.ppt == 4) launch_c8<BWD, CO_THREADS, 4, true>(p, pl.grid, st);
+    else if (pl.ppt == 2) launch_c8<BWD, CO_THREADS, 2, true>(p, pl.grid, st);
+    else launch_c8<BWD, CO_THREADS, 1, true>(p, pl.grid, st);
+}
 
 }  // namespace
 
@@ -387,25 +500,21 @@ size_t mtbc_instnorm_coop_state_bytes(void) { return CO_MAILBOX_OFF + (size_t)CO
 
 int mtbc_instnorm_c8_supported(const mtbc_instnorm_args* a, int32_t backward) {
     if (!a || a->N <= 0 || a->C <= 0 || a->H <= 0 || a->W <= 0 || a->C % 8) return 0;
-    if (backward && a->n_dy_extra != 0) return 0;
-    const bool f16 = a->out16_type == 2;
-    const CoPlan pl = backward ? plan_bwd(a->N * (a->C / 8), a->H * a->W, f16, a->coop_reserve_cus)
-                               : plan_fwd(a->N * (a->C / 8), a->H * a->W, f16, a->coop_reserve_cus);
+    if (backward && a->n_dy_extra != 0 && !(a->dy_layout == MTBC_LAYOUT_C8 && a->n_dy_extra == 1)) return 0;
+    if (a->H * a->W <= SOLO_MAX_HW) return 1;
+    const CoPlan pl = backward ? plan_team<true>(a->N * (a->C / 8), a->H * a->W, var_of(a), a->coop_reserve_cus)
+                               : plan_team<false>(a->N * (a->C / 8), a->H * a->W, var_of(a), a->coop_reserve_cus);
     return pl.ok ? 1 : 0;
 }
 
 int mtbc_i_instnorm_fwd_c8(const mtbc_instnorm_args* a, hipStream_t st) {
     CoP p; int rc = fill_coop(a, &p); if (rc) return rc;
-    if (!p.z || !p.y8 || !p.mean || !p.rstd || (reinterpret_cast<uintptr_t>(p.y8) & 15)) return MTBC_E_BADARG;
-    const CoPlan pl = plan_fwd(p.items, p.HW, p.f16 != 0, a->coop_reserve_cus);
+    if ((!p.z && !p.z8) || !p.y8 || !p.mean || !p.rstd || (reinterpret_cast<uintptr_t>(p.y8) & 15)) return MTBC_E_BADARG;
+    if (p.HW <= SOLO_MAX_HW) { launch_solo<false>(p, st); MTBC_CHECK_LAUNCH(); return MTBC_OK; }
+    if (!p.state) return MTBC_E_BADARG;
+    const CoPlan pl = plan_team<false>(p.items, p.HW, var_of(a), a->coop_reserve_cus);
     if (!pl.ok) return MTBC_E_UNSUPPORTED;
-    p.T = pl.T; p.nteams = pl.nteams;
-    const dim3 g(pl.grid), b(CO_THREADS);
-#define MTBC_CO_F(PPT_)                                                                                  \
-    do { if (p.f16) hipLaunchKernelGGL((in_fwd_coop_kernel<PPT_, true>), g, b, 0, st, p);                \
-         else hipLaunchKernelGGL((in_fwd_coop_kernel<PPT_, false>), g, b, 0, st, p); } while (0)
-    if (pl.ppt == 4) MTBC_CO_F(4); else if (pl.ppt == 2) MTBC_CO_F(2); else MTBC_CO_F(1);
-#undef MTBC_CO_F
+    launch_team<false>(p, pl, st);
     MTBC_CHECK_LAUNCH();
     return MTBC_OK;
 }
@@ -413,21 +522,28 @@ int mtbc_i_instnorm_fwd_c8(const mtbc_instnorm_args* a, hipStream_t st) {
 // members per team of the backward launch (the parameter-gradient partials are [N*C][3] + [N*C][T] floats)
 int mtbc_i_instnorm_bwd_c8_team(const mtbc_instnorm_args* a) {
     if (!a || a->N <= 0 || a->C <= 0 || a->C % 8) return 0;
-    const CoPlan pl = plan_bwd(a->N * (a->C / 8), a->H * a->W, a->out16_type == 2, a->coop_reserve_cus);
+    if (a->H * a->W <= SOLO_MAX_HW) return 1;
+    const CoPlan pl = plan_team<true>(a->N * (a->C / 8), a->H * a->W, var_of(a), a->coop_reserve_cus);
     return pl.ok ? pl.T : 0;
 }
 int mtbc_i_instnorm_bwd_c8(const mtbc_instnorm_args* a, float* part, hipStream_t st) {
     CoP p; int rc = fill_coop(a, &p); if (rc) return rc;
-    if (!p.z || !p.dy || !p.dz8 || !p.mean || !p.rstd || (reinterpret_cast<uintptr_t>(p.dz8) & 15) || a->n_dy_extra != 0) return MTBC_E_BADARG;
-    const CoPlan pl = plan_bwd(p.items, p.HW, p.f16 != 0, a->coop_reserve_cus);
+    if ((!p.z && !p.z8) || !p.dy || !p.dz8 || !p.mean || !p.rstd || (reinterpret_cast<uintptr_t>(p.dz8) & 15)) return MTBC_E_BADARG;
+    if (a->dy_layout == MTBC_LAYOUT_C8) {
+        if ((reinterpret_cast<uintptr_t>(a->dy) & 15) || a->dy_batch_stride % 8 || a->n_dy_extra < 0 || a->n_dy_extra > 1) return MTBC_E_BADARG;
+        p.dy8 = reinterpret_cast<const unsigned short*>(a->dy); p.dy8bs = a->dy_batch_stride; p.dy = nullptr;
+        if (a->n_dy_extra == 1) { if (!a->dy_extra[0]) return MTBC_E_BADARG; p.dyx = a->dy_extra[0]; }
+    } else if (a->n_dy_extra != 0) return MTBC_E_BADARG;
+    p.part = part;
+    if (p.HW <= SOLO_MAX_HW) {
+        p.part3 = part ? part + (size_t)3 * a->N * a->C : nullptr;
+        launch_solo<true>(p, st); MTBC_CHECK_LAUNCH(); return MTBC_OK;
+    }
+    if (!p.state) return MTBC_E_BADARG;
+    const CoPlan pl = plan_team<true>(p.items, p.HW, var_of(a), a->coop_reserve_cus);
     if (!pl.ok) return MTBC_E_UNSUPPORTED;
-    p.T = pl.T; p.nteams = pl.nteams; p.part = part; p.part3 = part ? part + (size_t)3 * a->N * a->C : nullptr;
-    const dim3 g(pl.grid), b(CO_THREADS);
-#define MTBC_CO_B(PPT_)                                                                                  \
-    do { if (p.f16) hipLaunchKernelGGL((in_bwd_coop_kernel<PPT_, true>), g, b, 0, st, p);                \
-         else hipLaunchKernelGGL((in_bwd_coop_kernel<PPT_, false>), g, b, 0, st, p); } while (0)
-    if (pl.ppt == 4) MTBC_CO_B(4); else if (pl.ppt == 2) MTBC_CO_B(2); else MTBC_CO_B(1);
-#undef MTBC_CO_B
+    p.part3 = part ? part + (size_t)3 * a->N * a->C : nullptr;
+    launch_team<true>(p, pl, st);
     MTBC_CHECK_LAUNCH();
     return MTBC_OK;
 }

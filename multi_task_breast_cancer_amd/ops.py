@@ -186,23 +186,40 @@ def _fill_segs_c8(arr, tensors: Sequence["C8"]):
         arr[i].accumulate = 0
 
 
-def conv3x3_fwd_c8(xs: Sequence["C8"], w: torch.Tensor, bias: Optional[torch.Tensor], packed: torch.Tensor) -> torch.Tensor:
-    """z (fp32 planar) = conv3x3(concat(xs)) with the inputs already in the MFMA's 16-bit channel-blocked layout."""
+def conv3x3_fwd_c8(xs: Sequence["C8"], w: torch.Tensor, bias: Optional[torch.Tensor], packed: torch.Tensor, out_c8: bool = False):
+    """z = conv3x3(concat(xs)) with the inputs already in the MFMA's 16-bit channel-blocked layout; z comes back as fp32
+    planes, or (out_c8, `out_layout = C8` of the C-ABI) as a channel-blocked 16-bit tensor of the inputs' type."""
     _chk(w, bias)
     N, _, H, W = xs[0].shape
     a = L.Conv3x3Args()
     a.N, a.H, a.W, a.Cin, a.Cout, a.n_in = N, H, W, sum(x.shape[1] for x in xs), w.shape[0], len(xs)
     _fill_segs_c8(a.in_, xs)
-    out = torch.empty(N, w.shape[0], H, W, dtype=torch.float32, device=w.device)
+    if out_c8:
+        out = torch.empty(N, w.shape[0] // 8, H * W, 8, dtype=torch.int16, device=w.device)
+        a.out_layout = L.LAYOUT_C8
+    else:
+        out = torch.empty(N, w.shape[0], H, W, dtype=torch.float32, device=w.device)
     a.w, a.w_packed, a.bias, a.out = w.data_ptr(), packed.data_ptr(), _p(bias), out.data_ptr()
     a.compute, a.operand_layout = xs[0].compute, L.LAYOUT_C8
     L.check(L.load().mtbc_conv3x3_fwd(C.byref(a), _s()), "conv3x3_fwd(c8)")
-    return out
+    return C8(out, (N, w.shape[0], H, W), xs[0].compute) if out_c8 else out
 
 
 def conv3x3_dgrad_c8(dz: "C8", w: torch.Tensor, dxs: Sequence[torch.Tensor], accumulate: Sequence[int], packed: torch.Tensor) -> None:
     """dx segments (fp32 planar, accumulate honoured; accumulate 2 = the segment is an int16 (N,C,H,W) tensor written as
     16-bit planar values of dz's type) from dz in the 16-bit channel-blocked layout."""
+    if any(isinstance(d, C8) for d in dxs):       # accumulate = 3: channel-blocked 16-bit segments (all of them)
+        N, _, H, W = dz.shape
+        a = L.Conv3x3Args()
+        a.N, a.H, a.W, a.Cin, a.Cout, a.n_in = N, H, W, sum(d.shape[1] for d in dxs), w.shape[0], len(dxs)
+        a.w = w.data_ptr()
+        _fill_segs_c8(a.in_, dxs)
+        for i in range(len(dxs)):
+            a.in_[i].accumulate = 3
+        a.w_packed, a.dout = packed.data_ptr(), dz.data.data_ptr()
+        a.compute, a.operand_layout = dz.compute, L.LAYOUT_C8
+        L.check(L.load().mtbc_conv3x3_dgrad(C.byref(a), _s()), "conv3x3_dgrad(c8 -> c8)")
+        return
     _chk(w, *[d for i, d in enumerate(dxs) if not (i < len(accumulate) and accumulate[i] == 2)])
     N, _, H, W = dz.shape
     a = _conv_args(dxs, w, N, H, W)
@@ -289,36 +306,57 @@ def coop_state(dev) -> torch.Tensor:
 
 
 def instnorm_lrelu_fwd_c8(z, gamma=None, beta=None, eps=1e-5, slope=0.01, compute: int = 1, want_planar: bool = False):
-    """InstanceNorm + LeakyReLU straight into the 16-bit channel-blocked layout (y8 of the C-ABI)."""
-    _chk(z, gamma, beta)
+    """InstanceNorm + LeakyReLU straight into the 16-bit channel-blocked layout (y8 of the C-ABI).  z: fp32 planes, or a
+    C8 tensor (z_layout = C8: the conv output of the 16-bit modes)."""
+    z8 = z if isinstance(z, C8) else None
+    if z8 is not None:
+        compute, zt = z8.compute, z8.data
+    else:
+        zt = z
+    _chk(zt if z8 is None else None, gamma, beta)
     N, Cc, H, W = z.shape
-    y8 = torch.empty(N, Cc // 8, H * W, 8, dtype=torch.int16, device=z.device)
-    y = torch.empty_like(z) if want_planar else None
-    mean = torch.empty(N * Cc, dtype=torch.float32, device=z.device)
+    dev = zt.device
+    y8 = torch.empty(N, Cc // 8, H * W, 8, dtype=torch.int16, device=dev)
+    y = torch.empty(N, Cc, H, W, dtype=torch.float32, device=dev) if want_planar else None
+    mean = torch.empty(N * Cc, dtype=torch.float32, device=dev)
     rstd = torch.empty_like(mean)
     a = L.InstNormArgs()
     a.N, a.C, a.H, a.W, a.eps, a.slope = N, Cc, H, W, eps, slope
-    a.z, a.gamma, a.beta, a.y, a.y_batch_stride = z.data_ptr(), _p(gamma), _p(beta), _p(y), Cc * H * W
+    a.z, a.gamma, a.beta, a.y, a.y_batch_stride = zt.data_ptr(), _p(gamma), _p(beta), _p(y), Cc * H * W
+    a.z_layout = L.LAYOUT_C8 if z8 is not None else L.LAYOUT_PLANAR
     a.mean, a.rstd = mean.data_ptr(), rstd.data_ptr()
-    a.y8, a.out16_type, a.coop_state = y8.data_ptr(), compute, coop_state(z.device).data_ptr()
+    a.y8, a.out16_type, a.coop_state = y8.data_ptr(), compute, coop_state(dev).data_ptr()
     if not L.load().mtbc_instnorm_c8_supported(C.byref(a), 0):
         raise L.MtbcError("instnorm_fwd: shape not supported with a channel-blocked output")
     L.check(L.load().mtbc_instnorm_lrelu_fwd(C.byref(a), _s()), "instnorm_fwd(c8)")
     return C8(y8, z.shape, compute), mean, rstd, y
 
 
-def instnorm_lrelu_bwd_c8(z, dy, mean, rstd, gamma=None, beta=None, eps=1e-5, slope=0.01, dbias_pre=None, compute: int = 1):
-    _chk(z, dy, mean, rstd, gamma, beta, dbias_pre)
+def instnorm_lrelu_bwd_c8(z, dy, mean, rstd, gamma=None, beta=None, eps=1e-5, slope=0.01, dbias_pre=None, compute: int = 1,
+                          dy_extra: Optional[torch.Tensor] = None):
+    """z / dy: fp32 planes or C8 tensors (z_layout / dy_layout = C8); dy_extra (with a C8 dy only): an fp32 planar partial
+    gradient added while loading."""
+    zt = z.data if isinstance(z, C8) else z
+    dyt = dy.data if isinstance(dy, C8) else dy
+    if isinstance(z, C8):
+        compute = z.compute
+    _chk(mean, rstd, gamma, beta, dbias_pre, dy_extra)
     N, Cc, H, W = z.shape
-    dz8 = torch.empty(N, Cc // 8, H * W, 8, dtype=torch.int16, device=z.device)
-    dg = torch.empty(Cc, dtype=torch.float32, device=z.device) if gamma is not None else None
-    db = torch.empty(Cc, dtype=torch.float32, device=z.device) if gamma is not None else None
-    ws = _ws(N * Cc * 131 * 4, z.device)
+    dev = zt.device
+    dz8 = torch.empty(N, Cc // 8, H * W, 8, dtype=torch.int16, device=dev)
+    dg = torch.empty(Cc, dtype=torch.float32, device=dev) if gamma is not None else None
+    db = torch.empty(Cc, dtype=torch.float32, device=dev) if gamma is not None else None
+    ws = _ws(N * Cc * 131 * 4, dev)
     a = L.InstNormArgs()
     a.N, a.C, a.H, a.W, a.eps, a.slope = N, Cc, H, W, eps, slope
-    a.z, a.gamma, a.beta, a.mean, a.rstd = z.data_ptr(), _p(gamma), _p(beta), mean.data_ptr(), rstd.data_ptr()
-    a.dy, a.dy_batch_stride, a.dgamma, a.dbeta, a.dbias_pre = dy.data_ptr(), Cc * H * W, _p(dg), _p(db), _p(dbias_pre)
-    a.dz8, a.out16_type, a.coop_state = dz8.data_ptr(), compute, coop_state(z.device).data_ptr()
+    a.z, a.gamma, a.beta, a.mean, a.rstd = zt.data_ptr(), _p(gamma), _p(beta), mean.data_ptr(), rstd.data_ptr()
+    a.dy, a.dy_batch_stride, a.dgamma, a.dbeta, a.dbias_pre = dyt.data_ptr(), Cc * H * W, _p(dg), _p(db), _p(dbias_pre)
+    a.z_layout = L.LAYOUT_C8 if isinstance(z, C8) else L.LAYOUT_PLANAR
+    a.dy_layout = L.LAYOUT_C8 if isinstance(dy, C8) else L.LAYOUT_PLANAR
+    if dy_extra is not None:
+        a.n_dy_extra = 1
+        a.dy_extra[0] = dy_extra.data_ptr()
+    a.dz8, a.out16_type, a.coop_state = dz8.data_ptr(), compute, coop_state(dev).data_ptr()
     a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel() * 4
     if not L.load().mtbc_instnorm_c8_supported(C.byref(a), 1):
         raise L.MtbcError("instnorm_bwd: shape not supported with a channel-blocked output")

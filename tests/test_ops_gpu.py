@@ -752,3 +752,90 @@ def test_convT_backward_reads_16bit_planar_dy(N, Cin, Cout, H, W, compute):
     r = lambda t: t.to(dt).double()
     want = F.conv2d(dy.cpu().double(), r(w.cpu()), stride=2)
     assert (dx.cpu().double() - want).abs().max().item() <= 1e-5 * max(1.0, want.abs().max().item())
+
+
+@pytest.mark.parametrize("compute", [1, 2])
+@pytest.mark.parametrize("N,segs,Cout,H,W", C8_CASES + [(2, [24, 24, 24, 24, 24, 24], 24, 256, 256), (16, [24, 24], 24, 256, 256),
+                                                        (1, [384, 384, 384], 512, 16, 16), (2, [192], 192, 32, 32)])
+def test_conv3x3_channel_blocked_16bit_output_is_the_rounded_fp32_output(N, segs, Cout, H, W, compute):
+    """out_layout = C8 (forward) / segment mode 3 (dgrad): the conv output / input gradient of the 16-bit modes stored as a
+    channel-blocked 16-bit tensor = the fp32 planar result of the same launch, + bias, rounded once (RNE) -- the MFMAs only
+    run transposed (channels on the rows)."""
+    if Cout % 8:
+        pytest.skip("channel-blocked outputs hold multiples of 8 channels")
+    g = _g(N * 53 + Cout + H + compute)
+    Cin = sum(segs)
+    xs = [torch.randn(N, c, H, W, generator=g) for c in segs]
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (9 * Cin)) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    dz = torch.randn(N, Cout, H, W, generator=g)
+    xd = [x.to(DEV) for x in xs]
+    wd, bd, dzd = w.to(DEV), b.to(DEV), dz.to(DEV)
+    pf, pd = ops.conv3x3_pack_lp(wd, compute)
+    x8 = [ops.C8.pack(x, compute) for x in xd]
+    dz8 = ops.C8.pack(dzd, compute)
+    z = ops.conv3x3_fwd_c8(x8, wd, bd, pf)
+    z8 = ops.conv3x3_fwd_c8(x8, wd, bd, pf, out_c8=True)
+    assert z8.data.shape == (N, Cout // 8, H * W, 8)
+    want = ops.C8.pack(z, compute)
+    assert torch.equal(z8.data, want.data), f"fwd: {(z8.unpack() - want.unpack()).abs().max().item():.3e}"
+    if all(c % 8 == 0 for c in segs):
+        d32 = [torch.empty(N, c, H, W, device=DEV) for c in segs]
+        ops.conv3x3_dgrad_c8(dz8, wd, d32, [0] * len(segs), pd)
+        d8 = [ops.C8(torch.empty(N, c // 8, H * W, 8, dtype=torch.int16, device=DEV), (N, c, H, W), compute) for c in segs]
+        ops.conv3x3_dgrad_c8(dz8, wd, d8, [3] * len(segs), pd)
+        for i in range(len(segs)):
+            assert torch.equal(d8[i].data, ops.C8.pack(d32[i], compute).data), f"dgrad seg {i}"
+
+
+@pytest.mark.parametrize("compute", [1, 2])
+@pytest.mark.parametrize("N,C,H,W,affine", [(2, 24, 256, 256, True), (3, 48, 128, 128, True), (2, 96, 64, 64, False), (5, 16, 32, 32, True),
+                                            (2, 8, 16, 16, True), (3, 8, 8, 8, False), (2, 16, 24, 40, True), (1, 24, 96, 96, True)])
+def test_instnorm_on_channel_blocked_16bit_inputs(N, C, H, W, affine, compute):
+    """z_layout / dy_layout = C8: InstanceNorm + LeakyReLU forward / backward reading the conv output (and the gradient)
+    as 16-bit channel-blocked tensors = the same kernels on the unpacked fp32 planes (the statistics are those of the stored
+    values): bit for bit where one workgroup owns a plane group; the cooperative kernels may split a plane differently per
+    variant (team size follows the variant's register count), so there to fp32 re-association / one 16-bit ulp.  A planar
+    fp32 partial gradient (dy_extra) is added in fp32 while loading."""
+    g = _g(N + C + H + 7 * compute)
+    z = (torch.randn(N, C, H, W, generator=g) * 2 + 0.5).to(DEV)
+    dy = torch.randn(N, C, H, W, generator=g).to(DEV)
+    ex = torch.randn(N, C, H, W, generator=g).to(DEV)
+    gamma = (torch.rand(C, generator=g) + 0.5).to(DEV) if affine else None
+    beta = (torch.randn(C, generator=g) * 0.1).to(DEV) if affine else None
+    z8, dy8 = ops.C8.pack(z, compute), ops.C8.pack(dy, compute)
+    zr, dyr = z8.unpack(), dy8.unpack()
+    ya, mean_a, rstd_a, ypa = ops.instnorm_lrelu_fwd_c8(zr, gamma, beta, slope=0.1, compute=compute, want_planar=True)
+    yb, mean_b, rstd_b, ypb = ops.instnorm_lrelu_fwd_c8(z8, gamma, beta, slope=0.1, want_planar=True)
+    solo = H * W <= 4096
+    ulp = 2.0 ** -7 if compute == 1 else 2.0 ** -10
+
+    def same8(a8, b8, exact=solo):
+        if exact:
+            return torch.equal(a8.data, b8.data)
+        a_, b_ = a8.unpack(), b8.unpack()
+        return bool(((a_ - b_).abs() <= ulp * b_.abs() + 2e-6 * b_.abs().max()).all())
+
+    def same(a_, b_):
+        return torch.equal(a_, b_) if solo else torch.allclose(a_, b_, rtol=1e-5, atol=1e-5 * max(1.0, b_.abs().max().item()))
+
+    assert same(mean_a, mean_b) and same(rstd_a, rstd_b)
+    assert same8(ya, yb) and same(ypa, ypb)
+    # ... and they ARE the statistics of the stored values
+    ref_mean = zr.double().mean((2, 3)).reshape(-1)
+    assert torch.allclose(mean_b.double(), ref_mean, rtol=1e-5, atol=1e-5)
+    for extra in (None, ex):
+        db1, db2 = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+        da, dga, dba = ops.instnorm_lrelu_bwd_c8(zr, dyr + (extra if extra is not None else 0), mean_b, rstd_b, gamma, beta, slope=0.1, dbias_pre=db1, compute=compute)
+        db, dgb, dbb = ops.instnorm_lrelu_bwd_c8(z8, dy8, mean_b, rstd_b, gamma, beta, slope=0.1, dbias_pre=db2, dy_extra=extra)
+        # (backward: the variants are separate instantiations whose fused multiply-adds may be contracted differently)
+        assert same8(da, db, False), (da.unpack() - db.unpack()).abs().max().item()
+        noise = 1e-6 * da.unpack().abs().sum((0, 2, 3)).max().item()
+        assert (db1 - db2).abs().max().item() <= max(1e-3, noise)
+        if affine:
+            assert torch.allclose(dga, dgb, rtol=1e-4, atol=1e-3 * max(1.0, dga.abs().max().item())) and torch.allclose(dba, dbb, rtol=1e-4, atol=1e-3 * max(1.0, dba.abs().max().item()))
+    # mixed: channel-blocked z with a planar fp32 gradient
+    dc, _, _ = ops.instnorm_lrelu_bwd_c8(z8, dyr, mean_b, rstd_b, gamma, beta, slope=0.1)
+    dd, _, _ = ops.instnorm_lrelu_bwd_c8(zr, dyr, mean_b, rstd_b, gamma, beta, slope=0.1, compute=compute)
+    assert same8(dc, dd, False)
+    assert ops.coop_error(DEV) == 0
