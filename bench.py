@@ -88,13 +88,13 @@ def conv_bytes(op, kind, L) -> float:
     rd = 2.0 if a.operand_layout == L.LAYOUT_C8 else 4.0
     w = 9.0 * a.Cin * a.Cout * (2.0 if a.compute else 4.0)
     if kind == L.OP_CONV3_FWD:          # (a gathered dgrad is a forward-type launch that may add to its output)
-        return (a.Cin * rd + a.Cout * (8.0 if a.out_accumulate else 4.0)) * px + w
+        return (a.Cin * rd + a.Cout * (2.0 if a.out_layout == L.LAYOUT_C8 else (8.0 if a.out_accumulate else 4.0))) * px + w
     if kind == L.OP_CONV3_WGRAD:
         return (a.Cin + a.Cout) * rd * px + 9.0 * a.Cin * a.Cout * 4.0
     out = 0.0
-    for i in range(a.n_in):          # dx segments: fp32 written (+ re-read when accumulated), or 16-bit planes (accumulate = 2)
+    for i in range(a.n_in):          # dx segments: fp32 written (+ re-read when accumulated), or 16-bit (accumulate = 2 planes, 3 channel-blocked)
         m = a.in_[i].accumulate
-        out += a.in_[i].channels * (2.0 if m == 2 else (8.0 if m == 1 else 4.0))
+        out += a.in_[i].channels * (2.0 if m >= 2 else (8.0 if m == 1 else 4.0))
     return (a.Cout * rd + out) * px + w
 
 
@@ -223,10 +223,12 @@ def run_mode(args, dtype, dev, rank, world, dist, want_roofline):
             if op.kind == L.OP_IN_FWD:
                 a = op.u.inorm; e = a.N * a.C * a.H * a.W
                 ob = (2 + (4 if a.y else 0)) if a.y8 else (2 if a.y16 else 4)        # channel-blocked (+ fp32 planes) / 16-bit planes / fp32 planes
-                h = hb["in_fwd"]; h[0] += e * (4 + ob); h[1] += time_op(prog, i); h[2] += 1      # read z, write y
+                zb = 2 if a.z_layout == L.LAYOUT_C8 else 4                                      # conv output stored in 16 bits (channel-blocked) or fp32 planes
+                h = hb["in_fwd"]; h[0] += e * (zb + ob); h[1] += time_op(prog, i); h[2] += 1      # read z, write y
             elif op.kind == L.OP_IN_BWD:
                 a = op.u.inorm; e = a.N * a.C * a.H * a.W
-                h = hb["in_bwd"]; h[0] += e * (8 + (2 if (a.dz16 or a.dz8) else 4)); h[1] += time_op(prog, i); h[2] += 1     # read z, dy; write dz
+                rb = (2 if a.z_layout == L.LAYOUT_C8 else 4) + ((2 + 4 * a.n_dy_extra) if a.dy_layout == L.LAYOUT_C8 else 4)
+                h = hb["in_bwd"]; h[0] += e * (rb + (2 if (a.dz16 or a.dz8) else 4)); h[1] += time_op(prog, i); h[2] += 1     # read z, dy (+ fp32 partial); write dz
             elif op.kind in (L.OP_CONVT_FWD, L.OP_CONVT_DGRAD, L.OP_CONVT_WGRAD):
                 a = op.u.convT; px = a.N * a.H * a.W
                 ob = 2 if (op.kind == L.OP_CONVT_FWD and a.y_layout == L.LAYOUT_C8) else 4

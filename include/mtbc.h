@@ -101,6 +101,13 @@ typedef struct {
                                         16-bit modes, read by mtbc_instnorm_args.z_layout = C8 (what torch.autocast stores
                                         between a convolution and its normalisation).  Cout % 8 == 0, out 16-byte aligned,
                                         out_accumulate = 0.                                                             */
+    float* stats_partial;            /* fwd with out_layout C8 only, or NULL: InstanceNorm statistics from the conv EPILOGUE
+                                        (MTnnUNet.py:30-38, MONAI ADN in MTUNetPlusPlus.py:20-22: the norm that follows every
+                                        3x3 conv).  [N][slots][Cout][2] floats, slots = mtbc_conv3x3_stats_slots(args): per
+                                        image, per wave-sized pixel subset and per channel {sum, sum of squares} of the STORED
+                                        (rounded) outputs, fp32, no atomics; mtbc_instnorm_lrelu_fwd(stats_partial, stats_slots)
+                                        combines them (fixed order, in double) and the normalisation becomes one streaming
+                                        pass with no reduction of its own.                                                  */
 } mtbc_conv3x3_args;
 #define MTBC_LAYOUT_PLANAR 0
 #define MTBC_LAYOUT_C8 1
@@ -150,6 +157,8 @@ typedef struct mtbc_pack_desc {
     int32_t kind, compute;
 } mtbc_pack_desc;
 int mtbc_conv3x3_pack_many(const mtbc_pack_desc* descs, int32_t n, void* stream);
+/* pixel subsets per image of the forward launch these arguments select (0: the launch does not produce statistics) */
+int32_t mtbc_conv3x3_stats_slots(const mtbc_conv3x3_args* a);
 size_t mtbc_conv3x3_wgrad_workspace(const mtbc_conv3x3_args* a);
 int mtbc_conv3x3_fwd(const mtbc_conv3x3_args* a, void* stream);
 int mtbc_conv3x3_dgrad(const mtbc_conv3x3_args* a, void* stream);
@@ -215,6 +224,10 @@ typedef struct {
                    readers (batch stride C*H*W), added to it in fp32 while loading.                                     */
     int32_t z_layout;
     int32_t dy_layout;
+    /* forward with z_layout C8 and y8: the statistics come from the producing convolution's epilogue
+       (mtbc_conv3x3_args.stats_partial, [N][stats_slots][C][2]); mean / rstd are still written for the backward pass. */
+    const float* stats_partial;
+    int32_t stats_slots;
 } mtbc_instnorm_args;
 size_t mtbc_instnorm_coop_state_bytes(void);
 /* Byte offset, inside a coop_state block, of the 32-bit STICKY error word: non-zero once any cooperative launch on that

@@ -34,7 +34,8 @@ class Conv3x3Args(C.Structure):
                 ("out", C.c_void_p), ("dout", C.c_void_p), ("dw", C.c_void_p), ("dbias", C.c_void_p),
                 ("accumulate_dw", C.c_int32), ("force_direct", C.c_int32),
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
-                ("compute", C.c_int32), ("operand_layout", C.c_int32), ("out_accumulate", C.c_int32), ("out_layout", C.c_int32)]
+                ("compute", C.c_int32), ("operand_layout", C.c_int32), ("out_accumulate", C.c_int32), ("out_layout", C.c_int32),
+                ("stats_partial", C.c_void_p)]
 
 
 class InstNormArgs(C.Structure):
@@ -50,7 +51,7 @@ class InstNormArgs(C.Structure):
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
                 ("y16", C.c_void_p), ("dz16", C.c_void_p), ("out16_type", C.c_int32),
                 ("y8", C.c_void_p), ("dz8", C.c_void_p), ("coop_state", C.c_void_p), ("coop_reserve_cus", C.c_int32),
-                ("z_layout", C.c_int32), ("dy_layout", C.c_int32)]
+                ("z_layout", C.c_int32), ("dy_layout", C.c_int32), ("stats_partial", C.c_void_p), ("stats_slots", C.c_int32)]
 
 
 class MaxPoolArgs(C.Structure):
@@ -205,7 +206,7 @@ class WViewDesc(C.Structure):
 EXPORTS = [
     "mtbc_version", "mtbc_strerror", "mtbc_arch",
     "mtbc_conv3x3_packed_elems", "mtbc_conv3x3_packed_dgrad_elems", "mtbc_conv3x3_pack_fwd",
-    "mtbc_conv3x3_pack_dgrad", "mtbc_conv3x3_packed_lp_elems", "mtbc_conv3x3_pack_lp", "mtbc_conv3x3_pack_many", "mtbc_c8_pack", "mtbc_c8_unpack", "mtbc_c8_pack16", "mtbc_conv3x3_weight_view", "mtbc_conv3x3_weight_view_many", "mtbc_augment_flip_rotate", "mtbc_convT_head_combine", "mtbc_convT_head_expand", "mtbc_conv3x3_wgrad_workspace", "mtbc_conv3x3_fwd", "mtbc_conv3x3_dgrad",
+    "mtbc_conv3x3_pack_dgrad", "mtbc_conv3x3_packed_lp_elems", "mtbc_conv3x3_pack_lp", "mtbc_conv3x3_pack_many", "mtbc_c8_pack", "mtbc_c8_unpack", "mtbc_c8_pack16", "mtbc_conv3x3_weight_view", "mtbc_conv3x3_weight_view_many", "mtbc_augment_flip_rotate", "mtbc_convT_head_combine", "mtbc_convT_head_expand", "mtbc_conv3x3_wgrad_workspace", "mtbc_conv3x3_stats_slots", "mtbc_conv3x3_fwd", "mtbc_conv3x3_dgrad",
     "mtbc_conv3x3_wgrad", "mtbc_instnorm_fwd_workspace", "mtbc_instnorm_coop_state_bytes", "mtbc_instnorm_coop_error_offset", "mtbc_instnorm_c8_supported", "mtbc_instnorm_lrelu_fwd", "mtbc_instnorm_lrelu_bwd", "mtbc_maxpool2_fwd",
     "mtbc_maxpool2_bwd", "mtbc_convT_wgrad_workspace", "mtbc_convT_fwd_c8_supported", "mtbc_convT_fwd", "mtbc_convT_dgrad", "mtbc_convT_wgrad",
     "mtbc_conv1x1_wgrad_workspace", "mtbc_conv1x1_fwd", "mtbc_conv1x1_dgrad", "mtbc_conv1x1_wgrad",
@@ -239,6 +240,8 @@ def load() -> C.CDLL:
     for _n in ("mtbc_convT_head_combine", "mtbc_convT_head_expand"):
         getattr(lib, _n).restype = C.c_int
         getattr(lib, _n).argtypes = [C.POINTER(HeadFuseArgs), C.c_void_p]
+    lib.mtbc_conv3x3_stats_slots.restype = C.c_int32
+    lib.mtbc_conv3x3_stats_slots.argtypes = [C.POINTER(Conv3x3Args)]
     lib.mtbc_instnorm_fwd_workspace.restype = C.c_size_t
     lib.mtbc_instnorm_fwd_workspace.argtypes = [C.POINTER(InstNormArgs)]
     lib.mtbc_augment_flip_rotate.restype = C.c_int

@@ -54,6 +54,7 @@ struct ConvP {
     int tiles_x, tiles_y, ntiles;
     int mtiles;
     int dbg;      // timing probes only (env MTBC_DBG): 1 = no global loads, 2 = no epilogue, 4 = no LDS stores
+    float* stats;               // channel-blocked 16-bit output only, or nullptr: [N][slots][Cout][2] per-wave {sum, sum of squares} of the stored values
 };
 
 constexpr int KC = 8;           // input channels per LDS chunk
@@ -546,6 +547,8 @@ template <> struct LP<false> {
         }
         return r; }
     static __device__ __forceinline__ f32x4 mfma(frag a, frag b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ float lo(unsigned u) { return __uint_as_float(u << 16); }       // the two stored values of a dword, exact
+    static __device__ __forceinline__ float hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
 };
 template <> struct LP<true> {
     typedef f16x8 frag;
@@ -557,6 +560,8 @@ template <> struct LP<true> {
         }
         return r; }
     static __device__ __forceinline__ f32x4 mfma(frag a, frag b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ float lo(unsigned u) { const f16x2 t = __builtin_bit_cast(f16x2, u); return (float)t[0]; }
+    static __device__ __forceinline__ float hi(unsigned u) { const f16x2 t = __builtin_bit_cast(f16x2, u); return (float)t[1]; }
 };
 
 // ------------------------------------------------------------------ igemm on the 16-bit MFMA (optional compute mode)
@@ -1027,6 +1032,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 4) void conv3x3_igemm_c8_ker
                 // piece (n, group, pixel) of the segment's tensor; this lane owns channels (co - cb) % 8 .. + 3 of it
                 gchar* cb = (gchar*)so.ptr + 2 * ((size_t)n * so.bs + (size_t)((co - so.cb) >> 3) * HW * 8) + 2 * ((co - so.cb) & 7);
                 const f32x4 bv = *reinterpret_cast<const f32x4*>(bias_s + m * 16 + 4 * kg);
+                f32x4 ss = (f32x4){0.f, 0.f, 0.f, 0.f}, sq = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
                     if (pix[g] >= 0) {
@@ -1034,7 +1040,26 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 4) void conv3x3_igemm_c8_ker
                         const float q[8] = {r[0], r[1], r[2], r[3], 0.f, 0.f, 0.f, 0.f};
                         const ep_u32x4 u = __builtin_bit_cast(ep_u32x4, T::pack(q));
                         *(guint2*)(cb + 16 * (size_t)pix[g]) = (ep_u32x2){u[0], u[1]};
+                        if (p.stats) {          // InstanceNorm statistics of the STORED values
+                            const unsigned u0 = u[0], u1 = u[1];
+                            const f32x4 v = (f32x4){T::lo(u0), T::hi(u0), T::lo(u1), T::hi(u1)};
+                            ss += v; sq += v * v;
+                        }
                     }
+                if (p.stats) {
+                    // this wave's pixels: the 16 lanes of a row group hold 16 pixels of the same 4 channels -> butterfly inside the group
+#pragma unroll
+                    for (int o = 8; o > 0; o >>= 1)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { ss[e] += __shfl_xor(ss[e], o, 64); sq[e] += __shfl_xor(sq[e], o, 64); }
+                    if (j == 0 && n < p.N) {
+                        const int slots = GEO == 2 ? 1 : p.tiles_x * p.tiles_y * NW;
+                        const int slot = GEO == 2 ? 0 : (ty * p.tiles_x + tx) * NW + wv;
+                        float* sp = p.stats + (((size_t)n * slots + slot) * p.Cout + co) * 2;
+                        *reinterpret_cast<f32x4*>(sp) = (f32x4){ss[0], sq[0], ss[1], sq[1]};
+                        *reinterpret_cast<f32x4*>(sp + 4) = (f32x4){ss[2], sq[2], ss[3], sq[3]};
+                    }
+                }
             }
             continue;
         }
@@ -2184,20 +2209,15 @@ int launch_igemm_c8_mt(int MT, const ConvP& p, int mblocks, bool f16, hipStream_
     return launch_igemm_c8<2, GEO, 4, O8>(p, mblocks, f16, st);
 }
 
-// shared by fwd and dgrad: `rows` = channels written, `red` = channels read; compute: 0 fp32, 1 bf16, 2 fp16 operands;
-// c8: the tensor read is 16-bit channel-blocked (MTBC_LAYOUT_C8)
-int run_igemm(int N, int H, int W, int red, int rows, const SegTable& in, const SegTable& out, const float* wp,
-              const float* bias, int compute, hipStream_t st, bool c8 = false, bool o8 = false) {
-    ConvP p;
-    p.N = N; p.H = H; p.W = W; p.Cin = red; p.Cout = rows; p.in = in; p.out = out; p.wp = wp; p.bias = bias;
-    static const int dbg = mtbc_probe_int("MTBC_DBG", 0);
-    p.dbg = dbg;
-
-    const int geo = pick_geo(H, W);
-    p.mtiles = cdiv(rows, 16);
-    if (geo == 0) { p.tiles_x = cdiv(W, 32); p.tiles_y = cdiv(H, 8); p.ntiles = p.tiles_x * p.tiles_y * N; }
-    else if (geo == 1) { p.tiles_x = cdiv(W, 16); p.tiles_y = cdiv(H, 16); p.ntiles = p.tiles_x * p.tiles_y * N; }
-    else { p.tiles_x = 1; p.tiles_y = 1; p.ntiles = cdiv(N, 4); }
+// geometry of an igemm launch: map geometry, pixel tiles, channel tiles per block, 8-wave (16 x 32 pixel) blocks
+struct IgemmPlan { int geo, tiles_x, tiles_y, ntiles, mtiles, MT, mblocks; bool nw8; };
+IgemmPlan plan_igemm(int N, int H, int W, int rows, int compute, bool c8) {
+    IgemmPlan q{};
+    q.geo = pick_geo(H, W);
+    q.mtiles = cdiv(rows, 16);
+    if (q.geo == 0) { q.tiles_x = cdiv(W, 32); q.tiles_y = cdiv(H, 8); q.ntiles = q.tiles_x * q.tiles_y * N; }
+    else if (q.geo == 1) { q.tiles_x = cdiv(W, 16); q.tiles_y = cdiv(H, 16); q.ntiles = q.tiles_x * q.tiles_y * N; }
+    else { q.tiles_x = 1; q.tiles_y = 1; q.ntiles = cdiv(N, 4); }
     // channel tiles per block: up to 3 (4 spills past 256 VGPRs), fewer when the launch would not fill 256 CUs twice over
     static const int mtmax_env = mtbc_probe_int("MTBC_LP_MT", 0);      // A/B probe
     // 16-bit kernels: 2 tiles per block keep LDS at 51 KB = 3 blocks per CU; 3 tiles (62 KB, 2 blocks) measured slower
@@ -2205,22 +2225,39 @@ int run_igemm(int N, int H, int W, int red, int rows, const SegTable& in, const 
     // ... except on the channel-blocked kernel when the channel tiles come in threes (48 / 96 / 192 / 384 channels): 3 tiles
     // per block are 49 KB there (still 3 blocks per CU) and the pixel tile is staged once per 48 channels instead of once
     // per 32 (Cout = 48: X read once instead of twice).  Not on 8x8 maps: that instantiation spills.
-    const int mtmax = compute != 0 ? (mtmax_env ? mtmax_env : ((c8 && geo != 2 && p.mtiles % 3 == 0) ? 3 : 2)) : 3;
-    int mblocks = cdiv(p.mtiles, mtmax);
-    int MT = cdiv(p.mtiles, mblocks);
-    while (MT > 1 && (long long)p.ntiles * mblocks < 512) {
-        --MT;
-        mblocks = cdiv(p.mtiles, MT);
+    const int mtmax = compute != 0 ? (mtmax_env ? mtmax_env : ((c8 && q.geo != 2 && q.mtiles % 3 == 0) ? 3 : 2)) : 3;
+    q.mblocks = cdiv(q.mtiles, mtmax);
+    q.MT = cdiv(q.mtiles, q.mblocks);
+    while (q.MT > 1 && (long long)q.ntiles * q.mblocks < 512) {
+        --q.MT;
+        q.mblocks = cdiv(q.mtiles, q.MT);
     }
-    MT = cdiv(p.mtiles, mblocks);
+    q.MT = cdiv(q.mtiles, q.mblocks);
+    q.nw8 = false;
     if (c8) {
         // wide maps with enough tiles for two 512-pixel blocks per CU several times over: 16 x 32 tiles, 8 waves
         static const int nw_env = mtbc_probe_int("MTBC_C8_NW", 0);      // A/B
-        const int t16 = p.tiles_x * cdiv(H, 16) * N;
-        if (geo == 0 && MT == 2 && (nw_env ? nw_env == 8 : (long long)t16 * mblocks >= 2048)) {
-            p.tiles_y = cdiv(H, 16); p.ntiles = t16;
-            return o8 ? launch_igemm_c8<2, 0, 8, true>(p, mblocks, compute == 2, st) : launch_igemm_c8<2, 0, 8, false>(p, mblocks, compute == 2, st);
+        const int t16 = q.tiles_x * cdiv(H, 16) * N;
+        if (q.geo == 0 && q.MT == 2 && (nw_env ? nw_env == 8 : (long long)t16 * q.mblocks >= 2048)) {
+            q.nw8 = true; q.tiles_y = cdiv(H, 16); q.ntiles = t16;
         }
+    }
+    return q;
+}
+
+// shared by fwd and dgrad: `rows` = channels written, `red` = channels read; compute: 0 fp32, 1 bf16, 2 fp16 operands;
+// c8: the tensor read is 16-bit channel-blocked (MTBC_LAYOUT_C8); o8: so is the tensor written (+ optional epilogue statistics)
+int run_igemm(int N, int H, int W, int red, int rows, const SegTable& in, const SegTable& out, const float* wp,
+              const float* bias, int compute, hipStream_t st, bool c8 = false, bool o8 = false, float* stats = nullptr) {
+    ConvP p;
+    p.N = N; p.H = H; p.W = W; p.Cin = red; p.Cout = rows; p.in = in; p.out = out; p.wp = wp; p.bias = bias; p.stats = stats;
+    static const int dbg = mtbc_probe_int("MTBC_DBG", 0);
+    p.dbg = dbg;
+    const IgemmPlan q = plan_igemm(N, H, W, rows, compute, c8);
+    const int geo = q.geo, MT = q.MT, mblocks = q.mblocks;
+    p.mtiles = q.mtiles; p.tiles_x = q.tiles_x; p.tiles_y = q.tiles_y; p.ntiles = q.ntiles;
+    if (c8) {
+        if (q.nw8) return o8 ? launch_igemm_c8<2, 0, 8, true>(p, mblocks, compute == 2, st) : launch_igemm_c8<2, 0, 8, false>(p, mblocks, compute == 2, st);
         if (o8) {
             if (geo == 0) return launch_igemm_c8_mt<0, true>(MT, p, mblocks, compute == 2, st);
             if (geo == 1) return launch_igemm_c8_mt<1, true>(MT, p, mblocks, compute == 2, st);
@@ -2392,8 +2429,10 @@ int mtbc_conv3x3_fwd(const mtbc_conv3x3_args* a, void* stream) {
             if (a->Cout % 8 || a->out_accumulate) return MTBC_E_BADARG;
             out.accumulate[0] = 3;
         }
-        return run_igemm(a->N, a->H, a->W, a->Cin, a->Cout, in, out, a->w_packed, a->bias, a->compute, st, true, o8);
+        if (a->stats_partial && (!o8 || (reinterpret_cast<uintptr_t>(a->stats_partial) & 15))) return MTBC_E_BADARG;
+        return run_igemm(a->N, a->H, a->W, a->Cin, a->Cout, in, out, a->w_packed, a->bias, a->compute, st, true, o8, a->stats_partial);
     }
+    if (a->stats_partial) return MTBC_E_UNSUPPORTED;
     if (a->operand_layout != MTBC_LAYOUT_PLANAR) return MTBC_E_BADARG;
     if (a->w_packed && !a->force_direct && mfma_ok(a->in, a->n_in, a->H, a->W))
         return run_igemm(a->N, a->H, a->W, a->Cin, a->Cout, in, out, a->w_packed, a->bias, a->compute, st);
@@ -2443,6 +2482,13 @@ int mtbc_conv3x3_dgrad(const mtbc_conv3x3_args* a, void* stream) {
     hipLaunchKernelGGL(conv3x3_direct_kernel, dim3(cdiv(a->H * a->W, 128), cdiv(a->Cin, 8), a->N), dim3(128), 0, st, p);
     MTBC_CHECK_LAUNCH();
     return MTBC_OK;
+}
+
+int32_t mtbc_conv3x3_stats_slots(const mtbc_conv3x3_args* a) {
+    if (check_conv(a) || a->operand_layout != MTBC_LAYOUT_C8 || a->out_layout != MTBC_LAYOUT_C8 || (a->compute != 1 && a->compute != 2)) return 0;
+    if (a->W % 4 || a->W < 8 || a->H < 8 || a->Cout % 8) return 0;
+    const IgemmPlan q = plan_igemm(a->N, a->H, a->W, a->Cout, a->compute, true);
+    return q.geo == 2 ? 1 : q.tiles_x * q.tiles_y * (q.nw8 ? 8 : 4);
 }
 
 size_t mtbc_conv3x3_wgrad_workspace(const mtbc_conv3x3_args* a) {

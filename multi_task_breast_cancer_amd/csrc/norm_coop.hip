@@ -381,6 +381,64 @@ __global__ __launch_bounds__(THREADS, THREADS >= 512 ? 4 : 2) void in_bwd_c8_ker
     if constexpr (COOP) coop_finish(hdr, epoch);
 }
 
+// ---------------------------------------------------------------- statistics from the conv epilogue + streaming normalisation
+// The producing convolution left {sum, sum of squares} of the stored z per (image, pixel subset, channel)
+// (mtbc_conv3x3_args.stats_partial): one wave per (n, c) adds the subsets up in a fixed order, in double (raw moments of
+// 16-bit values: the cancellation in E[z^2] - E[z]^2 is bounded by what the 16-bit storage of z leaves of a plane whose mean
+// dwarfs its spread), and the normalisation itself is ONE streaming pass -- no reduction, no team exchange, any grid.
+__global__ void in_stats_finalize_kernel(const float* __restrict__ part, int slots, int C, int HW, float eps, float* __restrict__ mean,
+                                         float* __restrict__ rstd, int planes) {
+    const int plane = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (plane >= planes) return;
+    const int n = plane / C, c = plane % C;
+    const float* q = part + ((size_t)n * slots * C + c) * 2;
+    double s = 0.0, qq = 0.0;
+    for (int t = lane; t < slots; t += 64) { const float2 v = *reinterpret_cast<const float2*>(q + (size_t)t * C * 2); s += (double)v.x; qq += (double)v.y; }
+    s = wave_sum_d(s); qq = wave_sum_d(qq);
+    if (lane == 0) {
+        const double m = s / (double)HW, var = fmax(qq / (double)HW - m * m, 0.0);
+        mean[plane] = (float)m; rstd[plane] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+}
+constexpr int AP_THREADS = 256, AP_PPT = 4;
+template <bool F16>
+__global__ __launch_bounds__(AP_THREADS) void in_apply_fwd_c8_kernel(const CoP p) {
+    const int item = blockIdx.y, n = item / p.G8, g = item % p.G8;
+    float mu[8], ga[8], be[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const size_t pl = (size_t)n * p.C + 8 * g + c;
+        mu[c] = p.mean[pl]; ga[c] = (p.gamma ? p.gamma[8 * g + c] : 1.f) * p.rstd[pl]; be[c] = p.beta ? p.beta[8 * g + c] : 0.f;
+    }
+    const unsigned short* zg = p.z8 + ((size_t)n * p.G8 + g) * p.HW * 8;
+    unsigned short* ob = p.y8 + ((size_t)n * p.G8 + g) * p.HW * 8;
+    float* yb = p.y ? p.y + (size_t)n * p.ybs + (size_t)(8 * g) * p.HW : nullptr;
+    const int px0 = blockIdx.x * (AP_THREADS * AP_PPT) + threadIdx.x;
+    co_u32x4 w[AP_PPT];
+#pragma unroll
+    for (int k = 0; k < AP_PPT; ++k) {
+        const int px = px0 + AP_THREADS * k;
+        if (px < p.HW) w[k] = *reinterpret_cast<const co_u32x4*>(zg + (size_t)px * 8);
+    }
+#pragma unroll
+    for (int k = 0; k < AP_PPT; ++k) {
+        const int px = px0 + AP_THREADS * k;
+        if (px >= p.HW) continue;
+        float v[8];
+        co_unpk<F16>(w[k], v);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) { const float t = (v[c] - mu[c]) * ga[c] + be[c]; v[c] = t > 0.f ? t : t * p.slope; }
+        co_u32x4 o;
+#pragma unroll
+        for (int h = 0; h < 4; ++h) o[h] = co_pk<F16>(v[2 * h], v[2 * h + 1]);
+        *reinterpret_cast<co_u32x4*>(ob + (size_t)px * 8) = o;
+        if (yb) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) yb[(size_t)c * p.HW + px] = v[c];
+        }
+    }
+}
+
 struct CoPlan { bool ok; int ppt, T, grid, nteams; };
 template <typename K> int resident_blocks(K kernel) {
     int per_cu = 0, dev = 0;
@@ -510,6 +568,17 @@ int mtbc_instnorm_c8_supported(const mtbc_instnorm_args* a, int32_t backward) {
 int mtbc_i_instnorm_fwd_c8(const mtbc_instnorm_args* a, hipStream_t st) {
     CoP p; int rc = fill_coop(a, &p); if (rc) return rc;
     if ((!p.z && !p.z8) || !p.y8 || !p.mean || !p.rstd || (reinterpret_cast<uintptr_t>(p.y8) & 15)) return MTBC_E_BADARG;
+    if (a->stats_partial) {         // statistics from the conv epilogue: finalize (one wave per plane) + one streaming pass
+        if (!p.z8 || a->stats_slots <= 0) return MTBC_E_BADARG;
+        const int planes = a->N * a->C;
+        hipLaunchKernelGGL(in_stats_finalize_kernel, dim3(cdiv(planes, 4)), dim3(256), 0, st, a->stats_partial, a->stats_slots, a->C, p.HW, a->eps, a->mean, a->rstd, planes);
+        MTBC_CHECK_LAUNCH();
+        const dim3 g(cdiv(p.HW, AP_THREADS * AP_PPT), p.items);
+        if (p.f16) hipLaunchKernelGGL(in_apply_fwd_c8_kernel<true>, g, dim3(AP_THREADS), 0, st, p);
+        else hipLaunchKernelGGL(in_apply_fwd_c8_kernel<false>, g, dim3(AP_THREADS), 0, st, p);
+        MTBC_CHECK_LAUNCH();
+        return MTBC_OK;
+    }
     if (p.HW <= SOLO_MAX_HW) { launch_solo<false>(p, st); MTBC_CHECK_LAUNCH(); return MTBC_OK; }
     if (!p.state) return MTBC_E_BADARG;
     const CoPlan pl = plan_team<false>(p.items, p.HW, var_of(a), a->coop_reserve_cus);

@@ -29,6 +29,8 @@ _NO_P16 = _sw.flag("MTBC_NO_P16")
 _FANIN = _sw.flag("MTBC_FANIN")
 _NO_C8_SMALL = _sw.flag("MTBC_NO_C8_SMALL_OPS")
 _NO_G16 = _sw.flag("MTBC_NO_G16")
+_NO_Z16 = _sw.flag("MTBC_NO_Z16")
+_NO_DA16 = _sw.flag("MTBC_NO_DA16")
 _BWD_OVERLAP = _sw.flag("MTBC_BWD_OVERLAP")
 _BWD_OVERLAP_MAX_HW = int(_sw.get("MTBC_BWD_OVERLAP_MAX_HW"))
 
@@ -57,6 +59,8 @@ class Act:
     readers: int = 0                   # ops that read this activation (any kind): 1 = its gradient has a single writer
     grad16_ok: bool = False            # ConvT output whose backward MFMAs round dy anyway: a lone 3x3-conv reader may hand
     grad16: Optional[torch.Tensor] = None   # them the gradient as 16-bit planes (mtbc_seg.accumulate = 2) instead of fp32
+    dy8_ok: bool = False               # conv-cell output whose InstanceNorm backward can read a channel-blocked 16-bit dy
+    grad8: Optional[torch.Tensor] = None    # ... the gradient from ALL its 3x3 consumers (one gathered launch), 16-bit channel-blocked
     in_op: Optional[object] = None     # the InstanceNorm forward op that writes this activation (conv cells)
     pack_op: Optional[object] = None   # the op that fills `c8` from `data`
 
@@ -353,7 +357,6 @@ class StepPlan:
                 op = _mk(L.OP_CONV3_PACK_DGRAD)
                 op.u.pack.w, op.u.pack.packed, op.u.pack.Cin, op.u.pack.Cout = w.data_ptr(), wp_d.data_ptr(), cin, cout
                 self.pack_ops.append(op)
-        z = self.alloc(N, cout, H, W)
         y = self.new_act(out_name, cout, H, W)
         # measured: private fan-in buffers summed by IN-backward (+1.25 ms there) cost more than the read-modify-write
         # they remove from the dgrad epilogues (-0.6 ms); the capability stays behind this switch
@@ -375,6 +378,17 @@ class StepPlan:
         # of once per consumer inside the staging (same RNE, same MFMA order: bit-identical forward / dgrad)
         c8 = (not _NO_C8) and use_packed and self.compute != 0 and not self.force_direct and W % 4 == 0 and H >= 8 and W >= 8
         c8_bwd = c8 and cout % 8 == 0
+        # 16-bit modes: the conv output z is stored once, in 16 bits, channel-blocked (what torch.autocast keeps between a
+        # convolution and its normalisation): written by the igemm's epilogue (fp32 accumulate + bias, one RNE), read by the
+        # InstanceNorm forward and backward as 16-byte pieces -- 2 + 2 + 2 instead of 4 + 4 + 4 bytes per element.  Needs the
+        # channel-group InstanceNorm kernels in both directions (norm_coop.hip).
+        z16 = False
+        if c8_bwd and not _NO_Z16 and not _NO_COOP:      # (the one-plane InstanceNorm kernels read fp32 planes)
+            q = L.InstNormArgs()
+            q.N, q.C, q.H, q.W, q.out16_type, q.z_layout, q.coop_reserve_cus = N, cout, H, W, self.compute, L.LAYOUT_C8, self.coop_reserve_cus
+            z16 = bool(self.lib.mtbc_instnorm_c8_supported(C.byref(q), 0)) and bool(self.lib.mtbc_instnorm_c8_supported(C.byref(q), 1))
+        z = self.alloc(N, cout // 8, H * W, 8, dtype=torch.int16) if z16 else self.alloc(N, cout, H, W)
+        y.dy8_ok = z16 and not _NO_DA16 and not _FANIN
         if not c8 and not all(a_.planar_valid for a_ in inputs):
             raise NotImplementedError(f"{out_name}: an input exists only in the channel-blocked 16-bit layout")
         for a_ in inputs:
@@ -398,6 +412,8 @@ class StepPlan:
         op.u.conv3.w_packed = _ptr(wp_f)
         op.u.conv3.bias = _ptr(self.pv(bname)) if bname else None
         op.u.conv3.out = z.data_ptr()
+        if z16:
+            op.u.conv3.out_layout = L.LAYOUT_C8
         self.fwd_ops.append(op)
 
         def base_in() -> L.Op:
@@ -405,6 +421,7 @@ class StepPlan:
             a = op.u.inorm
             a.N, a.C, a.H, a.W, a.eps, a.slope = N, cout, H, W, 1e-5, slope
             a.z = z.data_ptr()
+            a.z_layout = L.LAYOUT_C8 if z16 else L.LAYOUT_PLANAR
             a.gamma = _ptr(self.pv(gname)) if gname else None
             a.beta = _ptr(self.pv(betaname)) if betaname else None
             a.mean, a.rstd = mean.data_ptr(), rstd.data_ptr()
@@ -417,8 +434,8 @@ class StepPlan:
         y.in_op = op
         # (measured: the cooperative kernels win on planes >= 128x128 forward / 256x256 backward; on small planes their
         # barriers and 512-thread workgroups lose to the one-plane kernels + pack)
-        if self.compute and not _NO_C8 and not _NO_COOP and not self.force_direct and cout % 8 == 0 and H * W >= _COOP_MIN_FWD \
-                and self.lib.mtbc_instnorm_c8_supported(C.byref(op.u.inorm), 0):
+        if z16 or (self.compute and not _NO_C8 and not _NO_COOP and not self.force_direct and cout % 8 == 0 and H * W >= _COOP_MIN_FWD
+                   and self.lib.mtbc_instnorm_c8_supported(C.byref(op.u.inorm), 0)):
             # 16-bit modes: the cooperative kernel writes the channel-blocked operand tensor itself (and fp32 planes only
             # if something reads them -- decided in finalize(), when all consumers are known)
             y.c8 = self.alloc(N, cout // 8, H * W, 8, dtype=torch.int16)
@@ -445,6 +462,7 @@ class StepPlan:
         def emit_bwd() -> None:
             if not y.grad_written and not y.pending:
                 return
+            g8 = bool(y.pending) and y.dy8_ok
             if y.pending:
                 # Gathered dgrad: the gradient of y with respect to ALL its 3x3 consumers in ONE forward-type launch over
                 # their channel-blocked dz (K = sum of their Cout), instead of one read-modify-write of y's fp32 gradient
@@ -456,7 +474,14 @@ class StepPlan:
                     wview(wj, wg, coutj, cinj, offj, cout, 1, koff, K)
                     koff += coutj
                 wpg = pack_lp(wg, K, cout, 0)
-                gbuf, acc = self.grad_slot(y)
+                if g8:
+                    # ... written ONCE as a 16-bit channel-blocked tensor (fp32 sum over all consumers in the MFMA accumulators,
+                    # one RNE); what the tensor's other readers (pool / ConvT / 1x1 backward) wrote stays an fp32 planar
+                    # partial that the InstanceNorm backward adds while loading
+                    y.grad8 = self.alloc(N, cout // 8, H * W, 8, dtype=torch.int16)
+                    gbuf, acc = y.grad8, 0
+                else:
+                    gbuf, acc = self.grad_slot(y)
                 op = _mk(L.OP_CONV3_FWD, tag)
                 a = op.u.conv3
                 a.N, a.H, a.W, a.Cin, a.Cout, a.n_in = N, H, W, K, cout, len(y.pending)
@@ -464,20 +489,24 @@ class StepPlan:
                     a.in_[i_].ptr, a.in_[i_].batch_stride, a.in_[i_].channels, a.in_[i_].accumulate = dzj.data_ptr(), coutj * H * W, coutj, 0
                 a.w, a.w_packed, a.out = wg.data_ptr(), wpg.data_ptr(), gbuf.data_ptr()
                 a.compute, a.operand_layout, a.out_accumulate = self.compute, L.LAYOUT_C8, acc
+                if g8:
+                    a.out_layout = L.LAYOUT_C8
                 self.bwd_ops.append(op)
-            dy = self.grad_of(y)
+            dy = y.grad8 if g8 else self.grad_of(y)
             # IN+LReLU backward, dz written in place over dy (each element is read before it is written)
             op = base_in()
             op.kind = L.OP_IN_BWD
             a = op.u.inorm
             a.dy, a.dy_batch_stride, a.dz = dy.data_ptr(), y.bstride, dy.data_ptr()
+            if g8:
+                a.dy_layout, a.dz = L.LAYOUT_C8, None
             a.n_dy_extra = len(y.extra_grads)
             # inputs whose gradient is gathered later (by THEIR backward) from all their 3x3 consumers: a prefix of the
             # segment list, so that this conv's own dgrad covers a contiguous suffix of its input channels
             defer: List[Act] = []
             if c8_bwd and wp_d is not None and not _NO_GATHER:
                 for a_ in inputs:
-                    if a_.in_op is not None and a_.needs_grad and a_.conv_consumers >= 2 and not a_.no_gather and a_.C % 8 == 0:
+                    if a_.in_op is not None and a_.needs_grad and a_.conv_consumers >= (1 if a_.dy8_ok else 2) and not a_.no_gather and a_.C % 8 == 0:
                         defer.append(a_)
                     else:
                         break
@@ -485,7 +514,7 @@ class StepPlan:
             def dz8_buffer() -> torch.Tensor:      # the gathered launches read it later: it cannot be the shared scratch
                 return self.alloc(N * cout * H * W, dtype=torch.int16) if defer else self._scratch16("_dz8_buf", N * cout * H * W)
 
-            coop = c8_bwd and not _NO_COOP and H * W >= _COOP_MIN_BWD and self.lib.mtbc_instnorm_c8_supported(C.byref(a), 1)
+            coop = z16 or (c8_bwd and not _NO_COOP and H * W >= _COOP_MIN_BWD and bool(self.lib.mtbc_instnorm_c8_supported(C.byref(a), 1)))
             if coop:        # one pass straight into the channel-blocked dz the wgrad / dgrad MFMAs read
                 dz8 = dz8_buffer()
                 a.dz8, a.out16_type, a.coop_state = dz8.data_ptr(), self.compute, self._coop_state()
@@ -496,6 +525,10 @@ class StepPlan:
             a.n_dy_extra = len(y.extra_grads)
             for k_, t_ in enumerate(y.extra_grads):
                 a.dy_extra[k_] = t_.data_ptr()
+            if g8 and y.grad_written:
+                assert not y.extra_grads
+                a.n_dy_extra = 1
+                a.dy_extra[0] = y.grad.data_ptr()
             if gname or bname:
                 acc = None
                 if gname:
@@ -960,7 +993,7 @@ class StepPlan:
         for a in self.acts.values():
             hw = a.H * a.W
             if a.in_op is not None and a.in_op.u.inorm.y8:          # cooperative kernel: drop the output nobody reads
-                if not a.c8_used:
+                if not a.c8_used and a.in_op.u.inorm.z_layout != L.LAYOUT_C8:      # (a channel-blocked z is read by the channel-group kernels only: they keep their output)
                     a.in_op.u.inorm.y8 = None
                 elif not a.planar_used:
                     a.in_op.u.inorm.y = None

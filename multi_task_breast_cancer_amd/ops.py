@@ -186,7 +186,8 @@ def _fill_segs_c8(arr, tensors: Sequence["C8"]):
         arr[i].accumulate = 0
 
 
-def conv3x3_fwd_c8(xs: Sequence["C8"], w: torch.Tensor, bias: Optional[torch.Tensor], packed: torch.Tensor, out_c8: bool = False):
+def conv3x3_fwd_c8(xs: Sequence["C8"], w: torch.Tensor, bias: Optional[torch.Tensor], packed: torch.Tensor, out_c8: bool = False,
+                   stats: bool = False):
     """z = conv3x3(concat(xs)) with the inputs already in the MFMA's 16-bit channel-blocked layout; z comes back as fp32
     planes, or (out_c8, `out_layout = C8` of the C-ABI) as a channel-blocked 16-bit tensor of the inputs' type."""
     _chk(w, bias)
@@ -201,8 +202,16 @@ def conv3x3_fwd_c8(xs: Sequence["C8"], w: torch.Tensor, bias: Optional[torch.Ten
         out = torch.empty(N, w.shape[0], H, W, dtype=torch.float32, device=w.device)
     a.w, a.w_packed, a.bias, a.out = w.data_ptr(), packed.data_ptr(), _p(bias), out.data_ptr()
     a.compute, a.operand_layout = xs[0].compute, L.LAYOUT_C8
+    part = None
+    if stats:       # InstanceNorm statistics from the epilogue: (partials [N][slots][Cout][2], slots)
+        slots = L.load().mtbc_conv3x3_stats_slots(C.byref(a))
+        if slots <= 0:
+            raise L.MtbcError("conv3x3_fwd: no epilogue statistics for this launch")
+        part = torch.full((N, slots, w.shape[0], 2), float("nan"), dtype=torch.float32, device=w.device)
+        a.stats_partial = part.data_ptr()
     L.check(L.load().mtbc_conv3x3_fwd(C.byref(a), _s()), "conv3x3_fwd(c8)")
-    return C8(out, (N, w.shape[0], H, W), xs[0].compute) if out_c8 else out
+    z = C8(out, (N, w.shape[0], H, W), xs[0].compute) if out_c8 else out
+    return (z, part) if stats else z
 
 
 def conv3x3_dgrad_c8(dz: "C8", w: torch.Tensor, dxs: Sequence[torch.Tensor], accumulate: Sequence[int], packed: torch.Tensor) -> None:
@@ -305,7 +314,8 @@ def coop_state(dev) -> torch.Tensor:
     return _coop_states[key]
 
 
-def instnorm_lrelu_fwd_c8(z, gamma=None, beta=None, eps=1e-5, slope=0.01, compute: int = 1, want_planar: bool = False):
+def instnorm_lrelu_fwd_c8(z, gamma=None, beta=None, eps=1e-5, slope=0.01, compute: int = 1, want_planar: bool = False,
+                          stats: Optional[torch.Tensor] = None):
     """InstanceNorm + LeakyReLU straight into the 16-bit channel-blocked layout (y8 of the C-ABI).  z: fp32 planes, or a
     C8 tensor (z_layout = C8: the conv output of the 16-bit modes)."""
     z8 = z if isinstance(z, C8) else None
@@ -326,6 +336,8 @@ def instnorm_lrelu_fwd_c8(z, gamma=None, beta=None, eps=1e-5, slope=0.01, comput
     a.z_layout = L.LAYOUT_C8 if z8 is not None else L.LAYOUT_PLANAR
     a.mean, a.rstd = mean.data_ptr(), rstd.data_ptr()
     a.y8, a.out16_type, a.coop_state = y8.data_ptr(), compute, coop_state(dev).data_ptr()
+    if stats is not None:       # [N][slots][C][2] from conv3x3_fwd_c8(stats=True)
+        a.stats_partial, a.stats_slots = stats.data_ptr(), stats.shape[1]
     if not L.load().mtbc_instnorm_c8_supported(C.byref(a), 0):
         raise L.MtbcError("instnorm_fwd: shape not supported with a channel-blocked output")
     L.check(L.load().mtbc_instnorm_lrelu_fwd(C.byref(a), _s()), "instnorm_fwd(c8)")

@@ -424,14 +424,25 @@ def synthetic_batch(n: int, h: int, w: int, seed: int = 0) -> Tuple[torch.Tensor
 # torch.autocast; this restates what the HIP kernels do so the mode has an oracle of its own).  Every 3x3 conv rounds
 # its MFMA operands to bf16 / fp16 (round-to-nearest-even) and accumulates in the tensor dtype: forward rounds x and
 # w, dgrad rounds dy and w, wgrad rounds x and dy; everything else stays in the tensor dtype.
+# Storage (round 2, what torch.autocast keeps in 16 bits too): the conv OUTPUT z of a conv cell is stored rounded (the
+# InstanceNorm statistics are those of the stored values), and the gradient a conv-cell activation receives from ALL its
+# 3x3 consumers is summed in the accumulation dtype and stored rounded once; what its other readers (max-pool, ConvT, 1x1
+# head, average pool) send back is added to that un-rounded.
+def _z16_plane_ok(H: int, W: int) -> bool:
+    """Plane sizes the channel-group InstanceNorm kernels take (norm_coop.hip): one workgroup up to 64 x 64, teams of 512-thread
+    workgroups above."""
+    return H * W <= 4096 or (H * W) % 512 == 0
+
+
 class _LowpConv3x3(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, b, lp):
+    def forward(ctx, x, w, b, lp, z16=False):
         ctx.save_for_backward(x, w)
         ctx.lp = lp
         ctx.has_b = b is not None
         r = lambda t: t.to(lp).to(t.dtype)
-        return torch.conv2d(r(x), r(w), b, 1, 1)      # not F.conv2d: that name is patched inside lowp_conv3x3
+        z = torch.conv2d(r(x), r(w), b, 1, 1)      # not F.conv2d: that name is patched inside lowp_conv3x3
+        return r(z) if z16 else z
 
     @staticmethod
     def backward(ctx, dy):
@@ -441,7 +452,22 @@ class _LowpConv3x3(torch.autograd.Function):
         dx = torch.nn.grad.conv2d_input(x.shape, r(w), dyr, padding=1)
         dw = torch.nn.grad.conv2d_weight(r(x), w.shape, dyr, padding=1)
         db = dy.sum(dim=(0, 2, 3)) if ctx.has_b else None
-        return dx, dw, db, None
+        return dx, dw, db, None, None
+
+
+class _Detour(torch.autograd.Function):
+    """Identity whose backward parks the gradient in `stash` and sends zeros upstream: how a NON-conv reader of a conv-cell
+    activation (pool, ConvT, 1x1 head, average pool) keeps its contribution out of the 16-bit sum of the conv readers."""
+
+    @staticmethod
+    def forward(ctx, x, stash):
+        ctx.stash = stash
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        ctx.stash.append(g)
+        return torch.zeros_like(g), None
 
 
 class _LowpConv1x1(torch.autograd.Function):
@@ -498,8 +524,9 @@ class lowp_conv3x3:
     ConvTranspose2d -> 1x1 Conv2d heads stay exact (the product fuses them into one fp32 transposed conv,
     engine.convT_head)."""
 
-    def __init__(self, mode: str, model=None):
+    def __init__(self, mode: str, model=None, z16: bool = True, da16: bool = True):
         self.lp = {"bf16": torch.bfloat16, "f16": torch.float16}[mode]
+        self.z16, self.da16 = z16, z16 and da16       # (the product's MTBC_NO_Z16 / MTBC_NO_DA16 arms)
         self.exempt = set()
         models = [] if model is None else (list(model) if isinstance(model, (list, tuple)) else [model])
         for mod in models:
@@ -516,6 +543,41 @@ class lowp_conv3x3:
         orig, lp = self._orig, self.lp
         orig_t, exempt = self._orig_t, self.exempt
         orig_p = self._orig_p
+        self._orig_in, self._orig_lr, self._orig_ap, self._orig_do = F.instance_norm, F.leaky_relu, F.adaptive_avg_pool2d, F.dropout
+        orig_in, orig_lr, orig_ap, orig_do = self._orig_in, self._orig_lr, self._orig_ap, self._orig_do
+        z16, da16 = self.z16, self.da16
+
+        def detour(t):
+            """a conv-cell activation on its way into a non-conv reader"""
+            stash = getattr(t, "_mtbc_stash", None)
+            return _Detour.apply(t, stash) if stash is not None else t
+
+        def instance_norm(input, *a, **k):
+            out = orig_in(input, *a, **k)
+            if getattr(input, "_mtbc_z16", False):
+                out._mtbc_z16 = True
+            return out
+
+        def dropout(input, p=0.5, training=True, inplace=False):      # MONAI's ADN puts Dropout(0) between the norm and the activation
+            out = orig_do(input, p, training, inplace)
+            if getattr(input, "_mtbc_z16", False) and p == 0.0:
+                out._mtbc_z16 = True
+            return out
+
+        def leaky_relu(input, negative_slope=0.01, inplace=False):
+            flagged = getattr(input, "_mtbc_z16", False)
+            out = orig_lr(input, negative_slope, inplace)
+            if flagged and da16 and out.requires_grad:
+                stash = []
+                out._mtbc_stash = stash
+                # fires once every reader has sent its gradient: `g` holds the 3x3 convs' sum (the detours sent zeros)
+                out.register_hook(lambda g, stash=stash: g.to(lp).to(g.dtype) + sum(stash) if stash else g.to(lp).to(g.dtype))
+            return out
+
+        def adaptive_avg_pool2d(input, output_size):
+            return orig_ap(detour(input), output_size)
+
+        F.instance_norm, F.leaky_relu, F.adaptive_avg_pool2d, F.dropout = instance_norm, leaky_relu, adaptive_avg_pool2d, dropout
 
         def max_pool2d(input, kernel_size, stride=None, padding=0, dilation=1, ceil_mode=False, return_indices=False):
             # same eligibility as the product (engine.maxpool): channel groups of 8, and a pooled map the 3x3 convs take
@@ -524,7 +586,9 @@ class lowp_conv3x3:
             if (kernel_size in (2, (2, 2)) and stride in (None, 2, (2, 2)) and padding in (0, (0, 0)) and not return_indices
                     and input.dim() == 4 and input.shape[1] % 8 == 0 and (H * W) % 4 == 0 and H % 2 == 0 and W % 2 == 0
                     and (W // 2) % 4 == 0 and H // 2 >= 8 and W // 2 >= 8):
-                input = input.to(lp).to(input.dtype)
+                input = detour(input).to(lp).to(input.dtype)
+            else:
+                input = detour(input)
             return orig_p(input, kernel_size, stride, padding, dilation, ceil_mode, return_indices)
 
         F.max_pool2d = max_pool2d
@@ -532,6 +596,7 @@ class lowp_conv3x3:
         def conv_transpose2d(input, weight, bias=None, stride=1, padding=0, output_padding=0, groups=1, dilation=1):
             # same eligibility as the product (engine.convT): the direct-to-fragment backward kernels of convt2.hip
             H, W = input.shape[-2:]
+            input = detour(input)
             if (tuple(weight.shape[-2:]) == (2, 2) and stride in (2, (2, 2)) and padding in (0, (0, 0)) and groups == 1
                     and (H * W) % 32 == 0 and id(weight) not in exempt):
                 fwd_lp = weight.shape[0] % 8 == 0 and weight.shape[1] % 8 == 0      # forward: 16-bit MFMA on channel-blocked x
@@ -548,7 +613,13 @@ class lowp_conv3x3:
             H, W = input.shape[-2:]
             if (tuple(weight.shape[-2:]) == (3, 3) and padding in (1, (1, 1)) and stride in (1, (1, 1)) and groups == 1
                     and H >= 8 and W >= 8 and W % 4 == 0 and weight.shape[1] % 8 == 0 and weight.shape[0] % 8 == 0):
-                return _LowpConv3x3.apply(input, weight, bias, lp)
+                cell = z16 and _z16_plane_ok(H, W)
+                out = _LowpConv3x3.apply(input, weight, bias, lp, cell)
+                if cell:
+                    out._mtbc_z16 = True      # InstanceNorm + LeakyReLU behind it make a conv-cell activation
+                return out
+            if tuple(weight.shape[-2:]) == (1, 1):
+                input = detour(input)
             if (tuple(weight.shape[-2:]) == (1, 1) and padding in (0, (0, 0)) and stride in (1, (1, 1)) and groups == 1
                     and weight.shape[1] % 8 == 0 and weight.shape[0] <= 8 and (H * W) % 4 == 0 and id(weight) not in exempt):
                 return _LowpConv1x1.apply(input, weight, bias, lp)
@@ -561,6 +632,7 @@ class lowp_conv3x3:
         F.conv2d = self._orig
         F.conv_transpose2d = self._orig_t
         F.max_pool2d = self._orig_p
+        F.instance_norm, F.leaky_relu, F.adaptive_avg_pool2d, F.dropout = self._orig_in, self._orig_lr, self._orig_ap, self._orig_do
         return False
 
 

@@ -839,3 +839,36 @@ def test_instnorm_on_channel_blocked_16bit_inputs(N, C, H, W, affine, compute):
     dd, _, _ = ops.instnorm_lrelu_bwd_c8(zr, dyr, mean_b, rstd_b, gamma, beta, slope=0.1, compute=compute)
     assert same8(dc, dd, False)
     assert ops.coop_error(DEV) == 0
+
+
+@pytest.mark.parametrize("compute", [1, 2])
+@pytest.mark.parametrize("N,segs,Cout,H,W", [(2, [24], 24, 256, 256), (16, [24, 24], 24, 256, 256), (2, [48], 48, 128, 128), (3, [16], 40, 16, 16),
+                                             (5, [32], 80, 8, 8), (2, [96, 96], 96, 16, 16), (1, [24, 48], 24, 40, 64), (2, [8], 16, 36, 64)])
+def test_instnorm_statistics_from_the_conv_epilogue(N, segs, Cout, H, W, compute):
+    """mtbc_conv3x3_args.stats_partial: the forward conv's epilogue leaves {sum, sum of squares} of its STORED (rounded)
+    outputs per image, pixel subset and channel; summed they are the plane sums of the stored tensor, and the InstanceNorm
+    forward fed with them (finalize + one streaming pass) equals the channel-group kernels that reduce the tensor
+    themselves: statistics to fp32 re-association, outputs to one 16-bit ulp."""
+    g = _g(N * 19 + Cout + H + compute)
+    Cin = sum(segs)
+    xs = [(torch.randn(N, c, H, W, generator=g) + 0.3).to(DEV) for c in segs]
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (9 * Cin)) ** 0.5).to(DEV)
+    b = torch.randn(Cout, generator=g).to(DEV)
+    gamma, beta = (torch.rand(Cout, generator=g) + 0.5).to(DEV), (torch.randn(Cout, generator=g) * 0.1).to(DEV)
+    pf, _ = ops.conv3x3_pack_lp(w, compute)
+    x8 = [ops.C8.pack(x, compute) for x in xs]
+    z8, part = ops.conv3x3_fwd_c8(x8, w, b, pf, out_c8=True, stats=True)
+    assert torch.equal(z8.data, ops.conv3x3_fwd_c8(x8, w, b, pf, out_c8=True).data)      # the statistics change nothing else
+    assert not torch.isnan(part).any(), "a (image, subset, channel) entry was not written"
+    zr = z8.unpack().double()
+    tot = part.double().sum(1)                                                            # (N, Cout, 2)
+    s_ref, q_ref = zr.sum((2, 3)), (zr * zr).sum((2, 3))
+    assert torch.allclose(tot[..., 0].cpu(), s_ref.cpu(), rtol=1e-5, atol=1e-5 * q_ref.abs().max().item() ** 0.5 * H * W ** 0.5)
+    assert torch.allclose(tot[..., 1].cpu(), q_ref.cpu(), rtol=1e-5, atol=1e-3)
+    ya, mean_a, rstd_a, ypa = ops.instnorm_lrelu_fwd_c8(z8, gamma, beta, slope=0.1, want_planar=True)
+    yb, mean_b, rstd_b, ypb = ops.instnorm_lrelu_fwd_c8(z8, gamma, beta, slope=0.1, want_planar=True, stats=part)
+    assert torch.allclose(mean_a, mean_b, rtol=1e-5, atol=1e-5) and torch.allclose(rstd_a, rstd_b, rtol=2e-5, atol=1e-6)
+    ulp = 2.0 ** -7 if compute == 1 else 2.0 ** -10
+    ua, ub = ya.unpack(), yb.unpack()
+    assert bool(((ua - ub).abs() <= ulp * ua.abs() + 1e-5).all()), (ua - ub).abs().max().item()
+    assert torch.allclose(ypa, ypb, rtol=1e-4, atol=1e-4)

@@ -279,3 +279,59 @@ def test_16bit_emulation_of_pool_and_1x1_head_is_transparent_without_rounding_an
     small = torch.randn(1, 8, 8, 8, dtype=torch.float64)      # pooled map 4x4: the product keeps fp32 planes there
     with O.lowp_conv3x3("bf16"):
         assert torch.equal(pool(small), F.max_pool2d(small, 2, 2)) and not torch.equal(pool(small), r(pool(small)))
+
+
+def test_16bit_emulation_of_stored_conv_outputs_and_gathered_gradients():
+    """Round-2 storage of the 16-bit modes: the conv output of a conv cell is stored rounded, and the gradient its activation
+    receives from ALL 3x3 consumers is summed, then rounded once, the other readers' contributions added un-rounded.  With a
+    non-rounding type the patched functions reproduce autograd exactly; with bf16 the two rounding points are where they are
+    said to be."""
+    import torch
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from oracle import torch_oracle as O
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(2, 8, 16, 16, generator=g, dtype=torch.float64)
+    cell = nn.Sequential(nn.Conv2d(8, 8, 3, padding=1), nn.InstanceNorm2d(8, affine=True), nn.Dropout(0.0), nn.LeakyReLU(0.1, inplace=True)).double()
+    c1, c2 = nn.Conv2d(8, 8, 3, padding=1).double(), nn.Conv2d(16, 8, 3, padding=1).double()
+    pool, up, head, gap = nn.MaxPool2d(2, 2), nn.ConvTranspose2d(8, 8, 2, 2).double(), nn.Conv2d(8, 1, 1).double(), nn.AdaptiveAvgPool2d(1)
+    net = nn.ModuleList([cell, c1, c2, up, head])
+    seen = {}
+
+    def run():
+        for p in net.parameters():
+            p.grad = None
+        y = cell(x)
+        y.register_hook(lambda gr: seen.__setitem__("dy", gr.clone()))
+        other = pool(y).square().sum() + up(y).sum() + head(y).square().sum() + gap(y).sum()
+        convs = c1(y).square().sum() + c2(torch.cat([y, 2 * y], 1)).sum()
+        (other + convs).backward()
+        seen["y"] = y.detach().clone()
+        return [p.grad.clone() for p in net.parameters()]
+
+    want = run()
+    dy_exact = seen["dy"]
+    ctx = O.lowp_conv3x3("bf16")
+    ctx.lp = torch.float64
+    with ctx:
+        got = run()
+    assert F.instance_norm is ctx._orig_in and F.leaky_relu is ctx._orig_lr and F.dropout is ctx._orig_do and F.adaptive_avg_pool2d is ctx._orig_ap
+    for a, b in zip(got, want):
+        assert torch.allclose(a, b, rtol=1e-11, atol=1e-11)
+    assert torch.allclose(seen["dy"], dy_exact, rtol=1e-11, atol=1e-11)
+    r = lambda t: t.bfloat16().to(t.dtype)
+    with O.lowp_conv3x3("bf16"):
+        z = cell[0](x)
+        assert torch.equal(z, r(torch.conv2d(r(x), r(cell[0].weight), cell[0].bias, 1, 1)))       # the stored conv output
+        run()
+        y = seen["y"]
+        # the conv readers' share, recomputed: dgrads on rounded dy and w, summed, rounded once
+        yl = y.clone().requires_grad_(True)
+        (c1(yl).square().sum() + c2(torch.cat([yl, 2 * yl], 1)).sum()).backward()
+        conv_part = r(yl.grad)
+        yo = y.clone().requires_grad_(True)
+        (pool(yo).square().sum() + up(yo).sum() + head(yo).square().sum() + gap(yo).sum()).backward()
+        assert torch.allclose(seen["dy"], conv_part + yo.grad, rtol=1e-12, atol=1e-12)
+        assert not torch.allclose(seen["dy"], r(seen["dy"]), rtol=0, atol=0)                      # the sum itself is not rounded
+    with O.lowp_conv3x3("bf16", z16=False):
+        assert torch.equal(cell[0](x), torch.conv2d(r(x), r(cell[0].weight), cell[0].bias, 1, 1))
