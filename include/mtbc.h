@@ -108,6 +108,22 @@ typedef struct {
                                         (rounded) outputs, fp32, no atomics; mtbc_instnorm_lrelu_fwd(stats_partial, stats_slots)
                                         combines them (fixed order, in double) and the normalisation becomes one streaming
                                         pass with no reduction of its own.                                                  */
+    /* A gathered dgrad (forward-type launch over the dz of a tensor's 3x3 consumers, out_layout C8) can also prepare the
+       InstanceNorm + LeakyReLU BACKWARD of the tensor it differentiates (all optional, norm_z selects it):
+         out_partial : fp32 planar (N,Cout,H,W) partial gradient written by the tensor's other readers (pool / ConvT / 1x1
+                       backward), added in fp32 BEFORE the one rounding of `out`;
+         norm_z      : the tensor's own conv output z, 16-bit channel-blocked like `out`; norm_mean / norm_rstd (N*Cout),
+                       norm_gamma / norm_beta (Cout or NULL), norm_slope: its InstanceNorm + LeakyReLU;
+       stats_partial then receives, per image, pixel subset and channel, {sum g, sum g * xhat} with g = dy * lrelu'(.) of the
+       STORED dy -- the two reductions of the norm's backward (mtbc_instnorm_lrelu_bwd(stats_partial, stats_slots) becomes
+       one streaming pass).                                                                                               */
+    const float* out_partial;
+    const void* norm_z;
+    const float* norm_mean;
+    const float* norm_rstd;
+    const float* norm_gamma;
+    const float* norm_beta;
+    float norm_slope;
 } mtbc_conv3x3_args;
 #define MTBC_LAYOUT_PLANAR 0
 #define MTBC_LAYOUT_C8 1
@@ -225,7 +241,10 @@ typedef struct {
     int32_t z_layout;
     int32_t dy_layout;
     /* forward with z_layout C8 and y8: the statistics come from the producing convolution's epilogue
-       (mtbc_conv3x3_args.stats_partial, [N][stats_slots][C][2]); mean / rstd are still written for the backward pass. */
+       (mtbc_conv3x3_args.stats_partial, [N][stats_slots][C][2]); mean / rstd are still written for the backward pass.
+       backward with z_layout C8, dy_layout C8 and dz8: {sum g, sum g * xhat} come from the gathered dgrad that wrote dy
+       (mtbc_conv3x3_args.norm_z); the conv-bias gradient dbias_pre (mathematically zero in front of a norm) is then written
+       as exact zeros instead of the rounding noise of a sum.  workspace: N*C*5 floats.                                  */
     const float* stats_partial;
     int32_t stats_slots;
 } mtbc_instnorm_args;

@@ -35,7 +35,8 @@ class Conv3x3Args(C.Structure):
                 ("accumulate_dw", C.c_int32), ("force_direct", C.c_int32),
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
                 ("compute", C.c_int32), ("operand_layout", C.c_int32), ("out_accumulate", C.c_int32), ("out_layout", C.c_int32),
-                ("stats_partial", C.c_void_p)]
+                ("stats_partial", C.c_void_p), ("out_partial", C.c_void_p), ("norm_z", C.c_void_p), ("norm_mean", C.c_void_p),
+                ("norm_rstd", C.c_void_p), ("norm_gamma", C.c_void_p), ("norm_beta", C.c_void_p), ("norm_slope", C.c_float)]
 
 
 class InstNormArgs(C.Structure):

@@ -55,6 +55,11 @@ struct ConvP {
     int mtiles;
     int dbg;      // timing probes only (env MTBC_DBG): 1 = no global loads, 2 = no epilogue, 4 = no LDS stores
     float* stats;               // channel-blocked 16-bit output only, or nullptr: [N][slots][Cout][2] per-wave {sum, sum of squares} of the stored values
+    // O8 == 2 (gathered dgrad that prepares the InstanceNorm backward of its output tensor): stats = {sum g, sum g * xhat}
+    const float* extra;         // fp32 planar partial gradient added before the rounding, or nullptr
+    const unsigned short* nz;   // the tensor's conv output z, channel-blocked like the output
+    const float* nmean; const float* nrstd; const float* ngamma; const float* nbeta;
+    float nslope;
 };
 
 constexpr int KC = 8;           // input channels per LDS chunk
@@ -875,11 +880,20 @@ __global__ __launch_bounds__(256, 3) void conv3x3_igemm_lp_kernel(const ConvP p)
 // NW = waves per block: 4 (256 pixels: 8 x 32, 16 x 16 or four 8 x 8 images) or, wide maps only, 8 (512 pixels: 16 x 32 --
 // 19.5 % halo instead of 33 % and each weight chunk shared by twice the pixels; 58 KB of LDS = 2 blocks per CU.  Measured
 // (tools/experiments/c8_igemm_v2_probe.hip): 144->24 @256x256 -6..-17 %, 24->24 -3 %, 64x64 maps +15 %: chosen by run_igemm).
+// sum over the 16 lanes of a DPP row, result in lane 15 of the row: four v_add_f32 with row_shr modifiers (no LDS crossbar)
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x118, 0xf, 0xf, true));      // row_shr:8
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x114, 0xf, 0xf, true));      // row_shr:4
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x112, 0xf, 0xf, true));      // row_shr:2
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, true));      // row_shr:1
+    return v;
+}
+
 // O8 = the OUTPUT is 16-bit channel-blocked as well (conv outputs z / single-writer gradients of the 16-bit modes): the MFMAs
 // run as D = W X (channels on the rows), so a lane holds 4 consecutive channels of ONE pixel = half a 16-byte piece; the 16
 // lanes of a row group write 16 consecutive pixels, and the lane groups kg = 2q, 2q + 1 the two halves of the same pieces
 // (256 contiguous bytes per channel group and instruction).  fp32 accumulate + bias, one RNE.
-template <int MT, int GEO, bool F16, int NW, bool O8>
+template <int MT, int GEO, bool F16, int NW, int O8>      // O8: 0 = fp32 planar output, 1 = 16-bit channel-blocked (+ forward statistics), 2 = that + the norm-backward epilogue
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 4) void conv3x3_igemm_c8_kernel(const ConvP p) {
     using G = GeoLP<GEO>;
     using T = LP<F16>;
@@ -948,6 +962,29 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 4) void conv3x3_igemm_c8_ker
         for (int m = 0; m < MT; ++m)
 #pragma unroll
             for (int g = 0; g < 4; ++g) acc[m][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // O8 == 2: the tensor's own z at this lane's output positions, requested NOW so that it arrives under the MFMAs (loaded in
+        // the epilogue it is a full memory latency per tile with the accumulators parked)
+        typedef unsigned pre_u32x2 __attribute__((ext_vector_type(2)));
+        typedef __attribute__((address_space(1))) pre_u32x2 gpre2;
+        pre_u32x2 zpre[O8 == 2 ? MT : 1][4];
+        if constexpr (O8 == 2) {
+            const int nn = GEO == 2 ? n0 + wv : n0;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                int y, x;
+                if (GEO == 0) { y = y0 + 2 * wv + (g >> 1); x = x0 + 16 * (g & 1) + j; }
+                else if (GEO == 1) { y = y0 + 4 * wv + g; x = x0 + j; }
+                else { y = y0 + 2 * g + (j >> 3); x = x0 + (j & 7); }
+                const bool ok = nn < p.N && y < p.H && x < p.W;
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    const int co = (mt0 + m) * 16 + 4 * kg;
+                    zpre[m][g] = (pre_u32x2){0u, 0u};
+                    if (ok && co < p.Cout)
+                        zpre[m][g] = *(const gpre2*)((const gchar*)p.nz + 2 * ((size_t)nn * p.Cout * HW + (size_t)(co >> 3) * HW * 8) + 2 * (co & 7) + 16 * (size_t)(y * p.W + x));
+                }
+            }
+        }
 
         for (int ch = 0; ch < nchunks; ++ch) {
             lds_barrier();                        // the previous step's fragments are consumed
@@ -1003,14 +1040,14 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 4) void conv3x3_igemm_c8_ker
                 for (int m = 0; m < MT; ++m)
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
-                        if constexpr (O8) acc[m][g] = T::mfma(a[m], b[g], acc[m][g]);      // rows = channels, cols = pixels
+                        if constexpr (O8 != 0) acc[m][g] = T::mfma(a[m], b[g], acc[m][g]);      // rows = channels, cols = pixels
                         else acc[m][g] = T::mfma(b[g], a[m], acc[m][g]);                   // rows = pixels, cols = channels
                     }
             }
         }
         const int n = GEO == 2 ? n0 + wv : n0;
         if MTBC_DBG_BIT(p, 2) { if (acc[0][0][0] != 12345.678f) continue; }
-        if constexpr (O8) {
+        if constexpr (O8 != 0) {
             // ---- epilogue, channel-blocked 16-bit output: lane (j, kg) holds channels 16m + 4kg .. + 3 of pixel j of group g
             typedef unsigned ep_u32x2 __attribute__((ext_vector_type(2)));
             typedef unsigned ep_u32x4 __attribute__((ext_vector_type(4)));
@@ -1024,35 +1061,65 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 4) void conv3x3_igemm_c8_ker
                 else { y = y0 + 2 * g + (j >> 3); x = x0 + (j & 7); }
                 pix[g] = (n < p.N && y < p.H && x < p.W) ? y * p.W + x : -1;
             }
+            const bool want_stats = O8 == 2 || p.stats != nullptr;
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
                 const int co = (mt0 + m) * 16 + 4 * kg;
                 if (co >= p.Cout) continue;
                 const SegL so = segl_ref(seg_out, co);
                 // piece (n, group, pixel) of the segment's tensor; this lane owns channels (co - cb) % 8 .. + 3 of it
-                gchar* cb = (gchar*)so.ptr + 2 * ((size_t)n * so.bs + (size_t)((co - so.cb) >> 3) * HW * 8) + 2 * ((co - so.cb) & 7);
+                const size_t poff8 = 2 * ((size_t)n * so.bs + (size_t)((co - so.cb) >> 3) * HW * 8) + 2 * ((co - so.cb) & 7);
+                gchar* cb = (gchar*)so.ptr + poff8;
                 const f32x4 bv = *reinterpret_cast<const f32x4*>(bias_s + m * 16 + 4 * kg);
                 f32x4 ss = (f32x4){0.f, 0.f, 0.f, 0.f}, sq = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if constexpr (O8 == 2) {
+                    // gathered dgrad + the reductions of the InstanceNorm / LeakyReLU backward of the tensor it differentiates
+                    // (one output segment = the whole tensor): dy = sum over the 3x3 consumers (+ the other readers' fp32 partial),
+                    // rounded once and stored; g = dy_stored * lrelu'(gamma * xhat + beta); the wave's {sum g, sum g * xhat}
+                    const size_t plane = (size_t)n * p.Cout + co;
+                    f32x4 mean4 = (f32x4){0.f, 0.f, 0.f, 0.f}, rstd4 = mean4, ga4 = (f32x4){1.f, 1.f, 1.f, 1.f}, be4 = mean4;
+                    if (n < p.N) { mean4 = *reinterpret_cast<const f32x4*>(p.nmean + plane); rstd4 = *reinterpret_cast<const f32x4*>(p.nrstd + plane); }
+                    if (p.ngamma) { ga4 = *reinterpret_cast<const f32x4*>(p.ngamma + co); be4 = *reinterpret_cast<const f32x4*>(p.nbeta + co); }
+                    const float* eb = p.extra ? p.extra + plane * HW : nullptr;
 #pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    if (pix[g] >= 0) {
-                        const f32x4 r = acc[m][g] + bv;
-                        const float q[8] = {r[0], r[1], r[2], r[3], 0.f, 0.f, 0.f, 0.f};
-                        const ep_u32x4 u = __builtin_bit_cast(ep_u32x4, T::pack(q));
-                        *(guint2*)(cb + 16 * (size_t)pix[g]) = (ep_u32x2){u[0], u[1]};
-                        if (p.stats) {          // InstanceNorm statistics of the STORED values
-                            const unsigned u0 = u[0], u1 = u[1];
-                            const f32x4 v = (f32x4){T::lo(u0), T::hi(u0), T::lo(u1), T::hi(u1)};
-                            ss += v; sq += v * v;
+                    for (int g = 0; g < 4; ++g)
+                        if (pix[g] >= 0) {
+                            const pre_u32x2 zw = zpre[m][g];
+                            f32x4 ex = (f32x4){0.f, 0.f, 0.f, 0.f};
+                            if (eb) ex = (f32x4){eb[pix[g]], eb[(size_t)HW + pix[g]], eb[2 * (size_t)HW + pix[g]], eb[3 * (size_t)HW + pix[g]]};
+                            const f32x4 r = acc[m][g] + ex;
+                            const float q[8] = {r[0], r[1], r[2], r[3], 0.f, 0.f, 0.f, 0.f};
+                            const ep_u32x4 u = __builtin_bit_cast(ep_u32x4, T::pack(q));
+                            *(guint2*)(cb + 16 * (size_t)pix[g]) = (ep_u32x2){u[0], u[1]};
+                            const unsigned u0 = u[0], u1 = u[1], z0 = zw[0], z1 = zw[1];
+                            const f32x4 dyv = (f32x4){T::lo(u0), T::hi(u0), T::lo(u1), T::hi(u1)};
+                            const f32x4 xh = ((f32x4){T::lo(z0), T::hi(z0), T::lo(z1), T::hi(z1)} - mean4) * rstd4;
+                            const f32x4 pre = xh * ga4 + be4;
+                            f32x4 gg;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) gg[e] = dyv[e] * (pre[e] > 0.f ? 1.f : p.nslope);
+                            ss += gg; sq += gg * xh;
                         }
-                    }
-                if (p.stats) {
-                    // this wave's pixels: the 16 lanes of a row group hold 16 pixels of the same 4 channels -> butterfly inside the group
+                } else {
 #pragma unroll
-                    for (int o = 8; o > 0; o >>= 1)
+                    for (int g = 0; g < 4; ++g)
+                        if (pix[g] >= 0) {
+                            const f32x4 r = acc[m][g] + bv;
+                            const float q[8] = {r[0], r[1], r[2], r[3], 0.f, 0.f, 0.f, 0.f};
+                            const ep_u32x4 u = __builtin_bit_cast(ep_u32x4, T::pack(q));
+                            *(guint2*)(cb + 16 * (size_t)pix[g]) = (ep_u32x2){u[0], u[1]};
+                            if (p.stats) {          // InstanceNorm statistics of the STORED values
+                                const unsigned u0 = u[0], u1 = u[1];
+                                const f32x4 v = (f32x4){T::lo(u0), T::hi(u0), T::lo(u1), T::hi(u1)};
+                                ss += v; sq += v * v;
+                            }
+                        }
+                }
+                if (want_stats) {
+                    // this wave's pixels: the 16 lanes of a row group hold 16 pixels of the same 4 channels -> DPP row sums
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) { ss[e] += __shfl_xor(ss[e], o, 64); sq[e] += __shfl_xor(sq[e], o, 64); }
-                    if (j == 0 && n < p.N) {
+                    for (int e = 0; e < 4; ++e) { ss[e] = row16_sum(ss[e]); sq[e] = row16_sum(sq[e]); }
+                    if (j == 15 && n < p.N) {
                         const int slots = GEO == 2 ? 1 : p.tiles_x * p.tiles_y * NW;
                         const int slot = GEO == 2 ? 0 : (ty * p.tiles_x + tx) * NW + wv;
                         float* sp = p.stats + (((size_t)n * slots + slot) * p.Cout + co) * 2;
@@ -2177,7 +2244,7 @@ int launch_igemm_lp_mt(int MT, const ConvP& p, int mblocks, bool f16, hipStream_
     }
 }
 
-template <int MT, int GEO, int NW, bool O8>
+template <int MT, int GEO, int NW, int O8>
 int launch_igemm_c8(const ConvP& p, int mblocks, bool f16, hipStream_t st) {
     using G = GeoLP<GEO>;
     constexpr int TH = GEO == 0 ? 2 * NW : G::TH;
@@ -2202,7 +2269,7 @@ int launch_igemm_c8(const ConvP& p, int mblocks, bool f16, hipStream_t st) {
     MTBC_CHECK_LAUNCH();
     return MTBC_OK;
 }
-template <int GEO, bool O8>
+template <int GEO, int O8>
 int launch_igemm_c8_mt(int MT, const ConvP& p, int mblocks, bool f16, hipStream_t st) {
     if (MT == 1) return launch_igemm_c8<1, GEO, 4, O8>(p, mblocks, f16, st);
     if (MT == 3) return launch_igemm_c8<3, GEO, 4, O8>(p, mblocks, f16, st);
@@ -2211,7 +2278,7 @@ int launch_igemm_c8_mt(int MT, const ConvP& p, int mblocks, bool f16, hipStream_
 
 // geometry of an igemm launch: map geometry, pixel tiles, channel tiles per block, 8-wave (16 x 32 pixel) blocks
 struct IgemmPlan { int geo, tiles_x, tiles_y, ntiles, mtiles, MT, mblocks; bool nw8; };
-IgemmPlan plan_igemm(int N, int H, int W, int rows, int compute, bool c8) {
+IgemmPlan plan_igemm(int N, int H, int W, int rows, int compute, bool c8, bool allow_nw8 = true) {
     IgemmPlan q{};
     q.geo = pick_geo(H, W);
     q.mtiles = cdiv(rows, 16);
@@ -2238,7 +2305,7 @@ IgemmPlan plan_igemm(int N, int H, int W, int rows, int compute, bool c8) {
         // wide maps with enough tiles for two 512-pixel blocks per CU several times over: 16 x 32 tiles, 8 waves
         static const int nw_env = mtbc_probe_int("MTBC_C8_NW", 0);      // A/B
         const int t16 = q.tiles_x * cdiv(H, 16) * N;
-        if (q.geo == 0 && q.MT == 2 && (nw_env ? nw_env == 8 : (long long)t16 * q.mblocks >= 2048)) {
+        if (allow_nw8 && q.geo == 0 && q.MT == 2 && (nw_env ? nw_env == 8 : (long long)t16 * q.mblocks >= 2048)) {
             q.nw8 = true; q.tiles_y = cdiv(H, 16); q.ntiles = t16;
         }
     }
@@ -2248,24 +2315,35 @@ IgemmPlan plan_igemm(int N, int H, int W, int rows, int compute, bool c8) {
 // shared by fwd and dgrad: `rows` = channels written, `red` = channels read; compute: 0 fp32, 1 bf16, 2 fp16 operands;
 // c8: the tensor read is 16-bit channel-blocked (MTBC_LAYOUT_C8); o8: so is the tensor written (+ optional epilogue statistics)
 int run_igemm(int N, int H, int W, int red, int rows, const SegTable& in, const SegTable& out, const float* wp,
-              const float* bias, int compute, hipStream_t st, bool c8 = false, bool o8 = false, float* stats = nullptr) {
+              const float* bias, int compute, hipStream_t st, bool c8 = false, int o8 = 0, float* stats = nullptr,
+              const mtbc_conv3x3_args* nb = nullptr) {
     ConvP p;
     p.N = N; p.H = H; p.W = W; p.Cin = red; p.Cout = rows; p.in = in; p.out = out; p.wp = wp; p.bias = bias; p.stats = stats;
+    p.extra = nullptr; p.nz = nullptr; p.nmean = p.nrstd = p.ngamma = p.nbeta = nullptr; p.nslope = 0.f;
+    if (o8 == 2) {
+        p.extra = nb->out_partial; p.nz = reinterpret_cast<const unsigned short*>(nb->norm_z); p.nmean = nb->norm_mean; p.nrstd = nb->norm_rstd;
+        p.ngamma = nb->norm_gamma; p.nbeta = nb->norm_beta; p.nslope = nb->norm_slope;
+    }
     static const int dbg = mtbc_probe_int("MTBC_DBG", 0);
     p.dbg = dbg;
-    const IgemmPlan q = plan_igemm(N, H, W, rows, compute, c8);
+    const IgemmPlan q = plan_igemm(N, H, W, rows, compute, c8, o8 != 2);      // (the norm-backward epilogue spills in the 8-wave variant)
     const int geo = q.geo, MT = q.MT, mblocks = q.mblocks;
     p.mtiles = q.mtiles; p.tiles_x = q.tiles_x; p.tiles_y = q.tiles_y; p.ntiles = q.ntiles;
     if (c8) {
-        if (q.nw8) return o8 ? launch_igemm_c8<2, 0, 8, true>(p, mblocks, compute == 2, st) : launch_igemm_c8<2, 0, 8, false>(p, mblocks, compute == 2, st);
-        if (o8) {
-            if (geo == 0) return launch_igemm_c8_mt<0, true>(MT, p, mblocks, compute == 2, st);
-            if (geo == 1) return launch_igemm_c8_mt<1, true>(MT, p, mblocks, compute == 2, st);
-            return launch_igemm_c8_mt<2, true>(MT, p, mblocks, compute == 2, st);
+        if (q.nw8) return o8 == 1 ? launch_igemm_c8<2, 0, 8, 1>(p, mblocks, compute == 2, st) : launch_igemm_c8<2, 0, 8, 0>(p, mblocks, compute == 2, st);
+        if (o8 == 2) {
+            if (geo == 0) return launch_igemm_c8_mt<0, 2>(MT, p, mblocks, compute == 2, st);
+            if (geo == 1) return launch_igemm_c8_mt<1, 2>(MT, p, mblocks, compute == 2, st);
+            return launch_igemm_c8_mt<2, 2>(MT, p, mblocks, compute == 2, st);
         }
-        if (geo == 0) return launch_igemm_c8_mt<0, false>(MT, p, mblocks, compute == 2, st);
-        if (geo == 1) return launch_igemm_c8_mt<1, false>(MT, p, mblocks, compute == 2, st);
-        return launch_igemm_c8_mt<2, false>(MT, p, mblocks, compute == 2, st);
+        if (o8 == 1) {
+            if (geo == 0) return launch_igemm_c8_mt<0, 1>(MT, p, mblocks, compute == 2, st);
+            if (geo == 1) return launch_igemm_c8_mt<1, 1>(MT, p, mblocks, compute == 2, st);
+            return launch_igemm_c8_mt<2, 1>(MT, p, mblocks, compute == 2, st);
+        }
+        if (geo == 0) return launch_igemm_c8_mt<0, 0>(MT, p, mblocks, compute == 2, st);
+        if (geo == 1) return launch_igemm_c8_mt<1, 0>(MT, p, mblocks, compute == 2, st);
+        return launch_igemm_c8_mt<2, 0>(MT, p, mblocks, compute == 2, st);
     }
     if (compute != 0) {
         if (geo == 0) return launch_igemm_lp_mt<0>(MT, p, mblocks, compute == 2, st);
@@ -2430,9 +2508,15 @@ int mtbc_conv3x3_fwd(const mtbc_conv3x3_args* a, void* stream) {
             out.accumulate[0] = 3;
         }
         if (a->stats_partial && (!o8 || (reinterpret_cast<uintptr_t>(a->stats_partial) & 15))) return MTBC_E_BADARG;
-        return run_igemm(a->N, a->H, a->W, a->Cin, a->Cout, in, out, a->w_packed, a->bias, a->compute, st, true, o8, a->stats_partial);
+        if (a->norm_z || a->out_partial) {       // gathered dgrad + the reductions of the norm backward
+            if (!o8 || !a->norm_z || !a->norm_mean || !a->norm_rstd || !a->stats_partial || a->bias || (a->norm_gamma == nullptr) != (a->norm_beta == nullptr)) return MTBC_E_BADARG;
+            if ((reinterpret_cast<uintptr_t>(a->norm_z) | reinterpret_cast<uintptr_t>(a->norm_mean) | reinterpret_cast<uintptr_t>(a->norm_rstd) |
+                 reinterpret_cast<uintptr_t>(a->norm_gamma) | reinterpret_cast<uintptr_t>(a->norm_beta)) & 15) return MTBC_E_BADARG;
+            return run_igemm(a->N, a->H, a->W, a->Cin, a->Cout, in, out, a->w_packed, nullptr, a->compute, st, true, 2, a->stats_partial, a);
+        }
+        return run_igemm(a->N, a->H, a->W, a->Cin, a->Cout, in, out, a->w_packed, a->bias, a->compute, st, true, o8 ? 1 : 0, a->stats_partial);
     }
-    if (a->stats_partial) return MTBC_E_UNSUPPORTED;
+    if (a->stats_partial || a->norm_z || a->out_partial) return MTBC_E_UNSUPPORTED;
     if (a->operand_layout != MTBC_LAYOUT_PLANAR) return MTBC_E_BADARG;
     if (a->w_packed && !a->force_direct && mfma_ok(a->in, a->n_in, a->H, a->W))
         return run_igemm(a->N, a->H, a->W, a->Cin, a->Cout, in, out, a->w_packed, a->bias, a->compute, st);
@@ -2468,7 +2552,7 @@ int mtbc_conv3x3_dgrad(const mtbc_conv3x3_args* a, void* stream) {
             if (a->in[i].accumulate == 3) ++n3;
         }
         if (n3 != 0 && (n3 != a->n_in || !c8_segs_ok(a->in, a->n_in))) return MTBC_E_BADARG;      // channel-blocked dx: every segment or none
-        return run_igemm(a->N, a->H, a->W, a->Cout, a->Cin, in, out, a->w_packed, nullptr, a->compute, st, true, n3 != 0);
+        return run_igemm(a->N, a->H, a->W, a->Cout, a->Cin, in, out, a->w_packed, nullptr, a->compute, st, true, n3 != 0 ? 1 : 0);
     }
     if (a->operand_layout != MTBC_LAYOUT_PLANAR) return MTBC_E_BADARG;
     for (int i = 0; i < a->n_in; ++i)
@@ -2487,7 +2571,7 @@ int mtbc_conv3x3_dgrad(const mtbc_conv3x3_args* a, void* stream) {
 int32_t mtbc_conv3x3_stats_slots(const mtbc_conv3x3_args* a) {
     if (check_conv(a) || a->operand_layout != MTBC_LAYOUT_C8 || a->out_layout != MTBC_LAYOUT_C8 || (a->compute != 1 && a->compute != 2)) return 0;
     if (a->W % 4 || a->W < 8 || a->H < 8 || a->Cout % 8) return 0;
-    const IgemmPlan q = plan_igemm(a->N, a->H, a->W, a->Cout, a->compute, true);
+    const IgemmPlan q = plan_igemm(a->N, a->H, a->W, a->Cout, a->compute, true, a->norm_z == nullptr);
     return q.geo == 2 ? 1 : q.tiles_x * q.tiles_y * (q.nw8 ? 8 : 4);
 }
 

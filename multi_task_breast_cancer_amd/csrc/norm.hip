@@ -396,13 +396,15 @@ int mtbc_instnorm_lrelu_bwd(const mtbc_instnorm_args* a, void* stream) {
     }
     hipStream_t st = (hipStream_t)stream;
     if (a->dz8) {
-        const int T = mtbc_i_instnorm_bwd_c8_team(a);
+        const bool epi = a->stats_partial != nullptr;      // reductions from the gathered dgrad's epilogue: no team, no per-member partials
+        const int T = epi ? 2 : mtbc_i_instnorm_bwd_c8_team(a);
         if (T < 1) return MTBC_E_UNSUPPORTED;
-        if (want && a->workspace_bytes < (size_t)planes * (3 + T) * sizeof(float)) return MTBC_E_WORKSPACE;
-        rc = mtbc_i_instnorm_bwd_c8(a, p.part, st); if (rc) return rc;
+        if ((want || epi) && (!a->workspace || a->workspace_bytes < (size_t)planes * (3 + T) * sizeof(float))) return MTBC_E_WORKSPACE;
+        if (epi && !want) p.part = reinterpret_cast<float*>(a->workspace);
+        rc = mtbc_i_instnorm_bwd_c8(a, want ? p.part : nullptr, st); if (rc) return rc;
         if (want) {
             hipLaunchKernelGGL(in_dparam_kernel, dim3(a->C), dim3(64), 0, st, p.part, a->dgamma, a->dbeta,
-                               a->dbias_pre, a->N, a->C, a->accumulate_dparams, p.part + (size_t)3 * planes, T);
+                               a->dbias_pre, a->N, a->C, a->accumulate_dparams, epi ? nullptr : p.part + (size_t)3 * planes, epi ? 0 : T);
             MTBC_CHECK_LAUNCH();
         }
         return MTBC_OK;

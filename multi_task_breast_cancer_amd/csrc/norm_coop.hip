@@ -439,6 +439,63 @@ __global__ __launch_bounds__(AP_THREADS) void in_apply_fwd_c8_kernel(const CoP p
     }
 }
 
+// Backward twin: the gathered dgrad that wrote dy left {sum g, sum g * xhat} per (image, pixel subset, channel)
+// (mtbc_conv3x3_args.norm_z).  One wave per (n, c) adds them up (double, fixed order) -> m1 = S1 / HW, m2 = S2 / HW and the
+// parameter-gradient partials {S1, S2, 0}; then dz = rstd * gamma * (g - m1 - xhat * m2) is one streaming pass.
+__global__ void in_bstats_finalize_kernel(const float* __restrict__ part, int slots, int C, int HW, float* __restrict__ m12,
+                                          float* __restrict__ dparam_part, int planes) {
+    const int plane = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (plane >= planes) return;
+    const int n = plane / C, c = plane % C;
+    const float* q = part + ((size_t)n * slots * C + c) * 2;
+    double s1 = 0.0, s2 = 0.0;
+    for (int t = lane; t < slots; t += 64) { const float2 v = *reinterpret_cast<const float2*>(q + (size_t)t * C * 2); s1 += (double)v.x; s2 += (double)v.y; }
+    s1 = wave_sum_d(s1); s2 = wave_sum_d(s2);
+    if (lane == 0) {
+        m12[2 * plane] = (float)(s1 / (double)HW); m12[2 * plane + 1] = (float)(s2 / (double)HW);
+        if (dparam_part) { dparam_part[3 * plane] = (float)s1; dparam_part[3 * plane + 1] = (float)s2; dparam_part[3 * plane + 2] = 0.f; }
+    }
+}
+template <bool F16>
+__global__ __launch_bounds__(AP_THREADS) void in_apply_bwd_c8_kernel(const CoP p, const float* __restrict__ m12) {
+    const int item = blockIdx.y, n = item / p.G8, g = item % p.G8;
+    float mu[8], rs[8], ga[8], be[8], m1[8], m2[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const size_t pl = (size_t)n * p.C + 8 * g + c;
+        mu[c] = p.mean[pl]; rs[c] = p.rstd[pl]; ga[c] = p.gamma ? p.gamma[8 * g + c] : 1.f; be[c] = p.beta ? p.beta[8 * g + c] : 0.f;
+        m1[c] = m12[2 * pl]; m2[c] = m12[2 * pl + 1];
+    }
+    const unsigned short* zg = p.z8 + ((size_t)n * p.G8 + g) * p.HW * 8;
+    const unsigned short* dg = p.dy8 + (size_t)n * p.dy8bs + (size_t)g * p.HW * 8;
+    unsigned short* ob = p.dz8 + ((size_t)n * p.G8 + g) * p.HW * 8;
+    const int px0 = blockIdx.x * (AP_THREADS * AP_PPT) + threadIdx.x;
+    co_u32x4 wz[AP_PPT], wd[AP_PPT];
+#pragma unroll
+    for (int k = 0; k < AP_PPT; ++k) {
+        const int px = px0 + AP_THREADS * k;
+        if (px < p.HW) { wz[k] = *reinterpret_cast<const co_u32x4*>(zg + (size_t)px * 8); wd[k] = *reinterpret_cast<const co_u32x4*>(dg + (size_t)px * 8); }
+    }
+#pragma unroll
+    for (int k = 0; k < AP_PPT; ++k) {
+        const int px = px0 + AP_THREADS * k;
+        if (px >= p.HW) continue;
+        float z[8], d[8];
+        co_unpk<F16>(wz[k], z);
+        co_unpk<F16>(wd[k], d);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const float xh = (z[c] - mu[c]) * rs[c];
+            const float gg = d[c] * ((xh * ga[c] + be[c]) > 0.f ? 1.f : p.slope);
+            d[c] = rs[c] * ga[c] * (gg - m1[c] - xh * m2[c]);
+        }
+        co_u32x4 o;
+#pragma unroll
+        for (int h = 0; h < 4; ++h) o[h] = co_pk<F16>(d[2 * h], d[2 * h + 1]);
+        *reinterpret_cast<co_u32x4*>(ob + (size_t)px * 8) = o;
+    }
+}
+
 struct CoPlan { bool ok; int ppt, T, grid, nteams; };
 template <typename K> int resident_blocks(K kernel) {
     int per_cu = 0, dev = 0;
@@ -523,7 +580,10 @@ template <bool BWD, int THREADS, int PPT, bool COOP, typename F> auto with_kerne
 template <bool BWD, int PPT> int cap_ppt(const Var& v) { return with_kernel<BWD, CO_THREADS, PPT, true>(v, [](auto k) { return cap_of<decltype(k)::value>(); }); }
 template <bool BWD> CoPlan plan_team(int items, int HW, const Var& v, int reserve) {
     int cap[9] = {0};
-    cap[1] = cap_ppt<BWD, 1>(v); cap[2] = cap_ppt<BWD, 2>(v); cap[4] = cap_ppt<BWD, 4>(v);      // 8 pixels per thread spill at 4 waves/SIMD: not built
+    cap[1] = cap_ppt<BWD, 1>(v); cap[2] = cap_ppt<BWD, 2>(v); cap[4] = cap_ppt<BWD, 4>(v);
+    // (a backward that keeps its slab packed as stored -- 8 pixels per thread, half the team size and rounds -- was built: the
+    //  compiler spills ~150 VGPRs at 4 waves/SIMD; with 4 pixels per thread it is no faster than this one, nor is starting the
+    //  odd teams late so that their loads fall into the even teams' exchanges: tools/experiments/in_bwd_probe.sh)
     return plan_coop(items, HW, 4, cap, reserve);
 }
 Var var_of(const mtbc_instnorm_args* a) { return Var{a->out16_type == 2, a->z_layout == MTBC_LAYOUT_C8, a->dy_layout == MTBC_LAYOUT_C8 ? (a->n_dy_extra ? 2 : 1) : 0}; }
@@ -604,6 +664,18 @@ int mtbc_i_instnorm_bwd_c8(const mtbc_instnorm_args* a, float* part, hipStream_t
         if (a->n_dy_extra == 1) { if (!a->dy_extra[0]) return MTBC_E_BADARG; p.dyx = a->dy_extra[0]; }
     } else if (a->n_dy_extra != 0) return MTBC_E_BADARG;
     p.part = part;
+    if (a->stats_partial) {         // {sum g, sum g * xhat} from the gathered dgrad's epilogue: finalize + one streaming pass
+        if (!p.z8 || !p.dy8 || p.dyx || a->stats_slots <= 0 || !a->workspace || a->workspace_bytes < (size_t)a->N * a->C * 5 * sizeof(float)) return MTBC_E_BADARG;
+        const int planes = a->N * a->C;
+        float* m12 = reinterpret_cast<float*>(a->workspace) + (size_t)3 * planes;
+        hipLaunchKernelGGL(in_bstats_finalize_kernel, dim3(cdiv(planes, 4)), dim3(256), 0, st, a->stats_partial, a->stats_slots, a->C, p.HW, m12, part, planes);
+        MTBC_CHECK_LAUNCH();
+        const dim3 g(cdiv(p.HW, AP_THREADS * AP_PPT), p.items);
+        if (p.f16) hipLaunchKernelGGL(in_apply_bwd_c8_kernel<true>, g, dim3(AP_THREADS), 0, st, p, m12);
+        else hipLaunchKernelGGL(in_apply_bwd_c8_kernel<false>, g, dim3(AP_THREADS), 0, st, p, m12);
+        MTBC_CHECK_LAUNCH();
+        return MTBC_OK;
+    }
     if (p.HW <= SOLO_MAX_HW) {
         p.part3 = part ? part + (size_t)3 * a->N * a->C : nullptr;
         launch_solo<true>(p, st); MTBC_CHECK_LAUNCH(); return MTBC_OK;

@@ -31,6 +31,8 @@ _NO_C8_SMALL = _sw.flag("MTBC_NO_C8_SMALL_OPS")
 _NO_G16 = _sw.flag("MTBC_NO_G16")
 _NO_Z16 = _sw.flag("MTBC_NO_Z16")
 _NO_DA16 = _sw.flag("MTBC_NO_DA16")
+_NO_EPI_STATS = _sw.flag("MTBC_NO_EPI_STATS")
+_EPI_BSTATS = _sw.flag("MTBC_EPI_BSTATS")
 _BWD_OVERLAP = _sw.flag("MTBC_BWD_OVERLAP")
 _BWD_OVERLAP_MAX_HW = int(_sw.get("MTBC_BWD_OVERLAP_MAX_HW"))
 
@@ -170,6 +172,8 @@ class StepPlan:
         self.loss_ops: List[L.Op] = []
         self.ws_bytes = 0
         self.ws_users: List[Tuple[L.Op, str]] = []
+        self._stat_users: List[Tuple[L.Op, str]] = []      # conv forward / InstanceNorm forward pairs sharing the epilogue-statistics scratch
+        self._stat_bytes = 0
         self.arena_bytes = 0
         self._tag = 0
         self.acts: Dict[str, Act] = {}     # every activation by (reference module path) name, for parity probes
@@ -412,8 +416,16 @@ class StepPlan:
         op.u.conv3.w_packed = _ptr(wp_f)
         op.u.conv3.bias = _ptr(self.pv(bname)) if bname else None
         op.u.conv3.out = z.data_ptr()
+        stats_slots = 0
         if z16:
             op.u.conv3.out_layout = L.LAYOUT_C8
+            if not _NO_EPI_STATS:
+                # InstanceNorm statistics from the conv epilogue ({sum, sum of squares} of the stored values per wave): the
+                # normalisation that follows is then one streaming pass with no reduction / team exchange of its own
+                stats_slots = int(self.lib.mtbc_conv3x3_stats_slots(C.byref(op.u.conv3)))
+                if stats_slots > 0:
+                    self._stat_users.append((op, "conv3"))
+                    self._stat_bytes = max(self._stat_bytes, N * stats_slots * cout * 2 * 4)
         self.fwd_ops.append(op)
 
         def base_in() -> L.Op:
@@ -434,6 +446,9 @@ class StepPlan:
         y.in_op = op
         # (measured: the cooperative kernels win on planes >= 128x128 forward / 256x256 backward; on small planes their
         # barriers and 512-thread workgroups lose to the one-plane kernels + pack)
+        if stats_slots > 0:
+            op.u.inorm.stats_slots = stats_slots
+            self._stat_users.append((op, "inorm"))
         if z16 or (self.compute and not _NO_C8 and not _NO_COOP and not self.force_direct and cout % 8 == 0 and H * W >= _COOP_MIN_FWD
                    and self.lib.mtbc_instnorm_c8_supported(C.byref(op.u.inorm), 0)):
             # 16-bit modes: the cooperative kernel writes the channel-blocked operand tensor itself (and fp32 planes only
@@ -489,9 +504,26 @@ class StepPlan:
                     a.in_[i_].ptr, a.in_[i_].batch_stride, a.in_[i_].channels, a.in_[i_].accumulate = dzj.data_ptr(), coutj * H * W, coutj, 0
                 a.w, a.w_packed, a.out = wg.data_ptr(), wpg.data_ptr(), gbuf.data_ptr()
                 a.compute, a.operand_layout, a.out_accumulate = self.compute, L.LAYOUT_C8, acc
+                bslots = 0
                 if g8:
                     a.out_layout = L.LAYOUT_C8
+                    if _EPI_BSTATS:
+                        # ... and the same epilogue prepares this cell's InstanceNorm backward: it adds the other readers' fp32
+                        # partial BEFORE the one rounding, reads the cell's own z and leaves {sum g, sum g * xhat} per wave -- the
+                        # norm backward below is then one streaming pass (no reduction, no team exchange)
+                        a.norm_z, a.norm_mean, a.norm_rstd, a.norm_slope = z.data_ptr(), mean.data_ptr(), rstd.data_ptr(), slope
+                        a.norm_gamma = _ptr(self.pv(gname)) if gname else None
+                        a.norm_beta = _ptr(self.pv(betaname)) if gname else None
+                        a.out_partial = y.grad.data_ptr() if y.grad_written else None
+                        bslots = int(self.lib.mtbc_conv3x3_stats_slots(C.byref(a)))
+                        if bslots > 0:
+                            self._stat_users.append((op, "conv3"))
+                            self._stat_bytes = max(self._stat_bytes, N * bslots * cout * 2 * 4)
+                        else:
+                            a.norm_z = a.norm_mean = a.norm_rstd = a.norm_gamma = a.norm_beta = a.out_partial = None
                 self.bwd_ops.append(op)
+            else:
+                bslots = 0
             dy = y.grad8 if g8 else self.grad_of(y)
             # IN+LReLU backward, dz written in place over dy (each element is read before it is written)
             op = base_in()
@@ -525,7 +557,12 @@ class StepPlan:
             a.n_dy_extra = len(y.extra_grads)
             for k_, t_ in enumerate(y.extra_grads):
                 a.dy_extra[k_] = t_.data_ptr()
-            if g8 and y.grad_written:
+            if g8 and bslots > 0:
+                a.stats_slots = bslots
+                self._stat_users.append((op, "inorm"))
+                if not (gname or bname):
+                    self._need_ws(op, "inorm", N * cout * 5 * 4)
+            elif g8 and y.grad_written:
                 assert not y.extra_grads
                 a.n_dy_extra = 1
                 a.dy_extra[0] = y.grad.data_ptr()
@@ -567,6 +604,8 @@ class StepPlan:
                 a.dout = dy.data_ptr()
             a.accumulate_dw = self._mark_param(wname)
             a.dw = self.gv(wname).data_ptr()
+            # (batching the ~40 split-K reductions of a step into a few launches was built and measured: 15.20 vs 14.54 ms -- the
+            #  partials then live in buffers of their own and travel to HBM and back instead of being reduced out of the cache)
             self._need_ws(op, "conv3", self.lib.mtbc_conv3x3_wgrad_workspace(C.byref(a)))
             self.bwd_ops.append(op)
             if forked:
@@ -1013,6 +1052,10 @@ class StepPlan:
         for op, fieldname in self.ws_users:
             a = getattr(op.u, fieldname)
             a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+        if self._stat_bytes:       # one scratch for all cells: a conv's partials are consumed by the InstanceNorm op right behind it
+            sb = self.alloc((self._stat_bytes + 15) // 16 * 4)
+            for op, fieldname in self._stat_users:
+                getattr(op.u, fieldname).stats_partial = sb.data_ptr()
         side = torch.cuda.Stream(device=self.dev) if getattr(self, "_events", None) is not None else None
         return {
             "pack": Program(self.wview_ops + self.pack_ops, self.keep),

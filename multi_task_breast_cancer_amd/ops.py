@@ -187,7 +187,7 @@ def _fill_segs_c8(arr, tensors: Sequence["C8"]):
 
 
 def conv3x3_fwd_c8(xs: Sequence["C8"], w: torch.Tensor, bias: Optional[torch.Tensor], packed: torch.Tensor, out_c8: bool = False,
-                   stats: bool = False):
+                   stats: bool = False, norm=None, out_partial: Optional[torch.Tensor] = None):
     """z = conv3x3(concat(xs)) with the inputs already in the MFMA's 16-bit channel-blocked layout; z comes back as fp32
     planes, or (out_c8, `out_layout = C8` of the C-ABI) as a channel-blocked 16-bit tensor of the inputs' type."""
     _chk(w, bias)
@@ -203,6 +203,12 @@ def conv3x3_fwd_c8(xs: Sequence["C8"], w: torch.Tensor, bias: Optional[torch.Ten
     a.w, a.w_packed, a.bias, a.out = w.data_ptr(), packed.data_ptr(), _p(bias), out.data_ptr()
     a.compute, a.operand_layout = xs[0].compute, L.LAYOUT_C8
     part = None
+    if norm is not None:    # gathered dgrad + norm-backward reductions: norm = (z8, mean, rstd, gamma, beta, slope) of the output tensor
+        z8n, mean, rstd, gamma, beta, slope = norm
+        _chk(mean, rstd, gamma, beta, out_partial)
+        a.norm_z, a.norm_mean, a.norm_rstd, a.norm_gamma, a.norm_beta, a.norm_slope = z8n.data.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _p(gamma), _p(beta), slope
+        a.out_partial = _p(out_partial)
+        stats = True
     if stats:       # InstanceNorm statistics from the epilogue: (partials [N][slots][Cout][2], slots)
         slots = L.load().mtbc_conv3x3_stats_slots(C.byref(a))
         if slots <= 0:
@@ -345,7 +351,7 @@ def instnorm_lrelu_fwd_c8(z, gamma=None, beta=None, eps=1e-5, slope=0.01, comput
 
 
 def instnorm_lrelu_bwd_c8(z, dy, mean, rstd, gamma=None, beta=None, eps=1e-5, slope=0.01, dbias_pre=None, compute: int = 1,
-                          dy_extra: Optional[torch.Tensor] = None):
+                          dy_extra: Optional[torch.Tensor] = None, stats: Optional[torch.Tensor] = None):
     """z / dy: fp32 planes or C8 tensors (z_layout / dy_layout = C8); dy_extra (with a C8 dy only): an fp32 planar partial
     gradient added while loading."""
     zt = z.data if isinstance(z, C8) else z
@@ -370,6 +376,8 @@ def instnorm_lrelu_bwd_c8(z, dy, mean, rstd, gamma=None, beta=None, eps=1e-5, sl
         a.dy_extra[0] = dy_extra.data_ptr()
     a.dz8, a.out16_type, a.coop_state = dz8.data_ptr(), compute, coop_state(dev).data_ptr()
     a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+    if stats is not None:       # {sum g, sum g * xhat} partials from conv3x3_fwd_c8(norm=...)
+        a.stats_partial, a.stats_slots = stats.data_ptr(), stats.shape[1]
     if not L.load().mtbc_instnorm_c8_supported(C.byref(a), 1):
         raise L.MtbcError("instnorm_bwd: shape not supported with a channel-blocked output")
     L.check(L.load().mtbc_instnorm_lrelu_bwd(C.byref(a), _s()), "instnorm_bwd(c8)")

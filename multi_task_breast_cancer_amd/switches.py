@@ -27,6 +27,8 @@ PLAN_SWITCHES: Dict[str, tuple] = {
     "MTBC_NO_G16": ("0", "the gradient of an up-sampled (ConvT) tensor stays fp32 between the 3x3 conv's dgrad and the ConvT backward"),
     "MTBC_NO_Z16": ("0", "16-bit modes keep the conv outputs z as fp32 planes (InstanceNorm reads 4 bytes per element in both directions)"),
     "MTBC_NO_DA16": ("0", "the gradient a conv-cell activation gets from its 3x3 consumers stays fp32 planar (read-modify-write fan-in) instead of one 16-bit channel-blocked tensor"),
+    "MTBC_NO_EPI_STATS": ("0", "InstanceNorm forward reduces the stored conv output itself (channel-group kernels) instead of taking the statistics from the conv epilogue"),
+    "MTBC_EPI_BSTATS": ("0", "the gathered dgrad's epilogue adds the other readers' partial gradient, reads the cell's z and leaves the two sums of the InstanceNorm backward, which becomes one streaming pass (measured slower: the epilogue's VALU work costs what the norm saves)"),
     "MTBC_BWD_OVERLAP": ("0", "weight gradient and input gradient of a layer run side by side on two streams (measured slower: DESIGN.md)"),
     "MTBC_BWD_OVERLAP_MAX_HW": ("1024", "with MTBC_BWD_OVERLAP=1: largest map (pixels) whose weight / input gradient launches are overlapped"),
     "MTBC_COOP_RESERVE_CUS": ("64", "CUs kept out of the cooperative InstanceNorm grids under data parallel"),

@@ -524,9 +524,13 @@ class lowp_conv3x3:
     ConvTranspose2d -> 1x1 Conv2d heads stay exact (the product fuses them into one fp32 transposed conv,
     engine.convT_head)."""
 
-    def __init__(self, mode: str, model=None, z16: bool = True, da16: bool = True):
+    def __init__(self, mode: str, model=None, z16: bool = True, da16: bool = True, fold_partials: bool = False):
         self.lp = {"bf16": torch.bfloat16, "f16": torch.float16}[mode]
         self.z16, self.da16 = z16, z16 and da16       # (the product's MTBC_NO_Z16 / MTBC_NO_DA16 arms)
+        # False (the product's default): the other readers' fp32 partial gradient is added, un-rounded, to the rounded sum of the
+        # 3x3 consumers (inside the InstanceNorm backward); True (the MTBC_EPI_BSTATS arm): the gathered dgrad's epilogue adds
+        # it BEFORE the one rounding
+        self.fold = fold_partials
         self.exempt = set()
         models = [] if model is None else (list(model) if isinstance(model, (list, tuple)) else [model])
         for mod in models:
@@ -545,7 +549,7 @@ class lowp_conv3x3:
         orig_p = self._orig_p
         self._orig_in, self._orig_lr, self._orig_ap, self._orig_do = F.instance_norm, F.leaky_relu, F.adaptive_avg_pool2d, F.dropout
         orig_in, orig_lr, orig_ap, orig_do = self._orig_in, self._orig_lr, self._orig_ap, self._orig_do
-        z16, da16 = self.z16, self.da16
+        z16, da16, fold = self.z16, self.da16, self.fold
 
         def detour(t):
             """a conv-cell activation on its way into a non-conv reader"""
@@ -571,7 +575,16 @@ class lowp_conv3x3:
                 stash = []
                 out._mtbc_stash = stash
                 # fires once every reader has sent its gradient: `g` holds the 3x3 convs' sum (the detours sent zeros)
-                out.register_hook(lambda g, stash=stash: g.to(lp).to(g.dtype) + sum(stash) if stash else g.to(lp).to(g.dtype))
+                rr = lambda t: t.to(lp).to(t.dtype)
+
+                def hook(g, stash=stash):
+                    if not stash:
+                        return rr(g)
+                    if not bool(g.any()):           # no 3x3 consumer (the detours sent zeros): no gathered launch, the gradient stays as it is
+                        return sum(stash)
+                    return rr(g + sum(stash)) if fold else rr(g) + sum(stash)
+
+                out.register_hook(hook)
             return out
 
         def adaptive_avg_pool2d(input, output_size):

@@ -263,9 +263,10 @@ def test_distributed_step_single_rank_rccl_equals_local_step():
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("arch,dtype,size", [("MTUNetPlusPlus", "bf16", 64), ("MTUNetPlusPlus", "f16", 64), ("MTnnUNet", "bf16", 128),
-                                             ("MTUNetPlusPlus", "bf16", 128)])
-def test_16bit_mfma_modes_match_their_emulation(arch, dtype, size):
+@pytest.mark.parametrize("arch,dtype,size,arm", [("MTUNetPlusPlus", "bf16", 64, ""), ("MTUNetPlusPlus", "f16", 64, ""), ("MTnnUNet", "bf16", 128, ""),
+                                                 ("MTUNetPlusPlus", "bf16", 128, ""), ("MTUNetPlusPlus", "bf16", 128, "epi_bstats"),
+                                                 ("MTUNetPlusPlus", "bf16", 64, "no_z16"), ("MTUNetPlusPlus", "bf16", 64, "no_da16")])
+def test_16bit_mfma_modes_match_their_emulation(arch, dtype, size, arm, monkeypatch):
     """Optional compute modes: conv3x3 MFMA operands rounded to bf16 / fp16 (fp32 storage + accumulation).  Not the
     reference-parity path (that is fp32); the oracle for it is oracle.lowp_conv3x3, which rounds the same operands
     at the same places on the CPU (fwd: x, w; dgrad: dy, w; wgrad: x, dy; RNE).  Rounding to 16 bits is itself
@@ -276,6 +277,16 @@ def test_16bit_mfma_modes_match_their_emulation(arch, dtype, size):
     fp32-accumulating CPU emulation has from it (and a small floor).  A wrong operand / rounding place shows up in
     the forward as >= 3e-2.  fp16 runs with the static loss scale 4096 on both sides (unscaled, dz underflows fp16)."""
     import copy
+    from multi_task_breast_cancer_amd import engine
+    # A/B arms of the plan (switches.py), each with the emulation told the same thing: where the other readers' partial gradient
+    # meets the rounding (MTBC_EPI_BSTATS), conv outputs kept in fp32 (MTBC_NO_Z16), fp32 fan-in gradients (MTBC_NO_DA16)
+    emu = {"": {}, "epi_bstats": {"fold_partials": True}, "no_z16": {"z16": False}, "no_da16": {"da16": False}}[arm]
+    if arm == "epi_bstats":
+        monkeypatch.setattr(engine, "_EPI_BSTATS", True)
+    elif arm == "no_z16":
+        monkeypatch.setattr(engine, "_NO_Z16", True)
+    elif arm == "no_da16":
+        monkeypatch.setattr(engine, "_NO_DA16", True)
     N = 4 if size == 64 else 2          # 128x128: level 0 takes the cooperative InstanceNorm forward (planes >= 128x128)
     prod, ref = _oracle_and_product(arch, 1993)
     prod.set_compute(dtype)
@@ -285,7 +296,7 @@ def test_16bit_mfma_modes_match_their_emulation(arch, dtype, size):
     st = step.load_batch(img.to(DEV), mask.to(DEV), label.to(DEV))
     losses = step.run(st).cpu()
     ls = prod.loss_scale                      # 4096 in fp16 mode (dz would underflow fp16 otherwise), 1 in bf16
-    with O.lowp_conv3x3(dtype, model=[ref, ref64]):
+    with O.lowp_conv3x3(dtype, model=[ref, ref64], **emu):
         t32 = O.train_step(ref, O.make_adam(ref, 1e-4), img, mask, label, 0.5, True, 3, loss_scale=ls)
         t64 = O.train_step(ref64, O.make_adam(ref64, 1e-4), img.double(), mask.double(), label, 0.5, True, 3, loss_scale=ls)
     assert losses[3].item() == 0.0

@@ -872,3 +872,47 @@ def test_instnorm_statistics_from_the_conv_epilogue(N, segs, Cout, H, W, compute
     ua, ub = ya.unpack(), yb.unpack()
     assert bool(((ua - ub).abs() <= ulp * ua.abs() + 1e-5).all()), (ua - ub).abs().max().item()
     assert torch.allclose(ypa, ypb, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("compute", [1, 2])
+@pytest.mark.parametrize("extra", [False, True])
+@pytest.mark.parametrize("N,K,C,H,W,affine", [(2, 48, 24, 256, 256, True), (2, 96, 48, 128, 128, True), (3, 96, 96, 64, 64, False), (2, 40, 16, 16, 16, True),
+                                              (5, 32, 80, 8, 8, False), (1, 72, 24, 40, 64, True), (2, 192, 192, 32, 32, True)])
+def test_gathered_dgrad_prepares_the_instnorm_backward(N, K, C, H, W, affine, extra, compute):
+    """mtbc_conv3x3_args.norm_z / out_partial: a forward-type launch over the consumers' dz (the gathered dgrad) writes the
+    tensor's gradient once in 16 bits -- its fp32 sum plus the other readers' fp32 partial, one RNE -- and leaves the two
+    reductions of the InstanceNorm + LeakyReLU backward in stats_partial; the backward fed with them (finalize + one streaming
+    pass) equals the channel-group kernel that reduces the tensors itself."""
+    g = _g(N * 23 + K + C + H + compute)
+    dzs = ops.C8.pack((torch.randn(N, K, H, W, generator=g)).to(DEV), compute)             # the consumers' dz, side by side
+    wg = (torch.randn(C, K, 3, 3, generator=g) * (2.0 / (9 * K)) ** 0.5).to(DEV)             # their gathered weights
+    z8 = ops.C8.pack((torch.randn(N, C, H, W, generator=g) * 2 + 0.5).to(DEV), compute)      # the tensor's own conv output
+    gamma = (torch.rand(C, generator=g) + 0.5).to(DEV) if affine else None
+    beta = (torch.randn(C, generator=g) * 0.1).to(DEV) if affine else None
+    ex = torch.randn(N, C, H, W, generator=g).to(DEV) if extra else None
+    pf, _ = ops.conv3x3_pack_lp(wg, compute)
+    _, mean, rstd, _ = ops.instnorm_lrelu_fwd_c8(z8, gamma, beta, slope=0.1)
+    dy32 = ops.conv3x3_fwd_c8([dzs], wg, None, pf)                                           # fp32 planar result of the same launch
+    dy8, part = ops.conv3x3_fwd_c8([dzs], wg, None, pf, out_c8=True, norm=(z8, mean, rstd, gamma, beta, 0.1), out_partial=ex)
+    want8 = ops.C8.pack(dy32 + ex if extra else dy32, compute)
+    assert torch.equal(dy8.data, want8.data)
+    assert not torch.isnan(part).any()
+    # the reductions, recomputed from the stored tensors
+    zr, dyr = z8.unpack().double(), dy8.unpack().double()
+    xh = (zr - mean.double().view(N, C, 1, 1)) * rstd.double().view(N, C, 1, 1)
+    pre = xh * (gamma.double().view(1, C, 1, 1) if affine else 1.0) + (beta.double().view(1, C, 1, 1) if affine else 0.0)
+    gg = dyr * torch.where(pre > 0, 1.0, 0.1)
+    tot = part.double().sum(1)
+    s1, s2 = gg.sum((2, 3)), (gg * xh).sum((2, 3))
+    scale = gg.abs().sum((2, 3)).max().item()
+    assert (tot[..., 0] - s1).abs().max().item() <= 1e-5 * scale and (tot[..., 1] - s2).abs().max().item() <= 3e-5 * scale * max(1.0, xh.abs().max().item())
+    db1, db2 = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+    da, dga, dba = ops.instnorm_lrelu_bwd_c8(z8, dy8, mean, rstd, gamma, beta, slope=0.1, dbias_pre=db1)
+    db, dgb, dbb = ops.instnorm_lrelu_bwd_c8(z8, dy8, mean, rstd, gamma, beta, slope=0.1, dbias_pre=db2, stats=part)
+    ulp = 2.0 ** -7 if compute == 1 else 2.0 ** -10
+    ua, ub = da.unpack(), db.unpack()
+    assert bool(((ua - ub).abs() <= ulp * ua.abs() + 2e-6 * ua.abs().max()).all()), (ua - ub).abs().max().item()
+    assert torch.equal(db2, torch.zeros_like(db2))                     # a conv bias in front of a norm: its gradient IS zero
+    if affine:
+        assert torch.allclose(dga, dgb, rtol=1e-4, atol=1e-3 * max(1.0, dga.abs().max().item()))
+        assert torch.allclose(dba, dbb, rtol=1e-4, atol=1e-3 * max(1.0, dba.abs().max().item()))

@@ -331,7 +331,11 @@ def test_16bit_emulation_of_stored_conv_outputs_and_gathered_gradients():
         conv_part = r(yl.grad)
         yo = y.clone().requires_grad_(True)
         (pool(yo).square().sum() + up(yo).sum() + head(yo).square().sum() + gap(yo).sum()).backward()
+        # default: the other readers' fp32 partial is added un-rounded to the rounded sum of the 3x3 consumers
         assert torch.allclose(seen["dy"], conv_part + yo.grad, rtol=1e-12, atol=1e-12)
-        assert not torch.allclose(seen["dy"], r(seen["dy"]), rtol=0, atol=0)                      # the sum itself is not rounded
+        assert not torch.allclose(seen["dy"], r(seen["dy"]), rtol=0, atol=0)                      # the total itself is not rounded
+    with O.lowp_conv3x3("bf16", fold_partials=True):                                              # the MTBC_EPI_BSTATS arm
+        run()
+        assert torch.equal(seen["dy"], r(yl.grad + yo.grad))                                      # the partial joins the sum BEFORE the one rounding
     with O.lowp_conv3x3("bf16", z16=False):
         assert torch.equal(cell[0](x), torch.conv2d(r(x), r(cell[0].weight), cell[0].bias, 1, 1))
