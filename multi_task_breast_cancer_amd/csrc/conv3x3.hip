@@ -889,6 +889,145 @@ __device__ __forceinline__ float row16_sum(float v) {
     return v;
 }
 
+// Epilogue of the channel-blocked igemm kernels (one pixel tile's accumulators -> HBM), shared by the single-buffer kernel and
+// the ring kernel of the deep levels.  O8 = 0: fp32 planar segments (store / read-modify-write / 16-bit planes); 1: 16-bit
+// channel-blocked (+ forward InstanceNorm statistics); 2: that + the norm-backward reductions (zpre = the tensor's z, prefetched).
+template <int MT, int GEO, bool F16, int NW, int O8, typename ZPRE>
+__device__ __forceinline__ void c8_epilogue(const ConvP& p, f32x4 (&acc)[MT][4], const SegL* seg_out, const float* bias_s, const int n0,
+                                            const int y0, const int x0, const int tx, const int ty, const int mt0, const int wv,
+                                            const int j, const int kg, const int HW, ZPRE& zpre) {
+    using T = LP<F16>;
+    typedef unsigned pre_u32x2 __attribute__((ext_vector_type(2)));
+    const int n = GEO == 2 ? n0 + wv : n0;
+    if MTBC_DBG_BIT(p, 2) { if (acc[0][0][0] != 12345.678f) return; }
+    if constexpr (O8 != 0) {
+        // ---- epilogue, channel-blocked 16-bit output: lane (j, kg) holds channels 16m + 4kg .. + 3 of pixel j of group g
+        typedef unsigned ep_u32x2 __attribute__((ext_vector_type(2)));
+        typedef unsigned ep_u32x4 __attribute__((ext_vector_type(4)));
+        typedef __attribute__((address_space(1))) ep_u32x2 guint2;
+        int pix[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            int y, x;
+            if (GEO == 0) { y = y0 + 2 * wv + (g >> 1); x = x0 + 16 * (g & 1) + j; }
+            else if (GEO == 1) { y = y0 + 4 * wv + g; x = x0 + j; }
+            else { y = y0 + 2 * g + (j >> 3); x = x0 + (j & 7); }
+            pix[g] = (n < p.N && y < p.H && x < p.W) ? y * p.W + x : -1;
+        }
+        const bool want_stats = O8 == 2 || p.stats != nullptr;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int co = (mt0 + m) * 16 + 4 * kg;
+            if (co >= p.Cout) continue;
+            const SegL so = segl_ref(seg_out, co);
+            // piece (n, group, pixel) of the segment's tensor; this lane owns channels (co - cb) % 8 .. + 3 of it
+            const size_t poff8 = 2 * ((size_t)n * so.bs + (size_t)((co - so.cb) >> 3) * HW * 8) + 2 * ((co - so.cb) & 7);
+            gchar* cb = (gchar*)so.ptr + poff8;
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(bias_s + m * 16 + 4 * kg);
+            f32x4 ss = (f32x4){0.f, 0.f, 0.f, 0.f}, sq = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if constexpr (O8 == 2) {
+                // gathered dgrad + the reductions of the InstanceNorm / LeakyReLU backward of the tensor it differentiates
+                // (one output segment = the whole tensor): dy = sum over the 3x3 consumers (+ the other readers' fp32 partial),
+                // rounded once and stored; g = dy_stored * lrelu'(gamma * xhat + beta); the wave's {sum g, sum g * xhat}
+                const size_t plane = (size_t)n * p.Cout + co;
+                f32x4 mean4 = (f32x4){0.f, 0.f, 0.f, 0.f}, rstd4 = mean4, ga4 = (f32x4){1.f, 1.f, 1.f, 1.f}, be4 = mean4;
+                if (n < p.N) { mean4 = *reinterpret_cast<const f32x4*>(p.nmean + plane); rstd4 = *reinterpret_cast<const f32x4*>(p.nrstd + plane); }
+                if (p.ngamma) { ga4 = *reinterpret_cast<const f32x4*>(p.ngamma + co); be4 = *reinterpret_cast<const f32x4*>(p.nbeta + co); }
+                const float* eb = p.extra ? p.extra + plane * HW : nullptr;
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    if (pix[g] >= 0) {
+                        const pre_u32x2 zw = zpre[m][g];
+                        f32x4 ex = (f32x4){0.f, 0.f, 0.f, 0.f};
+                        if (eb) ex = (f32x4){eb[pix[g]], eb[(size_t)HW + pix[g]], eb[2 * (size_t)HW + pix[g]], eb[3 * (size_t)HW + pix[g]]};
+                        const f32x4 r = acc[m][g] + ex;
+                        const float q[8] = {r[0], r[1], r[2], r[3], 0.f, 0.f, 0.f, 0.f};
+                        const ep_u32x4 u = __builtin_bit_cast(ep_u32x4, T::pack(q));
+                        *(guint2*)(cb + 16 * (size_t)pix[g]) = (ep_u32x2){u[0], u[1]};
+                        const unsigned u0 = u[0], u1 = u[1], z0 = zw[0], z1 = zw[1];
+                        const f32x4 dyv = (f32x4){T::lo(u0), T::hi(u0), T::lo(u1), T::hi(u1)};
+                        const f32x4 xh = ((f32x4){T::lo(z0), T::hi(z0), T::lo(z1), T::hi(z1)} - mean4) * rstd4;
+                        const f32x4 pre = xh * ga4 + be4;
+                        f32x4 gg;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) gg[e] = dyv[e] * (pre[e] > 0.f ? 1.f : p.nslope);
+                        ss += gg; sq += gg * xh;
+                    }
+            } else {
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    if (pix[g] >= 0) {
+                        const f32x4 r = acc[m][g] + bv;
+                        const float q[8] = {r[0], r[1], r[2], r[3], 0.f, 0.f, 0.f, 0.f};
+                        const ep_u32x4 u = __builtin_bit_cast(ep_u32x4, T::pack(q));
+                        *(guint2*)(cb + 16 * (size_t)pix[g]) = (ep_u32x2){u[0], u[1]};
+                        if (p.stats) {          // InstanceNorm statistics of the STORED values
+                            const unsigned u0 = u[0], u1 = u[1];
+                            const f32x4 v = (f32x4){T::lo(u0), T::hi(u0), T::lo(u1), T::hi(u1)};
+                            ss += v; sq += v * v;
+                        }
+                    }
+            }
+            if (want_stats) {
+                // this wave's pixels: the 16 lanes of a row group hold 16 pixels of the same 4 channels -> DPP row sums
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { ss[e] = row16_sum(ss[e]); sq[e] = row16_sum(sq[e]); }
+                if (j == 15 && n < p.N) {
+                    const int slots = GEO == 2 ? 1 : p.tiles_x * p.tiles_y * NW;
+                    const int slot = GEO == 2 ? 0 : (ty * p.tiles_x + tx) * NW + wv;
+                    float* sp = p.stats + (((size_t)n * slots + slot) * p.Cout + co) * 2;
+                    *reinterpret_cast<f32x4*>(sp) = (f32x4){ss[0], sq[0], ss[1], sq[1]};
+                    *reinterpret_cast<f32x4*>(sp + 4) = (f32x4){ss[2], sq[2], ss[3], sq[3]};
+                }
+            }
+        }
+        return;
+    }
+    // ---- epilogue: identical to conv3x3_igemm_lp_kernel (fp32 planar output, 16-byte stores / read-modify-write)
+    int poff[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        int y, x;
+        if (GEO == 0) { y = y0 + 2 * wv + (g >> 1); x = x0 + 16 * (g & 1) + 4 * kg; }
+        else if (GEO == 1) { y = y0 + 4 * wv + g; x = x0 + 4 * kg; }
+        else { y = y0 + 2 * g + (kg >> 1); x = x0 + 4 * (kg & 1); }
+        poff[g] = (n < p.N && y < p.H && x < p.W) ? y * p.W + x : -1;
+    }
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int co = (mt0 + m) * 16 + j;
+        if (co >= p.Cout) continue;
+        const SegL so = segl_ref(seg_out, co);
+        gfloat* cb = (gfloat*)so.ptr + (size_t)n * so.bs + (size_t)(co - so.cb) * HW;
+        const float bv = bias_s[m * 16 + j];
+        if (so.acc == 2) {          // 16-bit planar segment: the lane's 4 consecutive pixels of its channel = one 8-byte store
+            typedef unsigned ep_u32x2 __attribute__((ext_vector_type(2)));
+            typedef unsigned ep_u32x4 __attribute__((ext_vector_type(4)));
+            typedef __attribute__((address_space(1))) ep_u32x2 guint2;
+            gchar* c16 = (gchar*)so.ptr + 2 * ((size_t)n * so.bs + (size_t)(co - so.cb) * HW);
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                if (poff[g] >= 0) {
+                    const float q[8] = {acc[m][g][0] + bv, acc[m][g][1] + bv, acc[m][g][2] + bv, acc[m][g][3] + bv, 0.f, 0.f, 0.f, 0.f};
+                    const typename T::frag h = T::pack(q);          // RNE, the conversion every consumer's staging would apply
+                    const ep_u32x4 u = __builtin_bit_cast(ep_u32x4, h);
+                    *(guint2*)(c16 + 2 * (size_t)poff[g]) = (ep_u32x2){u[0], u[1]};
+                }
+        } else if (so.acc) {
+            f32x4 old[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) old[g] = poff[g] >= 0 ? *(const gf32x4*)(cb + poff[g]) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                if (poff[g] >= 0) *(gf32x4*)(cb + poff[g]) = old[g] + (acc[m][g] + bv);
+        } else {
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                if (poff[g] >= 0) *(gf32x4*)(cb + poff[g]) = acc[m][g] + bv;
+        }
+    }
+}
+
 // O8 = the OUTPUT is 16-bit channel-blocked as well (conv outputs z / single-writer gradients of the 16-bit modes): the MFMAs
 // run as D = W X (channels on the rows), so a lane holds 4 consecutive channels of ONE pixel = half a 16-byte piece; the 16
 // lanes of a row group write 16 consecutive pixels, and the lane groups kg = 2q, 2q + 1 the two halves of the same pieces
@@ -1045,134 +1184,149 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 4) void conv3x3_igemm_c8_ker
                     }
             }
         }
-        const int n = GEO == 2 ? n0 + wv : n0;
-        if MTBC_DBG_BIT(p, 2) { if (acc[0][0][0] != 12345.678f) continue; }
-        if constexpr (O8 != 0) {
-            // ---- epilogue, channel-blocked 16-bit output: lane (j, kg) holds channels 16m + 4kg .. + 3 of pixel j of group g
-            typedef unsigned ep_u32x2 __attribute__((ext_vector_type(2)));
-            typedef unsigned ep_u32x4 __attribute__((ext_vector_type(4)));
-            typedef __attribute__((address_space(1))) ep_u32x2 guint2;
-            int pix[4];
+        c8_epilogue<MT, GEO, F16, NW, O8>(p, acc, seg_out, bias_s, n0, y0, x0, tx, ty, mt0, wv, j, kg, HW, zpre);
+    }
+}
+
+// ------------------------------------------------------------------ deep levels: the same igemm with an LDS ring
+// Maps <= 32 x 32 give a launch at most two blocks per CU (few pixel tiles, K = 9 x 96 .. 1152): resident blocks cannot hide each
+// other's DMA latency, and the single-buffer kernel spends ~3 us per 32-channel chunk of which 0.7 are MFMAs.  Same LDS images,
+// fragment reads, MFMA order and epilogues as conv3x3_igemm_c8_kernel -- bit-identical results -- but R slots of {X chunk, W chunk}
+// (one block per CU, 147 KB for R = 3): the DMA of chunk c + R - 1 is issued before the MFMAs of chunk c, a COUNTED vmcnt waits for
+// chunk c only, one raw barrier per chunk (it publishes chunk c and retires the slot chunk c + R - 1 overwrites).  Every wave
+// issues the same number of DMA instructions per chunk (surplus weight instructions read out of range into a pad), so the count
+// is a compile-time constant.
+template <int MT, int GEO> struct RingGeo {
+    using G = GeoLP<GEO>;
+    static constexpr int HR = G::TH + 2, HC = G::TW + 2, HP = HR * HC, HPP = (HP + 15) / 16 * 16;
+    static constexpr int XB = 4 * HPP * 8, WB = MT * 9 * 16 * WROW, PAD = 512;      // 16-bit elements
+    static constexpr int XQ = (HPP + 63) / 64, W16 = WB / 8, WI = (W16 + 63) / 64, WPW = (WI + 3) / 4;
+    static constexpr int CNT = XQ + WPW;                                             // vector-memory instructions per wave and chunk
+    static constexpr int SLOT = XB + WB + PAD;
+};
+// DMA of chunk `ch` into ring slot `sl`: wave w brings channel group w of X (XQ instructions) and its share of W (WPW instructions)
+template <int MT, int GEO>
+__device__ __forceinline__ void ring_issue(const ConvP& p, unsigned short* smem16, const SegL* seg_in,
+                                           const unsigned* pixo, const int ch, const int sl, const int wvu, const int lane,
+                                           const int n0, const int mt0, const int nchunks, const int HW) {
+    using RG = RingGeo<MT, GEO>;
+    constexpr int NW = 4, HPP = RG::HPP, XB = RG::XB, WB = RG::WB, XQ = RG::XQ;
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.wp), 0, (int)((size_t)p.mtiles * nchunks * (9 * 16 * WROW) * 2), 0x00020000);
+        unsigned short* Xs = smem16 + sl * RG::SLOT;
+        unsigned short* Ws = Xs + XB;
+        const int c0 = ch * LPKC + 8 * wvu;
+        const bool xgrp = c0 < p.Cin;
+        const SegL sr = segl_ref(seg_in, xgrp ? c0 : 0);
+        const unsigned long long pu = reinterpret_cast<unsigned long long>(sr.ptr);
+        const unsigned plo = __builtin_amdgcn_readfirstlane((unsigned)pu), phi = __builtin_amdgcn_readfirstlane((unsigned)(pu >> 32));
+        const unsigned blo = __builtin_amdgcn_readfirstlane((unsigned)sr.bs), bhi = __builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)sr.bs >> 32));
+        const int cb = __builtin_amdgcn_readfirstlane(sr.cb);
+        const long long bs = (long long)(((unsigned long long)bhi << 32) | blo);
+        unsigned short* base = reinterpret_cast<unsigned short*>(((unsigned long long)phi << 32) | plo) +
+                               ((size_t)n0 * bs + (size_t)((xgrp ? c0 : 0) - cb) * HW);
+        const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(base, 0, xgrp ? (int)((unsigned)HW * 16u) : 0, 0x00020000);
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                int y, x;
-                if (GEO == 0) { y = y0 + 2 * wv + (g >> 1); x = x0 + 16 * (g & 1) + j; }
-                else if (GEO == 1) { y = y0 + 4 * wv + g; x = x0 + j; }
-                else { y = y0 + 2 * g + (j >> 3); x = x0 + (j & 7); }
-                pix[g] = (n < p.N && y < p.H && x < p.W) ? y * p.W + x : -1;
-            }
-            const bool want_stats = O8 == 2 || p.stats != nullptr;
+        for (int q = 0; q < XQ; ++q)      // (lanes past the padded image write into the next group's head / the weight head: rewritten by their owners? no -- masked)
+            if (lane + 64 * q < HPP)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_ptr_t)(Xs + (wvu * HPP + 64 * q) * 8), 16, pixo[q], 0, 0, 0);
 #pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                const int co = (mt0 + m) * 16 + 4 * kg;
-                if (co >= p.Cout) continue;
-                const SegL so = segl_ref(seg_out, co);
-                // piece (n, group, pixel) of the segment's tensor; this lane owns channels (co - cb) % 8 .. + 3 of it
-                const size_t poff8 = 2 * ((size_t)n * so.bs + (size_t)((co - so.cb) >> 3) * HW * 8) + 2 * ((co - so.cb) & 7);
-                gchar* cb = (gchar*)so.ptr + poff8;
-                const f32x4 bv = *reinterpret_cast<const f32x4*>(bias_s + m * 16 + 4 * kg);
-                f32x4 ss = (f32x4){0.f, 0.f, 0.f, 0.f}, sq = (f32x4){0.f, 0.f, 0.f, 0.f};
-                if constexpr (O8 == 2) {
-                    // gathered dgrad + the reductions of the InstanceNorm / LeakyReLU backward of the tensor it differentiates
-                    // (one output segment = the whole tensor): dy = sum over the 3x3 consumers (+ the other readers' fp32 partial),
-                    // rounded once and stored; g = dy_stored * lrelu'(gamma * xhat + beta); the wave's {sum g, sum g * xhat}
-                    const size_t plane = (size_t)n * p.Cout + co;
-                    f32x4 mean4 = (f32x4){0.f, 0.f, 0.f, 0.f}, rstd4 = mean4, ga4 = (f32x4){1.f, 1.f, 1.f, 1.f}, be4 = mean4;
-                    if (n < p.N) { mean4 = *reinterpret_cast<const f32x4*>(p.nmean + plane); rstd4 = *reinterpret_cast<const f32x4*>(p.nrstd + plane); }
-                    if (p.ngamma) { ga4 = *reinterpret_cast<const f32x4*>(p.ngamma + co); be4 = *reinterpret_cast<const f32x4*>(p.nbeta + co); }
-                    const float* eb = p.extra ? p.extra + plane * HW : nullptr;
+        for (int k = 0; k < RG::WPW; ++k) {
+            const int inst = wvu + NW * k;
+            const int idx = inst * 64 + lane;
+            const int mt = idx / (9 * 16 * WROW / 8), r = idx % (9 * 16 * WROW / 8);
+            const bool ok = inst < RG::WI && idx < RG::W16 && (mt0 + mt) < p.mtiles;
+            const unsigned voff = ok ? (unsigned)((((mt0 + mt) * nchunks + ch) * (9 * 16 * WROW / 8) + r) * 16) : 0xfffffff0u;
+            // a wave without a real instruction left still issues one (zeros into the slot's pad): uniform count per wave
+            unsigned short* dst = inst < RG::WI ? Ws + inst * 512 : Ws + WB;
+            if (inst >= RG::WI || idx < RG::W16)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_ptr_t)dst, 16, voff, 0, 0, 0);
+        }
+    }
+template <int MT, int GEO, bool F16, int O8, int R>
+__global__ __launch_bounds__(256, 1) void conv3x3_igemm_c8_ring_kernel(const ConvP p) {
+    using G = GeoLP<GEO>;
+    using T = LP<F16>;
+    using RG = RingGeo<MT, GEO>;
+    static_assert(GEO != 2 && (O8 == 0 || O8 == 1) && R >= 2 && R <= 3, "wide / 16-wide maps, plain epilogues");
+    constexpr int NW = 4, TH = G::TH, HR = RG::HR, HC = RG::HC, HP = RG::HP, HPP = RG::HPP, XB = RG::XB, WB = RG::WB, XQ = RG::XQ;
+    extern __shared__ __attribute__((aligned(16))) unsigned short smem16[];
+    SegL* seg_in = reinterpret_cast<SegL*>(smem16 + R * RG::SLOT);
+    SegL* seg_out = seg_in + MTBC_MAX_SEGS;
+    float* bias_s = reinterpret_cast<float*>(seg_out + MTBC_MAX_SEGS);      // MT*16 floats
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wvu = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int HW = p.H * p.W;
+    const int mt0 = blockIdx.y * MT;
+    segl_fill(seg_in, p.in);
+    segl_fill(seg_out, p.out);
+    if (tid < MT * 16) { const int co = mt0 * 16 + tid; bias_s[tid] = (p.bias && co < p.Cout) ? p.bias[co] : 0.f; }
+    __syncthreads();
+
+    const int nchunks = (p.Cin + LPKC - 1) / LPKC;
+    const int j = lane & 15, kg = lane >> 4;
+    int bpix[4];
 #pragma unroll
-                    for (int g = 0; g < 4; ++g)
-                        if (pix[g] >= 0) {
-                            const pre_u32x2 zw = zpre[m][g];
-                            f32x4 ex = (f32x4){0.f, 0.f, 0.f, 0.f};
-                            if (eb) ex = (f32x4){eb[pix[g]], eb[(size_t)HW + pix[g]], eb[2 * (size_t)HW + pix[g]], eb[3 * (size_t)HW + pix[g]]};
-                            const f32x4 r = acc[m][g] + ex;
-                            const float q[8] = {r[0], r[1], r[2], r[3], 0.f, 0.f, 0.f, 0.f};
-                            const ep_u32x4 u = __builtin_bit_cast(ep_u32x4, T::pack(q));
-                            *(guint2*)(cb + 16 * (size_t)pix[g]) = (ep_u32x2){u[0], u[1]};
-                            const unsigned u0 = u[0], u1 = u[1], z0 = zw[0], z1 = zw[1];
-                            const f32x4 dyv = (f32x4){T::lo(u0), T::hi(u0), T::lo(u1), T::hi(u1)};
-                            const f32x4 xh = ((f32x4){T::lo(z0), T::hi(z0), T::lo(z1), T::hi(z1)} - mean4) * rstd4;
-                            const f32x4 pre = xh * ga4 + be4;
-                            f32x4 gg;
+    for (int g = 0; g < 4; ++g) {
+        int y, x;
+        if (GEO == 0) { y = 2 * wv + (g >> 1); x = 16 * (g & 1) + j; }
+        else { y = 4 * wv + g; x = j; }
+        bpix[g] = y * HC + x;
+    }
+    for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+        int t = tile;
+        const int tx = t % p.tiles_x; t /= p.tiles_x;
+        const int ty = t % p.tiles_y; t /= p.tiles_y;
+        const int n0 = t, x0 = tx * G::TW, y0 = ty * TH;
+        unsigned pixo[XQ];
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) gg[e] = dyv[e] * (pre[e] > 0.f ? 1.f : p.nslope);
-                            ss += gg; sq += gg * xh;
-                        }
-                } else {
+        for (int q = 0; q < XQ; ++q) {
+            const int hp = lane + 64 * q;
+            const int row = hp / HC, col = hp % HC;
+            const int y = y0 + row - 1, x = x0 + col - 1;
+            const bool ok = hp < HP && y >= 0 && y < p.H && x >= 0 && x < p.W;
+            pixo[q] = ok ? 16u * (unsigned)(y * p.W + x) : 0xfffffff0u;
+        }
+        f32x4 acc[MT][4];
 #pragma unroll
-                    for (int g = 0; g < 4; ++g)
-                        if (pix[g] >= 0) {
-                            const f32x4 r = acc[m][g] + bv;
-                            const float q[8] = {r[0], r[1], r[2], r[3], 0.f, 0.f, 0.f, 0.f};
-                            const ep_u32x4 u = __builtin_bit_cast(ep_u32x4, T::pack(q));
-                            *(guint2*)(cb + 16 * (size_t)pix[g]) = (ep_u32x2){u[0], u[1]};
-                            if (p.stats) {          // InstanceNorm statistics of the STORED values
-                                const unsigned u0 = u[0], u1 = u[1];
-                                const f32x4 v = (f32x4){T::lo(u0), T::hi(u0), T::lo(u1), T::hi(u1)};
-                                ss += v; sq += v * v;
-                            }
-                        }
-                }
-                if (want_stats) {
-                    // this wave's pixels: the 16 lanes of a row group hold 16 pixels of the same 4 channels -> DPP row sums
+        for (int m = 0; m < MT; ++m)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { ss[e] = row16_sum(ss[e]); sq[e] = row16_sum(sq[e]); }
-                    if (j == 15 && n < p.N) {
-                        const int slots = GEO == 2 ? 1 : p.tiles_x * p.tiles_y * NW;
-                        const int slot = GEO == 2 ? 0 : (ty * p.tiles_x + tx) * NW + wv;
-                        float* sp = p.stats + (((size_t)n * slots + slot) * p.Cout + co) * 2;
-                        *reinterpret_cast<f32x4*>(sp) = (f32x4){ss[0], sq[0], ss[1], sq[1]};
-                        *reinterpret_cast<f32x4*>(sp + 4) = (f32x4){ss[2], sq[2], ss[3], sq[3]};
+            for (int g = 0; g < 4; ++g) acc[m][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        lds_barrier();                            // the previous tile's fragments are consumed (its stores were waited for below)
+#pragma unroll
+        for (int s0 = 0; s0 < R - 1; ++s0)
+            if (s0 < nchunks) ring_issue<MT, GEO>(p, smem16, seg_in, pixo, s0, s0, wvu, lane, n0, mt0, nchunks, HW);
+        for (int ch = 0; ch < nchunks; ++ch) {
+            // chunks ch + 1 .. ch + R - 2 may stay in flight
+            const int rem = min(R - 2, nchunks - 1 - ch);
+            if (rem >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RG::CNT) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // chunk ch is in LDS for everybody; everybody is done with chunk ch - 1
+            if (ch + R - 1 < nchunks) ring_issue<MT, GEO>(p, smem16, seg_in, pixo, ch + R - 1, (ch + R - 1) % R, wvu, lane, n0, mt0, nchunks, HW);
+            const unsigned short* Xs = smem16 + (ch % R) * RG::SLOT;
+            const unsigned short* Ws = Xs + XB;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int toff = (tap / 3) * HC + tap % 3;
+                typename T::frag a[MT], b[4];
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+                    a[m] = *reinterpret_cast<const typename T::frag*>(Ws + ((m * 9 + tap) * 16 + j) * WROW + 8 * (kg ^ ((j >> 1) & 3)));
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    b[g] = *reinterpret_cast<const typename T::frag*>(Xs + (kg * HPP + bpix[g] + toff) * 8);
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        if constexpr (O8 != 0) acc[m][g] = T::mfma(a[m], b[g], acc[m][g]);
+                        else acc[m][g] = T::mfma(b[g], a[m], acc[m][g]);
                     }
-                }
-            }
-            continue;
-        }
-        // ---- epilogue: identical to conv3x3_igemm_lp_kernel (fp32 planar output, 16-byte stores / read-modify-write)
-        int poff[4];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            int y, x;
-            if (GEO == 0) { y = y0 + 2 * wv + (g >> 1); x = x0 + 16 * (g & 1) + 4 * kg; }
-            else if (GEO == 1) { y = y0 + 4 * wv + g; x = x0 + 4 * kg; }
-            else { y = y0 + 2 * g + (kg >> 1); x = x0 + 4 * (kg & 1); }
-            poff[g] = (n < p.N && y < p.H && x < p.W) ? y * p.W + x : -1;
-        }
-#pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            const int co = (mt0 + m) * 16 + j;
-            if (co >= p.Cout) continue;
-            const SegL so = segl_ref(seg_out, co);
-            gfloat* cb = (gfloat*)so.ptr + (size_t)n * so.bs + (size_t)(co - so.cb) * HW;
-            const float bv = bias_s[m * 16 + j];
-            if (so.acc == 2) {          // 16-bit planar segment: the lane's 4 consecutive pixels of its channel = one 8-byte store
-                typedef unsigned ep_u32x2 __attribute__((ext_vector_type(2)));
-                typedef unsigned ep_u32x4 __attribute__((ext_vector_type(4)));
-                typedef __attribute__((address_space(1))) ep_u32x2 guint2;
-                gchar* c16 = (gchar*)so.ptr + 2 * ((size_t)n * so.bs + (size_t)(co - so.cb) * HW);
-#pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    if (poff[g] >= 0) {
-                        const float q[8] = {acc[m][g][0] + bv, acc[m][g][1] + bv, acc[m][g][2] + bv, acc[m][g][3] + bv, 0.f, 0.f, 0.f, 0.f};
-                        const typename T::frag h = T::pack(q);          // RNE, the conversion every consumer's staging would apply
-                        const ep_u32x4 u = __builtin_bit_cast(ep_u32x4, h);
-                        *(guint2*)(c16 + 2 * (size_t)poff[g]) = (ep_u32x2){u[0], u[1]};
-                    }
-            } else if (so.acc) {
-                f32x4 old[4];
-#pragma unroll
-                for (int g = 0; g < 4; ++g) old[g] = poff[g] >= 0 ? *(const gf32x4*)(cb + poff[g]) : (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    if (poff[g] >= 0) *(gf32x4*)(cb + poff[g]) = old[g] + (acc[m][g] + bv);
-            } else {
-#pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    if (poff[g] >= 0) *(gf32x4*)(cb + poff[g]) = acc[m][g] + bv;
             }
         }
+        int zpre = 0;
+        c8_epilogue<MT, GEO, F16, NW, O8>(p, acc, seg_out, bias_s, n0, y0, x0, tx, ty, mt0, wv, j, kg, HW, zpre);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the stores: the next tile counts its DMA instructions from zero
     }
 }
 
@@ -2276,15 +2430,54 @@ int launch_igemm_c8_mt(int MT, const ConvP& p, int mblocks, bool f16, hipStream_
     return launch_igemm_c8<2, GEO, 4, O8>(p, mblocks, f16, st);
 }
 
-// geometry of an igemm launch: map geometry, pixel tiles, channel tiles per block, 8-wave (16 x 32 pixel) blocks
-struct IgemmPlan { int geo, tiles_x, tiles_y, ntiles, mtiles, MT, mblocks; bool nw8; };
-IgemmPlan plan_igemm(int N, int H, int W, int rows, int compute, bool c8, bool allow_nw8 = true) {
+template <int MT, int GEO, int O8>
+int launch_igemm_c8_ring(const ConvP& p, int mblocks, bool f16, hipStream_t st) {
+    constexpr int R = 3;
+    using RG = RingGeo<MT, GEO>;
+    const size_t lds = (size_t)R * RG::SLOT * 2 + (SEGL_FLOATS + MT * 16) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_igemm_c8_ring_kernel<MT, GEO, false, O8, R>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_igemm_c8_ring_kernel<MT, GEO, true, O8, R>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    int gx = 256 / mblocks;                  // one resident block per CU (147 KB of LDS), one wave of blocks
+    if (gx < 1) gx = 1;
+    if (gx > p.ntiles) gx = p.ntiles;
+    const dim3 grid(gx, mblocks);
+    if (f16) hipLaunchKernelGGL((conv3x3_igemm_c8_ring_kernel<MT, GEO, true, O8, R>), grid, dim3(256), lds, st, p);
+    else hipLaunchKernelGGL((conv3x3_igemm_c8_ring_kernel<MT, GEO, false, O8, R>), grid, dim3(256), lds, st, p);
+    MTBC_CHECK_LAUNCH();
+    return MTBC_OK;
+}
+template <int GEO, int O8>
+int launch_igemm_c8_ring_mt(int MT, const ConvP& p, int mblocks, bool f16, hipStream_t st) {
+    if (MT == 1) return launch_igemm_c8_ring<1, GEO, O8>(p, mblocks, f16, st);
+    if (MT == 3) return launch_igemm_c8_ring<3, GEO, O8>(p, mblocks, f16, st);
+    return launch_igemm_c8_ring<2, GEO, O8>(p, mblocks, f16, st);
+}
+
+// geometry of an igemm launch: map geometry, pixel tiles, channel tiles per block, 8-wave (16 x 32 pixel) blocks, LDS-ring kernel
+struct IgemmPlan { int geo, tiles_x, tiles_y, ntiles, mtiles, MT, mblocks; bool nw8, ring; };
+IgemmPlan plan_igemm(int N, int H, int W, int rows, int compute, bool c8, bool allow_nw8 = true, int red = 0) {
     IgemmPlan q{};
     q.geo = pick_geo(H, W);
     q.mtiles = cdiv(rows, 16);
     if (q.geo == 0) { q.tiles_x = cdiv(W, 32); q.tiles_y = cdiv(H, 8); q.ntiles = q.tiles_x * q.tiles_y * N; }
     else if (q.geo == 1) { q.tiles_x = cdiv(W, 16); q.tiles_y = cdiv(H, 16); q.ntiles = q.tiles_x * q.tiles_y * N; }
     else { q.tiles_x = 1; q.tiles_y = 1; q.ntiles = cdiv(N, 4); }
+    q.nw8 = false; q.ring = false;
+    static const int ring_env = mtbc_probe_int("MTBC_C8_RING", -1);      // A/B
+    if (c8 && allow_nw8 && q.geo != 2 && red >= 96 && ring_env != 0) {
+        // deep levels: a launch of at most ONE block per CU -- the ring kernel (chunks prefetched two ahead) with as many channel
+        // tiles per block as divide evenly (the pixel tile is staged once per block).  Measured (U-Net++ B=32, 16 x 16 maps):
+        // 192->384 29 -> 23 us, 384->384 40 -> 35 us; with two rounds of blocks (512->512: 512 blocks) it LOSES, 50 -> 60 us, and
+        // 1152->512 85 -> 121 us: these launches are bound by the L2 -> LDS fill rate (~4.3 TB/s over the chip, 2.4x the
+        // algorithmic bytes), not by its latency, and one block per CU cannot overlap its rounds
+        const int mtr = q.mtiles % 3 == 0 ? 3 : (q.mtiles >= 2 ? 2 : 1);
+        const int mb = cdiv(q.mtiles, mtr);
+        if ((long long)q.ntiles * mb <= 256) { q.ring = true; q.MT = mtr; q.mblocks = mb; return q; }
+    }
     // channel tiles per block: up to 3 (4 spills past 256 VGPRs), fewer when the launch would not fill 256 CUs twice over
     static const int mtmax_env = mtbc_probe_int("MTBC_LP_MT", 0);      // A/B probe
     // 16-bit kernels: 2 tiles per block keep LDS at 51 KB = 3 blocks per CU; 3 tiles (62 KB, 2 blocks) measured slower
@@ -2300,7 +2493,6 @@ IgemmPlan plan_igemm(int N, int H, int W, int rows, int compute, bool c8, bool a
         q.mblocks = cdiv(q.mtiles, q.MT);
     }
     q.MT = cdiv(q.mtiles, q.mblocks);
-    q.nw8 = false;
     if (c8) {
         // wide maps with enough tiles for two 512-pixel blocks per CU several times over: 16 x 32 tiles, 8 waves
         static const int nw_env = mtbc_probe_int("MTBC_C8_NW", 0);      // A/B
@@ -2326,9 +2518,13 @@ int run_igemm(int N, int H, int W, int red, int rows, const SegTable& in, const 
     }
     static const int dbg = mtbc_probe_int("MTBC_DBG", 0);
     p.dbg = dbg;
-    const IgemmPlan q = plan_igemm(N, H, W, rows, compute, c8, o8 != 2);      // (the norm-backward epilogue spills in the 8-wave variant)
+    const IgemmPlan q = plan_igemm(N, H, W, rows, compute, c8, o8 != 2, red);      // (the norm-backward epilogue: neither the 8-wave nor the ring variant)
     const int geo = q.geo, MT = q.MT, mblocks = q.mblocks;
     p.mtiles = q.mtiles; p.tiles_x = q.tiles_x; p.tiles_y = q.tiles_y; p.ntiles = q.ntiles;
+    if (c8 && q.ring) {
+        if (o8 == 1) return geo == 0 ? launch_igemm_c8_ring_mt<0, 1>(MT, p, mblocks, compute == 2, st) : launch_igemm_c8_ring_mt<1, 1>(MT, p, mblocks, compute == 2, st);
+        return geo == 0 ? launch_igemm_c8_ring_mt<0, 0>(MT, p, mblocks, compute == 2, st) : launch_igemm_c8_ring_mt<1, 0>(MT, p, mblocks, compute == 2, st);
+    }
     if (c8) {
         if (q.nw8) return o8 == 1 ? launch_igemm_c8<2, 0, 8, 1>(p, mblocks, compute == 2, st) : launch_igemm_c8<2, 0, 8, 0>(p, mblocks, compute == 2, st);
         if (o8 == 2) {
@@ -2571,7 +2767,7 @@ int mtbc_conv3x3_dgrad(const mtbc_conv3x3_args* a, void* stream) {
 int32_t mtbc_conv3x3_stats_slots(const mtbc_conv3x3_args* a) {
     if (check_conv(a) || a->operand_layout != MTBC_LAYOUT_C8 || a->out_layout != MTBC_LAYOUT_C8 || (a->compute != 1 && a->compute != 2)) return 0;
     if (a->W % 4 || a->W < 8 || a->H < 8 || a->Cout % 8) return 0;
-    const IgemmPlan q = plan_igemm(a->N, a->H, a->W, a->Cout, a->compute, true, a->norm_z == nullptr);
+    const IgemmPlan q = plan_igemm(a->N, a->H, a->W, a->Cout, a->compute, true, a->norm_z == nullptr, a->Cin);
     return q.geo == 2 ? 1 : q.tiles_x * q.tiles_y * (q.nw8 ? 8 : 4);
 }
 
