@@ -156,7 +156,7 @@ def run_mode(args, dtype, dev, rank, world, dist, want_roofline):
     L = _lib
     peak = PEAK_F32_MFMA_TFLOPS if dtype == "f32" else PEAK_16BIT_MFMA_TFLOPS
     # ---- the 3x3 convolutions: every MFMA launch of a step, timed one by one
-    fam = {"igemm": [0.0, 0.0, 0.0, 0], "wgrad": [0.0, 0.0, 0.0, 0]}          # flops, bytes, seconds, launches
+    fam = {"igemm": [0.0, 0.0, 0.0, 0, 0.0, 0, 0.0], "wgrad": [0.0, 0.0, 0.0, 0, 0.0, 0, 0.0]}   # flops, bytes, seconds, launches, roofline seconds, HBM-bound launches, their seconds
     for prog in (st.programs["fwd"], st.programs["bwd"]):
         for i in range(prog.n):
             op = prog.array[i]
@@ -167,7 +167,14 @@ def run_mode(args, dtype, dev, rank, world, dist, want_roofline):
                 f = fam["wgrad"]
             else:
                 continue
-            f[0] += conv_flops(op); f[1] += conv_bytes(op, op.kind, L); f[2] += time_op(prog, i); f[3] += 1
+            fl_, by_, t_ = conv_flops(op), conv_bytes(op, op.kind, L), time_op(prog, i)
+            f[0] += fl_; f[1] += by_; f[2] += t_; f[3] += 1
+            # each launch against ITS OWN roof: the level-0 launches sit under the HBM roof, the deep levels (K = 9 x 384 .. 1152 on
+            # 16 x 16 maps) under the MFMA roof -- one byte rate over both families prices the deep levels against the wrong roof
+            t_hbm, t_mfma = by_ / PEAK_HBM_BYTES, fl_ / (peak * 1e12)
+            f[4] += max(t_hbm, t_mfma)
+            if t_hbm >= t_mfma:
+                f[5] += 1; f[6] += t_
     fl = fam["igemm"][0] + fam["wgrad"][0]
     by = fam["igemm"][1] + fam["wgrad"][1]
     sec = fam["igemm"][2] + fam["wgrad"][2]
@@ -205,6 +212,9 @@ def run_mode(args, dtype, dev, rank, world, dist, want_roofline):
                  "algorithmic_MB_per_launch": round(ig[1] / ig[3] / 1e6, 1),
                  "tflops": round(ig[0] / ig[2] / 1e12, 2), "frac_of_mfma_peak": round(ig[0] / ig[2] / 1e12 / peak, 4),
                  "GBps": round(ig[1] / ig[2] / 1e9, 1), "frac_of_hbm_peak": round(ig[1] / ig[2] / PEAK_HBM_BYTES, 4)})
+    roof["per_launch_roofs"] = {"frac": round(ig[4] / ig[2], 4), "hbm_bound_launches": ig[5], "mfma_bound_launches": ig[3] - ig[5],
+                                "hbm_bound_share_of_time": round(ig[6] / ig[2], 3),
+                                "note": "sum over launches of max(bytes / 8 TB/s, flops / MFMA peak) / sum of measured launch times"}
     wg = fam["wgrad"]
     roof["wgrad"] = {"kernel": names[1] + " + split-K reduce", "tflops": round(wg[0] / wg[2] / 1e12, 2),
                      "frac_of_mfma_peak": round(wg[0] / wg[2] / 1e12 / peak, 4), "GBps": round(wg[1] / wg[2] / 1e9, 1),

@@ -401,14 +401,39 @@ __global__ void in_stats_finalize_kernel(const float* __restrict__ part, int slo
     }
 }
 constexpr int AP_THREADS = 256, AP_PPT = 4;
-template <bool F16>
-__global__ __launch_bounds__(AP_THREADS) void in_apply_fwd_c8_kernel(const CoP p) {
+// FIN: the workgroup first adds up the conv epilogue's partials of its 8 channels itself (few pixel subsets: planes up to 64 x 64)
+// -- no separate finalize launch; thread t sums subsets t/8, t/8 + 32, ... of channel t % 8 in double, the 32 partial sums are
+// added in a fixed order, and the workgroup of the plane group's first pixels writes mean / rstd for the backward pass.
+template <bool F16, bool FIN>
+__global__ __launch_bounds__(AP_THREADS) void in_apply_fwd_c8_kernel(const CoP p, const float* __restrict__ part, const int slots) {
     const int item = blockIdx.y, n = item / p.G8, g = item % p.G8;
     float mu[8], ga[8], be[8];
+    if constexpr (FIN) {
+        __shared__ double acc_s[32][8], acc_q[32][8];
+        __shared__ float st[2][8];
+        const int c = threadIdx.x & 7, sub = threadIdx.x >> 3;
+        const float* q = part + (((size_t)n * slots) * p.C + 8 * g + c) * 2;
+        double s = 0.0, qq = 0.0;
+        for (int t = sub; t < slots; t += 32) { const float2 v = *reinterpret_cast<const float2*>(q + (size_t)t * p.C * 2); s += (double)v.x; qq += (double)v.y; }
+        acc_s[sub][c] = s; acc_q[sub][c] = qq;
+        __syncthreads();
+        if (threadIdx.x < 8) {
+            double ts = 0.0, tq = 0.0;
+            for (int k = 0; k < 32; ++k) { ts += acc_s[k][threadIdx.x]; tq += acc_q[k][threadIdx.x]; }
+            const double m = ts / (double)p.HW, var = fmax(tq / (double)p.HW - m * m, 0.0);
+            const float mean = (float)m, rstd = (float)(1.0 / sqrt(var + (double)p.eps));
+            st[0][threadIdx.x] = mean; st[1][threadIdx.x] = rstd;
+            if (blockIdx.x == 0) { p.mean[(size_t)n * p.C + 8 * g + threadIdx.x] = mean; p.rstd[(size_t)n * p.C + 8 * g + threadIdx.x] = rstd; }
+        }
+        __syncthreads();
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
-        const size_t pl = (size_t)n * p.C + 8 * g + c;
-        mu[c] = p.mean[pl]; ga[c] = (p.gamma ? p.gamma[8 * g + c] : 1.f) * p.rstd[pl]; be[c] = p.beta ? p.beta[8 * g + c] : 0.f;
+        for (int c2 = 0; c2 < 8; ++c2) { mu[c2] = st[0][c2]; ga[c2] = (p.gamma ? p.gamma[8 * g + c2] : 1.f) * st[1][c2]; be[c2] = p.beta ? p.beta[8 * g + c2] : 0.f; }
+    } else {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const size_t pl = (size_t)n * p.C + 8 * g + c;
+            mu[c] = p.mean[pl]; ga[c] = (p.gamma ? p.gamma[8 * g + c] : 1.f) * p.rstd[pl]; be[c] = p.beta ? p.beta[8 * g + c] : 0.f;
+        }
     }
     const unsigned short* zg = p.z8 + ((size_t)n * p.G8 + g) * p.HW * 8;
     unsigned short* ob = p.y8 + ((size_t)n * p.G8 + g) * p.HW * 8;
@@ -631,11 +656,17 @@ int mtbc_i_instnorm_fwd_c8(const mtbc_instnorm_args* a, hipStream_t st) {
     if (a->stats_partial) {         // statistics from the conv epilogue: finalize (one wave per plane) + one streaming pass
         if (!p.z8 || a->stats_slots <= 0) return MTBC_E_BADARG;
         const int planes = a->N * a->C;
+        const dim3 g(cdiv(p.HW, AP_THREADS * AP_PPT), p.items);
+        if (a->stats_slots <= 64) {          // few subsets per plane: every workgroup finalizes its own 8 channels (one launch)
+            if (p.f16) hipLaunchKernelGGL((in_apply_fwd_c8_kernel<true, true>), g, dim3(AP_THREADS), 0, st, p, a->stats_partial, a->stats_slots);
+            else hipLaunchKernelGGL((in_apply_fwd_c8_kernel<false, true>), g, dim3(AP_THREADS), 0, st, p, a->stats_partial, a->stats_slots);
+            MTBC_CHECK_LAUNCH();
+            return MTBC_OK;
+        }
         hipLaunchKernelGGL(in_stats_finalize_kernel, dim3(cdiv(planes, 4)), dim3(256), 0, st, a->stats_partial, a->stats_slots, a->C, p.HW, a->eps, a->mean, a->rstd, planes);
         MTBC_CHECK_LAUNCH();
-        const dim3 g(cdiv(p.HW, AP_THREADS * AP_PPT), p.items);
-        if (p.f16) hipLaunchKernelGGL(in_apply_fwd_c8_kernel<true>, g, dim3(AP_THREADS), 0, st, p);
-        else hipLaunchKernelGGL(in_apply_fwd_c8_kernel<false>, g, dim3(AP_THREADS), 0, st, p);
+        if (p.f16) hipLaunchKernelGGL((in_apply_fwd_c8_kernel<true, false>), g, dim3(AP_THREADS), 0, st, p, a->stats_partial, a->stats_slots);
+        else hipLaunchKernelGGL((in_apply_fwd_c8_kernel<false, false>), g, dim3(AP_THREADS), 0, st, p, a->stats_partial, a->stats_slots);
         MTBC_CHECK_LAUNCH();
         return MTBC_OK;
     }

@@ -1,0 +1,10 @@
+# second sweep: 10 more seeds x {default, MTBC_NO_DA16, MTBC_NO_Z16}
+mkdir -p gpurun_out/r02z2
+C="--steps 3000 --batch 32 --size 256 --lr 3e-4 --cosine --eval-every 3000 --eval-batches 32 --dtypes bf16"
+for seed in 21 22 23 24 25 26 27 28 29 30; do
+  for arm in default MTBC_NO_DA16 MTBC_NO_Z16; do
+    if [ $arm = default ]; then E=""; else E="$arm=1"; fi
+    env $E python tools/train_parity.py $C --seed $seed --out gpurun_out/r02z2/tp_${arm}_s${seed}.json > gpurun_out/r02z2/tp_${arm}_s${seed}.log 2>&1
+    echo "seed $seed $arm $(grep 'step  3000' gpurun_out/r02z2/tp_${arm}_s${seed}.log)" | tee -a gpurun_out/r02z2/summary.txt
+  done
+done
