@@ -124,6 +124,9 @@ typedef struct {
     const float* norm_gamma;
     const float* norm_beta;
     float norm_slope;
+    int32_t out_type;                /* fwd with out_layout C8: 0 = the type of `compute`; 2 with compute = 1 (bf16 operands): the
+                                        output is stored as fp16 (saturated at +-65504) -- for conv outputs of O(1) that a norm
+                                        follows: 11 significant bits in the same 2 bytes (mtbc_instnorm_args.z_type)              */
 } mtbc_conv3x3_args;
 #define MTBC_LAYOUT_PLANAR 0
 #define MTBC_LAYOUT_C8 1
@@ -247,6 +250,7 @@ typedef struct {
        as exact zeros instead of the rounding noise of a sum.  workspace: N*C*5 floats.                                  */
     const float* stats_partial;
     int32_t stats_slots;
+    int32_t z_type;                  /* with z_layout C8: 0 = z has the type of out16_type; 2 = z is fp16 although out16_type is bf16 */
 } mtbc_instnorm_args;
 size_t mtbc_instnorm_coop_state_bytes(void);
 /* Byte offset, inside a coop_state block, of the 32-bit STICKY error word: non-zero once any cooperative launch on that

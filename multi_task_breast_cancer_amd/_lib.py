@@ -36,7 +36,8 @@ class Conv3x3Args(C.Structure):
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
                 ("compute", C.c_int32), ("operand_layout", C.c_int32), ("out_accumulate", C.c_int32), ("out_layout", C.c_int32),
                 ("stats_partial", C.c_void_p), ("out_partial", C.c_void_p), ("norm_z", C.c_void_p), ("norm_mean", C.c_void_p),
-                ("norm_rstd", C.c_void_p), ("norm_gamma", C.c_void_p), ("norm_beta", C.c_void_p), ("norm_slope", C.c_float)]
+                ("norm_rstd", C.c_void_p), ("norm_gamma", C.c_void_p), ("norm_beta", C.c_void_p), ("norm_slope", C.c_float),
+                ("out_type", C.c_int32)]
 
 
 class InstNormArgs(C.Structure):
@@ -52,7 +53,8 @@ class InstNormArgs(C.Structure):
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
                 ("y16", C.c_void_p), ("dz16", C.c_void_p), ("out16_type", C.c_int32),
                 ("y8", C.c_void_p), ("dz8", C.c_void_p), ("coop_state", C.c_void_p), ("coop_reserve_cus", C.c_int32),
-                ("z_layout", C.c_int32), ("dy_layout", C.c_int32), ("stats_partial", C.c_void_p), ("stats_slots", C.c_int32)]
+                ("z_layout", C.c_int32), ("dy_layout", C.c_int32), ("stats_partial", C.c_void_p), ("stats_slots", C.c_int32),
+                ("z_type", C.c_int32)]
 
 
 class MaxPoolArgs(C.Structure):

@@ -897,6 +897,7 @@ __device__ __forceinline__ void c8_epilogue(const ConvP& p, f32x4 (&acc)[MT][4],
                                             const int y0, const int x0, const int tx, const int ty, const int mt0, const int wv,
                                             const int j, const int kg, const int HW, ZPRE& zpre) {
     using T = LP<F16>;
+    using TO = LP<F16 || O8 == 3>;       // type of a channel-blocked output: the operands' type, or fp16 for the conv output z of the bf16 mode (O8 == 3)
     typedef unsigned pre_u32x2 __attribute__((ext_vector_type(2)));
     const int n = GEO == 2 ? n0 + wv : n0;
     if MTBC_DBG_BIT(p, 2) { if (acc[0][0][0] != 12345.678f) return; }
@@ -957,13 +958,17 @@ __device__ __forceinline__ void c8_epilogue(const ConvP& p, f32x4 (&acc)[MT][4],
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
                     if (pix[g] >= 0) {
-                        const f32x4 r = acc[m][g] + bv;
+                        f32x4 r = acc[m][g] + bv;
+                        if constexpr (O8 == 3) {          // fp16 storage of a bf16-mode conv output: saturate (an inf would poison the norm behind it)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) r[e] = __builtin_amdgcn_fmed3f(r[e], -65504.f, 65504.f);
+                        }
                         const float q[8] = {r[0], r[1], r[2], r[3], 0.f, 0.f, 0.f, 0.f};
-                        const ep_u32x4 u = __builtin_bit_cast(ep_u32x4, T::pack(q));
+                        const ep_u32x4 u = __builtin_bit_cast(ep_u32x4, TO::pack(q));
                         *(guint2*)(cb + 16 * (size_t)pix[g]) = (ep_u32x2){u[0], u[1]};
                         if (p.stats) {          // InstanceNorm statistics of the STORED values
                             const unsigned u0 = u[0], u1 = u[1];
-                            const f32x4 v = (f32x4){T::lo(u0), T::hi(u0), T::lo(u1), T::hi(u1)};
+                            const f32x4 v = (f32x4){TO::lo(u0), TO::hi(u0), TO::lo(u1), TO::hi(u1)};
                             ss += v; sq += v * v;
                         }
                     }
@@ -1032,7 +1037,7 @@ __device__ __forceinline__ void c8_epilogue(const ConvP& p, f32x4 (&acc)[MT][4],
 // run as D = W X (channels on the rows), so a lane holds 4 consecutive channels of ONE pixel = half a 16-byte piece; the 16
 // lanes of a row group write 16 consecutive pixels, and the lane groups kg = 2q, 2q + 1 the two halves of the same pieces
 // (256 contiguous bytes per channel group and instruction).  fp32 accumulate + bias, one RNE.
-template <int MT, int GEO, bool F16, int NW, int O8>      // O8: 0 = fp32 planar output, 1 = 16-bit channel-blocked (+ forward statistics), 2 = that + the norm-backward epilogue
+template <int MT, int GEO, bool F16, int NW, int O8>      // O8: 0 = fp32 planar output, 1 = 16-bit channel-blocked (+ forward statistics), 2 = that + the norm-backward epilogue, 3 = 1 stored as fp16 (bf16 operands)
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 4) void conv3x3_igemm_c8_kernel(const ConvP p) {
     using G = GeoLP<GEO>;
     using T = LP<F16>;
@@ -1248,7 +1253,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_igemm_c8_ring_kernel(const Con
     using G = GeoLP<GEO>;
     using T = LP<F16>;
     using RG = RingGeo<MT, GEO>;
-    static_assert(GEO != 2 && (O8 == 0 || O8 == 1) && R >= 2 && R <= 3, "wide / 16-wide maps, plain epilogues");
+    static_assert(GEO != 2 && (O8 == 0 || O8 == 1 || O8 == 3) && R >= 2 && R <= 3, "wide / 16-wide maps, plain epilogues");
     constexpr int NW = 4, TH = G::TH, HR = RG::HR, HC = RG::HC, HP = RG::HP, HPP = RG::HPP, XB = RG::XB, WB = RG::WB, XQ = RG::XQ;
     extern __shared__ __attribute__((aligned(16))) unsigned short smem16[];
     SegL* seg_in = reinterpret_cast<SegL*>(smem16 + R * RG::SLOT);
@@ -2522,11 +2527,18 @@ int run_igemm(int N, int H, int W, int red, int rows, const SegTable& in, const 
     const int geo = q.geo, MT = q.MT, mblocks = q.mblocks;
     p.mtiles = q.mtiles; p.tiles_x = q.tiles_x; p.tiles_y = q.tiles_y; p.ntiles = q.ntiles;
     if (c8 && q.ring) {
+        if (o8 == 3) return geo == 0 ? launch_igemm_c8_ring_mt<0, 3>(MT, p, mblocks, false, st) : launch_igemm_c8_ring_mt<1, 3>(MT, p, mblocks, false, st);
         if (o8 == 1) return geo == 0 ? launch_igemm_c8_ring_mt<0, 1>(MT, p, mblocks, compute == 2, st) : launch_igemm_c8_ring_mt<1, 1>(MT, p, mblocks, compute == 2, st);
         return geo == 0 ? launch_igemm_c8_ring_mt<0, 0>(MT, p, mblocks, compute == 2, st) : launch_igemm_c8_ring_mt<1, 0>(MT, p, mblocks, compute == 2, st);
     }
     if (c8) {
-        if (q.nw8) return o8 == 1 ? launch_igemm_c8<2, 0, 8, 1>(p, mblocks, compute == 2, st) : launch_igemm_c8<2, 0, 8, 0>(p, mblocks, compute == 2, st);
+        if (q.nw8) return o8 == 3 ? launch_igemm_c8<2, 0, 8, 3>(p, mblocks, false, st)
+                        : o8 == 1 ? launch_igemm_c8<2, 0, 8, 1>(p, mblocks, compute == 2, st) : launch_igemm_c8<2, 0, 8, 0>(p, mblocks, compute == 2, st);
+        if (o8 == 3) {
+            if (geo == 0) return launch_igemm_c8_mt<0, 3>(MT, p, mblocks, false, st);
+            if (geo == 1) return launch_igemm_c8_mt<1, 3>(MT, p, mblocks, false, st);
+            return launch_igemm_c8_mt<2, 3>(MT, p, mblocks, false, st);
+        }
         if (o8 == 2) {
             if (geo == 0) return launch_igemm_c8_mt<0, 2>(MT, p, mblocks, compute == 2, st);
             if (geo == 1) return launch_igemm_c8_mt<1, 2>(MT, p, mblocks, compute == 2, st);
@@ -2699,18 +2711,20 @@ int mtbc_conv3x3_fwd(const mtbc_conv3x3_args* a, void* stream) {
         if (!a->w_packed || (a->compute != 1 && a->compute != 2) || !c8_segs_ok(a->in, a->n_in)) return MTBC_E_BADARG;
         if (a->W % 4 || a->W < 8 || a->H < 8 || (reinterpret_cast<uintptr_t>(a->out) & 15)) return MTBC_E_UNSUPPORTED;
         const bool o8 = a->out_layout == MTBC_LAYOUT_C8;
+        if (a->out_type != 0 && a->out_type != a->compute && !(o8 && a->out_type == 2 && a->compute == 1)) return MTBC_E_BADARG;
+        const bool of16 = o8 && a->compute == 1 && a->out_type == 2;          // bf16 operands, output stored as fp16
         if (o8) {
             if (a->Cout % 8 || a->out_accumulate) return MTBC_E_BADARG;
             out.accumulate[0] = 3;
         }
         if (a->stats_partial && (!o8 || (reinterpret_cast<uintptr_t>(a->stats_partial) & 15))) return MTBC_E_BADARG;
         if (a->norm_z || a->out_partial) {       // gathered dgrad + the reductions of the norm backward
-            if (!o8 || !a->norm_z || !a->norm_mean || !a->norm_rstd || !a->stats_partial || a->bias || (a->norm_gamma == nullptr) != (a->norm_beta == nullptr)) return MTBC_E_BADARG;
+            if (!o8 || of16 || !a->norm_z || !a->norm_mean || !a->norm_rstd || !a->stats_partial || a->bias || (a->norm_gamma == nullptr) != (a->norm_beta == nullptr)) return MTBC_E_BADARG;
             if ((reinterpret_cast<uintptr_t>(a->norm_z) | reinterpret_cast<uintptr_t>(a->norm_mean) | reinterpret_cast<uintptr_t>(a->norm_rstd) |
                  reinterpret_cast<uintptr_t>(a->norm_gamma) | reinterpret_cast<uintptr_t>(a->norm_beta)) & 15) return MTBC_E_BADARG;
             return run_igemm(a->N, a->H, a->W, a->Cin, a->Cout, in, out, a->w_packed, nullptr, a->compute, st, true, 2, a->stats_partial, a);
         }
-        return run_igemm(a->N, a->H, a->W, a->Cin, a->Cout, in, out, a->w_packed, a->bias, a->compute, st, true, o8 ? 1 : 0, a->stats_partial);
+        return run_igemm(a->N, a->H, a->W, a->Cin, a->Cout, in, out, a->w_packed, a->bias, a->compute, st, true, of16 ? 3 : (o8 ? 1 : 0), a->stats_partial);
     }
     if (a->stats_partial || a->norm_z || a->out_partial) return MTBC_E_UNSUPPORTED;
     if (a->operand_layout != MTBC_LAYOUT_PLANAR) return MTBC_E_BADARG;

@@ -48,6 +48,7 @@ struct CoP {
     const unsigned short* z8;                // z as 16-bit channel-blocked [n][C/8][HW][8] (else nullptr: fp32 planes `z`)
     const unsigned short* dy8; long long dy8bs;   // dy as 16-bit channel-blocked (else nullptr: fp32 planes `dy`)
     const float* dyx;                        // with dy8: optional fp32 planar partial gradient (N,C,H,W), added while loading
+    int zf16;                                // z8 holds fp16 values (whatever the output type)
 };
 
 typedef float co_f32x2 __attribute__((ext_vector_type(2)));
@@ -157,8 +158,9 @@ __device__ __forceinline__ void coop_finish(CoopHdr* hdr, unsigned epoch) {
 // whole group of 8 planes (up to 64 x 64: THREADS x PPT >= H*W), grid = items, no mailbox, no state.
 // Inputs per launch (uniform branches): z / dy as fp32 planes (raw buffer loads, plane stride in the scalar offset) or as
 // 16-bit channel-blocked pieces (ONE 16-byte load per pixel = its 8 channels).
-template <int THREADS, int PPT, bool F16, bool COOP, bool ZC8>
+template <int THREADS, int PPT, bool F16, bool COOP, int ZC8>      // ZC8: 0 = fp32 planar z, 1 = 16-bit channel-blocked of the output's type, 2 = channel-blocked fp16 (bf16 output)
 __global__ __launch_bounds__(THREADS, THREADS >= 512 ? 4 : 2) void in_fwd_c8_kernel(const CoP p) {
+    constexpr bool ZF16 = F16 || ZC8 == 2;
     __shared__ float red[THREADS / 64][16];
     __shared__ float xch[COOP ? CO_MAXT : 1][CO_NV];
     __shared__ float tot[16];
@@ -175,7 +177,7 @@ __global__ __launch_bounds__(THREADS, THREADS >= 512 ? 4 : 2) void in_fwd_c8_ker
     for (int item = team; item < p.items; item += p.nteams) {
         const int n = item / p.G8, g = item % p.G8;
         float v[8][PPT];
-        if constexpr (ZC8) {
+        if constexpr (ZC8 != 0) {
             // one 16-byte piece per pixel; padding lanes read the plane's first pixel (= the pivot)
             const unsigned short* zg = p.z8 + ((size_t)n * p.G8 + g) * p.HW * 8;
 #pragma unroll
@@ -183,11 +185,11 @@ __global__ __launch_bounds__(THREADS, THREADS >= 512 ? 4 : 2) void in_fwd_c8_ker
                 const int px = tid + THREADS * k;
                 const size_t idx = px < slab ? (size_t)member * slab + px : 0;
                 float o[8];
-                co_unpk<F16>(*reinterpret_cast<const co_u32x4*>(zg + idx * 8), o);
+                co_unpk<ZF16>(*reinterpret_cast<const co_u32x4*>(zg + idx * 8), o);
 #pragma unroll
                 for (int c = 0; c < 8; ++c) v[c][k] = o[c];
             }
-            if (tid < 8) cst[3][tid] = F16 ? (float)reinterpret_cast<const _Float16*>(zg)[tid] : __uint_as_float((unsigned)zg[tid] << 16);
+            if (tid < 8) cst[3][tid] = ZF16 ? (float)reinterpret_cast<const _Float16*>(zg)[tid] : __uint_as_float((unsigned)zg[tid] << 16);
         } else {
             const float* zp = p.z + ((size_t)n * p.C + 8 * g) * p.HW;         // the 8 planes of the group
             // raw buffer loads over the group's 8 planes: the plane stride rides in the scalar offset, so a load costs one
@@ -252,8 +254,9 @@ __global__ __launch_bounds__(THREADS, THREADS >= 512 ? 4 : 2) void in_fwd_c8_ker
     if constexpr (COOP) coop_finish(hdr, epoch);
 }
 
-template <int THREADS, int PPT, bool F16, bool COOP, bool ZC8, int DY8>      // DY8: 0 = fp32 planar dy, 1 = 16-bit channel-blocked, 2 = that + an fp32 planar partial
+template <int THREADS, int PPT, bool F16, bool COOP, int ZC8, int DY8>      // ZC8 as above; DY8: 0 = fp32 planar dy, 1 = 16-bit channel-blocked, 2 = that + an fp32 planar partial
 __global__ __launch_bounds__(THREADS, THREADS >= 512 ? 4 : 2) void in_bwd_c8_kernel(const CoP p) {
+    constexpr bool ZF16 = F16 || ZC8 == 2;
     __shared__ float red[THREADS / 64][16];
     __shared__ float xch[COOP ? CO_MAXT : 1][CO_NV];
     __shared__ float tot[16];
@@ -273,14 +276,14 @@ __global__ __launch_bounds__(THREADS, THREADS >= 512 ? 4 : 2) void in_bwd_c8_ker
         const int plane_b = p.HW * 4;
         float xh[8][PPT], gy[8][PPT];
         // out-of-slab lanes: offsets past the buffer, the bounds check returns 0
-        if constexpr (ZC8) {
+        if constexpr (ZC8 != 0) {
             const __amdgpu_buffer_rsrc_t zr = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.z8 + ((size_t)n * p.G8 + g) * p.HW * 8), 0, p.HW * 16, 0x00020000);
 #pragma unroll
             for (int k = 0; k < PPT; ++k) {
                 const int px = tid + THREADS * k;
                 const int off = px < slab ? (member * slab + px) * 16 : 0x7ffffff0;
                 float o[8];
-                co_unpk<F16>(__builtin_bit_cast(co_u32x4, __builtin_amdgcn_raw_buffer_load_b128(zr, off, 0, 0)), o);
+                co_unpk<ZF16>(__builtin_bit_cast(co_u32x4, __builtin_amdgcn_raw_buffer_load_b128(zr, off, 0, 0)), o);
 #pragma unroll
                 for (int c = 0; c < 8; ++c) xh[c][k] = o[c];
             }
@@ -404,7 +407,7 @@ constexpr int AP_THREADS = 256, AP_PPT = 4;
 // FIN: the workgroup first adds up the conv epilogue's partials of its 8 channels itself (few pixel subsets: planes up to 64 x 64)
 // -- no separate finalize launch; thread t sums subsets t/8, t/8 + 32, ... of channel t % 8 in double, the 32 partial sums are
 // added in a fixed order, and the workgroup of the plane group's first pixels writes mean / rstd for the backward pass.
-template <bool F16, bool FIN>
+template <bool F16, bool FIN, bool ZF16>
 __global__ __launch_bounds__(AP_THREADS) void in_apply_fwd_c8_kernel(const CoP p, const float* __restrict__ part, const int slots) {
     const int item = blockIdx.y, n = item / p.G8, g = item % p.G8;
     float mu[8], ga[8], be[8];
@@ -450,7 +453,7 @@ __global__ __launch_bounds__(AP_THREADS) void in_apply_fwd_c8_kernel(const CoP p
         const int px = px0 + AP_THREADS * k;
         if (px >= p.HW) continue;
         float v[8];
-        co_unpk<F16>(w[k], v);
+        co_unpk<ZF16>(w[k], v);
 #pragma unroll
         for (int c = 0; c < 8; ++c) { const float t = (v[c] - mu[c]) * ga[c] + be[c]; v[c] = t > 0.f ? t : t * p.slope; }
         co_u32x4 o;
@@ -481,7 +484,7 @@ __global__ void in_bstats_finalize_kernel(const float* __restrict__ part, int sl
         if (dparam_part) { dparam_part[3 * plane] = (float)s1; dparam_part[3 * plane + 1] = (float)s2; dparam_part[3 * plane + 2] = 0.f; }
     }
 }
-template <bool F16>
+template <bool F16, bool ZF16>
 __global__ __launch_bounds__(AP_THREADS) void in_apply_bwd_c8_kernel(const CoP p, const float* __restrict__ m12) {
     const int item = blockIdx.y, n = item / p.G8, g = item % p.G8;
     float mu[8], rs[8], ga[8], be[8], m1[8], m2[8];
@@ -506,7 +509,7 @@ __global__ __launch_bounds__(AP_THREADS) void in_apply_bwd_c8_kernel(const CoP p
         const int px = px0 + AP_THREADS * k;
         if (px >= p.HW) continue;
         float z[8], d[8];
-        co_unpk<F16>(wz[k], z);
+        co_unpk<ZF16>(wz[k], z);
         co_unpk<F16>(wd[k], d);
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
@@ -575,6 +578,8 @@ int fill_coop(const mtbc_instnorm_args* a, CoP* p) {
     p->y8 = reinterpret_cast<unsigned short*>(a->y8); p->mean = a->mean; p->rstd = a->rstd; p->dy = a->dy; p->dybs = a->dy_batch_stride;
     p->dz8 = reinterpret_cast<unsigned short*>(a->dz8); p->part = nullptr; p->part3 = nullptr; p->state = a->coop_state;
     p->z8 = nullptr; p->dy8 = nullptr; p->dy8bs = 0; p->dyx = nullptr;
+    if (a->z_type != 0 && a->z_type != a->out16_type && !(a->z_type == 2 && a->z_layout == MTBC_LAYOUT_C8)) return MTBC_E_BADARG;
+    p->zf16 = (a->out16_type == 2 || a->z_type == 2) ? 1 : 0;
     if (a->z_layout == MTBC_LAYOUT_C8) {
         if (reinterpret_cast<uintptr_t>(a->z) & 15) return MTBC_E_BADARG;
         p->z8 = reinterpret_cast<const unsigned short*>(a->z); p->z = nullptr;
@@ -587,8 +592,8 @@ constexpr int SOLO_MAX_HW = 4096;
 // query each, cached in a function-local static (thread-safe initialisation, immutable afterwards).
 template <auto K> int cap_of() { static const int c = resident_blocks(K); return c; }
 // the variant a launch runs: (output type, z layout, dy layout)
-struct Var { bool f16, zc8; int dy8; };
-template <bool BWD, int THREADS, int PPT, bool COOP, bool F16, bool ZC8, int DY8> constexpr auto kernel_of() {
+struct Var { bool f16; int zc8, dy8; };
+template <bool BWD, int THREADS, int PPT, bool COOP, bool F16, int ZC8, int DY8> constexpr auto kernel_of() {
     if constexpr (BWD) return &in_bwd_c8_kernel<THREADS, PPT, F16, COOP, ZC8, DY8>;
     else return &in_fwd_c8_kernel<THREADS, PPT, F16, COOP, ZC8>;
 }
@@ -597,8 +602,8 @@ template <bool BWD, int THREADS, int PPT, bool COOP, typename F> auto with_kerne
 #define MTBC_V(F16_, Z_, D_) f(std::integral_constant<decltype(kernel_of<BWD, THREADS, PPT, COOP, F16_, Z_, D_>()), kernel_of<BWD, THREADS, PPT, COOP, F16_, Z_, D_>()>{})
     const int d = BWD ? v.dy8 : 0;
 #define MTBC_VD(F16_, Z_) (d == 2 ? MTBC_V(F16_, Z_, 2) : d == 1 ? MTBC_V(F16_, Z_, 1) : MTBC_V(F16_, Z_, 0))
-    if (v.f16) return v.zc8 ? MTBC_VD(true, true) : MTBC_VD(true, false);
-    return v.zc8 ? MTBC_VD(false, true) : MTBC_VD(false, false);
+    if (v.f16) return v.zc8 ? MTBC_VD(true, 1) : MTBC_VD(true, 0);
+    return v.zc8 == 2 ? MTBC_VD(false, 2) : v.zc8 == 1 ? MTBC_VD(false, 1) : MTBC_VD(false, 0);
 #undef MTBC_VD
 #undef MTBC_V
 }
@@ -611,11 +616,11 @@ template <bool BWD> CoPlan plan_team(int items, int HW, const Var& v, int reserv
     //  odd teams late so that their loads fall into the even teams' exchanges: tools/experiments/in_bwd_probe.sh)
     return plan_coop(items, HW, 4, cap, reserve);
 }
-Var var_of(const mtbc_instnorm_args* a) { return Var{a->out16_type == 2, a->z_layout == MTBC_LAYOUT_C8, a->dy_layout == MTBC_LAYOUT_C8 ? (a->n_dy_extra ? 2 : 1) : 0}; }
+Var var_of(const mtbc_instnorm_args* a) { return Var{a->out16_type == 2, a->z_layout == MTBC_LAYOUT_C8 ? ((a->z_type == 2 && a->out16_type == 1) ? 2 : 1) : 0, a->dy_layout == MTBC_LAYOUT_C8 ? (a->n_dy_extra ? 2 : 1) : 0}; }
 
 template <bool BWD, int THREADS, int PPT, bool COOP>
 void launch_c8(const CoP& p, int grid, hipStream_t st) {
-    const Var v{p.f16 != 0, p.z8 != nullptr, p.dy8 ? (p.dyx ? 2 : 1) : 0};
+    const Var v{p.f16 != 0, p.z8 ? (p.zf16 && !p.f16 ? 2 : 1) : 0, p.dy8 ? (p.dyx ? 2 : 1) : 0};
     with_kernel<BWD, THREADS, PPT, COOP>(v, [&](auto k) { hipLaunchKernelGGL(decltype(k)::value, dim3(grid), dim3(THREADS), 0, st, p); return 0; });
 }
 // one workgroup per item, sized to the plane
@@ -658,15 +663,17 @@ int mtbc_i_instnorm_fwd_c8(const mtbc_instnorm_args* a, hipStream_t st) {
         const int planes = a->N * a->C;
         const dim3 g(cdiv(p.HW, AP_THREADS * AP_PPT), p.items);
         if (a->stats_slots <= 64) {          // few subsets per plane: every workgroup finalizes its own 8 channels (one launch)
-            if (p.f16) hipLaunchKernelGGL((in_apply_fwd_c8_kernel<true, true>), g, dim3(AP_THREADS), 0, st, p, a->stats_partial, a->stats_slots);
-            else hipLaunchKernelGGL((in_apply_fwd_c8_kernel<false, true>), g, dim3(AP_THREADS), 0, st, p, a->stats_partial, a->stats_slots);
+            if (p.f16) hipLaunchKernelGGL((in_apply_fwd_c8_kernel<true, true, true>), g, dim3(AP_THREADS), 0, st, p, a->stats_partial, a->stats_slots);
+            else if (p.zf16) hipLaunchKernelGGL((in_apply_fwd_c8_kernel<false, true, true>), g, dim3(AP_THREADS), 0, st, p, a->stats_partial, a->stats_slots);
+            else hipLaunchKernelGGL((in_apply_fwd_c8_kernel<false, true, false>), g, dim3(AP_THREADS), 0, st, p, a->stats_partial, a->stats_slots);
             MTBC_CHECK_LAUNCH();
             return MTBC_OK;
         }
         hipLaunchKernelGGL(in_stats_finalize_kernel, dim3(cdiv(planes, 4)), dim3(256), 0, st, a->stats_partial, a->stats_slots, a->C, p.HW, a->eps, a->mean, a->rstd, planes);
         MTBC_CHECK_LAUNCH();
-        if (p.f16) hipLaunchKernelGGL((in_apply_fwd_c8_kernel<true, false>), g, dim3(AP_THREADS), 0, st, p, a->stats_partial, a->stats_slots);
-        else hipLaunchKernelGGL((in_apply_fwd_c8_kernel<false, false>), g, dim3(AP_THREADS), 0, st, p, a->stats_partial, a->stats_slots);
+        if (p.f16) hipLaunchKernelGGL((in_apply_fwd_c8_kernel<true, false, true>), g, dim3(AP_THREADS), 0, st, p, a->stats_partial, a->stats_slots);
+        else if (p.zf16) hipLaunchKernelGGL((in_apply_fwd_c8_kernel<false, false, true>), g, dim3(AP_THREADS), 0, st, p, a->stats_partial, a->stats_slots);
+        else hipLaunchKernelGGL((in_apply_fwd_c8_kernel<false, false, false>), g, dim3(AP_THREADS), 0, st, p, a->stats_partial, a->stats_slots);
         MTBC_CHECK_LAUNCH();
         return MTBC_OK;
     }
@@ -702,8 +709,9 @@ int mtbc_i_instnorm_bwd_c8(const mtbc_instnorm_args* a, float* part, hipStream_t
         hipLaunchKernelGGL(in_bstats_finalize_kernel, dim3(cdiv(planes, 4)), dim3(256), 0, st, a->stats_partial, a->stats_slots, a->C, p.HW, m12, part, planes);
         MTBC_CHECK_LAUNCH();
         const dim3 g(cdiv(p.HW, AP_THREADS * AP_PPT), p.items);
-        if (p.f16) hipLaunchKernelGGL(in_apply_bwd_c8_kernel<true>, g, dim3(AP_THREADS), 0, st, p, m12);
-        else hipLaunchKernelGGL(in_apply_bwd_c8_kernel<false>, g, dim3(AP_THREADS), 0, st, p, m12);
+        if (p.f16) hipLaunchKernelGGL((in_apply_bwd_c8_kernel<true, true>), g, dim3(AP_THREADS), 0, st, p, m12);
+        else if (p.zf16) hipLaunchKernelGGL((in_apply_bwd_c8_kernel<false, true>), g, dim3(AP_THREADS), 0, st, p, m12);
+        else hipLaunchKernelGGL((in_apply_bwd_c8_kernel<false, false>), g, dim3(AP_THREADS), 0, st, p, m12);
         MTBC_CHECK_LAUNCH();
         return MTBC_OK;
     }

@@ -30,9 +30,10 @@ _FANIN = _sw.flag("MTBC_FANIN")
 _NO_C8_SMALL = _sw.flag("MTBC_NO_C8_SMALL_OPS")
 _NO_G16 = _sw.flag("MTBC_NO_G16")
 _NO_Z16 = _sw.flag("MTBC_NO_Z16")
-_NO_DA16 = _sw.flag("MTBC_NO_DA16")
+_DA16 = _sw.flag("MTBC_DA16")
 _NO_EPI_STATS = _sw.flag("MTBC_NO_EPI_STATS")
 _EPI_BSTATS = _sw.flag("MTBC_EPI_BSTATS")
+_Z_BF16 = _sw.flag("MTBC_Z_BF16")
 _BWD_OVERLAP = _sw.flag("MTBC_BWD_OVERLAP")
 _BWD_OVERLAP_MAX_HW = int(_sw.get("MTBC_BWD_OVERLAP_MAX_HW"))
 
@@ -392,7 +393,11 @@ class StepPlan:
             q.N, q.C, q.H, q.W, q.out16_type, q.z_layout, q.coop_reserve_cus = N, cout, H, W, self.compute, L.LAYOUT_C8, self.coop_reserve_cus
             z16 = bool(self.lib.mtbc_instnorm_c8_supported(C.byref(q), 0)) and bool(self.lib.mtbc_instnorm_c8_supported(C.byref(q), 1))
         z = self.alloc(N, cout // 8, H * W, 8, dtype=torch.int16) if z16 else self.alloc(N, cout, H, W)
-        y.dy8_ok = z16 and not _NO_DA16 and not _FANIN
+        # ... as fp16 also in the bf16 mode: a conv output in front of a norm is O(1), and fp16 keeps 11 significant bits of it in the
+        # same 2 bytes (bf16: 8) -- measured on the held-out Dice of 3000-step runs (profiles/r02b_quality_sweep.md); the MFMA
+        # operands (activations, dz, weights) stay bf16.  (the norm-backward epilogue arm reads z as an operand-typed tensor)
+        zf16 = z16 and self.compute == 1 and not _Z_BF16 and not _EPI_BSTATS
+        y.dy8_ok = z16 and (_DA16 or _EPI_BSTATS) and not _FANIN
         if not c8 and not all(a_.planar_valid for a_ in inputs):
             raise NotImplementedError(f"{out_name}: an input exists only in the channel-blocked 16-bit layout")
         for a_ in inputs:
@@ -419,6 +424,8 @@ class StepPlan:
         stats_slots = 0
         if z16:
             op.u.conv3.out_layout = L.LAYOUT_C8
+            if zf16:
+                op.u.conv3.out_type = 2
             if not _NO_EPI_STATS:
                 # InstanceNorm statistics from the conv epilogue ({sum, sum of squares} of the stored values per wave): the
                 # normalisation that follows is then one streaming pass with no reduction / team exchange of its own
@@ -434,6 +441,7 @@ class StepPlan:
             a.N, a.C, a.H, a.W, a.eps, a.slope = N, cout, H, W, 1e-5, slope
             a.z = z.data_ptr()
             a.z_layout = L.LAYOUT_C8 if z16 else L.LAYOUT_PLANAR
+            a.z_type = 2 if zf16 else 0
             a.gamma = _ptr(self.pv(gname)) if gname else None
             a.beta = _ptr(self.pv(betaname)) if betaname else None
             a.mean, a.rstd = mean.data_ptr(), rstd.data_ptr()

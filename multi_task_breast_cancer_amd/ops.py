@@ -187,7 +187,7 @@ def _fill_segs_c8(arr, tensors: Sequence["C8"]):
 
 
 def conv3x3_fwd_c8(xs: Sequence["C8"], w: torch.Tensor, bias: Optional[torch.Tensor], packed: torch.Tensor, out_c8: bool = False,
-                   stats: bool = False, norm=None, out_partial: Optional[torch.Tensor] = None):
+                   stats: bool = False, norm=None, out_partial: Optional[torch.Tensor] = None, out_fp16: bool = False):
     """z = conv3x3(concat(xs)) with the inputs already in the MFMA's 16-bit channel-blocked layout; z comes back as fp32
     planes, or (out_c8, `out_layout = C8` of the C-ABI) as a channel-blocked 16-bit tensor of the inputs' type."""
     _chk(w, bias)
@@ -198,6 +198,8 @@ def conv3x3_fwd_c8(xs: Sequence["C8"], w: torch.Tensor, bias: Optional[torch.Ten
     if out_c8:
         out = torch.empty(N, w.shape[0] // 8, H * W, 8, dtype=torch.int16, device=w.device)
         a.out_layout = L.LAYOUT_C8
+        if out_fp16:            # bf16 operands, the output stored as fp16 (out_type of the C-ABI)
+            a.out_type = 2
     else:
         out = torch.empty(N, w.shape[0], H, W, dtype=torch.float32, device=w.device)
     a.w, a.w_packed, a.bias, a.out = w.data_ptr(), packed.data_ptr(), _p(bias), out.data_ptr()
@@ -216,7 +218,7 @@ def conv3x3_fwd_c8(xs: Sequence["C8"], w: torch.Tensor, bias: Optional[torch.Ten
         part = torch.full((N, slots, w.shape[0], 2), float("nan"), dtype=torch.float32, device=w.device)
         a.stats_partial = part.data_ptr()
     L.check(L.load().mtbc_conv3x3_fwd(C.byref(a), _s()), "conv3x3_fwd(c8)")
-    z = C8(out, (N, w.shape[0], H, W), xs[0].compute) if out_c8 else out
+    z = C8(out, (N, w.shape[0], H, W), 2 if out_fp16 else xs[0].compute) if out_c8 else out
     return (z, part) if stats else z
 
 
@@ -320,15 +322,14 @@ def coop_state(dev) -> torch.Tensor:
     return _coop_states[key]
 
 
-def instnorm_lrelu_fwd_c8(z, gamma=None, beta=None, eps=1e-5, slope=0.01, compute: int = 1, want_planar: bool = False,
+def instnorm_lrelu_fwd_c8(z, gamma=None, beta=None, eps=1e-5, slope=0.01, compute: Optional[int] = None, want_planar: bool = False,
                           stats: Optional[torch.Tensor] = None):
     """InstanceNorm + LeakyReLU straight into the 16-bit channel-blocked layout (y8 of the C-ABI).  z: fp32 planes, or a
     C8 tensor (z_layout = C8: the conv output of the 16-bit modes)."""
     z8 = z if isinstance(z, C8) else None
-    if z8 is not None:
-        compute, zt = z8.compute, z8.data
-    else:
-        zt = z
+    if compute is None:         # output type: given, else the type of a channel-blocked z, else bf16
+        compute = z8.compute if z8 is not None else 1
+    zt = z8.data if z8 is not None else z
     _chk(zt if z8 is None else None, gamma, beta)
     N, Cc, H, W = z.shape
     dev = zt.device
@@ -340,6 +341,8 @@ def instnorm_lrelu_fwd_c8(z, gamma=None, beta=None, eps=1e-5, slope=0.01, comput
     a.N, a.C, a.H, a.W, a.eps, a.slope = N, Cc, H, W, eps, slope
     a.z, a.gamma, a.beta, a.y, a.y_batch_stride = zt.data_ptr(), _p(gamma), _p(beta), _p(y), Cc * H * W
     a.z_layout = L.LAYOUT_C8 if z8 is not None else L.LAYOUT_PLANAR
+    if z8 is not None and z8.compute != compute:
+        a.z_type = z8.compute           # fp16 z with bf16 outputs
     a.mean, a.rstd = mean.data_ptr(), rstd.data_ptr()
     a.y8, a.out16_type, a.coop_state = y8.data_ptr(), compute, coop_state(dev).data_ptr()
     if stats is not None:       # [N][slots][C][2] from conv3x3_fwd_c8(stats=True)
@@ -350,14 +353,14 @@ def instnorm_lrelu_fwd_c8(z, gamma=None, beta=None, eps=1e-5, slope=0.01, comput
     return C8(y8, z.shape, compute), mean, rstd, y
 
 
-def instnorm_lrelu_bwd_c8(z, dy, mean, rstd, gamma=None, beta=None, eps=1e-5, slope=0.01, dbias_pre=None, compute: int = 1,
+def instnorm_lrelu_bwd_c8(z, dy, mean, rstd, gamma=None, beta=None, eps=1e-5, slope=0.01, dbias_pre=None, compute: Optional[int] = None,
                           dy_extra: Optional[torch.Tensor] = None, stats: Optional[torch.Tensor] = None):
     """z / dy: fp32 planes or C8 tensors (z_layout / dy_layout = C8); dy_extra (with a C8 dy only): an fp32 planar partial
     gradient added while loading."""
     zt = z.data if isinstance(z, C8) else z
     dyt = dy.data if isinstance(dy, C8) else dy
-    if isinstance(z, C8):
-        compute = z.compute
+    if compute is None:         # output (and channel-blocked dy) type: given, else dy's, else z's, else bf16
+        compute = dy.compute if isinstance(dy, C8) else (z.compute if isinstance(z, C8) else 1)
     _chk(mean, rstd, gamma, beta, dbias_pre, dy_extra)
     N, Cc, H, W = z.shape
     dev = zt.device
@@ -370,6 +373,8 @@ def instnorm_lrelu_bwd_c8(z, dy, mean, rstd, gamma=None, beta=None, eps=1e-5, sl
     a.z, a.gamma, a.beta, a.mean, a.rstd = zt.data_ptr(), _p(gamma), _p(beta), mean.data_ptr(), rstd.data_ptr()
     a.dy, a.dy_batch_stride, a.dgamma, a.dbeta, a.dbias_pre = dyt.data_ptr(), Cc * H * W, _p(dg), _p(db), _p(dbias_pre)
     a.z_layout = L.LAYOUT_C8 if isinstance(z, C8) else L.LAYOUT_PLANAR
+    if isinstance(z, C8) and z.compute != compute:
+        a.z_type = z.compute
     a.dy_layout = L.LAYOUT_C8 if isinstance(dy, C8) else L.LAYOUT_PLANAR
     if dy_extra is not None:
         a.n_dy_extra = 1

@@ -26,7 +26,8 @@ PLAN_SWITCHES: Dict[str, tuple] = {
     "MTBC_NO_C8_SMALL_OPS": ("0", "max-pool and the 1x1 heads keep reading fp32 planes in the 16-bit modes (InstanceNorm then writes them too)"),
     "MTBC_NO_G16": ("0", "the gradient of an up-sampled (ConvT) tensor stays fp32 between the 3x3 conv's dgrad and the ConvT backward"),
     "MTBC_NO_Z16": ("0", "16-bit modes keep the conv outputs z as fp32 planes (InstanceNorm reads 4 bytes per element in both directions)"),
-    "MTBC_NO_DA16": ("0", "the gradient a conv-cell activation gets from its 3x3 consumers stays fp32 planar (read-modify-write fan-in) instead of one 16-bit channel-blocked tensor"),
+    "MTBC_DA16": ("0", "the gradient a conv-cell activation gets from ALL its 3x3 consumers is one gathered launch writing a 16-bit channel-blocked tensor instead of fp32 planar fan-in (no faster on this workload -- the norm backward that reads it is latency-bound -- and about 1 pt of held-out Dice in the 3000-step sweep: off)"),
+    "MTBC_Z_BF16": ("0", "bf16 mode stores the conv outputs as bf16 instead of fp16 (same bytes, 8 instead of 11 significant bits)"),
     "MTBC_NO_EPI_STATS": ("0", "InstanceNorm forward reduces the stored conv output itself (channel-group kernels) instead of taking the statistics from the conv epilogue"),
     "MTBC_EPI_BSTATS": ("0", "the gathered dgrad's epilogue adds the other readers' partial gradient, reads the cell's z and leaves the two sums of the InstanceNorm backward, which becomes one streaming pass (measured slower: the epilogue's VALU work costs what the norm saves)"),
     "MTBC_BWD_OVERLAP": ("0", "weight gradient and input gradient of a layer run side by side on two streams (measured slower: DESIGN.md)"),

@@ -436,13 +436,19 @@ def _z16_plane_ok(H: int, W: int) -> bool:
 
 class _LowpConv3x3(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, b, lp, z16=False):
+    def forward(ctx, x, w, b, lp, zt=None):
+        """zt: the type the conv output is STORED in (None: fp32, not rounded).  A type other than the operands' (fp16 storage
+        of the bf16 mode) saturates at its largest finite value, like the kernel's epilogue."""
         ctx.save_for_backward(x, w)
         ctx.lp = lp
         ctx.has_b = b is not None
         r = lambda t: t.to(lp).to(t.dtype)
         z = torch.conv2d(r(x), r(w), b, 1, 1)      # not F.conv2d: that name is patched inside lowp_conv3x3
-        return r(z) if z16 else z
+        if zt is None:
+            return z
+        if zt != lp and zt == torch.float16:
+            z = z.clamp(-65504.0, 65504.0)
+        return z.to(zt).to(z.dtype)
 
     @staticmethod
     def backward(ctx, dy):
@@ -524,9 +530,12 @@ class lowp_conv3x3:
     ConvTranspose2d -> 1x1 Conv2d heads stay exact (the product fuses them into one fp32 transposed conv,
     engine.convT_head)."""
 
-    def __init__(self, mode: str, model=None, z16: bool = True, da16: bool = True, fold_partials: bool = False):
+    def __init__(self, mode: str, model=None, z16: bool = True, da16: bool = False, fold_partials: bool = False, z_fp16: bool = True):
         self.lp = {"bf16": torch.bfloat16, "f16": torch.float16}[mode]
-        self.z16, self.da16 = z16, z16 and da16       # (the product's MTBC_NO_Z16 / MTBC_NO_DA16 arms)
+        self.z16, self.da16 = z16, z16 and da16       # (the product's MTBC_NO_Z16 / MTBC_DA16 arms)
+        # the conv outputs are stored as fp16 in BOTH modes (bf16 mode: same bytes, 11 instead of 8 significant bits; the
+        # MTBC_Z_BF16 arm stores bf16)
+        self.zt = torch.float16 if (z_fp16 or self.lp == torch.float16) else self.lp
         # False (the product's default): the other readers' fp32 partial gradient is added, un-rounded, to the rounded sum of the
         # 3x3 consumers (inside the InstanceNorm backward); True (the MTBC_EPI_BSTATS arm): the gathered dgrad's epilogue adds
         # it BEFORE the one rounding
@@ -549,7 +558,7 @@ class lowp_conv3x3:
         orig_p = self._orig_p
         self._orig_in, self._orig_lr, self._orig_ap, self._orig_do = F.instance_norm, F.leaky_relu, F.adaptive_avg_pool2d, F.dropout
         orig_in, orig_lr, orig_ap, orig_do = self._orig_in, self._orig_lr, self._orig_ap, self._orig_do
-        z16, da16, fold = self.z16, self.da16, self.fold
+        z16, da16, fold, zt = self.z16, self.da16, self.fold, self.zt
 
         def detour(t):
             """a conv-cell activation on its way into a non-conv reader"""
@@ -627,7 +636,7 @@ class lowp_conv3x3:
             if (tuple(weight.shape[-2:]) == (3, 3) and padding in (1, (1, 1)) and stride in (1, (1, 1)) and groups == 1
                     and H >= 8 and W >= 8 and W % 4 == 0 and weight.shape[1] % 8 == 0 and weight.shape[0] % 8 == 0):
                 cell = z16 and _z16_plane_ok(H, W)
-                out = _LowpConv3x3.apply(input, weight, bias, lp, cell)
+                out = _LowpConv3x3.apply(input, weight, bias, lp, zt if cell else None)
                 if cell:
                     out._mtbc_z16 = True      # InstanceNorm + LeakyReLU behind it make a conv-cell activation
                 return out

@@ -265,7 +265,8 @@ def test_distributed_step_single_rank_rccl_equals_local_step():
 
 @pytest.mark.parametrize("arch,dtype,size,arm", [("MTUNetPlusPlus", "bf16", 64, ""), ("MTUNetPlusPlus", "f16", 64, ""), ("MTnnUNet", "bf16", 128, ""),
                                                  ("MTUNetPlusPlus", "bf16", 128, ""), ("MTUNetPlusPlus", "bf16", 128, "epi_bstats"),
-                                                 ("MTUNetPlusPlus", "bf16", 64, "no_z16"), ("MTUNetPlusPlus", "bf16", 64, "no_da16")])
+                                                 ("MTUNetPlusPlus", "bf16", 64, "no_z16"), ("MTUNetPlusPlus", "bf16", 64, "da16"),
+                                                 ("MTUNetPlusPlus", "bf16", 64, "z_bf16")])
 def test_16bit_mfma_modes_match_their_emulation(arch, dtype, size, arm, monkeypatch):
     """Optional compute modes: conv3x3 MFMA operands rounded to bf16 / fp16 (fp32 storage + accumulation).  Not the
     reference-parity path (that is fp32); the oracle for it is oracle.lowp_conv3x3, which rounds the same operands
@@ -278,15 +279,19 @@ def test_16bit_mfma_modes_match_their_emulation(arch, dtype, size, arm, monkeypa
     the forward as >= 3e-2.  fp16 runs with the static loss scale 4096 on both sides (unscaled, dz underflows fp16)."""
     import copy
     from multi_task_breast_cancer_amd import engine
-    # A/B arms of the plan (switches.py), each with the emulation told the same thing: where the other readers' partial gradient
-    # meets the rounding (MTBC_EPI_BSTATS), conv outputs kept in fp32 (MTBC_NO_Z16), fp32 fan-in gradients (MTBC_NO_DA16)
-    emu = {"": {}, "epi_bstats": {"fold_partials": True}, "no_z16": {"z16": False}, "no_da16": {"da16": False}}[arm]
+    # A/B arms of the plan (switches.py), each with the emulation told the same thing: the gathered 16-bit activation gradients
+    # (MTBC_DA16), the norm-backward epilogue where the other readers' partial meets the rounding (MTBC_EPI_BSTATS: bf16 z),
+    # conv outputs kept in fp32 (MTBC_NO_Z16) or stored as bf16 instead of fp16 (MTBC_Z_BF16)
+    emu = {"": {}, "da16": {"da16": True}, "epi_bstats": {"da16": True, "fold_partials": True, "z_fp16": False},
+           "no_z16": {"z16": False}, "z_bf16": {"z_fp16": False}}[arm]
     if arm == "epi_bstats":
         monkeypatch.setattr(engine, "_EPI_BSTATS", True)
     elif arm == "no_z16":
         monkeypatch.setattr(engine, "_NO_Z16", True)
-    elif arm == "no_da16":
-        monkeypatch.setattr(engine, "_NO_DA16", True)
+    elif arm == "da16":
+        monkeypatch.setattr(engine, "_DA16", True)
+    elif arm == "z_bf16":
+        monkeypatch.setattr(engine, "_Z_BF16", True)
     N = 4 if size == 64 else 2          # 128x128: level 0 takes the cooperative InstanceNorm forward (planes >= 128x128)
     prod, ref = _oracle_and_product(arch, 1993)
     prod.set_compute(dtype)

@@ -916,3 +916,49 @@ def test_gathered_dgrad_prepares_the_instnorm_backward(N, K, C, H, W, affine, ex
     if affine:
         assert torch.allclose(dga, dgb, rtol=1e-4, atol=1e-3 * max(1.0, dga.abs().max().item()))
         assert torch.allclose(dba, dbb, rtol=1e-4, atol=1e-3 * max(1.0, dba.abs().max().item()))
+
+
+@pytest.mark.parametrize("N,segs,Cout,H,W", [(2, [24], 24, 256, 256), (2, [48], 48, 128, 128), (3, [96], 96, 64, 64), (2, [96, 96], 96, 16, 16), (5, [32], 80, 8, 8)])
+def test_bf16_mode_conv_output_stored_as_fp16(N, segs, Cout, H, W):
+    """out_type = 2 / z_type = 2: in the bf16 mode the conv output z is stored as fp16 (same 2 bytes, 11 significant bits,
+    saturated at +-65504) while the MFMA operands and the activation stay bf16: the stored tensor = the fp32 planar result of the
+    same launch, clamped and rounded once to fp16; its InstanceNorm (statistics from the epilogue, and the channel-group kernels
+    in both directions) = the same kernels fed with that fp16 tensor unpacked to fp32 planes."""
+    g = _g(N * 29 + Cout + H)
+    Cin = sum(segs)
+    xs = [(torch.randn(N, c, H, W, generator=g) + 0.2).to(DEV) for c in segs]
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (9 * Cin)) ** 0.5).to(DEV)
+    b = torch.randn(Cout, generator=g).to(DEV)
+    b[0] = 1.0e5                                          # one channel past the fp16 range: it must saturate, not overflow
+    gamma, beta = (torch.rand(Cout, generator=g) + 0.5).to(DEV), (torch.randn(Cout, generator=g) * 0.1).to(DEV)
+    pf, _ = ops.conv3x3_pack_lp(w, 1)
+    x8 = [ops.C8.pack(x, 1) for x in xs]
+    z32 = ops.conv3x3_fwd_c8(x8, w, b, pf)
+    z8, part = ops.conv3x3_fwd_c8(x8, w, b, pf, out_c8=True, out_fp16=True, stats=True)
+    assert z8.compute == 2
+    want = ops.C8.pack(z32.clamp(-65504.0, 65504.0), 2)
+    assert torch.equal(z8.data, want.data)
+    zr = z8.unpack()
+    assert bool(torch.isfinite(zr).all()) and zr[:, 0].abs().max().item() == 65504.0
+    tot = part.double().sum(1)
+    assert torch.allclose(tot[..., 0].cpu(), zr.double().sum((2, 3)).cpu(), rtol=1e-5, atol=1e-2)
+    # InstanceNorm forward: statistics from the epilogue, bf16 activation
+    y_a, mean_a, rstd_a, _ = ops.instnorm_lrelu_fwd_c8(z8, gamma, beta, slope=0.1, compute=1, stats=part)
+    y_b, mean_b, rstd_b, _ = ops.instnorm_lrelu_fwd_c8(zr, gamma, beta, slope=0.1, compute=1)
+    y_c, mean_c, rstd_c, _ = ops.instnorm_lrelu_fwd_c8(z8, gamma, beta, slope=0.1, compute=1)
+    assert y_a.compute == 1
+    for m_, r_, y_ in ((mean_a, rstd_a, y_a), (mean_c, rstd_c, y_c)):
+        assert torch.allclose(m_[Cout > 1:], mean_b[Cout > 1:], rtol=1e-5, atol=1e-3) and torch.allclose(r_, rstd_b, rtol=3e-5, atol=1e-7)
+        ua, ub = y_.unpack(), y_b.unpack()
+        assert bool(((ua - ub).abs() <= 2.0 ** -7 * ub.abs() + 1e-5).all()), (ua - ub).abs().max().item()
+    # backward: fp16 z, fp32 planar dy (the default plan) and bf16 channel-blocked dy
+    dy = torch.randn(N, Cout, H, W, generator=g).to(DEV)
+    dz_a, _, _ = ops.instnorm_lrelu_bwd_c8(z8, dy, mean_b, rstd_b, gamma, beta, slope=0.1, compute=1)
+    dz_b, _, _ = ops.instnorm_lrelu_bwd_c8(zr, dy, mean_b, rstd_b, gamma, beta, slope=0.1, compute=1)
+    dy8 = ops.C8.pack(dy, 1)
+    dz_c, _, _ = ops.instnorm_lrelu_bwd_c8(z8, dy8, mean_b, rstd_b, gamma, beta, slope=0.1)
+    dz_d, _, _ = ops.instnorm_lrelu_bwd_c8(zr, dy8.unpack(), mean_b, rstd_b, gamma, beta, slope=0.1, compute=1)
+    for a_, b_ in ((dz_a, dz_b), (dz_c, dz_d)):
+        assert a_.compute == 1
+        ua, ub = a_.unpack(), b_.unpack()
+        assert bool(((ua - ub).abs() <= 2.0 ** -7 * ub.abs() + 2e-6 * ub.abs().max()).all()), (ua - ub).abs().max().item()

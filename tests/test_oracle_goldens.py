@@ -199,7 +199,7 @@ def test_16bit_emulation_contexts_are_transparent_without_rounding():
 
     want = run()
     ctx = O.lowp_conv3x3("bf16", model=net)
-    ctx.lp = torch.float64
+    ctx.lp = ctx.zt = torch.float64
     with ctx:
         assert F.conv2d is not ctx._orig and F.conv_transpose2d is not ctx._orig_t
         got = run()
@@ -257,7 +257,7 @@ def test_16bit_emulation_of_pool_and_1x1_head_is_transparent_without_rounding_an
 
     want = run()
     ctx = O.lowp_conv3x3("bf16")
-    ctx.lp = torch.float64
+    ctx.lp = ctx.zt = torch.float64
     with ctx:
         assert F.max_pool2d is not ctx._orig_p
         got = run()
@@ -311,8 +311,8 @@ def test_16bit_emulation_of_stored_conv_outputs_and_gathered_gradients():
 
     want = run()
     dy_exact = seen["dy"]
-    ctx = O.lowp_conv3x3("bf16")
-    ctx.lp = torch.float64
+    ctx = O.lowp_conv3x3("bf16", da16=True)
+    ctx.lp = ctx.zt = torch.float64
     with ctx:
         got = run()
     assert F.instance_norm is ctx._orig_in and F.leaky_relu is ctx._orig_lr and F.dropout is ctx._orig_do and F.adaptive_avg_pool2d is ctx._orig_ap
@@ -322,7 +322,11 @@ def test_16bit_emulation_of_stored_conv_outputs_and_gathered_gradients():
     r = lambda t: t.bfloat16().to(t.dtype)
     with O.lowp_conv3x3("bf16"):
         z = cell[0](x)
-        assert torch.equal(z, r(torch.conv2d(r(x), r(cell[0].weight), cell[0].bias, 1, 1)))       # the stored conv output
+        # the stored conv output: fp16 (11 significant bits in the same 2 bytes), the MTBC_Z_BF16 arm bf16
+        assert torch.equal(z, torch.conv2d(r(x), r(cell[0].weight), cell[0].bias, 1, 1).half().to(z.dtype))
+    with O.lowp_conv3x3("bf16", z_fp16=False):
+        assert torch.equal(cell[0](x), r(torch.conv2d(r(x), r(cell[0].weight), cell[0].bias, 1, 1)))
+    with O.lowp_conv3x3("bf16", da16=True):
         run()
         y = seen["y"]
         # the conv readers' share, recomputed: dgrads on rounded dy and w, summed, rounded once
@@ -334,7 +338,7 @@ def test_16bit_emulation_of_stored_conv_outputs_and_gathered_gradients():
         # default: the other readers' fp32 partial is added un-rounded to the rounded sum of the 3x3 consumers
         assert torch.allclose(seen["dy"], conv_part + yo.grad, rtol=1e-12, atol=1e-12)
         assert not torch.allclose(seen["dy"], r(seen["dy"]), rtol=0, atol=0)                      # the total itself is not rounded
-    with O.lowp_conv3x3("bf16", fold_partials=True):                                              # the MTBC_EPI_BSTATS arm
+    with O.lowp_conv3x3("bf16", da16=True, fold_partials=True):                                   # the MTBC_EPI_BSTATS arm
         run()
         assert torch.equal(seen["dy"], r(yl.grad + yo.grad))                                      # the partial joins the sum BEFORE the one rounding
     with O.lowp_conv3x3("bf16", z16=False):
