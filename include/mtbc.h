@@ -251,6 +251,12 @@ typedef struct {
     const float* stats_partial;
     int32_t stats_slots;
     int32_t z_type;                  /* with z_layout C8: 0 = z has the type of out16_type; 2 = z is fp16 although out16_type is bf16 */
+    /* backward with dz8: the input gradient of a ONE-output 1x1 conv head that reads this activation (MTUNetPlusPlus.py:73-76,
+       final_conv_0_j) is rank 1 -- dy[n,c,p] += dy_rank1_w[c] * dy_rank1[n*H*W + p] -- and is formed here from the head's own
+       gradient (N,1,H,W) and weight (C) instead of being written by mtbc_conv1x1_dgrad and read back; dy may then be NULL
+       (a tensor nothing else reads).  Both NULL or both set.                                                                */
+    const float* dy_rank1;
+    const float* dy_rank1_w;
 } mtbc_instnorm_args;
 size_t mtbc_instnorm_coop_state_bytes(void);
 /* Byte offset, inside a coop_state block, of the 32-bit STICKY error word: non-zero once any cooperative launch on that

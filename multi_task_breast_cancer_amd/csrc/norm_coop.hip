@@ -49,6 +49,7 @@ struct CoP {
     const unsigned short* dy8; long long dy8bs;   // dy as 16-bit channel-blocked (else nullptr: fp32 planes `dy`)
     const float* dyx;                        // with dy8: optional fp32 planar partial gradient (N,C,H,W), added while loading
     int zf16;                                // z8 holds fp16 values (whatever the output type)
+    const float* r1; const float* r1w;       // backward: rank-1 gradient term w[c] * r1[n][pixel] (a one-output 1x1 head), or nullptr
 };
 
 typedef float co_f32x2 __attribute__((ext_vector_type(2)));
@@ -318,7 +319,7 @@ __global__ __launch_bounds__(THREADS, THREADS >= 512 ? 4 : 2) void in_bwd_c8_ker
                     for (int c = 0; c < 8; ++c) gy[c][k] += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(er, off, c * plane_b, 0));
                 }
             }
-        } else {
+        } else if (p.dy) {
             const __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dy + (size_t)n * p.dybs + (size_t)(8 * g) * p.HW), 0, 8 * p.HW * 4, 0x00020000);
 #pragma unroll
             for (int k = 0; k < PPT; ++k) {
@@ -326,6 +327,29 @@ __global__ __launch_bounds__(THREADS, THREADS >= 512 ? 4 : 2) void in_bwd_c8_ker
                 const int off = px < slab ? (member * slab + px) * 4 : 0x7ffffff0;
 #pragma unroll
                 for (int c = 0; c < 8; ++c) gy[c][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(gr, off, c * plane_b, 0));
+            }
+        } else {        // no gradient tensor at all: the rank-1 term below is everything (a tensor that only a 1x1 head reads)
+#pragma unroll
+            for (int k = 0; k < PPT; ++k)
+#pragma unroll
+                for (int c = 0; c < 8; ++c) gy[c][k] = 0.f;
+        }
+        if (p.r1) {
+            // the input gradient of a ONE-output 1x1 conv head reading this activation is rank 1, w[c] * dyhead[n, pixel]: formed
+            // here from the head's 4-byte-per-pixel gradient instead of being written (4 B x C per pixel) by the head's dgrad
+            // and read back -- same products, added in the order the fan-in would have added them last
+            const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.r1 + (size_t)n * p.HW), 0, p.HW * 4, 0x00020000);
+            float hv[PPT];
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) {
+                const int px = tid + THREADS * k;
+                hv[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr, px < slab ? (member * slab + px) * 4 : 0x7ffffff0, 0, 0));
+            }
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const float wc = p.r1w[8 * g + c];
+#pragma unroll
+                for (int k = 0; k < PPT; ++k) gy[c][k] += wc * hv[k];
             }
         }
         float ss[16];
@@ -580,6 +604,8 @@ int fill_coop(const mtbc_instnorm_args* a, CoP* p) {
     p->z8 = nullptr; p->dy8 = nullptr; p->dy8bs = 0; p->dyx = nullptr;
     if (a->z_type != 0 && a->z_type != a->out16_type && !(a->z_type == 2 && a->z_layout == MTBC_LAYOUT_C8)) return MTBC_E_BADARG;
     p->zf16 = (a->out16_type == 2 || a->z_type == 2) ? 1 : 0;
+    p->r1 = a->dy_rank1; p->r1w = a->dy_rank1_w;
+    if ((p->r1 == nullptr) != (p->r1w == nullptr)) return MTBC_E_BADARG;
     if (a->z_layout == MTBC_LAYOUT_C8) {
         if (reinterpret_cast<uintptr_t>(a->z) & 15) return MTBC_E_BADARG;
         p->z8 = reinterpret_cast<const unsigned short*>(a->z); p->z = nullptr;
@@ -695,7 +721,9 @@ int mtbc_i_instnorm_bwd_c8_team(const mtbc_instnorm_args* a) {
 }
 int mtbc_i_instnorm_bwd_c8(const mtbc_instnorm_args* a, float* part, hipStream_t st) {
     CoP p; int rc = fill_coop(a, &p); if (rc) return rc;
-    if ((!p.z && !p.z8) || !p.dy || !p.dz8 || !p.mean || !p.rstd || (reinterpret_cast<uintptr_t>(p.dz8) & 15)) return MTBC_E_BADARG;
+    if ((!p.z && !p.z8) || (!p.dy && !p.r1) || !p.dz8 || !p.mean || !p.rstd || (reinterpret_cast<uintptr_t>(p.dz8) & 15)) return MTBC_E_BADARG;
+    if (!p.dy && a->dy_layout == MTBC_LAYOUT_C8) return MTBC_E_BADARG;
+    if (p.r1 && a->stats_partial) return MTBC_E_UNSUPPORTED;
     if (a->dy_layout == MTBC_LAYOUT_C8) {
         if ((reinterpret_cast<uintptr_t>(a->dy) & 15) || a->dy_batch_stride % 8 || a->n_dy_extra < 0 || a->n_dy_extra > 1) return MTBC_E_BADARG;
         p.dy8 = reinterpret_cast<const unsigned short*>(a->dy); p.dy8bs = a->dy_batch_stride; p.dy = nullptr;

@@ -34,6 +34,7 @@ _DA16 = _sw.flag("MTBC_DA16")
 _NO_EPI_STATS = _sw.flag("MTBC_NO_EPI_STATS")
 _EPI_BSTATS = _sw.flag("MTBC_EPI_BSTATS")
 _Z_BF16 = _sw.flag("MTBC_Z_BF16")
+_NO_R1 = _sw.flag("MTBC_NO_R1")
 _BWD_OVERLAP = _sw.flag("MTBC_BWD_OVERLAP")
 _BWD_OVERLAP_MAX_HW = int(_sw.get("MTBC_BWD_OVERLAP_MAX_HW"))
 
@@ -64,6 +65,8 @@ class Act:
     grad16: Optional[torch.Tensor] = None   # them the gradient as 16-bit planes (mtbc_seg.accumulate = 2) instead of fp32
     dy8_ok: bool = False               # conv-cell output whose InstanceNorm backward can read a channel-blocked 16-bit dy
     grad8: Optional[torch.Tensor] = None    # ... the gradient from ALL its 3x3 consumers (one gathered launch), 16-bit channel-blocked
+    z16: bool = False                  # conv-cell output whose InstanceNorm runs on the channel-group kernels (16-bit z)
+    r1: Optional[tuple] = None         # (dy of a one-output 1x1 head, its weight): rank-1 gradient term formed inside the InstanceNorm backward
     in_op: Optional[object] = None     # the InstanceNorm forward op that writes this activation (conv cells)
     pack_op: Optional[object] = None   # the op that fills `c8` from `data`
 
@@ -398,6 +401,7 @@ class StepPlan:
         # operands (activations, dz, weights) stay bf16.  (the norm-backward epilogue arm reads z as an operand-typed tensor)
         zf16 = z16 and self.compute == 1 and not _Z_BF16 and not _EPI_BSTATS
         y.dy8_ok = z16 and (_DA16 or _EPI_BSTATS) and not _FANIN
+        y.z16 = z16
         if not c8 and not all(a_.planar_valid for a_ in inputs):
             raise NotImplementedError(f"{out_name}: an input exists only in the channel-blocked 16-bit layout")
         for a_ in inputs:
@@ -483,7 +487,7 @@ class StepPlan:
             return t
 
         def emit_bwd() -> None:
-            if not y.grad_written and not y.pending:
+            if not y.grad_written and not y.pending and y.r1 is None:
                 return
             g8 = bool(y.pending) and y.dy8_ok
             if y.pending:
@@ -532,12 +536,15 @@ class StepPlan:
                 self.bwd_ops.append(op)
             else:
                 bslots = 0
-            dy = y.grad8 if g8 else self.grad_of(y)
+            only_r1 = y.r1 is not None and not g8 and not y.grad_written       # nothing but a 1x1 head reads this tensor
+            dy = y.grad8 if g8 else (None if only_r1 else self.grad_of(y))
             # IN+LReLU backward, dz written in place over dy (each element is read before it is written)
             op = base_in()
             op.kind = L.OP_IN_BWD
             a = op.u.inorm
-            a.dy, a.dy_batch_stride, a.dz = dy.data_ptr(), y.bstride, dy.data_ptr()
+            a.dy, a.dy_batch_stride, a.dz = _ptr(dy), y.bstride, _ptr(dy)
+            if y.r1 is not None:
+                a.dy_rank1, a.dy_rank1_w = y.r1[0].data_ptr(), y.r1[1].data_ptr()
             if g8:
                 a.dy_layout, a.dz = L.LAYOUT_C8, None
             a.n_dy_extra = len(y.extra_grads)
@@ -644,7 +651,7 @@ class StepPlan:
                 op.kind = L.OP_CONV3_DGRAD
                 a = op.u.conv3
                 self._segs(a.in_, inputs, grads=True, g16=bool(c8_bwd and wp_d is not None))
-                a.dout = dy.data_ptr()
+                a.dout = _ptr(dy)
                 if c8_bwd and wp_d is not None:
                     a.dout, a.operand_layout = dz8.data_ptr(), L.LAYOUT_C8
                 a.w_packed = _ptr(wp_d)
@@ -887,7 +894,11 @@ class StepPlan:
             a.dw, a.dbias = self.gv(wname).data_ptr(), self.gv(bname).data_ptr()
             self._need_ws(op, "conv1", self.lib.mtbc_conv1x1_wgrad_workspace(C.byref(a)))
             self.bwd_ops.append(op)
-            if x.needs_grad:
+            if x.needs_grad and cout == 1 and x.z16 and not _NO_R1 and not _EPI_BSTATS and x.r1 is None:
+                # dx = w[c] * dy[n, pixel] is rank 1: the InstanceNorm backward of x forms it from dy (4 B per pixel) and w instead of
+                # this head writing C fp32 planes that the fan-in and the norm read back (mtbc_instnorm_args.dy_rank1)
+                x.r1 = (dy, w)
+            elif x.needs_grad:
                 op = base()
                 op.kind = L.OP_CONV1_DGRAD
                 a = op.u.conv1

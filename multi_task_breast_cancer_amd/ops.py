@@ -354,9 +354,10 @@ def instnorm_lrelu_fwd_c8(z, gamma=None, beta=None, eps=1e-5, slope=0.01, comput
 
 
 def instnorm_lrelu_bwd_c8(z, dy, mean, rstd, gamma=None, beta=None, eps=1e-5, slope=0.01, dbias_pre=None, compute: Optional[int] = None,
-                          dy_extra: Optional[torch.Tensor] = None, stats: Optional[torch.Tensor] = None):
+                          dy_extra: Optional[torch.Tensor] = None, stats: Optional[torch.Tensor] = None, rank1=None):
     """z / dy: fp32 planes or C8 tensors (z_layout / dy_layout = C8); dy_extra (with a C8 dy only): an fp32 planar partial
-    gradient added while loading."""
+    gradient added while loading; rank1 = (dyhead (N,1,H,W), w (C)): the rank-1 gradient term of a one-output 1x1 head (dy may
+    then be None)."""
     zt = z.data if isinstance(z, C8) else z
     dyt = dy.data if isinstance(dy, C8) else dy
     if compute is None:         # output (and channel-blocked dy) type: given, else dy's, else z's, else bf16
@@ -371,7 +372,10 @@ def instnorm_lrelu_bwd_c8(z, dy, mean, rstd, gamma=None, beta=None, eps=1e-5, sl
     a = L.InstNormArgs()
     a.N, a.C, a.H, a.W, a.eps, a.slope = N, Cc, H, W, eps, slope
     a.z, a.gamma, a.beta, a.mean, a.rstd = zt.data_ptr(), _p(gamma), _p(beta), mean.data_ptr(), rstd.data_ptr()
-    a.dy, a.dy_batch_stride, a.dgamma, a.dbeta, a.dbias_pre = dyt.data_ptr(), Cc * H * W, _p(dg), _p(db), _p(dbias_pre)
+    a.dy, a.dy_batch_stride, a.dgamma, a.dbeta, a.dbias_pre = (dyt.data_ptr() if dyt is not None else None), Cc * H * W, _p(dg), _p(db), _p(dbias_pre)
+    if rank1 is not None:
+        _chk(*rank1)
+        a.dy_rank1, a.dy_rank1_w = rank1[0].data_ptr(), rank1[1].data_ptr()
     a.z_layout = L.LAYOUT_C8 if isinstance(z, C8) else L.LAYOUT_PLANAR
     if isinstance(z, C8) and z.compute != compute:
         a.z_type = z.compute

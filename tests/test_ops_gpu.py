@@ -962,3 +962,27 @@ def test_bf16_mode_conv_output_stored_as_fp16(N, segs, Cout, H, W):
         assert a_.compute == 1
         ua, ub = a_.unpack(), b_.unpack()
         assert bool(((ua - ub).abs() <= 2.0 ** -7 * ub.abs() + 2e-6 * ub.abs().max()).all()), (ua - ub).abs().max().item()
+
+
+@pytest.mark.parametrize("compute", [1, 2])
+@pytest.mark.parametrize("N,C,H,W,with_dy", [(2, 24, 256, 256, True), (2, 24, 256, 256, False), (3, 48, 64, 64, True), (2, 16, 16, 16, False), (1, 24, 96, 96, True)])
+def test_instnorm_backward_forms_the_rank1_head_gradient(N, C, H, W, with_dy, compute):
+    """mtbc_instnorm_args.dy_rank1 / dy_rank1_w: the input gradient of a one-output 1x1 head, w[c] * dyhead[n, pixel], is formed
+    inside the InstanceNorm backward = the same backward with that tensor written out and added to dy (or standing for a dy
+    nothing else wrote)."""
+    g = _g(N + C + H + 3 * compute)
+    z = ops.C8.pack((torch.randn(N, C, H, W, generator=g) * 2 + 0.5).to(DEV), compute)
+    dy = torch.randn(N, C, H, W, generator=g).to(DEV) if with_dy else None
+    dyh = torch.randn(N, 1, H, W, generator=g).to(DEV)
+    wh = torch.randn(C, generator=g).to(DEV)
+    gamma, beta = (torch.rand(C, generator=g) + 0.5).to(DEV), (torch.randn(C, generator=g) * 0.1).to(DEV)
+    _, mean, rstd, _ = ops.instnorm_lrelu_fwd_c8(z, gamma, beta, slope=0.1)
+    full = wh.view(1, C, 1, 1) * dyh + (dy if with_dy else 0)
+    db1, db2 = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    a_, dga, dba = ops.instnorm_lrelu_bwd_c8(z, full.contiguous(), mean, rstd, gamma, beta, slope=0.1, dbias_pre=db1, compute=compute)
+    b_, dgb, dbb = ops.instnorm_lrelu_bwd_c8(z, dy, mean, rstd, gamma, beta, slope=0.1, dbias_pre=db2, compute=compute, rank1=(dyh, wh))
+    ulp = 2.0 ** -7 if compute == 1 else 2.0 ** -10
+    ua, ub = a_.unpack(), b_.unpack()
+    assert bool(((ua - ub).abs() <= ulp * ua.abs() + 2e-6 * ua.abs().max()).all()), (ua - ub).abs().max().item()
+    assert torch.allclose(dga, dgb, rtol=1e-4, atol=1e-3 * max(1.0, dga.abs().max().item()))
+    assert torch.allclose(dba, dbb, rtol=1e-4, atol=1e-3 * max(1.0, dba.abs().max().item()))
