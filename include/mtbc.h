@@ -257,6 +257,12 @@ typedef struct {
        (a tensor nothing else reads).  Both NULL or both set.                                                                */
     const float* dy_rank1;
     const float* dy_rank1_w;
+    /* ... and, optionally, that head's OWN parameter gradients (what mtbc_conv1x1_wgrad computes from the stored activation):
+       dy_rank1_dw[c] (+)= sum_{n,p} y_stored[n,c,p] * dy_rank1[n,p] with y re-formed from z and rounded to out16_type,
+       dy_rank1_db[0] (+)= sum dy_rank1.  workspace: N*C*(3 + 2T) + N*T floats, T = team size (131 -> 260 per plane covers it). */
+    float* dy_rank1_dw;
+    float* dy_rank1_db;
+    int32_t dy_rank1_accumulate;
 } mtbc_instnorm_args;
 size_t mtbc_instnorm_coop_state_bytes(void);
 /* Byte offset, inside a coop_state block, of the 32-bit STICKY error word: non-zero once any cooperative launch on that

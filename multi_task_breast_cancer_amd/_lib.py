@@ -54,7 +54,8 @@ class InstNormArgs(C.Structure):
                 ("y16", C.c_void_p), ("dz16", C.c_void_p), ("out16_type", C.c_int32),
                 ("y8", C.c_void_p), ("dz8", C.c_void_p), ("coop_state", C.c_void_p), ("coop_reserve_cus", C.c_int32),
                 ("z_layout", C.c_int32), ("dy_layout", C.c_int32), ("stats_partial", C.c_void_p), ("stats_slots", C.c_int32),
-                ("z_type", C.c_int32), ("dy_rank1", C.c_void_p), ("dy_rank1_w", C.c_void_p)]
+                ("z_type", C.c_int32), ("dy_rank1", C.c_void_p), ("dy_rank1_w", C.c_void_p),
+                ("dy_rank1_dw", C.c_void_p), ("dy_rank1_db", C.c_void_p), ("dy_rank1_accumulate", C.c_int32)]
 
 
 class MaxPoolArgs(C.Structure):

@@ -50,6 +50,7 @@ struct CoP {
     const float* dyx;                        // with dy8: optional fp32 planar partial gradient (N,C,H,W), added while loading
     int zf16;                                // z8 holds fp16 values (whatever the output type)
     const float* r1; const float* r1w;       // backward: rank-1 gradient term w[c] * r1[n][pixel] (a one-output 1x1 head), or nullptr
+    float* r1dw; float* r1db;                // ... and the head's own weight / bias gradient partials: [N*C][T], [N][T], or nullptr
 };
 
 typedef float co_f32x2 __attribute__((ext_vector_type(2)));
@@ -334,12 +335,14 @@ __global__ __launch_bounds__(THREADS, THREADS >= 512 ? 4 : 2) void in_bwd_c8_ker
 #pragma unroll
                 for (int c = 0; c < 8; ++c) gy[c][k] = 0.f;
         }
+        float hv[PPT];          // the head's gradient at this thread's pixels (0 without a head, and outside the slab)
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) hv[k] = 0.f;
         if (p.r1) {
             // the input gradient of a ONE-output 1x1 conv head reading this activation is rank 1, w[c] * dyhead[n, pixel]: formed
             // here from the head's 4-byte-per-pixel gradient instead of being written (4 B x C per pixel) by the head's dgrad
             // and read back -- same products, added in the order the fan-in would have added them last
             const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.r1 + (size_t)n * p.HW), 0, p.HW * 4, 0x00020000);
-            float hv[PPT];
 #pragma unroll
             for (int k = 0; k < PPT; ++k) {
                 const int px = tid + THREADS * k;
@@ -352,21 +355,39 @@ __global__ __launch_bounds__(THREADS, THREADS >= 512 ? 4 : 2) void in_bwd_c8_ker
                 for (int k = 0; k < PPT; ++k) gy[c][k] += wc * hv[k];
             }
         }
-        float ss[16];
+        float ss[16], sw[9];
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
             const float mean = p.mean[plane0 + c], rstd = p.rstd[plane0 + c];
             const float ga = p.gamma ? p.gamma[8 * g + c] : 1.f, be = p.beta ? p.beta[8 * g + c] : 0.f;
-            float s1 = 0.f, s2 = 0.f;
+            float s1 = 0.f, s2 = 0.f, s4 = 0.f;
 #pragma unroll
             for (int k = 0; k < PPT; ++k) {
                 const bool ok = tid + THREADS * k < slab;
                 const float x = ok ? (xh[c][k] - mean) * rstd : 0.f;
-                const float y = gy[c][k] * ((x * ga + be) > 0.f ? 1.f : p.slope);
+                const float pre = x * ga + be;
+                const float y = gy[c][k] * (pre > 0.f ? 1.f : p.slope);
                 xh[c][k] = x; gy[c][k] = y;
                 s1 += y; s2 += y * x;
+                if (p.r1dw) {           // the head's weight gradient: sum over pixels of the STORED (rounded) activation times the head's gradient
+                    const float act = pre > 0.f ? pre : pre * p.slope;
+                    const unsigned u = co_pk<F16>(act, 0.f);
+                    float ar;
+                    if constexpr (F16) { const co_f16x2 t2 = __builtin_bit_cast(co_f16x2, u); ar = (float)t2[0]; } else ar = __uint_as_float(u << 16);
+                    s4 += ar * hv[k];
+                }
             }
-            ss[c] = s1; ss[8 + c] = s2;
+            ss[c] = s1; ss[8 + c] = s2; sw[c] = s4;
+        }
+        if (p.r1dw) {
+            float sb = 0.f;
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) sb += hv[k];
+            sw[8] = sb;
+            block_reduce_lds<9, THREADS>(sw, red, tot);
+            if (tid < 8) p.r1dw[(plane0 + tid) * p.T + member] = tot[tid];
+            if (tid == 8 && g == 0) p.r1db[(size_t)n * p.T + member] = tot[8];
+            __syncthreads();
         }
         block_reduce_lds<16, THREADS>(ss, red, tot);
         if constexpr (COOP) team_sum<16, THREADS>(tot, mb, member, p.T, seq, epoch, hdr, xch);
@@ -548,6 +569,20 @@ __global__ __launch_bounds__(AP_THREADS) void in_apply_bwd_c8_kernel(const CoP p
     }
 }
 
+// the one-output 1x1 head's weight / bias gradient from the per-member partials the InstanceNorm backward left: one wave per
+// channel (the last wave: the bias), lanes over (image, member), fixed butterfly
+__global__ void in_r1_finalize_kernel(const float* __restrict__ dwp, const float* __restrict__ dbp, float* __restrict__ dw, float* __restrict__ db,
+                                      int N, int C, int T, int accumulate) {
+    const int c = blockIdx.x, lane = threadIdx.x;
+    float s = 0.f;
+    if (c < C) { for (int i = lane; i < N * T; i += 64) s += dwp[((size_t)(i / T) * C + c) * T + i % T]; }
+    else { for (int i = lane; i < N * T; i += 64) s += dbp[i]; }
+    s = wave_sum(s);
+    if (lane != 0) return;
+    if (c < C) dw[c] = accumulate ? dw[c] + s : s;
+    else if (db) db[0] = accumulate ? db[0] + s : s;
+}
+
 struct CoPlan { bool ok; int ppt, T, grid, nteams; };
 template <typename K> int resident_blocks(K kernel) {
     int per_cu = 0, dev = 0;
@@ -604,7 +639,7 @@ int fill_coop(const mtbc_instnorm_args* a, CoP* p) {
     p->z8 = nullptr; p->dy8 = nullptr; p->dy8bs = 0; p->dyx = nullptr;
     if (a->z_type != 0 && a->z_type != a->out16_type && !(a->z_type == 2 && a->z_layout == MTBC_LAYOUT_C8)) return MTBC_E_BADARG;
     p->zf16 = (a->out16_type == 2 || a->z_type == 2) ? 1 : 0;
-    p->r1 = a->dy_rank1; p->r1w = a->dy_rank1_w;
+    p->r1 = a->dy_rank1; p->r1w = a->dy_rank1_w; p->r1dw = nullptr; p->r1db = nullptr;
     if ((p->r1 == nullptr) != (p->r1w == nullptr)) return MTBC_E_BADARG;
     if (a->z_layout == MTBC_LAYOUT_C8) {
         if (reinterpret_cast<uintptr_t>(a->z) & 15) return MTBC_E_BADARG;
@@ -730,6 +765,16 @@ int mtbc_i_instnorm_bwd_c8(const mtbc_instnorm_args* a, float* part, hipStream_t
         if (a->n_dy_extra == 1) { if (!a->dy_extra[0]) return MTBC_E_BADARG; p.dyx = a->dy_extra[0]; }
     } else if (a->n_dy_extra != 0) return MTBC_E_BADARG;
     p.part = part;
+    const bool head_dw = a->dy_rank1 && a->dy_rank1_dw;
+    const int planes_ = a->N * a->C;
+    int T_ = 1;
+    if (p.HW > SOLO_MAX_HW) { const CoPlan pl0 = plan_team<true>(p.items, p.HW, var_of(a), a->coop_reserve_cus); if (!pl0.ok) return MTBC_E_UNSUPPORTED; T_ = pl0.T; }
+    if (head_dw) {       // partials behind the parameter-gradient regions of the workspace: [3 * planes][planes * T] | [planes * T][N * T]
+        const size_t need = ((size_t)planes_ * (3 + 2 * T_) + (size_t)a->N * T_) * sizeof(float);
+        if (!a->workspace || a->workspace_bytes < need || a->stats_partial) return MTBC_E_WORKSPACE;
+        p.r1dw = reinterpret_cast<float*>(a->workspace) + (size_t)planes_ * (3 + T_);
+        p.r1db = p.r1dw + (size_t)planes_ * T_;
+    }
     if (a->stats_partial) {         // {sum g, sum g * xhat} from the gathered dgrad's epilogue: finalize + one streaming pass
         if (!p.z8 || !p.dy8 || p.dyx || a->stats_slots <= 0 || !a->workspace || a->workspace_bytes < (size_t)a->N * a->C * 5 * sizeof(float)) return MTBC_E_BADARG;
         const int planes = a->N * a->C;
@@ -745,14 +790,19 @@ int mtbc_i_instnorm_bwd_c8(const mtbc_instnorm_args* a, float* part, hipStream_t
     }
     if (p.HW <= SOLO_MAX_HW) {
         p.part3 = part ? part + (size_t)3 * a->N * a->C : nullptr;
-        launch_solo<true>(p, st); MTBC_CHECK_LAUNCH(); return MTBC_OK;
+        launch_solo<true>(p, st); MTBC_CHECK_LAUNCH();
+    } else {
+        if (!p.state) return MTBC_E_BADARG;
+        const CoPlan pl = plan_team<true>(p.items, p.HW, var_of(a), a->coop_reserve_cus);
+        if (!pl.ok) return MTBC_E_UNSUPPORTED;
+        p.part3 = part ? part + (size_t)3 * a->N * a->C : nullptr;
+        launch_team<true>(p, pl, st);
+        MTBC_CHECK_LAUNCH();
     }
-    if (!p.state) return MTBC_E_BADARG;
-    const CoPlan pl = plan_team<true>(p.items, p.HW, var_of(a), a->coop_reserve_cus);
-    if (!pl.ok) return MTBC_E_UNSUPPORTED;
-    p.part3 = part ? part + (size_t)3 * a->N * a->C : nullptr;
-    launch_team<true>(p, pl, st);
-    MTBC_CHECK_LAUNCH();
+    if (head_dw) {
+        hipLaunchKernelGGL(in_r1_finalize_kernel, dim3(a->C + 1), dim3(64), 0, st, p.r1dw, p.r1db, a->dy_rank1_dw, a->dy_rank1_db, a->N, a->C, T_, a->dy_rank1_accumulate);
+        MTBC_CHECK_LAUNCH();
+    }
     return MTBC_OK;
 }
 

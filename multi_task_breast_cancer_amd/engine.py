@@ -545,6 +545,7 @@ class StepPlan:
             a.dy, a.dy_batch_stride, a.dz = _ptr(dy), y.bstride, _ptr(dy)
             if y.r1 is not None:
                 a.dy_rank1, a.dy_rank1_w = y.r1[0].data_ptr(), y.r1[1].data_ptr()
+                a.dy_rank1_dw, a.dy_rank1_db, a.dy_rank1_accumulate = y.r1[2].data_ptr(), y.r1[3].data_ptr(), y.r1[4]
             if g8:
                 a.dy_layout, a.dz = L.LAYOUT_C8, None
             a.n_dy_extra = len(y.extra_grads)
@@ -594,7 +595,12 @@ class StepPlan:
                     a.dbias_pre = self.gv(bname).data_ptr()
                 a.accumulate_dparams = acc
                 self._need_ws(op, "inorm", N * cout * (131 if coop else 3) * 4)
+            if y.r1 is not None:
+                self._need_ws(op, "inorm", N * (cout + 1) * 262 * 4)
             self.bwd_ops.append(op)
+            if y.r1 is not None:            # the head's parameter gradients are written by THIS op
+                for name in y.r1[5]:
+                    self.slots[name].ready_at = len(self.bwd_ops) - 1
             if c8_bwd and not coop:
                 dz8 = dz8_buffer()
                 pk = self._c8_pack_op(dz16 if p16 else dy, dz8, cout, H * W)
@@ -885,6 +891,16 @@ class StepPlan:
             if not y.grad_written:
                 return
             dy = self.grad_of(y)
+            r1 = x.needs_grad and c8 and cout == 1 and x.z16 and not _NO_R1 and not _EPI_BSTATS and x.r1 is None
+            if r1:
+                # dx = w[c] * dy[n, pixel] is rank 1: the InstanceNorm backward of x forms it from dy (4 B per pixel) and w instead of
+                # this head writing C fp32 planes that the fan-in and the norm read back (mtbc_instnorm_args.dy_rank1) -- and since it
+                # re-forms the activation anyway, it also leaves the head's own weight / bias gradient (dy_rank1_dw / _db): no launch
+                # of this head in the backward program at all
+                acc = self._mark_param(wname)
+                self._mark_param(bname)
+                x.r1 = (dy, w, self.gv(wname), self.gv(bname), acc, (wname, bname))
+                return
             op = base()
             op.kind = L.OP_CONV1_WGRAD
             a = op.u.conv1
@@ -894,11 +910,7 @@ class StepPlan:
             a.dw, a.dbias = self.gv(wname).data_ptr(), self.gv(bname).data_ptr()
             self._need_ws(op, "conv1", self.lib.mtbc_conv1x1_wgrad_workspace(C.byref(a)))
             self.bwd_ops.append(op)
-            if x.needs_grad and cout == 1 and x.z16 and not _NO_R1 and not _EPI_BSTATS and x.r1 is None:
-                # dx = w[c] * dy[n, pixel] is rank 1: the InstanceNorm backward of x forms it from dy (4 B per pixel) and w instead of
-                # this head writing C fp32 planes that the fan-in and the norm read back (mtbc_instnorm_args.dy_rank1)
-                x.r1 = (dy, w)
-            elif x.needs_grad:
+            if x.needs_grad:
                 op = base()
                 op.kind = L.OP_CONV1_DGRAD
                 a = op.u.conv1

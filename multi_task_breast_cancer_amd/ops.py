@@ -354,7 +354,7 @@ def instnorm_lrelu_fwd_c8(z, gamma=None, beta=None, eps=1e-5, slope=0.01, comput
 
 
 def instnorm_lrelu_bwd_c8(z, dy, mean, rstd, gamma=None, beta=None, eps=1e-5, slope=0.01, dbias_pre=None, compute: Optional[int] = None,
-                          dy_extra: Optional[torch.Tensor] = None, stats: Optional[torch.Tensor] = None, rank1=None):
+                          dy_extra: Optional[torch.Tensor] = None, stats: Optional[torch.Tensor] = None, rank1=None, rank1_grads: bool = False):
     """z / dy: fp32 planes or C8 tensors (z_layout / dy_layout = C8); dy_extra (with a C8 dy only): an fp32 planar partial
     gradient added while loading; rank1 = (dyhead (N,1,H,W), w (C)): the rank-1 gradient term of a one-output 1x1 head (dy may
     then be None)."""
@@ -368,7 +368,7 @@ def instnorm_lrelu_bwd_c8(z, dy, mean, rstd, gamma=None, beta=None, eps=1e-5, sl
     dz8 = torch.empty(N, Cc // 8, H * W, 8, dtype=torch.int16, device=dev)
     dg = torch.empty(Cc, dtype=torch.float32, device=dev) if gamma is not None else None
     db = torch.empty(Cc, dtype=torch.float32, device=dev) if gamma is not None else None
-    ws = _ws(N * Cc * 131 * 4, dev)
+    ws = _ws(N * (Cc + 1) * 262 * 4, dev)
     a = L.InstNormArgs()
     a.N, a.C, a.H, a.W, a.eps, a.slope = N, Cc, H, W, eps, slope
     a.z, a.gamma, a.beta, a.mean, a.rstd = zt.data_ptr(), _p(gamma), _p(beta), mean.data_ptr(), rstd.data_ptr()
@@ -376,6 +376,10 @@ def instnorm_lrelu_bwd_c8(z, dy, mean, rstd, gamma=None, beta=None, eps=1e-5, sl
     if rank1 is not None:
         _chk(*rank1)
         a.dy_rank1, a.dy_rank1_w = rank1[0].data_ptr(), rank1[1].data_ptr()
+    hdw = hdb = None
+    if rank1_grads:             # the head's own weight / bias gradient from the same pass
+        hdw, hdb = torch.empty(Cc, dtype=torch.float32, device=dev), torch.empty(1, dtype=torch.float32, device=dev)
+        a.dy_rank1_dw, a.dy_rank1_db = hdw.data_ptr(), hdb.data_ptr()
     a.z_layout = L.LAYOUT_C8 if isinstance(z, C8) else L.LAYOUT_PLANAR
     if isinstance(z, C8) and z.compute != compute:
         a.z_type = z.compute
@@ -390,6 +394,8 @@ def instnorm_lrelu_bwd_c8(z, dy, mean, rstd, gamma=None, beta=None, eps=1e-5, sl
     if not L.load().mtbc_instnorm_c8_supported(C.byref(a), 1):
         raise L.MtbcError("instnorm_bwd: shape not supported with a channel-blocked output")
     L.check(L.load().mtbc_instnorm_lrelu_bwd(C.byref(a), _s()), "instnorm_bwd(c8)")
+    if rank1_grads:
+        return C8(dz8, z.shape, compute), dg, db, hdw, hdb
     return C8(dz8, z.shape, compute), dg, db
 
 

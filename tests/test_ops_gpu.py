@@ -980,7 +980,14 @@ def test_instnorm_backward_forms_the_rank1_head_gradient(N, C, H, W, with_dy, co
     full = wh.view(1, C, 1, 1) * dyh + (dy if with_dy else 0)
     db1, db2 = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
     a_, dga, dba = ops.instnorm_lrelu_bwd_c8(z, full.contiguous(), mean, rstd, gamma, beta, slope=0.1, dbias_pre=db1, compute=compute)
-    b_, dgb, dbb = ops.instnorm_lrelu_bwd_c8(z, dy, mean, rstd, gamma, beta, slope=0.1, dbias_pre=db2, compute=compute, rank1=(dyh, wh))
+    b_, dgb, dbb, hdw, hdb = ops.instnorm_lrelu_bwd_c8(z, dy, mean, rstd, gamma, beta, slope=0.1, dbias_pre=db2, compute=compute, rank1=(dyh, wh),
+                                                       rank1_grads=True)
+    # ... and the head's own gradients: the weight gradient contracts the STORED activation (what the head's forward read)
+    y8, _, _, _ = ops.instnorm_lrelu_fwd_c8(z, gamma, beta, slope=0.1, compute=compute)
+    yr = y8.unpack().double()
+    dw_ref = (yr * dyh.double()).sum((0, 2, 3))
+    assert torch.allclose(hdw.double(), dw_ref, rtol=2e-4, atol=2e-4 * max(1.0, dw_ref.abs().max().item())), (hdw.double() - dw_ref).abs().max().item()
+    assert abs(hdb.item() - dyh.double().sum().item()) <= 1e-4 * max(1.0, dyh.abs().sum().item() ** 0.5 * 10)
     ulp = 2.0 ** -7 if compute == 1 else 2.0 ** -10
     ua, ub = a_.unpack(), b_.unpack()
     assert bool(((ua - ub).abs() <= ulp * ua.abs() + 2e-6 * ua.abs().max()).all()), (ua - ub).abs().max().item()
