@@ -263,6 +263,11 @@ typedef struct {
     float* dy_rank1_dw;
     float* dy_rank1_db;
     int32_t dy_rank1_accumulate;
+    /* backward with dz8: the gradient coming back through a MaxPool2d(2,2) that reads this activation (MTnnUNet.py:103, MONAI Down):
+       dy[n,c,y,x] += dy_pool[n,c,y/2,x/2] if the window's maximum sits at (y,x) according to dy_pool_arg (mtbc_maxpool_args.argmax),
+       formed while loading.  dy_pool: fp32 planar (N,C,H/2,W/2).  Both NULL or both set; H and W even.                          */
+    const float* dy_pool;
+    const void* dy_pool_arg;
 } mtbc_instnorm_args;
 size_t mtbc_instnorm_coop_state_bytes(void);
 /* Byte offset, inside a coop_state block, of the 32-bit STICKY error word: non-zero once any cooperative launch on that
@@ -293,6 +298,11 @@ typedef struct {
                                         by mtbc_c8_pack, bit for bit (max commutes with rounding); backward routes on the
                                         stored values; dy / dx stay fp32 planar                                            */
     int32_t type16;
+    void* argmax;                    /* fwd with layout C8, optional: (N, C/8, H/2 * W/2) 16-bit codes, bits [2c+1 : 2c] = which of the four
+                                        window positions (0,0),(0,1),(1,0),(1,1) holds the first maximum of channel 8g + c -- where the
+                                        backward routes the gradient.  With it the backward of the pool can be formed inside the
+                                        InstanceNorm backward of the pooled tensor (mtbc_instnorm_args.dy_pool) instead of writing a
+                                        4x larger, three-quarters-zero fp32 tensor that is read back                                   */
 } mtbc_maxpool_args;
 
 int mtbc_maxpool2_fwd(const mtbc_maxpool_args* a, void* stream);

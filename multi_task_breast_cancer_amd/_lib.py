@@ -55,7 +55,8 @@ class InstNormArgs(C.Structure):
                 ("y8", C.c_void_p), ("dz8", C.c_void_p), ("coop_state", C.c_void_p), ("coop_reserve_cus", C.c_int32),
                 ("z_layout", C.c_int32), ("dy_layout", C.c_int32), ("stats_partial", C.c_void_p), ("stats_slots", C.c_int32),
                 ("z_type", C.c_int32), ("dy_rank1", C.c_void_p), ("dy_rank1_w", C.c_void_p),
-                ("dy_rank1_dw", C.c_void_p), ("dy_rank1_db", C.c_void_p), ("dy_rank1_accumulate", C.c_int32)]
+                ("dy_rank1_dw", C.c_void_p), ("dy_rank1_db", C.c_void_p), ("dy_rank1_accumulate", C.c_int32),
+                ("dy_pool", C.c_void_p), ("dy_pool_arg", C.c_void_p)]
 
 
 class MaxPoolArgs(C.Structure):
@@ -64,7 +65,7 @@ class MaxPoolArgs(C.Structure):
                 ("y", C.c_void_p), ("y_batch_stride", C.c_int64),
                 ("dy", C.c_void_p), ("dy_batch_stride", C.c_int64),
                 ("dx", C.c_void_p), ("dx_batch_stride", C.c_int64),
-                ("accumulate_dx", C.c_int32), ("layout", C.c_int32), ("type16", C.c_int32)]
+                ("accumulate_dx", C.c_int32), ("layout", C.c_int32), ("type16", C.c_int32), ("argmax", C.c_void_p)]
 
 
 class ConvTArgs(C.Structure):

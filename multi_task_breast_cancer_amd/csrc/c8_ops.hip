@@ -38,6 +38,7 @@ struct MpC8P {
     const unsigned short* x; long long xbs;          // batch strides in 16-bit elements
     unsigned short* y; long long ybs;
     const float* dy; long long dybs; float* dx; long long dxbs; int acc;      // backward: fp32 planar gradients
+    unsigned short* arg;                   // forward, optional: per (n, group, output pixel) the 8 two-bit positions of the maxima
 };
 // forward: one lane = one output pixel of one channel group: reads 2 rows x 32 contiguous bytes, writes one piece.
 // max commutes with the (monotonic) rounding, so this IS the fp32 pool followed by the pack.
@@ -61,6 +62,18 @@ __global__ void maxpool_c8_fwd_kernel(const MpC8P p) {
         o[i] = pack2<F16>(fmaxf(fmaxf(va[2 * i], vb[2 * i]), fmaxf(vc[2 * i], vd[2 * i])),
                           fmaxf(fmaxf(va[2 * i + 1], vb[2 * i + 1]), fmaxf(vc[2 * i + 1], vd[2 * i + 1])));
     *reinterpret_cast<u32x4*>(p.y + (size_t)n * p.ybs + ((size_t)g * oH * oW + (size_t)oy * oW + ox) * 8) = o;
+    if (p.arg) {        // where the backward sends a window's gradient: its first maximal element in (0,0),(0,1),(1,0),(1,1) order (ATen)
+        unsigned code = 0;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            float m = va[c]; unsigned arg = 0;
+            if (vb[c] > m || vb[c] != vb[c]) { m = vb[c]; arg = 1; }
+            if (vc[c] > m || vc[c] != vc[c]) { m = vc[c]; arg = 2; }
+            if (vd[c] > m || vd[c] != vd[c]) { m = vd[c]; arg = 3; }
+            code |= arg << (2 * c);
+        }
+        p.arg[((size_t)n * p.G8 + g) * oH * oW + (size_t)oy * oW + ox] = (unsigned short)code;
+    }
 }
 // backward: the gradient of a window goes to its first maximal element in (0,0),(0,1),(1,0),(1,1) order (ATen), judged
 // on the stored (rounded) values -- the tensor the forward pooled.  dy / dx: fp32 planar.
@@ -188,7 +201,7 @@ int mtbc_i_maxpool_c8_fwd(const mtbc_maxpool_args* a, hipStream_t st) {
     if (a->C % 8 || (a->type16 != 1 && a->type16 != 2)) return MTBC_E_BADARG;
     if (!al16p(a->x) || !al16p(a->y) || (a->x_batch_stride & 7) || (a->y_batch_stride & 7)) return MTBC_E_UNSUPPORTED;
     MpC8P p{a->N, a->C / 8, a->H, a->W, reinterpret_cast<const unsigned short*>(a->x), a->x_batch_stride,
-            reinterpret_cast<unsigned short*>(a->y), a->y_batch_stride, nullptr, 0, nullptr, 0, 0};
+            reinterpret_cast<unsigned short*>(a->y), a->y_batch_stride, nullptr, 0, nullptr, 0, 0, reinterpret_cast<unsigned short*>(a->argmax)};
     const size_t total = (size_t)a->N * p.G8 * (a->H / 2) * (a->W / 2);
     if (a->type16 == 2) hipLaunchKernelGGL(maxpool_c8_fwd_kernel<true>, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, st, p);
     else hipLaunchKernelGGL(maxpool_c8_fwd_kernel<false>, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, st, p);
@@ -199,7 +212,7 @@ int mtbc_i_maxpool_c8_bwd(const mtbc_maxpool_args* a, hipStream_t st) {
     if (a->C % 8 || (a->type16 != 1 && a->type16 != 2)) return MTBC_E_BADARG;
     if (!al16p(a->x) || (a->x_batch_stride & 7) || (reinterpret_cast<uintptr_t>(a->dx) & 7) || (a->dx_batch_stride & 1)) return MTBC_E_UNSUPPORTED;
     MpC8P p{a->N, a->C / 8, a->H, a->W, reinterpret_cast<const unsigned short*>(a->x), a->x_batch_stride, nullptr, 0,
-            a->dy, a->dy_batch_stride, a->dx, a->dx_batch_stride, a->accumulate_dx};
+            a->dy, a->dy_batch_stride, a->dx, a->dx_batch_stride, a->accumulate_dx, nullptr};
     const size_t total = (size_t)a->N * p.G8 * (a->H / 2) * (a->W / 2);
     if (a->type16 == 2) hipLaunchKernelGGL(maxpool_c8_bwd_kernel<true>, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, st, p);
     else hipLaunchKernelGGL(maxpool_c8_bwd_kernel<false>, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, st, p);

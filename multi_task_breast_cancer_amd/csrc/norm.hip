@@ -385,8 +385,8 @@ int mtbc_instnorm_lrelu_fwd(const mtbc_instnorm_args* a, void* stream) {
 
 int mtbc_instnorm_lrelu_bwd(const mtbc_instnorm_args* a, void* stream) {
     InP p; int rc = fill(a, &p); if (rc) return rc;
-    if (!p.z || (!p.dy && !(a->dz8 && a->dy_rank1)) || (!p.dz && !p.dz16 && !a->dz8) || !p.mean || !p.rstd) return MTBC_E_BADARG;
-    if (a->dy_rank1 && !a->dz8) return MTBC_E_UNSUPPORTED;      // the rank-1 head term: channel-group kernels only
+    if (!p.z || (!p.dy && !(a->dz8 && (a->dy_rank1 || a->dy_pool))) || (!p.dz && !p.dz16 && !a->dz8) || !p.mean || !p.rstd) return MTBC_E_BADARG;
+    if ((a->dy_rank1 || a->dy_pool) && !a->dz8) return MTBC_E_UNSUPPORTED;      // the rank-1 head / pooled terms: channel-group kernels only
     if (p.nx < 0 || p.nx > 4) return MTBC_E_BADARG;
     for (int k = 0; k < p.nx; ++k) if (!p.dyx[k] || !al16(p.dyx[k])) return MTBC_E_BADARG;
     const bool want = a->dgamma || a->dbeta || a->dbias_pre;

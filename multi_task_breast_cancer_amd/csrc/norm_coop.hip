@@ -51,6 +51,7 @@ struct CoP {
     int zf16;                                // z8 holds fp16 values (whatever the output type)
     const float* r1; const float* r1w;       // backward: rank-1 gradient term w[c] * r1[n][pixel] (a one-output 1x1 head), or nullptr
     float* r1dw; float* r1db;                // ... and the head's own weight / bias gradient partials: [N*C][T], [N][T], or nullptr
+    const float* pg; const unsigned short* pa; int W;      // backward: gradient of a 2 x 2 max-pool of this activation (pooled fp32 planes + argmax codes), or nullptr
 };
 
 typedef float co_f32x2 __attribute__((ext_vector_type(2)));
@@ -355,6 +356,29 @@ __global__ __launch_bounds__(THREADS, THREADS >= 512 ? 4 : 2) void in_bwd_c8_ker
                 for (int k = 0; k < PPT; ++k) gy[c][k] += wc * hv[k];
             }
         }
+        if (p.pg) {
+            // the gradient coming back through a 2 x 2 max-pool of this activation: the pooled gradient goes to the window position the
+            // forward recorded (2 bits per channel); formed here instead of being written as a 4x larger fp32 tensor and read back
+            const int oHW = p.HW >> 2, oW = p.W >> 1;
+            const __amdgpu_buffer_rsrc_t pr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.pg + plane0 * oHW), 0, 8 * oHW * 4, 0x00020000);
+            const unsigned short* pa = p.pa + ((size_t)n * p.G8 + g) * oHW;
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) {
+                const int px = tid + THREADS * k;
+                const bool ok = px < slab;
+                const int q = ok ? member * slab + px : 0;
+                const int yy = q / p.W, xx = q - yy * p.W;
+                const int pq = (yy >> 1) * oW + (xx >> 1);
+                const unsigned pos = ((yy & 1) << 1) | (xx & 1);
+                const unsigned code = ok ? pa[pq] : 0u;
+                const int off = ok ? pq * 4 : 0x7ffffff0;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const float gv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(pr, off, c * oHW * 4, 0));
+                    gy[c][k] += ((code >> (2 * c)) & 3u) == pos ? gv : 0.f;
+                }
+            }
+        }
         float ss[16], sw[9];
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
@@ -641,6 +665,8 @@ int fill_coop(const mtbc_instnorm_args* a, CoP* p) {
     p->zf16 = (a->out16_type == 2 || a->z_type == 2) ? 1 : 0;
     p->r1 = a->dy_rank1; p->r1w = a->dy_rank1_w; p->r1dw = nullptr; p->r1db = nullptr;
     if ((p->r1 == nullptr) != (p->r1w == nullptr)) return MTBC_E_BADARG;
+    p->pg = a->dy_pool; p->pa = reinterpret_cast<const unsigned short*>(a->dy_pool_arg); p->W = a->W;
+    if ((p->pg == nullptr) != (p->pa == nullptr) || (p->pg && ((a->H | a->W) & 1))) return MTBC_E_BADARG;
     if (a->z_layout == MTBC_LAYOUT_C8) {
         if (reinterpret_cast<uintptr_t>(a->z) & 15) return MTBC_E_BADARG;
         p->z8 = reinterpret_cast<const unsigned short*>(a->z); p->z = nullptr;
@@ -756,9 +782,9 @@ int mtbc_i_instnorm_bwd_c8_team(const mtbc_instnorm_args* a) {
 }
 int mtbc_i_instnorm_bwd_c8(const mtbc_instnorm_args* a, float* part, hipStream_t st) {
     CoP p; int rc = fill_coop(a, &p); if (rc) return rc;
-    if ((!p.z && !p.z8) || (!p.dy && !p.r1) || !p.dz8 || !p.mean || !p.rstd || (reinterpret_cast<uintptr_t>(p.dz8) & 15)) return MTBC_E_BADARG;
+    if ((!p.z && !p.z8) || (!p.dy && !p.r1 && !p.pg) || !p.dz8 || !p.mean || !p.rstd || (reinterpret_cast<uintptr_t>(p.dz8) & 15)) return MTBC_E_BADARG;
     if (!p.dy && a->dy_layout == MTBC_LAYOUT_C8) return MTBC_E_BADARG;
-    if (p.r1 && a->stats_partial) return MTBC_E_UNSUPPORTED;
+    if ((p.r1 || p.pg) && a->stats_partial) return MTBC_E_UNSUPPORTED;
     if (a->dy_layout == MTBC_LAYOUT_C8) {
         if ((reinterpret_cast<uintptr_t>(a->dy) & 15) || a->dy_batch_stride % 8 || a->n_dy_extra < 0 || a->n_dy_extra > 1) return MTBC_E_BADARG;
         p.dy8 = reinterpret_cast<const unsigned short*>(a->dy); p.dy8bs = a->dy_batch_stride; p.dy = nullptr;

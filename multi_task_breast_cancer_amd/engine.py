@@ -35,6 +35,7 @@ _NO_EPI_STATS = _sw.flag("MTBC_NO_EPI_STATS")
 _EPI_BSTATS = _sw.flag("MTBC_EPI_BSTATS")
 _Z_BF16 = _sw.flag("MTBC_Z_BF16")
 _NO_R1 = _sw.flag("MTBC_NO_R1")
+_NO_POOLFOLD = _sw.flag("MTBC_NO_POOLFOLD")
 _BWD_OVERLAP = _sw.flag("MTBC_BWD_OVERLAP")
 _BWD_OVERLAP_MAX_HW = int(_sw.get("MTBC_BWD_OVERLAP_MAX_HW"))
 
@@ -67,6 +68,7 @@ class Act:
     grad8: Optional[torch.Tensor] = None    # ... the gradient from ALL its 3x3 consumers (one gathered launch), 16-bit channel-blocked
     z16: bool = False                  # conv-cell output whose InstanceNorm runs on the channel-group kernels (16-bit z)
     r1: Optional[tuple] = None         # (dy of a one-output 1x1 head, its weight): rank-1 gradient term formed inside the InstanceNorm backward
+    pool: Optional[tuple] = None       # (gradient of this tensor's 2 x 2 max-pool, argmax codes): routed inside the InstanceNorm backward
     in_op: Optional[object] = None     # the InstanceNorm forward op that writes this activation (conv cells)
     pack_op: Optional[object] = None   # the op that fills `c8` from `data`
 
@@ -487,7 +489,7 @@ class StepPlan:
             return t
 
         def emit_bwd() -> None:
-            if not y.grad_written and not y.pending and y.r1 is None:
+            if not y.grad_written and not y.pending and y.r1 is None and y.pool is None:
                 return
             g8 = bool(y.pending) and y.dy8_ok
             if y.pending:
@@ -536,13 +538,15 @@ class StepPlan:
                 self.bwd_ops.append(op)
             else:
                 bslots = 0
-            only_r1 = y.r1 is not None and not g8 and not y.grad_written       # nothing but a 1x1 head reads this tensor
+            only_r1 = (y.r1 is not None or y.pool is not None) and not g8 and not y.grad_written       # no gradient TENSOR: only folded terms
             dy = y.grad8 if g8 else (None if only_r1 else self.grad_of(y))
             # IN+LReLU backward, dz written in place over dy (each element is read before it is written)
             op = base_in()
             op.kind = L.OP_IN_BWD
             a = op.u.inorm
             a.dy, a.dy_batch_stride, a.dz = _ptr(dy), y.bstride, _ptr(dy)
+            if y.pool is not None:
+                a.dy_pool, a.dy_pool_arg = y.pool[0].data_ptr(), y.pool[1].data_ptr()
             if y.r1 is not None:
                 a.dy_rank1, a.dy_rank1_w = y.r1[0].data_ptr(), y.r1[1].data_ptr()
                 a.dy_rank1_dw, a.dy_rank1_db, a.dy_rank1_accumulate = y.r1[2].data_ptr(), y.r1[3].data_ptr(), y.r1[4]
@@ -679,10 +683,16 @@ class StepPlan:
         # rounding: bit-identical to the fp32 pool + pack) -- the pooled tensor feeds 3x3 convs only, and x then needs no
         # fp32 planes on the pool's account.  Only when those convs can take the layout (else they need planes of y).
         c8 = self._c8_small_ok(x) and (x.W // 2) % 4 == 0 and x.H // 2 >= 8 and x.W // 2 >= 8 and x.H % 2 == 0 and x.W % 2 == 0
+        fold = False
         if c8:
             y.c8 = self.alloc(self.N, x.C // 8, y.H * y.W, 8, dtype=torch.int16)
             y.planar_valid = False
             x8 = self.c8_of(x)
+            # the pool's backward inside the InstanceNorm backward of x (mtbc_instnorm_args.dy_pool): the forward records where
+            # each window's maximum sits (2 bits per channel), the pooled gradient is routed while the norm backward loads its
+            # slab -- no 4x larger, three-quarters-zero fp32 tensor written, read-modify-written by the fan-in and read back
+            fold = x.z16 and x.needs_grad and not _NO_POOLFOLD and not _EPI_BSTATS and x.pool is None
+        arg = self.alloc(self.N, x.C // 8, y.H * y.W, dtype=torch.int16) if fold else None
 
         def base() -> L.Op:
             op = _mk(0)
@@ -699,10 +709,15 @@ class StepPlan:
 
         op = base()
         op.kind = L.OP_POOL_FWD
+        if fold:
+            op.u.pool.argmax = arg.data_ptr()
         self.fwd_ops.append(op)
 
         def emit_bwd() -> None:
             if not y.grad_written or not x.needs_grad:
+                return
+            if fold:
+                x.pool = (self.grad_of(y), arg)
                 return
             op = base()
             op.kind = L.OP_POOL_BWD

@@ -354,7 +354,8 @@ def instnorm_lrelu_fwd_c8(z, gamma=None, beta=None, eps=1e-5, slope=0.01, comput
 
 
 def instnorm_lrelu_bwd_c8(z, dy, mean, rstd, gamma=None, beta=None, eps=1e-5, slope=0.01, dbias_pre=None, compute: Optional[int] = None,
-                          dy_extra: Optional[torch.Tensor] = None, stats: Optional[torch.Tensor] = None, rank1=None, rank1_grads: bool = False):
+                          dy_extra: Optional[torch.Tensor] = None, stats: Optional[torch.Tensor] = None, rank1=None, rank1_grads: bool = False,
+                          pool=None):
     """z / dy: fp32 planes or C8 tensors (z_layout / dy_layout = C8); dy_extra (with a C8 dy only): an fp32 planar partial
     gradient added while loading; rank1 = (dyhead (N,1,H,W), w (C)): the rank-1 gradient term of a one-output 1x1 head (dy may
     then be None)."""
@@ -376,6 +377,9 @@ def instnorm_lrelu_bwd_c8(z, dy, mean, rstd, gamma=None, beta=None, eps=1e-5, sl
     if rank1 is not None:
         _chk(*rank1)
         a.dy_rank1, a.dy_rank1_w = rank1[0].data_ptr(), rank1[1].data_ptr()
+    if pool is not None:        # (gradient of the 2x2 max-pool of this activation (N,C,H/2,W/2) fp32, argmax codes from maxpool2_fwd_c8)
+        _chk(pool[0])
+        a.dy_pool, a.dy_pool_arg = pool[0].data_ptr(), pool[1].data_ptr()
     hdw = hdb = None
     if rank1_grads:             # the head's own weight / bias gradient from the same pass
         hdw, hdb = torch.empty(Cc, dtype=torch.float32, device=dev), torch.empty(1, dtype=torch.float32, device=dev)
@@ -430,15 +434,20 @@ def maxpool2_bwd(x, dy, dx=None, accumulate=False):
     return dx
 
 
-def maxpool2_fwd_c8(x8: "C8") -> "C8":
-    """2x2 max-pool of a channel-blocked 16-bit tensor into one (mtbc_maxpool_args.layout = MTBC_LAYOUT_C8)."""
+def maxpool2_fwd_c8(x8: "C8", want_argmax: bool = False):
+    """2x2 max-pool of a channel-blocked 16-bit tensor into one (mtbc_maxpool_args.layout = MTBC_LAYOUT_C8); want_argmax: also the
+    (N, C/8, H/2*W/2) int16 codes of where each window's maximum sits (mtbc_maxpool_args.argmax)."""
     N, Cc, H, W = x8.shape
     y = torch.empty(N, Cc // 8, (H // 2) * (W // 2), 8, dtype=torch.int16, device=x8.data.device)
     a = L.MaxPoolArgs()
     a.N, a.C, a.H, a.W, a.layout, a.type16 = N, Cc, H, W, L.LAYOUT_C8, x8.compute
     a.x, a.x_batch_stride, a.y, a.y_batch_stride = x8.data.data_ptr(), Cc * H * W, y.data_ptr(), Cc * H * W // 4
+    arg = torch.empty(N, Cc // 8, (H // 2) * (W // 2), dtype=torch.int16, device=x8.data.device) if want_argmax else None
+    if arg is not None:
+        a.argmax = arg.data_ptr()
     L.check(L.load().mtbc_maxpool2_fwd(C.byref(a), _s()), "maxpool_fwd c8")
-    return C8(y, (N, Cc, H // 2, W // 2), x8.compute)
+    out = C8(y, (N, Cc, H // 2, W // 2), x8.compute)
+    return (out, arg) if want_argmax else out
 
 
 def maxpool2_bwd_c8(x8: "C8", dy, dx=None, accumulate=False):

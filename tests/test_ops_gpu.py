@@ -993,3 +993,29 @@ def test_instnorm_backward_forms_the_rank1_head_gradient(N, C, H, W, with_dy, co
     assert bool(((ua - ub).abs() <= ulp * ua.abs() + 2e-6 * ua.abs().max()).all()), (ua - ub).abs().max().item()
     assert torch.allclose(dga, dgb, rtol=1e-4, atol=1e-3 * max(1.0, dga.abs().max().item()))
     assert torch.allclose(dba, dbb, rtol=1e-4, atol=1e-3 * max(1.0, dba.abs().max().item()))
+
+
+@pytest.mark.parametrize("compute", [1, 2])
+@pytest.mark.parametrize("N,C,H,W,with_dy", [(2, 24, 256, 256, True), (2, 48, 128, 128, False), (3, 96, 64, 64, True), (2, 16, 16, 16, False), (1, 24, 96, 80, True)])
+def test_instnorm_backward_routes_the_maxpool_gradient(N, C, H, W, with_dy, compute):
+    """mtbc_maxpool_args.argmax + mtbc_instnorm_args.dy_pool: the backward of MaxPool2d(2,2) formed inside the InstanceNorm
+    backward of the tensor it pooled = the pool's own backward kernel writing its fp32 tensor, added to dy (or standing for a dy
+    nothing else wrote).  Ties included (equal activations in a window: the FIRST maximum gets the gradient)."""
+    g = _g(N + C + H + 5 * compute)
+    z = ops.C8.pack((torch.randn(N, C, H, W, generator=g) * 2 + 0.5).to(DEV), compute)
+    gamma, beta = (torch.rand(C, generator=g) + 0.5).to(DEV), (torch.randn(C, generator=g) * 0.1).to(DEV)
+    y8, mean, rstd, _ = ops.instnorm_lrelu_fwd_c8(z, gamma, beta, slope=0.1)
+    yp8, arg = ops.maxpool2_fwd_c8(y8, want_argmax=True)
+    assert torch.equal(yp8.data, ops.maxpool2_fwd_c8(y8).data)
+    dyp = torch.randn(N, C, H // 2, W // 2, generator=g).to(DEV)
+    dy = torch.randn(N, C, H, W, generator=g).to(DEV) if with_dy else None
+    routed = ops.maxpool2_bwd_c8(y8, dyp)                                     # the pool's own backward (fp32 planar, 3/4 zeros)
+    assert int((routed != 0).sum()) <= dyp.numel()
+    full = routed + dy if with_dy else routed
+    a_, dga, dba = ops.instnorm_lrelu_bwd_c8(z, full.contiguous(), mean, rstd, gamma, beta, slope=0.1, compute=compute)
+    b_, dgb, dbb = ops.instnorm_lrelu_bwd_c8(z, dy, mean, rstd, gamma, beta, slope=0.1, compute=compute, pool=(dyp, arg))
+    ulp = 2.0 ** -7 if compute == 1 else 2.0 ** -10
+    ua, ub = a_.unpack(), b_.unpack()
+    assert bool(((ua - ub).abs() <= ulp * ua.abs() + 2e-6 * ua.abs().max()).all()), (ua - ub).abs().max().item()
+    assert torch.allclose(dga, dgb, rtol=1e-4, atol=1e-3 * max(1.0, dga.abs().max().item()))
+    assert torch.allclose(dba, dbb, rtol=1e-4, atol=1e-3 * max(1.0, dba.abs().max().item()))
