@@ -187,7 +187,7 @@ def run_mode(args, dtype, dev, rank, world, dist, want_roofline):
     # from the committed summary of the separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same command
     # (tools/profile_round.sh); `traffic_source` names the file, and the field is null when no summary fits the build
     traffic, traffic_source = None, None
-    for tag in ("r02", "r01"):
+    for tag in ("r02b", "r02", "r01"):
         tpath = os.path.join(ROOT, "profiles", f"{tag}_hbm_traffic_{dtype}.json")
         if not os.path.exists(tpath):
             continue

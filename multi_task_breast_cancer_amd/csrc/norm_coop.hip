@@ -330,6 +330,16 @@ __global__ __launch_bounds__(THREADS, THREADS >= 512 ? 4 : 2) void in_bwd_c8_ker
 #pragma unroll
                 for (int c = 0; c < 8; ++c) gy[c][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(gr, off, c * plane_b, 0));
             }
+            if (p.dyx) {        // a second fp32 planar contribution (the gathered dgrad wrote its own buffer instead of read-modify-writing dy)
+                const __amdgpu_buffer_rsrc_t er = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dyx + plane0 * p.HW), 0, 8 * p.HW * 4, 0x00020000);
+#pragma unroll
+                for (int k = 0; k < PPT; ++k) {
+                    const int px = tid + THREADS * k;
+                    const int off = px < slab ? (member * slab + px) * 4 : 0x7ffffff0;
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) gy[c][k] += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(er, off, c * plane_b, 0));
+                }
+            }
         } else {        // no gradient tensor at all: the rank-1 term below is everything (a tensor that only a 1x1 head reads)
 #pragma unroll
             for (int k = 0; k < PPT; ++k)
@@ -707,7 +717,7 @@ Var var_of(const mtbc_instnorm_args* a) { return Var{a->out16_type == 2, a->z_la
 
 template <bool BWD, int THREADS, int PPT, bool COOP>
 void launch_c8(const CoP& p, int grid, hipStream_t st) {
-    const Var v{p.f16 != 0, p.z8 ? (p.zf16 && !p.f16 ? 2 : 1) : 0, p.dy8 ? (p.dyx ? 2 : 1) : 0};
+    const Var v{p.f16 != 0, p.z8 ? (p.zf16 && !p.f16 ? 2 : 1) : 0, p.dy8 ? (p.dyx ? 2 : 1) : 0};      // (planar dy: a second planar contribution is a runtime branch)
     with_kernel<BWD, THREADS, PPT, COOP>(v, [&](auto k) { hipLaunchKernelGGL(decltype(k)::value, dim3(grid), dim3(THREADS), 0, st, p); return 0; });
 }
 // one workgroup per item, sized to the plane
@@ -735,7 +745,7 @@ size_t mtbc_instnorm_coop_state_bytes(void) { return CO_MAILBOX_OFF + (size_t)CO
 
 int mtbc_instnorm_c8_supported(const mtbc_instnorm_args* a, int32_t backward) {
     if (!a || a->N <= 0 || a->C <= 0 || a->H <= 0 || a->W <= 0 || a->C % 8) return 0;
-    if (backward && a->n_dy_extra != 0 && !(a->dy_layout == MTBC_LAYOUT_C8 && a->n_dy_extra == 1)) return 0;
+    if (backward && a->n_dy_extra != 0 && a->n_dy_extra != 1) return 0;
     if (a->H * a->W <= SOLO_MAX_HW) return 1;
     const CoPlan pl = backward ? plan_team<true>(a->N * (a->C / 8), a->H * a->W, var_of(a), a->coop_reserve_cus)
                                : plan_team<false>(a->N * (a->C / 8), a->H * a->W, var_of(a), a->coop_reserve_cus);
@@ -789,6 +799,9 @@ int mtbc_i_instnorm_bwd_c8(const mtbc_instnorm_args* a, float* part, hipStream_t
         if ((reinterpret_cast<uintptr_t>(a->dy) & 15) || a->dy_batch_stride % 8 || a->n_dy_extra < 0 || a->n_dy_extra > 1) return MTBC_E_BADARG;
         p.dy8 = reinterpret_cast<const unsigned short*>(a->dy); p.dy8bs = a->dy_batch_stride; p.dy = nullptr;
         if (a->n_dy_extra == 1) { if (!a->dy_extra[0]) return MTBC_E_BADARG; p.dyx = a->dy_extra[0]; }
+    } else if (a->n_dy_extra == 1 && p.dy) {        // fp32 planar dy + one more fp32 planar contribution (batch stride C*H*W)
+        if (!a->dy_extra[0]) return MTBC_E_BADARG;
+        p.dyx = a->dy_extra[0];
     } else if (a->n_dy_extra != 0) return MTBC_E_BADARG;
     p.part = part;
     const bool head_dw = a->dy_rank1 && a->dy_rank1_dw;

@@ -36,6 +36,7 @@ _EPI_BSTATS = _sw.flag("MTBC_EPI_BSTATS")
 _Z_BF16 = _sw.flag("MTBC_Z_BF16")
 _NO_R1 = _sw.flag("MTBC_NO_R1")
 _NO_POOLFOLD = _sw.flag("MTBC_NO_POOLFOLD")
+_NO_SPLIT_FANIN = _sw.flag("MTBC_NO_SPLIT_FANIN")
 _BWD_OVERLAP = _sw.flag("MTBC_BWD_OVERLAP")
 _BWD_OVERLAP_MAX_HW = int(_sw.get("MTBC_BWD_OVERLAP_MAX_HW"))
 
@@ -492,6 +493,7 @@ class StepPlan:
             if not y.grad_written and not y.pending and y.r1 is None and y.pool is None:
                 return
             g8 = bool(y.pending) and y.dy8_ok
+            split_buf = None
             if y.pending:
                 # Gathered dgrad: the gradient of y with respect to ALL its 3x3 consumers in ONE forward-type launch over
                 # their channel-blocked dz (K = sum of their Cout), instead of one read-modify-write of y's fp32 gradient
@@ -509,6 +511,12 @@ class StepPlan:
                     # partial that the InstanceNorm backward adds while loading
                     y.grad8 = self.alloc(N, cout // 8, H * W, 8, dtype=torch.int16)
                     gbuf, acc = y.grad8, 0
+                elif y.z16 and y.grad_written and not y.extra_grads and not _NO_SPLIT_FANIN and not _FANIN:
+                    # something else (a ConvT backward) already wrote y's gradient: instead of read-modify-writing it (4 + 4 bytes per
+                    # element in a bandwidth-bound launch) the gathered launch writes a buffer of its own and the InstanceNorm backward
+                    # -- latency-bound, its loads are free -- adds the two while loading (n_dy_extra = 1)
+                    gbuf, acc = self.alloc(*y.data.shape), 0
+                    split_buf = gbuf
                 else:
                     gbuf, acc = self.grad_slot(y)
                 op = _mk(L.OP_CONV3_FWD, tag)
@@ -586,6 +594,9 @@ class StepPlan:
                 assert not y.extra_grads
                 a.n_dy_extra = 1
                 a.dy_extra[0] = y.grad.data_ptr()
+            elif split_buf is not None:
+                a.n_dy_extra = 1
+                a.dy_extra[0] = split_buf.data_ptr()
             if gname or bname:
                 acc = None
                 if gname:

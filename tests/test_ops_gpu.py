@@ -1019,3 +1019,17 @@ def test_instnorm_backward_routes_the_maxpool_gradient(N, C, H, W, with_dy, comp
     assert bool(((ua - ub).abs() <= ulp * ua.abs() + 2e-6 * ua.abs().max()).all()), (ua - ub).abs().max().item()
     assert torch.allclose(dga, dgb, rtol=1e-4, atol=1e-3 * max(1.0, dga.abs().max().item()))
     assert torch.allclose(dba, dbb, rtol=1e-4, atol=1e-3 * max(1.0, dba.abs().max().item()))
+
+
+@pytest.mark.parametrize("N,C,H,W", [(2, 48, 128, 128), (3, 96, 64, 64), (2, 16, 16, 16)])
+def test_instnorm_backward_adds_a_second_planar_gradient(N, C, H, W):
+    """fp32 planar dy + n_dy_extra = 1: the gathered dgrad's own output buffer added while loading = the backward of the sum."""
+    g = _g(N + C + H)
+    z = ops.C8.pack((torch.randn(N, C, H, W, generator=g) * 2 + 0.5).to(DEV), 2)
+    dy, ex = torch.randn(N, C, H, W, generator=g).to(DEV), torch.randn(N, C, H, W, generator=g).to(DEV)
+    gamma, beta = (torch.rand(C, generator=g) + 0.5).to(DEV), (torch.randn(C, generator=g) * 0.1).to(DEV)
+    _, mean, rstd, _ = ops.instnorm_lrelu_fwd_c8(z, gamma, beta, slope=0.1, compute=1)
+    a_, _, _ = ops.instnorm_lrelu_bwd_c8(z, (dy + ex).contiguous(), mean, rstd, gamma, beta, slope=0.1, compute=1)
+    b_, _, _ = ops.instnorm_lrelu_bwd_c8(z, dy, mean, rstd, gamma, beta, slope=0.1, compute=1, dy_extra=ex)
+    ua, ub = a_.unpack(), b_.unpack()
+    assert bool(((ua - ub).abs() <= 2.0 ** -7 * ua.abs() + 2e-6 * ua.abs().max()).all()), (ua - ub).abs().max().item()
