@@ -36,7 +36,7 @@ _EPI_BSTATS = _sw.flag("MTBC_EPI_BSTATS")
 _Z_BF16 = _sw.flag("MTBC_Z_BF16")
 _NO_R1 = _sw.flag("MTBC_NO_R1")
 _NO_POOLFOLD = _sw.flag("MTBC_NO_POOLFOLD")
-_NO_SPLIT_FANIN = _sw.flag("MTBC_NO_SPLIT_FANIN")
+_SPLIT_FANIN = _sw.flag("MTBC_SPLIT_FANIN")
 _BWD_OVERLAP = _sw.flag("MTBC_BWD_OVERLAP")
 _BWD_OVERLAP_MAX_HW = int(_sw.get("MTBC_BWD_OVERLAP_MAX_HW"))
 
@@ -511,10 +511,9 @@ class StepPlan:
                     # partial that the InstanceNorm backward adds while loading
                     y.grad8 = self.alloc(N, cout // 8, H * W, 8, dtype=torch.int16)
                     gbuf, acc = y.grad8, 0
-                elif y.z16 and y.grad_written and not y.extra_grads and not _NO_SPLIT_FANIN and not _FANIN:
-                    # something else (a ConvT backward) already wrote y's gradient: instead of read-modify-writing it (4 + 4 bytes per
-                    # element in a bandwidth-bound launch) the gathered launch writes a buffer of its own and the InstanceNorm backward
-                    # -- latency-bound, its loads are free -- adds the two while loading (n_dy_extra = 1)
+                elif y.z16 and y.grad_written and not y.extra_grads and _SPLIT_FANIN and not _FANIN:
+                    # (opt-in, measured +0.05 ms: something else (a ConvT backward) already wrote y's gradient; instead of read-modify-
+                    # writing it the gathered launch writes a buffer of its own and the InstanceNorm backward adds the two while loading)
                     gbuf, acc = self.alloc(*y.data.shape), 0
                     split_buf = gbuf
                 else:
