@@ -2223,6 +2223,138 @@ __global__ void conv3x3_stem_fwd_kernel(const float* __restrict__ x, long long x
     }
 }
 
+// The stem in the 16-bit modes: same arithmetic (fp32 operands -- a 1-channel image has no 16-bit operand tensor -- same fmaf order),
+// but the output goes out as the cell's conv output goes out everywhere else: channel-blocked 16-bit (OF16: fp16, saturated; else
+// bf16), one 16-byte piece = the thread's 8 channels of one pixel, + the InstanceNorm statistics of the stored values:
+// per block {sum, sum of squares} of its 128 x 4 pixels -> stats[n][blockIdx.x][co][2] (slots = gridDim.x).
+template <bool OF16>
+__global__ __launch_bounds__(128) void conv3x3_stem_fwd_c8_kernel(const float* __restrict__ x, long long xbs, const float* __restrict__ w,
+                                                                  const float* __restrict__ bias, unsigned short* __restrict__ out,
+                                                                  float* __restrict__ stats, int N, int H, int W, int Cout) {
+    using TO = LP<OF16>;
+    typedef unsigned st_u32x4 __attribute__((ext_vector_type(4)));
+    __shared__ float red[2][16];
+    const int w4 = W >> 2;
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;           // 4-pixel group inside a plane
+    const int cog = blockIdx.y * 8, n = blockIdx.z;
+    const bool live = q < H * w4;
+    const int y = live ? q / w4 : 0, x0 = live ? (q % w4) * 4 : 0;
+    const float* src = x + (size_t)n * xbs;
+    float v[3][6];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const int yy = y + r - 1;
+        const bool rowok = live && yy >= 0 && yy < H;
+        const float4 mid = rowok ? *reinterpret_cast<const float4*>(src + (size_t)yy * W + x0) : make_float4(0.f, 0.f, 0.f, 0.f);
+        v[r][0] = (rowok && x0 > 0) ? src[(size_t)yy * W + x0 - 1] : 0.f;
+        v[r][1] = mid.x; v[r][2] = mid.y; v[r][3] = mid.z; v[r][4] = mid.w;
+        v[r][5] = (rowok && x0 + 4 < W) ? src[(size_t)yy * W + x0 + 4] : 0.f;
+    }
+    const size_t HW = (size_t)H * W;
+    float o[4][8];                  // [pixel][channel]
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int co = cog + i;                      // Cout % 8 == 0
+        float wk[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) wk[t] = w[co * 9 + t];
+        float a[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a[e] = fmaf(wk[t], v[t / 3][e + t % 3], a[e]);
+        const float b = bias ? bias[co] : 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e][i] = OF16 ? __builtin_amdgcn_fmed3f(a[e] + b, -65504.f, 65504.f) : a[e] + b;
+    }
+    float ss[8], sq[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { ss[i] = 0.f; sq[i] = 0.f; }
+    unsigned short* dst = out + (((size_t)n * (Cout / 8) + blockIdx.y) * HW + (size_t)y * W + x0) * 8;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const st_u32x4 u = __builtin_bit_cast(st_u32x4, TO::pack(o[e]));
+        if (live) *reinterpret_cast<st_u32x4*>(dst + e * 8) = u;
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            const unsigned uu = u[h];
+            const float lo = live ? TO::lo(uu) : 0.f, hi = live ? TO::hi(uu) : 0.f;
+            ss[2 * h] += lo; sq[2 * h] += lo * lo; ss[2 * h + 1] += hi; sq[2 * h + 1] += hi * hi;
+        }
+    }
+    if (stats) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { ss[i] = wave_sum(ss[i]); sq[i] = wave_sum(sq[i]); }
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        if (lane == 0) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { red[wv][2 * i] = ss[i]; red[wv][2 * i + 1] = sq[i]; }
+        }
+        __syncthreads();
+        if (threadIdx.x < 16)
+            stats[(((size_t)n * gridDim.x + blockIdx.x) * Cout + cog) * 2 + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x];
+    }
+}
+
+// The stem's weight gradient with dz 16-bit channel-blocked (what the cell's InstanceNorm backward writes in the 16-bit modes) and the
+// 1-channel input fp32: block = (image, 8-channel group, band of 4-pixel groups); a thread keeps 8 channels x 9 taps of sums over
+// its pixels (one 16-byte piece of dz per pixel), block-reduced at the end.  partial[(n * S + band)][co][9], as the fp32 kernel's.
+template <bool F16>
+__global__ __launch_bounds__(256) void conv3x3_wgrad_stem_c8_kernel(const float* __restrict__ x, long long xbs, const unsigned short* __restrict__ dz8,
+                                                                    float* __restrict__ partial, int N, int H, int W, int Cout, int S) {
+    using T = LP<F16>;
+    typedef unsigned st_u32x4 __attribute__((ext_vector_type(4)));
+    __shared__ float red[32];
+    const int G8 = Cout / 8;
+    int b = blockIdx.x;
+    const int band = b % S; b /= S;
+    const int g = b % G8, n = b / G8;
+    const int HW = H * W, W4 = W >> 2, n4 = HW >> 2;
+    const int q_lo = (int)((long long)n4 * band / S), q_hi = (int)((long long)n4 * (band + 1) / S);
+    const float* src = x + (size_t)n * xbs;
+    const unsigned short* gz = dz8 + ((size_t)n * G8 + g) * (size_t)HW * 8;
+    float acc[8][9];
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc[c][t] = 0.f;
+    for (int q = q_lo + threadIdx.x; q < q_hi; q += blockDim.x) {
+        const int y = q / W4, x4 = (q % W4) * 4;
+        float xv[3][6];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int yy = y + r - 1;
+#pragma unroll
+            for (int e = 0; e < 6; ++e) xv[r][e] = 0.f;
+            if (yy >= 0 && yy < H) {
+                const float* row = src + (size_t)yy * W;
+                const float4 c = *reinterpret_cast<const float4*>(row + x4);
+                xv[r][1] = c.x; xv[r][2] = c.y; xv[r][3] = c.z; xv[r][4] = c.w;
+                xv[r][0] = x4 > 0 ? row[x4 - 1] : 0.f;
+                xv[r][5] = x4 + 4 < W ? row[x4 + 4] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const st_u32x4 u = *reinterpret_cast<const st_u32x4*>(gz + ((size_t)y * W + x4 + e) * 8);
+            float ge[8];
+#pragma unroll
+            for (int h = 0; h < 4; ++h) { const unsigned uu = u[h]; ge[2 * h] = T::lo(uu); ge[2 * h + 1] = T::hi(uu); }
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+#pragma unroll
+                for (int t = 0; t < 9; ++t) acc[c][t] = fmaf(ge[c], xv[t / 3][e + t % 3], acc[c][t]);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const float tsum = block_sum(acc[c][t], red);
+            if (threadIdx.x == 0) partial[(((size_t)n * S + band) * Cout + 8 * g + c) * 9 + t] = tsum;
+        }
+}
+
 // wgrad direct: block = (co, ci, split over n); 9 sums per thread, block-reduced.  partial[split][co][ci][9]
 struct DirWgP {
     int N, H, W, Cin, Cout, nsplit;
@@ -2572,6 +2704,13 @@ bool c8_segs_ok(const mtbc_seg* segs, int nseg) {
 }
 WgPlan plan_wgrad(const mtbc_conv3x3_args* a) {
     WgPlan w{};
+    if (a->operand_layout == MTBC_LAYOUT_C8 && a->Cin == 1) {      // conv3x3_wgrad_stem_c8_kernel: (image, band) splits
+        const int bands = (a->H * a->W >= 16384) ? 4 : 1;
+        w.nsplit = a->N * bands;
+        w.partial_elems = (size_t)w.nsplit * a->Cout * 9;
+        w.dbias_elems = 0;
+        return w;
+    }
     if (a->operand_layout == MTBC_LAYOUT_C8) {      // conv3x3_wgrad_c8_kernel: 32 x 32 channel blocks, 4 x 32 pixel tiles, 4 blocks per CU
         w.mfma = true; w.geo = a->W <= 16 ? 1 : 0; w.cot = 2;
         w.tiles_x = cdiv(a->W, w.geo ? C8WGeo<1>::TW : C8WGeo<0>::TW); w.tiles_y = cdiv(a->H, w.geo ? C8WGeo<1>::TH : C8WGeo<0>::TH);
@@ -2706,6 +2845,22 @@ int mtbc_conv3x3_fwd(const mtbc_conv3x3_args* a, void* stream) {
     rc = make_segtable(&o, 1, a->Cout, &out); if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
     if (a->out_accumulate && a->operand_layout != MTBC_LAYOUT_C8) return MTBC_E_UNSUPPORTED;
+    const bool stem = a->Cin == 1 && a->n_in == 1 && !a->force_direct && a->W % 4 == 0 && a->in[0].batch_stride % 4 == 0 &&
+                      (reinterpret_cast<uintptr_t>(a->in[0].ptr) & 15) == 0 && (reinterpret_cast<uintptr_t>(a->out) & 15) == 0;
+    if (a->out_layout == MTBC_LAYOUT_C8 && a->operand_layout == MTBC_LAYOUT_PLANAR) {
+        // the stem (Cin == 1) of the 16-bit modes: fp32 operands, output channel-blocked 16-bit (+ InstanceNorm statistics)
+        if (!stem || !a->w || a->Cout % 8 || (a->compute != 1 && a->compute != 2) || a->out_accumulate) return MTBC_E_UNSUPPORTED;
+        if (a->out_type != 0 && a->out_type != a->compute && !(a->out_type == 2 && a->compute == 1)) return MTBC_E_BADARG;
+        if (a->stats_partial && (reinterpret_cast<uintptr_t>(a->stats_partial) & 15)) return MTBC_E_BADARG;
+        const dim3 grid(cdiv(a->H * (a->W / 4), 128), a->Cout / 8, a->N);
+        unsigned short* o16 = reinterpret_cast<unsigned short*>(a->out);
+        if (a->compute == 2 || a->out_type == 2)
+            hipLaunchKernelGGL(conv3x3_stem_fwd_c8_kernel<true>, grid, dim3(128), 0, st, a->in[0].ptr, (long long)a->in[0].batch_stride, a->w, a->bias, o16, a->stats_partial, a->N, a->H, a->W, a->Cout);
+        else
+            hipLaunchKernelGGL(conv3x3_stem_fwd_c8_kernel<false>, grid, dim3(128), 0, st, a->in[0].ptr, (long long)a->in[0].batch_stride, a->w, a->bias, o16, a->stats_partial, a->N, a->H, a->W, a->Cout);
+        MTBC_CHECK_LAUNCH();
+        return MTBC_OK;
+    }
     if (a->out_layout != MTBC_LAYOUT_PLANAR && (a->out_layout != MTBC_LAYOUT_C8 || a->operand_layout != MTBC_LAYOUT_C8)) return MTBC_E_UNSUPPORTED;
     if (a->operand_layout == MTBC_LAYOUT_C8) {
         if (!a->w_packed || (a->compute != 1 && a->compute != 2) || !c8_segs_ok(a->in, a->n_in)) return MTBC_E_BADARG;
@@ -2731,8 +2886,7 @@ int mtbc_conv3x3_fwd(const mtbc_conv3x3_args* a, void* stream) {
     if (a->w_packed && !a->force_direct && mfma_ok(a->in, a->n_in, a->H, a->W))
         return run_igemm(a->N, a->H, a->W, a->Cin, a->Cout, in, out, a->w_packed, a->bias, a->compute, st);
     if (!a->w) return MTBC_E_BADARG;
-    if (a->Cin == 1 && a->n_in == 1 && !a->force_direct && a->W % 4 == 0 && a->in[0].batch_stride % 4 == 0 &&
-        (reinterpret_cast<uintptr_t>(a->in[0].ptr) & 15) == 0 && (reinterpret_cast<uintptr_t>(a->out) & 15) == 0) {
+    if (stem) {
         hipLaunchKernelGGL(conv3x3_stem_fwd_kernel, dim3(cdiv(a->H * (a->W / 4), 128), cdiv(a->Cout, 8), a->N), dim3(128), 0, st,
                            a->in[0].ptr, (long long)a->in[0].batch_stride, a->w, a->bias, a->out, a->N, a->H, a->W, a->Cout);
         MTBC_CHECK_LAUNCH();
@@ -2779,7 +2933,10 @@ int mtbc_conv3x3_dgrad(const mtbc_conv3x3_args* a, void* stream) {
 }
 
 int32_t mtbc_conv3x3_stats_slots(const mtbc_conv3x3_args* a) {
-    if (check_conv(a) || a->operand_layout != MTBC_LAYOUT_C8 || a->out_layout != MTBC_LAYOUT_C8 || (a->compute != 1 && a->compute != 2)) return 0;
+    if (check_conv(a) || a->out_layout != MTBC_LAYOUT_C8 || (a->compute != 1 && a->compute != 2)) return 0;
+    if (a->operand_layout == MTBC_LAYOUT_PLANAR)          // the stem: one subset per 512-pixel block
+        return (a->Cin == 1 && a->n_in == 1 && a->W % 4 == 0 && a->Cout % 8 == 0) ? cdiv(a->H * (a->W / 4), 128) : 0;
+    if (a->operand_layout != MTBC_LAYOUT_C8) return 0;
     if (a->W % 4 || a->W < 8 || a->H < 8 || a->Cout % 8) return 0;
     const IgemmPlan q = plan_igemm(a->N, a->H, a->W, a->Cout, a->compute, true, a->norm_z == nullptr, a->Cin);
     return q.geo == 2 ? 1 : q.tiles_x * q.tiles_y * (q.nw8 ? 8 : 4);
@@ -2801,6 +2958,18 @@ int mtbc_conv3x3_wgrad(const mtbc_conv3x3_args* a, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     float* partial = reinterpret_cast<float*>(a->workspace);
     const size_t wel = (size_t)a->Cout * a->Cin * 9;
+    if (a->operand_layout == MTBC_LAYOUT_C8 && a->Cin == 1) {
+        // the stem: dz channel-blocked 16-bit, the 1-channel input fp32 planar (it has no channel-blocked form)
+        if ((a->compute != 1 && a->compute != 2) || a->n_in != 1 || a->Cout % 8 || a->W % 4 || a->dbias || a->in[0].batch_stride % 4 ||
+            ((reinterpret_cast<uintptr_t>(a->in[0].ptr) | reinterpret_cast<uintptr_t>(a->dout)) & 15)) return MTBC_E_UNSUPPORTED;
+        const int S = w.nsplit / a->N;
+        const dim3 grid(a->N * (a->Cout / 8) * S);
+        const unsigned short* dz8 = reinterpret_cast<const unsigned short*>(a->dout);
+        if (a->compute == 2) hipLaunchKernelGGL(conv3x3_wgrad_stem_c8_kernel<true>, grid, dim3(256), 0, st, a->in[0].ptr, (long long)a->in[0].batch_stride, dz8, partial, a->N, a->H, a->W, a->Cout, S);
+        else hipLaunchKernelGGL(conv3x3_wgrad_stem_c8_kernel<false>, grid, dim3(256), 0, st, a->in[0].ptr, (long long)a->in[0].batch_stride, dz8, partial, a->N, a->H, a->W, a->Cout, S);
+        MTBC_CHECK_LAUNCH();
+        return mtbc_i_splitk_reduce(partial, a->dw, w.nsplit, wel, a->accumulate_dw, st);
+    }
     if (a->operand_layout == MTBC_LAYOUT_C8) {
         mtbc_seg g{const_cast<float*>(a->dout), (int64_t)a->Cout * a->H * a->W, a->Cout, 0};
         if ((a->compute != 1 && a->compute != 2) || !c8_segs_ok(a->in, a->n_in) || !c8_segs_ok(&g, 1)) return MTBC_E_BADARG;

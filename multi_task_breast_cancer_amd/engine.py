@@ -36,6 +36,7 @@ _EPI_BSTATS = _sw.flag("MTBC_EPI_BSTATS")
 _Z_BF16 = _sw.flag("MTBC_Z_BF16")
 _NO_R1 = _sw.flag("MTBC_NO_R1")
 _NO_POOLFOLD = _sw.flag("MTBC_NO_POOLFOLD")
+_NO_STEM16 = _sw.flag("MTBC_NO_STEM16")
 _SPLIT_FANIN = _sw.flag("MTBC_SPLIT_FANIN")
 _BWD_OVERLAP = _sw.flag("MTBC_BWD_OVERLAP")
 _BWD_OVERLAP_MAX_HW = int(_sw.get("MTBC_BWD_OVERLAP_MAX_HW"))
@@ -393,8 +394,12 @@ class StepPlan:
         # convolution and its normalisation): written by the igemm's epilogue (fp32 accumulate + bias, one RNE), read by the
         # InstanceNorm forward and backward as 16-byte pieces -- 2 + 2 + 2 instead of 4 + 4 + 4 bytes per element.  Needs the
         # channel-group InstanceNorm kernels in both directions (norm_coop.hip).
+        # the stem (Cin = 1: fp32 operands, no MFMA) takes part: its forward writes z in the same layout and leaves the same statistics,
+        # its weight gradient reads the channel-blocked dz
+        stem16 = bool(self.compute) and cin == 1 and len(inputs) == 1 and cout % 8 == 0 and not self.force_direct and W % 4 == 0 \
+            and H >= 8 and W >= 8 and not _NO_C8 and not _NO_STEM16 and inputs[0].planar_valid and not inputs[0].needs_grad
         z16 = False
-        if c8_bwd and not _NO_Z16 and not _NO_COOP:      # (the one-plane InstanceNorm kernels read fp32 planes)
+        if (c8_bwd or stem16) and not _NO_Z16 and not _NO_COOP:      # (the one-plane InstanceNorm kernels read fp32 planes)
             q = L.InstNormArgs()
             q.N, q.C, q.H, q.W, q.out16_type, q.z_layout, q.coop_reserve_cus = N, cout, H, W, self.compute, L.LAYOUT_C8, self.coop_reserve_cus
             z16 = bool(self.lib.mtbc_instnorm_c8_supported(C.byref(q), 0)) and bool(self.lib.mtbc_instnorm_c8_supported(C.byref(q), 1))
@@ -403,7 +408,8 @@ class StepPlan:
         # same 2 bytes (bf16: 8) -- measured on the held-out Dice of 3000-step runs (profiles/r02b_quality_sweep.md); the MFMA
         # operands (activations, dz, weights) stay bf16.  (the norm-backward epilogue arm reads z as an operand-typed tensor)
         zf16 = z16 and self.compute == 1 and not _Z_BF16 and not _EPI_BSTATS
-        y.dy8_ok = z16 and (_DA16 or _EPI_BSTATS) and not _FANIN
+        stem16 = stem16 and z16
+        y.dy8_ok = z16 and (_DA16 or _EPI_BSTATS) and not _FANIN and not stem16
         y.z16 = z16
         if not c8 and not all(a_.planar_valid for a_ in inputs):
             raise NotImplementedError(f"{out_name}: an input exists only in the channel-blocked 16-bit layout")
@@ -429,6 +435,8 @@ class StepPlan:
         op.u.conv3.bias = _ptr(self.pv(bname)) if bname else None
         op.u.conv3.out = z.data_ptr()
         stats_slots = 0
+        if stem16:
+            op.u.conv3.compute = self.compute
         if z16:
             op.u.conv3.out_layout = L.LAYOUT_C8
             if zf16:
@@ -634,6 +642,9 @@ class StepPlan:
             if c8_bwd:
                 segs_c8(a.in_)
                 a.dout, a.operand_layout = dz8.data_ptr(), L.LAYOUT_C8
+            elif stem16:          # fp32 planar 1-channel input, channel-blocked dz
+                self._segs(a.in_, inputs)
+                a.dout, a.operand_layout, a.compute = dz8.data_ptr(), L.LAYOUT_C8, self.compute
             else:
                 self._segs(a.in_, inputs)
                 a.dout = dy.data_ptr()

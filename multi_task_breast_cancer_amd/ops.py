@@ -115,6 +115,29 @@ def conv3x3_fwd(xs: Sequence[torch.Tensor], w: torch.Tensor, bias: Optional[torc
     return out
 
 
+def conv3x3_stem_fwd_c8(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], compute: int, out_fp16: bool = False, stats: bool = False):
+    """The 1-channel stem conv of the 16-bit modes: fp32 operands, the output channel-blocked 16-bit (out_layout = C8 with
+    operand_layout = planar) + optional InstanceNorm statistics partials."""
+    _chk(x, w, bias)
+    N, _, H, W = x.shape
+    a = _conv_args([x], w, N, H, W)
+    _fill_segs(a.in_, [x])
+    out = torch.empty(N, w.shape[0] // 8, H * W, 8, dtype=torch.int16, device=w.device)
+    a.bias, a.out, a.compute, a.out_layout = _p(bias), out.data_ptr(), compute, L.LAYOUT_C8
+    if out_fp16:
+        a.out_type = 2
+    part = None
+    if stats:
+        slots = L.load().mtbc_conv3x3_stats_slots(C.byref(a))
+        if slots <= 0:
+            raise L.MtbcError("conv3x3_fwd: no epilogue statistics for this launch")
+        part = torch.full((N, slots, w.shape[0], 2), float("nan"), dtype=torch.float32, device=w.device)
+        a.stats_partial = part.data_ptr()
+    L.check(L.load().mtbc_conv3x3_fwd(C.byref(a), _s()), "conv3x3_fwd(stem c8)")
+    z = C8(out, (N, w.shape[0], H, W), 2 if out_fp16 else compute)
+    return (z, part) if stats else z
+
+
 def conv3x3_dgrad(dz: torch.Tensor, w: torch.Tensor, dxs: Sequence[torch.Tensor], accumulate: Sequence[int] = (),
                   packed: Optional[torch.Tensor] = None, force_direct: bool = False, compute: int = 0) -> None:
     _chk(dz, w, *dxs)
@@ -255,7 +278,10 @@ def conv3x3_wgrad_c8(xs: Sequence["C8"], dz: "C8", w_shape, want_bias: bool = Fa
     db = torch.empty(w_shape[0], dtype=torch.float32, device=dev) if want_bias else None
     a = L.Conv3x3Args()
     a.N, a.H, a.W, a.Cin, a.Cout, a.n_in = N, H, W, w_shape[1], w_shape[0], len(xs)
-    _fill_segs_c8(a.in_, xs)
+    if w_shape[1] == 1 and isinstance(xs[0], torch.Tensor):      # the stem: fp32 planar 1-channel input, channel-blocked dz
+        _fill_segs(a.in_, xs)
+    else:
+        _fill_segs_c8(a.in_, xs)
     a.dout, a.dw, a.dbias, a.accumulate_dw = dz.data.data_ptr(), dw.data_ptr(), _p(db), int(accumulate)
     a.compute, a.operand_layout = dz.compute, L.LAYOUT_C8
     nb = L.load().mtbc_conv3x3_wgrad_workspace(C.byref(a))

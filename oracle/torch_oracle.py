@@ -461,6 +461,18 @@ class _LowpConv3x3(torch.autograd.Function):
         return dx, dw, db, None, None
 
 
+class _StoreRounded(torch.autograd.Function):
+    """A tensor stored in a 16-bit type: rounded in forward, straight-through in backward."""
+
+    @staticmethod
+    def forward(ctx, z, zt):
+        return z.to(zt).to(z.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, None
+
+
 class _Detour(torch.autograd.Function):
     """Identity whose backward parks the gradient in `stash` and sends zeros upstream: how a NON-conv reader of a conv-cell
     activation (pool, ConvT, 1x1 head, average pool) keeps its contribution out of the 16-bit sum of the conv readers."""
@@ -530,7 +542,8 @@ class lowp_conv3x3:
     ConvTranspose2d -> 1x1 Conv2d heads stay exact (the product fuses them into one fp32 transposed conv,
     engine.convT_head)."""
 
-    def __init__(self, mode: str, model=None, z16: bool = True, da16: bool = False, fold_partials: bool = False, z_fp16: bool = True):
+    def __init__(self, mode: str, model=None, z16: bool = True, da16: bool = False, fold_partials: bool = False, z_fp16: bool = True,
+                 stem16: bool = True):
         self.lp = {"bf16": torch.bfloat16, "f16": torch.float16}[mode]
         self.z16, self.da16 = z16, z16 and da16       # (the product's MTBC_NO_Z16 / MTBC_DA16 arms)
         # the conv outputs are stored as fp16 in BOTH modes (bf16 mode: same bytes, 11 instead of 8 significant bits; the
@@ -540,6 +553,7 @@ class lowp_conv3x3:
         # 3x3 consumers (inside the InstanceNorm backward); True (the MTBC_EPI_BSTATS arm): the gathered dgrad's epilogue adds
         # it BEFORE the one rounding
         self.fold = fold_partials
+        self.stem16 = stem16       # the 1-channel stem stores its conv output in 16 bits too (MTBC_NO_STEM16 arm: False)
         self.exempt = set()
         models = [] if model is None else (list(model) if isinstance(model, (list, tuple)) else [model])
         for mod in models:
@@ -558,7 +572,7 @@ class lowp_conv3x3:
         orig_p = self._orig_p
         self._orig_in, self._orig_lr, self._orig_ap, self._orig_do = F.instance_norm, F.leaky_relu, F.adaptive_avg_pool2d, F.dropout
         orig_in, orig_lr, orig_ap, orig_do = self._orig_in, self._orig_lr, self._orig_ap, self._orig_do
-        z16, da16, fold, zt = self.z16, self.da16, self.fold, self.zt
+        z16, da16, fold, zt, stem16 = self.z16, self.da16, self.fold, self.zt, self.stem16
 
         def detour(t):
             """a conv-cell activation on its way into a non-conv reader"""
@@ -639,6 +653,15 @@ class lowp_conv3x3:
                 out = _LowpConv3x3.apply(input, weight, bias, lp, zt if cell else None)
                 if cell:
                     out._mtbc_z16 = True      # InstanceNorm + LeakyReLU behind it make a conv-cell activation
+                return out
+            if (tuple(weight.shape[-2:]) == (3, 3) and padding in (1, (1, 1)) and stride in (1, (1, 1)) and groups == 1 and z16 and stem16
+                    and weight.shape[1] == 1 and weight.shape[0] % 8 == 0 and H >= 8 and W >= 8 and W % 4 == 0 and _z16_plane_ok(H, W)):
+                # the stem: exact fp32 operands (a 1-channel image has no 16-bit operand tensor), the output stored like every other
+                z = orig(input, weight, bias, stride, padding, dilation, groups)
+                if zt == torch.float16 and lp != torch.float16:
+                    z = z.clamp(-65504.0, 65504.0)
+                out = _StoreRounded.apply(z, zt)
+                out._mtbc_z16 = True
                 return out
             if tuple(weight.shape[-2:]) == (1, 1):
                 input = detour(input)

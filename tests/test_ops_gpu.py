@@ -1033,3 +1033,30 @@ def test_instnorm_backward_adds_a_second_planar_gradient(N, C, H, W):
     b_, _, _ = ops.instnorm_lrelu_bwd_c8(z, dy, mean, rstd, gamma, beta, slope=0.1, compute=1, dy_extra=ex)
     ua, ub = a_.unpack(), b_.unpack()
     assert bool(((ua - ub).abs() <= 2.0 ** -7 * ua.abs() + 2e-6 * ua.abs().max()).all()), (ua - ub).abs().max().item()
+
+
+@pytest.mark.parametrize("compute,out_fp16", [(1, True), (1, False), (2, False)])
+@pytest.mark.parametrize("N,Cout,H,W", [(2, 24, 256, 256), (3, 32, 40, 24), (1, 8, 8, 12), (2, 24, 96, 96)])
+def test_stem_conv_on_the_16bit_path(N, Cout, H, W, compute, out_fp16):
+    """The 1-channel stem in the 16-bit modes: fp32 operands and the stem kernel's fmaf order, output channel-blocked 16-bit
+    (= the fp32 stem output, clamped for fp16 storage, rounded once) + InstanceNorm statistics of the stored values; its weight
+    gradient from a channel-blocked dz = the fp32 weight-gradient kernel on the unpacked dz."""
+    g = _g(N + Cout + H + compute)
+    x = (torch.rand(N, 1, H, W, generator=g) * 255.0).to(DEV)
+    w = (torch.randn(Cout, 1, 3, 3, generator=g) * 0.05).to(DEV)
+    b = torch.randn(Cout, generator=g).to(DEV)
+    z32 = ops.conv3x3_fwd([x], w, b)
+    z8, part = ops.conv3x3_stem_fwd_c8(x, w, b, compute, out_fp16=out_fp16, stats=True)
+    t = 2 if out_fp16 else compute
+    want = ops.C8.pack(z32.clamp(-65504.0, 65504.0) if t == 2 else z32, t)
+    assert z8.compute == t and torch.equal(z8.data, want.data)
+    assert not torch.isnan(part).any()
+    zr = z8.unpack().double()
+    tot = part.double().sum(1)
+    assert torch.allclose(tot[..., 0].cpu(), zr.sum((2, 3)).cpu(), rtol=1e-5, atol=1e-2)
+    assert torch.allclose(tot[..., 1].cpu(), (zr * zr).sum((2, 3)).cpu(), rtol=1e-5, atol=1e-1)
+    dz = torch.randn(N, Cout, H, W, generator=g).to(DEV)
+    dz8 = ops.C8.pack(dz, compute)
+    dw_ref, _ = ops.conv3x3_wgrad([x], dz8.unpack(), tuple(w.shape))
+    dw, _ = ops.conv3x3_wgrad_c8([x], dz8, tuple(w.shape))
+    assert torch.allclose(dw, dw_ref, rtol=1e-4, atol=1e-4 * max(1.0, dw_ref.abs().max().item())), (dw - dw_ref).abs().max().item()
