@@ -482,7 +482,7 @@ __global__ void in_stats_finalize_kernel(const float* __restrict__ part, int slo
         mean[plane] = (float)m; rstd[plane] = (float)(1.0 / sqrt(var + (double)eps));
     }
 }
-constexpr int AP_THREADS = 256, AP_PPT = 4;
+constexpr int AP_THREADS = 256, AP_PPT = 2;
 // FIN: the workgroup first adds up the conv epilogue's partials of its 8 channels itself (few pixel subsets: planes up to 64 x 64)
 // -- no separate finalize launch; thread t sums subsets t/8, t/8 + 32, ... of channel t % 8 in double, the 32 partial sums are
 // added in a fixed order, and the workgroup of the plane group's first pixels writes mean / rstd for the backward pass.
