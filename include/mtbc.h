@@ -268,6 +268,10 @@ typedef struct {
        formed while loading.  dy_pool: fp32 planar (N,C,H/2,W/2).  Both NULL or both set; H and W even.                          */
     const float* dy_pool;
     const void* dy_pool_arg;
+    int32_t defer_dparams;           /* backward with dz8 and any of dgamma / dbeta / dbias_pre: 1 = stop after the norm kernel: the
+                                        per-plane partial sums stay in `workspace` (a buffer of the caller's that lives until
+                                        mtbc_instnorm_dparam_many has reduced it) and dgamma / dbeta / dbias_pre are not touched --
+                                        one launch for the parameter gradients of many cells instead of one 5 us launch each      */
 } mtbc_instnorm_args;
 size_t mtbc_instnorm_coop_state_bytes(void);
 /* Byte offset, inside a coop_state block, of the 32-bit STICKY error word: non-zero once any cooperative launch on that
@@ -275,6 +279,19 @@ size_t mtbc_instnorm_coop_state_bytes(void);
  * it is then garbage: callers read the word when they read their losses and stop (trainer.FusedTrainStep.check_nan).   */
 size_t mtbc_instnorm_coop_error_offset(void);
 int mtbc_instnorm_c8_supported(const mtbc_instnorm_args* a, int32_t backward);
+/* team size of the channel-group backward these arguments select (1 for planes <= 64 x 64; 0: not supported) */
+int32_t mtbc_instnorm_bwd_team(const mtbc_instnorm_args* a);
+/* dgamma[c] (+)= sum_n part[n,c,1] ; dbeta[c] (+)= sum_n part[n,c,0] ; dbias_pre[c] (+)= sum_n (part[n,c,2] + sum_m part3[n,c,m]) for
+ * every descriptor in ONE launch, from the partials a deferred backward left: part = workspace, part3 = workspace + 3*N*C (T floats per
+ * plane).  Same summation order as the reduction inside mtbc_instnorm_lrelu_bwd.                                                   */
+typedef struct mtbc_dparam_desc {
+    const float* part;
+    float* dgamma;                   /* (C) or NULL */
+    float* dbeta;                    /* (C) or NULL */
+    float* dbias_pre;                /* (C) or NULL */
+    int32_t N, C, T, accumulate;
+} mtbc_dparam_desc;
+int mtbc_instnorm_dparam_many(const mtbc_dparam_desc* descs, int32_t n, void* stream);
 
 /* workspace bytes the forward can use for planes > 64K elements (chunked statistics: 2 reads + 1 write instead of the
  * streaming kernel's 3 + 1); 0 for smaller planes.  Passing no workspace is valid (streaming kernel). */
@@ -475,7 +492,8 @@ enum {
     MTBC_OP_DICE_FWD, MTBC_OP_DICE_BWD, MTBC_OP_FOCAL, MTBC_OP_LOSS_MIX, MTBC_OP_ADAM,
     MTBC_OP_MEMSET, MTBC_OP_DICE_COUNTS, MTBC_OP_CONV3_PACK_LP, MTBC_OP_HEAD_COMBINE, MTBC_OP_HEAD_EXPAND,
     MTBC_OP_C8_PACK, MTBC_OP_C8_PACK16, MTBC_OP_CONV3_WVIEW,
-    MTBC_OP_SET_STREAM, MTBC_OP_EVENT_RECORD, MTBC_OP_EVENT_WAIT
+    MTBC_OP_SET_STREAM, MTBC_OP_EVENT_RECORD, MTBC_OP_EVENT_WAIT,
+    MTBC_OP_IN_DPARAM
 };
 /* (the last three: stream control of mtbc_program_run_ms -- independent ops of a step, the weight gradient and the input
  * gradient of one layer, overlap on two HIP streams: the small latency-bound launches of the deep levels fill the chip together) */
@@ -529,6 +547,7 @@ typedef struct {
         mtbc_head_fuse_args head;
         struct { const float* w; float* dst; int32_t Cout, Cin, ci_off, ci_cnt, mode, k_off, K; } wview;
         struct { const float* src; int64_t src_batch_stride; void* dst; int32_t N, C, HW, compute; } c8pack;   /* C8_PACK and C8_PACK16 (src = 16-bit planar, `compute` unused) */
+        mtbc_dparam_desc dparam;         /* MTBC_OP_IN_DPARAM: a run of them is issued as one mtbc_instnorm_dparam_many launch */
         struct { void* event; int32_t index; } sync;      /* SET_STREAM: following ops go to streams[index]; EVENT_RECORD / EVENT_WAIT: on the current stream */
     } u;
 } mtbc_op;

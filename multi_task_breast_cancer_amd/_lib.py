@@ -56,7 +56,7 @@ class InstNormArgs(C.Structure):
                 ("z_layout", C.c_int32), ("dy_layout", C.c_int32), ("stats_partial", C.c_void_p), ("stats_slots", C.c_int32),
                 ("z_type", C.c_int32), ("dy_rank1", C.c_void_p), ("dy_rank1_w", C.c_void_p),
                 ("dy_rank1_dw", C.c_void_p), ("dy_rank1_db", C.c_void_p), ("dy_rank1_accumulate", C.c_int32),
-                ("dy_pool", C.c_void_p), ("dy_pool_arg", C.c_void_p)]
+                ("dy_pool", C.c_void_p), ("dy_pool_arg", C.c_void_p), ("defer_dparams", C.c_int32)]
 
 
 class MaxPoolArgs(C.Structure):
@@ -145,6 +145,12 @@ class _C8PackArgs(C.Structure):
                 ("N", C.c_int32), ("C", C.c_int32), ("HW", C.c_int32), ("compute", C.c_int32)]
 
 
+class DparamDesc(C.Structure):
+    """mtbc_dparam_desc (include/mtbc.h)."""
+    _fields_ = [("part", C.c_void_p), ("dgamma", C.c_void_p), ("dbeta", C.c_void_p), ("dbias_pre", C.c_void_p),
+                ("N", C.c_int32), ("C", C.c_int32), ("T", C.c_int32), ("accumulate", C.c_int32)]
+
+
 class _SyncArgs(C.Structure):
     _fields_ = [("event", C.c_void_p), ("index", C.c_int32)]
 
@@ -167,7 +173,7 @@ class _OpUnion(C.Union):
     _fields_ = [("conv3", Conv3x3Args), ("inorm", InstNormArgs), ("pool", MaxPoolArgs), ("convT", ConvTArgs),
                 ("conv1", Conv1x1Args), ("gap", GapArgs), ("linear", LinearArgs), ("dice", DiceArgs),
                 ("focal", FocalArgs), ("adam", AdamArgs), ("pack", _PackArgs), ("mix", _MixArgs),
-                ("memset0", _MemsetArgs), ("counts", _CountsArgs), ("head", HeadFuseArgs), ("c8pack", _C8PackArgs), ("wview", _WViewArgs), ("sync", _SyncArgs)]
+                ("memset0", _MemsetArgs), ("counts", _CountsArgs), ("head", HeadFuseArgs), ("c8pack", _C8PackArgs), ("wview", _WViewArgs), ("dparam", DparamDesc), ("sync", _SyncArgs)]
 
 
 class Op(C.Structure):
@@ -180,7 +186,7 @@ class Op(C.Structure):
  OP_CONV1_FWD, OP_CONV1_DGRAD, OP_CONV1_WGRAD, OP_GAP_FWD, OP_GAP_BWD, OP_LINEAR_FWD, OP_LINEAR_BWD,
  OP_DICE_FWD, OP_DICE_BWD, OP_FOCAL, OP_LOSS_MIX, OP_ADAM, OP_MEMSET, OP_DICE_COUNTS, OP_CONV3_PACK_LP,
  OP_HEAD_COMBINE, OP_HEAD_EXPAND, OP_C8_PACK, OP_C8_PACK16, OP_CONV3_WVIEW,
- OP_SET_STREAM, OP_EVENT_RECORD, OP_EVENT_WAIT) = range(1, 36)
+ OP_SET_STREAM, OP_EVENT_RECORD, OP_EVENT_WAIT, OP_IN_DPARAM) = range(1, 37)
 
 OP_UNION_FIELD = {
     OP_CONV3_FWD: "conv3", OP_CONV3_DGRAD: "conv3", OP_CONV3_WGRAD: "conv3",
@@ -192,7 +198,7 @@ OP_UNION_FIELD = {
     OP_DICE_FWD: "dice", OP_DICE_BWD: "dice", OP_FOCAL: "focal", OP_LOSS_MIX: "mix", OP_ADAM: "adam",
     OP_MEMSET: "memset0", OP_DICE_COUNTS: "counts", OP_CONV3_PACK_LP: "pack",
     OP_HEAD_COMBINE: "head", OP_HEAD_EXPAND: "head", OP_C8_PACK: "c8pack", OP_C8_PACK16: "c8pack", OP_CONV3_WVIEW: "wview",
-    OP_SET_STREAM: "sync", OP_EVENT_RECORD: "sync", OP_EVENT_WAIT: "sync",
+    OP_SET_STREAM: "sync", OP_EVENT_RECORD: "sync", OP_EVENT_WAIT: "sync", OP_IN_DPARAM: "dparam",
 }
 
 # every symbol include/mtbc.h declares (tests check the library exports all of them)
@@ -212,7 +218,7 @@ EXPORTS = [
     "mtbc_version", "mtbc_strerror", "mtbc_arch",
     "mtbc_conv3x3_packed_elems", "mtbc_conv3x3_packed_dgrad_elems", "mtbc_conv3x3_pack_fwd",
     "mtbc_conv3x3_pack_dgrad", "mtbc_conv3x3_packed_lp_elems", "mtbc_conv3x3_pack_lp", "mtbc_conv3x3_pack_many", "mtbc_c8_pack", "mtbc_c8_unpack", "mtbc_c8_pack16", "mtbc_conv3x3_weight_view", "mtbc_conv3x3_weight_view_many", "mtbc_augment_flip_rotate", "mtbc_convT_head_combine", "mtbc_convT_head_expand", "mtbc_conv3x3_wgrad_workspace", "mtbc_conv3x3_stats_slots", "mtbc_conv3x3_fwd", "mtbc_conv3x3_dgrad",
-    "mtbc_conv3x3_wgrad", "mtbc_instnorm_fwd_workspace", "mtbc_instnorm_coop_state_bytes", "mtbc_instnorm_coop_error_offset", "mtbc_instnorm_c8_supported", "mtbc_instnorm_lrelu_fwd", "mtbc_instnorm_lrelu_bwd", "mtbc_maxpool2_fwd",
+    "mtbc_conv3x3_wgrad", "mtbc_instnorm_fwd_workspace", "mtbc_instnorm_coop_state_bytes", "mtbc_instnorm_coop_error_offset", "mtbc_instnorm_c8_supported", "mtbc_instnorm_bwd_team", "mtbc_instnorm_dparam_many", "mtbc_instnorm_lrelu_fwd", "mtbc_instnorm_lrelu_bwd", "mtbc_maxpool2_fwd",
     "mtbc_maxpool2_bwd", "mtbc_convT_wgrad_workspace", "mtbc_convT_fwd_c8_supported", "mtbc_convT_fwd", "mtbc_convT_dgrad", "mtbc_convT_wgrad",
     "mtbc_conv1x1_wgrad_workspace", "mtbc_conv1x1_fwd", "mtbc_conv1x1_dgrad", "mtbc_conv1x1_wgrad",
     "mtbc_gap_fwd", "mtbc_gap_bwd", "mtbc_linear_fwd", "mtbc_linear_bwd", "mtbc_dice_fwd", "mtbc_dice_bwd",
@@ -288,6 +294,10 @@ def load() -> C.CDLL:
     lib.mtbc_instnorm_coop_state_bytes.argtypes = []
     lib.mtbc_instnorm_coop_error_offset.restype = C.c_size_t
     lib.mtbc_instnorm_coop_error_offset.argtypes = []
+    lib.mtbc_instnorm_bwd_team.restype = C.c_int32
+    lib.mtbc_instnorm_bwd_team.argtypes = [C.POINTER(InstNormArgs)]
+    lib.mtbc_instnorm_dparam_many.restype = C.c_int
+    lib.mtbc_instnorm_dparam_many.argtypes = [C.POINTER(DparamDesc), C.c_int32, C.c_void_p]
     lib.mtbc_instnorm_c8_supported.restype = C.c_int
     lib.mtbc_instnorm_c8_supported.argtypes = [C.POINTER(InstNormArgs), C.c_int32]
     lib.mtbc_convT_fwd_c8_supported.restype = C.c_int

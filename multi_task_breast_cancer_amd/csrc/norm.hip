@@ -330,6 +330,38 @@ __global__ void in_dparam_kernel(const float* __restrict__ part, float* dgamma, 
     if (dbias_pre) dbias_pre[c] = accumulate ? dbias_pre[c] + sz : sz;
 }
 
+// the same reduction for many cells in one launch (descriptors by value): block -> (descriptor, channel) by a scalar scan
+constexpr int DPARAM_MANY = 40;
+struct DparamManyP {
+    const float* part[DPARAM_MANY];
+    float* dgamma[DPARAM_MANY]; float* dbeta[DPARAM_MANY]; float* dbias[DPARAM_MANY];
+    int N[DPARAM_MANY], C[DPARAM_MANY], T[DPARAM_MANY];
+    unsigned char acc[DPARAM_MANY];
+    int first_block[DPARAM_MANY + 1];
+    int n;
+};
+__global__ void in_dparam_many_kernel(const DparamManyP q) {
+    int d = 0;
+    while (d + 1 < q.n && (int)blockIdx.x >= q.first_block[d + 1]) ++d;
+    const int c = (int)blockIdx.x - q.first_block[d], lane = threadIdx.x;
+    const int N = q.N[d], C = q.C[d], T = q.T[d];
+    const float* part = q.part[d];
+    const float* part3 = part + (size_t)3 * N * C;
+    float sb = 0.f, sg = 0.f, sz = 0.f;
+    for (int n = lane; n < N; n += 64) {
+        const float* p3 = part + 3 * ((size_t)n * C + c);
+        sb += p3[0]; sg += p3[1]; sz += p3[2];
+        const float* r = part3 + ((size_t)n * C + c) * T;
+        for (int m = 0; m < T; ++m) sz += r[m];
+    }
+    sb = wave_sum(sb); sg = wave_sum(sg); sz = wave_sum(sz);
+    if (lane != 0) return;
+    const bool acc = q.acc[d] != 0;
+    if (q.dgamma[d]) q.dgamma[d][c] = acc ? q.dgamma[d][c] + sg : sg;
+    if (q.dbeta[d]) q.dbeta[d][c] = acc ? q.dbeta[d][c] + sb : sb;
+    if (q.dbias[d]) q.dbias[d][c] = acc ? q.dbias[d][c] + sz : sz;
+}
+
 int fill(const mtbc_instnorm_args* a, InP* p) {
     if (!a || a->N <= 0 || a->C <= 0 || a->H <= 0 || a->W <= 0) return MTBC_E_BADSHAPE;
     p->N = a->N; p->C = a->C; p->HW = a->H * a->W; p->eps = a->eps; p->slope = a->slope;
@@ -383,6 +415,32 @@ int mtbc_instnorm_lrelu_fwd(const mtbc_instnorm_args* a, void* stream) {
     return MTBC_OK;
 }
 
+int32_t mtbc_instnorm_bwd_team(const mtbc_instnorm_args* a) { return mtbc_i_instnorm_bwd_c8_team(a); }
+
+int mtbc_instnorm_dparam_many(const mtbc_dparam_desc* descs, int32_t n, void* stream) {
+    if (n < 0 || (n > 0 && !descs)) return MTBC_E_BADARG;
+    int done = 0;
+    while (done < n) {
+        DparamManyP q;
+        q.n = 0;
+        int blocks = 0;
+        while (done < n && q.n < DPARAM_MANY) {
+            const mtbc_dparam_desc& d = descs[done];
+            if (!d.part || d.N < 1 || d.C < 1 || d.T < 0 || (!d.dgamma && !d.dbeta && !d.dbias_pre)) return MTBC_E_BADARG;
+            const int i = q.n++;
+            q.part[i] = d.part; q.dgamma[i] = d.dgamma; q.dbeta[i] = d.dbeta; q.dbias[i] = d.dbias_pre;
+            q.N[i] = d.N; q.C[i] = d.C; q.T[i] = d.T; q.acc[i] = d.accumulate ? 1 : 0;
+            q.first_block[i] = blocks;
+            blocks += d.C;
+            ++done;
+        }
+        q.first_block[q.n] = blocks;
+        hipLaunchKernelGGL(in_dparam_many_kernel, dim3(blocks), dim3(64), 0, (hipStream_t)stream, q);
+        MTBC_CHECK_LAUNCH();
+    }
+    return MTBC_OK;
+}
+
 int mtbc_instnorm_lrelu_bwd(const mtbc_instnorm_args* a, void* stream) {
     InP p; int rc = fill(a, &p); if (rc) return rc;
     if (!p.z || (!p.dy && !(a->dz8 && (a->dy_rank1 || a->dy_pool))) || (!p.dz && !p.dz16 && !a->dz8) || !p.mean || !p.rstd) return MTBC_E_BADARG;
@@ -403,13 +461,15 @@ int mtbc_instnorm_lrelu_bwd(const mtbc_instnorm_args* a, void* stream) {
         if ((want || epi) && (!a->workspace || a->workspace_bytes < (size_t)planes * (3 + T) * sizeof(float))) return MTBC_E_WORKSPACE;
         if (epi && !want) p.part = reinterpret_cast<float*>(a->workspace);
         rc = mtbc_i_instnorm_bwd_c8(a, want ? p.part : nullptr, st); if (rc) return rc;
-        if (want) {
+        if (a->defer_dparams && (epi || !want)) return MTBC_E_UNSUPPORTED;
+        if (want && !a->defer_dparams) {
             hipLaunchKernelGGL(in_dparam_kernel, dim3(a->C), dim3(64), 0, st, p.part, a->dgamma, a->dbeta,
                                a->dbias_pre, a->N, a->C, a->accumulate_dparams, epi ? nullptr : p.part + (size_t)3 * planes, epi ? 0 : T);
             MTBC_CHECK_LAUNCH();
         }
         return MTBC_OK;
     }
+    if (a->defer_dparams) return MTBC_E_UNSUPPORTED;
     const bool vec = p.HW % 4 == 0 && al16(p.z) && al16(p.dy) && p.dybs % 4 == 0 &&
                      (p.dz16 ? (reinterpret_cast<uintptr_t>(p.dz16) & 7) == 0 : al16(p.dz));
     const int threads = p.HW >= 16384 ? 1024 : (p.HW >= 1024 ? 256 : 64);

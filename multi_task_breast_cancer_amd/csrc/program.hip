@@ -92,6 +92,15 @@ int mtbc_program_run_ms(const mtbc_op* ops, int32_t first, int32_t count, void* 
                 continue;
             }
         }
+        if (o->kind == MTBC_OP_IN_DPARAM) {            // ... and a run of deferred InstanceNorm parameter-gradient reductions
+            mtbc_dparam_desc d[64];
+            int32_t n = 0;
+            while (n < 64 && i + n < first + count && ops[i + n].kind == MTBC_OP_IN_DPARAM) { d[n] = ops[i + n].u.dparam; ++n; }
+            rc = mtbc_instnorm_dparam_many(d, n, stream);
+            if (rc != MTBC_OK) { if (failed_index) *failed_index = i; return rc; }
+            i += n - 1;
+            continue;
+        }
         switch (o->kind) {
             case MTBC_OP_CONV3_FWD: rc = mtbc_conv3x3_fwd(&o->u.conv3, stream); break;
             case MTBC_OP_CONV3_DGRAD: rc = mtbc_conv3x3_dgrad(&o->u.conv3, stream); break;

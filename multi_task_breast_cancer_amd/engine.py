@@ -37,6 +37,8 @@ _Z_BF16 = _sw.flag("MTBC_Z_BF16")
 _NO_R1 = _sw.flag("MTBC_NO_R1")
 _NO_POOLFOLD = _sw.flag("MTBC_NO_POOLFOLD")
 _NO_STEM16 = _sw.flag("MTBC_NO_STEM16")
+_NO_DEFER_DPARAM = _sw.flag("MTBC_NO_DEFER_DPARAM")
+_DPARAM_BATCH = int(_sw.get("MTBC_DPARAM_BATCH"))
 _SPLIT_FANIN = _sw.flag("MTBC_SPLIT_FANIN")
 _BWD_OVERLAP = _sw.flag("MTBC_BWD_OVERLAP")
 _BWD_OVERLAP_MAX_HW = int(_sw.get("MTBC_BWD_OVERLAP_MAX_HW"))
@@ -180,6 +182,7 @@ class StepPlan:
         self.loss_ops: List[L.Op] = []
         self.ws_bytes = 0
         self.ws_users: List[Tuple[L.Op, str]] = []
+        self._pending_dparams: List[Tuple[L.Op, tuple]] = []   # deferred InstanceNorm parameter-gradient reductions: (op, parameter names)
         self._stat_users: List[Tuple[L.Op, str]] = []      # conv forward / InstanceNorm forward pairs sharing the epilogue-statistics scratch
         self._stat_bytes = 0
         self.arena_bytes = 0
@@ -300,6 +303,16 @@ class StepPlan:
         self.bwd_ops.append(self._sync_op(L.OP_EVENT_WAIT, 1))
         for name in params:
             self.slots[name].ready_at = len(self.bwd_ops) - 1
+
+    def flush_dparams(self) -> None:
+        """Emit the pending InstanceNorm parameter-gradient reductions (the runner issues a run of them as ONE launch); the gradients
+        they finish are ready from the last of them on -- what the data-parallel bucket schedule keys on."""
+        for dop, names in self._pending_dparams:
+            self.bwd_ops.append(dop)
+        for dop, names in self._pending_dparams:
+            for name in names:
+                self.slots[name].ready_at = len(self.bwd_ops) - 1
+        self._pending_dparams = []
 
     def _need_ws(self, op: L.Op, fieldname: str, nbytes: int) -> None:
         self.ws_bytes = max(self.ws_bytes, int(nbytes))
@@ -619,7 +632,24 @@ class StepPlan:
                 self._need_ws(op, "inorm", N * cout * (131 if coop else 3) * 4)
             if y.r1 is not None:
                 self._need_ws(op, "inorm", N * (cout + 1) * 262 * 4)
+            dop = None
+            if (gname or bname) and z16 and not _NO_DEFER_DPARAM and not (g8 and bslots > 0) and self.dev.type == "cuda":
+                # the per-plane partial sums of dgamma / dbeta / dbias stay in a (small) buffer of this cell's own and are reduced later,
+                # many cells per launch (a step has 36 of these 5 us reductions): after every MTBC_DPARAM_BATCH cells and at the end
+                if a.accumulate_dparams:
+                    self.flush_dparams()            # an earlier contribution to the same parameters lands first
+                buf = self.alloc(N * (cout + 1) * 262)
+                self.ws_users = [u for u in self.ws_users if u[0] is not op]
+                a.workspace, a.workspace_bytes, a.defer_dparams = buf.data_ptr(), buf.numel() * 4, 1
+                dop = _mk(L.OP_IN_DPARAM, tag)
+                d = dop.u.dparam
+                d.part, d.dgamma, d.dbeta, d.dbias_pre = buf.data_ptr(), a.dgamma, a.dbeta, a.dbias_pre
+                d.N, d.C, d.T, d.accumulate = N, cout, int(self.lib.mtbc_instnorm_bwd_team(C.byref(a))), a.accumulate_dparams
             self.bwd_ops.append(op)
+            if dop is not None:
+                self._pending_dparams.append((dop, tuple(n_ for n_ in (gname, betaname, bname) if n_)))
+                if len(self._pending_dparams) >= _DPARAM_BATCH:
+                    self.flush_dparams()
             if y.r1 is not None:            # the head's parameter gradients are written by THIS op
                 for name in y.r1[5]:
                     self.slots[name].ready_at = len(self.bwd_ops) - 1
@@ -1089,6 +1119,7 @@ class StepPlan:
     def emit_backward(self) -> None:
         for em in reversed(self.bwd_emitters):
             em()
+        self.flush_dparams()
 
     def _narrow_activations(self) -> None:
         """Conv-cell outputs that ONLY 3x3 convs read (the first conv of every double-conv block): InstanceNorm writes

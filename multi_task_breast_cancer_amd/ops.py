@@ -381,7 +381,7 @@ def instnorm_lrelu_fwd_c8(z, gamma=None, beta=None, eps=1e-5, slope=0.01, comput
 
 def instnorm_lrelu_bwd_c8(z, dy, mean, rstd, gamma=None, beta=None, eps=1e-5, slope=0.01, dbias_pre=None, compute: Optional[int] = None,
                           dy_extra: Optional[torch.Tensor] = None, stats: Optional[torch.Tensor] = None, rank1=None, rank1_grads: bool = False,
-                          pool=None):
+                          pool=None, defer_dparams: bool = False):
     """z / dy: fp32 planes or C8 tensors (z_layout / dy_layout = C8); dy_extra (with a C8 dy only): an fp32 planar partial
     gradient added while loading; rank1 = (dyhead (N,1,H,W), w (C)): the rank-1 gradient term of a one-output 1x1 head (dy may
     then be None)."""
@@ -423,7 +423,14 @@ def instnorm_lrelu_bwd_c8(z, dy, mean, rstd, gamma=None, beta=None, eps=1e-5, sl
         a.stats_partial, a.stats_slots = stats.data_ptr(), stats.shape[1]
     if not L.load().mtbc_instnorm_c8_supported(C.byref(a), 1):
         raise L.MtbcError("instnorm_bwd: shape not supported with a channel-blocked output")
+    if defer_dparams:           # leave the partials in the workspace, reduce them with the batched entry point afterwards
+        a.defer_dparams = 1
     L.check(L.load().mtbc_instnorm_lrelu_bwd(C.byref(a), _s()), "instnorm_bwd(c8)")
+    if defer_dparams:
+        d = (L.DparamDesc * 1)()
+        d[0].part, d[0].dgamma, d[0].dbeta, d[0].dbias_pre = ws.data_ptr(), _p(dg), _p(db), _p(dbias_pre)
+        d[0].N, d[0].C, d[0].T, d[0].accumulate = N, Cc, L.load().mtbc_instnorm_bwd_team(C.byref(a)), 0
+        L.check(L.load().mtbc_instnorm_dparam_many(d, 1, _s()), "instnorm_dparam_many")
     if rank1_grads:
         return C8(dz8, z.shape, compute), dg, db, hdw, hdb
     return C8(dz8, z.shape, compute), dg, db

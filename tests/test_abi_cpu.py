@@ -78,7 +78,7 @@ def test_op_kind_enum_in_sync():
             "POOL_FWD", "POOL_BWD", "CONVT_FWD", "CONVT_DGRAD", "CONVT_WGRAD", "CONV1_FWD", "CONV1_DGRAD", "CONV1_WGRAD",
             "GAP_FWD", "GAP_BWD", "LINEAR_FWD", "LINEAR_BWD", "DICE_FWD", "DICE_BWD", "FOCAL", "LOSS_MIX", "ADAM",
             "MEMSET", "DICE_COUNTS", "CONV3_PACK_LP", "HEAD_COMBINE", "HEAD_EXPAND", "C8_PACK", "C8_PACK16", "CONV3_WVIEW",
-            "SET_STREAM", "EVENT_RECORD", "EVENT_WAIT"]
+            "SET_STREAM", "EVENT_RECORD", "EVENT_WAIT", "IN_DPARAM"]
     assert names == ["MTBC_OP_" + w for w in want]
     for i, w in enumerate(want, start=1):
         assert getattr(L, "OP_" + w) == i

@@ -1060,3 +1060,18 @@ def test_stem_conv_on_the_16bit_path(N, Cout, H, W, compute, out_fp16):
     dw_ref, _ = ops.conv3x3_wgrad([x], dz8.unpack(), tuple(w.shape))
     dw, _ = ops.conv3x3_wgrad_c8([x], dz8, tuple(w.shape))
     assert torch.allclose(dw, dw_ref, rtol=1e-4, atol=1e-4 * max(1.0, dw_ref.abs().max().item())), (dw - dw_ref).abs().max().item()
+
+
+@pytest.mark.parametrize("N,C,H,W", [(2, 24, 256, 256), (3, 96, 64, 64), (2, 16, 16, 16)])
+def test_deferred_instnorm_parameter_gradients_equal_the_immediate_ones(N, C, H, W):
+    """defer_dparams + mtbc_instnorm_dparam_many: the per-plane partials left in the workspace, reduced by the batched entry point
+    = the reduction inside mtbc_instnorm_lrelu_bwd, bit for bit (same summation order)."""
+    g = _g(N + C + H)
+    z = ops.C8.pack((torch.randn(N, C, H, W, generator=g) * 2 + 0.5).to(DEV), 2)
+    dy = torch.randn(N, C, H, W, generator=g).to(DEV)
+    gamma, beta = (torch.rand(C, generator=g) + 0.5).to(DEV), (torch.randn(C, generator=g) * 0.1).to(DEV)
+    _, mean, rstd, _ = ops.instnorm_lrelu_fwd_c8(z, gamma, beta, slope=0.1, compute=1)
+    b1, b2 = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    a_, dga, dba = ops.instnorm_lrelu_bwd_c8(z, dy, mean, rstd, gamma, beta, slope=0.1, compute=1, dbias_pre=b1)
+    b_, dgb, dbb = ops.instnorm_lrelu_bwd_c8(z, dy, mean, rstd, gamma, beta, slope=0.1, compute=1, dbias_pre=b2, defer_dparams=True)
+    assert torch.equal(a_.data, b_.data) and torch.equal(dga, dgb) and torch.equal(dba, dbb) and torch.equal(b1, b2)
