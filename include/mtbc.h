@@ -268,6 +268,11 @@ typedef struct {
        formed while loading.  dy_pool: fp32 planar (N,C,H/2,W/2).  Both NULL or both set; H and W even.                          */
     const float* dy_pool;
     const void* dy_pool_arg;
+    /* forward with stats_partial (the streaming pass): also write the activation's MaxPool2d(2,2) -- pool_y8: channel-blocked 16-bit
+       [N][C/8][H/2*W/2][8] of out16_type, the maxima of the STORED values (= mtbc_maxpool2_fwd on y8, bit for bit); pool_arg: optional
+       argmax codes (mtbc_maxpool_args.argmax).  H and W even.                                                                     */
+    void* pool_y8;
+    void* pool_arg;
     int32_t defer_dparams;           /* backward with dz8 and any of dgamma / dbeta / dbias_pre: 1 = stop after the norm kernel: the
                                         per-plane partial sums stay in `workspace` (a buffer of the caller's that lives until
                                         mtbc_instnorm_dparam_many has reduced it) and dgamma / dbeta / dbias_pre are not touched --

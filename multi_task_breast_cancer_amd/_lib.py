@@ -56,7 +56,8 @@ class InstNormArgs(C.Structure):
                 ("z_layout", C.c_int32), ("dy_layout", C.c_int32), ("stats_partial", C.c_void_p), ("stats_slots", C.c_int32),
                 ("z_type", C.c_int32), ("dy_rank1", C.c_void_p), ("dy_rank1_w", C.c_void_p),
                 ("dy_rank1_dw", C.c_void_p), ("dy_rank1_db", C.c_void_p), ("dy_rank1_accumulate", C.c_int32),
-                ("dy_pool", C.c_void_p), ("dy_pool_arg", C.c_void_p), ("defer_dparams", C.c_int32)]
+                ("dy_pool", C.c_void_p), ("dy_pool_arg", C.c_void_p), ("pool_y8", C.c_void_p), ("pool_arg", C.c_void_p),
+                ("defer_dparams", C.c_int32)]
 
 
 class MaxPoolArgs(C.Structure):

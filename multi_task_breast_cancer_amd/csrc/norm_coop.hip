@@ -52,6 +52,7 @@ struct CoP {
     const float* r1; const float* r1w;       // backward: rank-1 gradient term w[c] * r1[n][pixel] (a one-output 1x1 head), or nullptr
     float* r1dw; float* r1db;                // ... and the head's own weight / bias gradient partials: [N*C][T], [N][T], or nullptr
     const float* pg; const unsigned short* pa; int W;      // backward: gradient of a 2 x 2 max-pool of this activation (pooled fp32 planes + argmax codes), or nullptr
+    unsigned short* py8; unsigned short* parg;             // forward (streaming pass): the 2 x 2 max-pool of the activation + its argmax codes, or nullptr
 };
 
 typedef float co_f32x2 __attribute__((ext_vector_type(2)));
@@ -486,7 +487,10 @@ constexpr int AP_THREADS = 256, AP_PPT = 2;
 // FIN: the workgroup first adds up the conv epilogue's partials of its 8 channels itself (few pixel subsets: planes up to 64 x 64)
 // -- no separate finalize launch; thread t sums subsets t/8, t/8 + 32, ... of channel t % 8 in double, the 32 partial sums are
 // added in a fixed order, and the workgroup of the plane group's first pixels writes mean / rstd for the backward pass.
-template <bool F16, bool FIN, bool ZF16>
+// POOL: the activation is max-pooled (2 x 2) by its next reader: a thread normalises one WINDOW (2 rows x 2 adjacent pixels = 4 pieces) and
+// also writes the window's maxima of the STORED values as one piece of the pooled tensor (+ the 2-bit positions of the maxima for the
+// pool's backward) -- what maxpool_c8_fwd_kernel would compute from the tensor this kernel has just written, without reading it back.
+template <bool F16, bool FIN, bool ZF16, bool POOL = false>
 __global__ __launch_bounds__(AP_THREADS) void in_apply_fwd_c8_kernel(const CoP p, const float* __restrict__ part, const int slots) {
     const int item = blockIdx.y, n = item / p.G8, g = item % p.G8;
     float mu[8], ga[8], be[8];
@@ -520,6 +524,48 @@ __global__ __launch_bounds__(AP_THREADS) void in_apply_fwd_c8_kernel(const CoP p
     const unsigned short* zg = p.z8 + ((size_t)n * p.G8 + g) * p.HW * 8;
     unsigned short* ob = p.y8 + ((size_t)n * p.G8 + g) * p.HW * 8;
     float* yb = p.y ? p.y + (size_t)n * p.ybs + (size_t)(8 * g) * p.HW : nullptr;
+    if constexpr (POOL) {
+        const int oW = p.W >> 1, oHW = p.HW >> 2;
+        unsigned short* pb = p.py8 + ((size_t)n * p.G8 + g) * oHW * 8;
+        for (int q = blockIdx.x * AP_THREADS + threadIdx.x; q < oHW; q += gridDim.x * AP_THREADS) {
+            const int oy = q / oW, ox = q - oy * oW;
+            const size_t p00 = (size_t)(2 * oy) * p.W + 2 * ox;
+            const size_t pos[4] = {p00, p00 + 1, p00 + p.W, p00 + p.W + 1};
+            co_u32x4 wz[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) wz[e] = *reinterpret_cast<const co_u32x4*>(zg + pos[e] * 8);
+            float best[8];
+            unsigned code = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float v[8];
+                co_unpk<ZF16>(wz[e], v);
+#pragma unroll
+                for (int c = 0; c < 8; ++c) { const float t = (v[c] - mu[c]) * ga[c] + be[c]; v[c] = t > 0.f ? t : t * p.slope; }
+                co_u32x4 o;
+#pragma unroll
+                for (int h = 0; h < 4; ++h) o[h] = co_pk<F16>(v[2 * h], v[2 * h + 1]);
+                *reinterpret_cast<co_u32x4*>(ob + pos[e] * 8) = o;
+                if (yb) {
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) yb[(size_t)c * p.HW + pos[e]] = v[c];
+                }
+                float r[8];
+                co_unpk<F16>(o, r);              // the stored values: what the pool compares
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    if (e == 0) best[c] = r[c];
+                    else if (r[c] > best[c] || r[c] != r[c]) { best[c] = r[c]; code = (code & ~(3u << (2 * c))) | ((unsigned)e << (2 * c)); }
+                }
+            }
+            co_u32x4 o;
+#pragma unroll
+            for (int h = 0; h < 4; ++h) o[h] = co_pk<F16>(best[2 * h], best[2 * h + 1]);
+            *reinterpret_cast<co_u32x4*>(pb + (size_t)q * 8) = o;
+            if (p.parg) p.parg[((size_t)n * p.G8 + g) * oHW + q] = (unsigned short)code;
+        }
+        return;
+    }
     const int px0 = blockIdx.x * (AP_THREADS * AP_PPT) + threadIdx.x;
     co_u32x4 w[AP_PPT];
 #pragma unroll
@@ -676,6 +722,7 @@ int fill_coop(const mtbc_instnorm_args* a, CoP* p) {
     p->r1 = a->dy_rank1; p->r1w = a->dy_rank1_w; p->r1dw = nullptr; p->r1db = nullptr;
     if ((p->r1 == nullptr) != (p->r1w == nullptr)) return MTBC_E_BADARG;
     p->pg = a->dy_pool; p->pa = reinterpret_cast<const unsigned short*>(a->dy_pool_arg); p->W = a->W;
+    p->py8 = reinterpret_cast<unsigned short*>(a->pool_y8); p->parg = reinterpret_cast<unsigned short*>(a->pool_arg);
     if ((p->pg == nullptr) != (p->pa == nullptr) || (p->pg && ((a->H | a->W) & 1))) return MTBC_E_BADARG;
     if (a->z_layout == MTBC_LAYOUT_C8) {
         if (reinterpret_cast<uintptr_t>(a->z) & 15) return MTBC_E_BADARG;
@@ -758,6 +805,23 @@ int mtbc_i_instnorm_fwd_c8(const mtbc_instnorm_args* a, hipStream_t st) {
     if (a->stats_partial) {         // statistics from the conv epilogue: finalize (one wave per plane) + one streaming pass
         if (!p.z8 || a->stats_slots <= 0) return MTBC_E_BADARG;
         const int planes = a->N * a->C;
+        if (p.py8) {           // the activation's 2 x 2 max-pool written by the same pass (one thread per window)
+            if (((a->H | a->W) & 1) || (reinterpret_cast<uintptr_t>(p.py8) & 15)) return MTBC_E_BADARG;
+            int gx = cdiv(p.HW / 4, AP_THREADS * 2); if (gx < 1) gx = 1;
+            const dim3 gp(gx, p.items);
+            const bool fin = a->stats_slots <= 64;
+            if (!fin) {
+                hipLaunchKernelGGL(in_stats_finalize_kernel, dim3(cdiv(planes, 4)), dim3(256), 0, st, a->stats_partial, a->stats_slots, a->C, p.HW, a->eps, a->mean, a->rstd, planes);
+                MTBC_CHECK_LAUNCH();
+            }
+#define MTBC_AP(F16_, FIN_, ZF_) hipLaunchKernelGGL((in_apply_fwd_c8_kernel<F16_, FIN_, ZF_, true>), gp, dim3(AP_THREADS), 0, st, p, a->stats_partial, a->stats_slots)
+            if (p.f16) { if (fin) MTBC_AP(true, true, true); else MTBC_AP(true, false, true); }
+            else if (p.zf16) { if (fin) MTBC_AP(false, true, true); else MTBC_AP(false, false, true); }
+            else { if (fin) MTBC_AP(false, true, false); else MTBC_AP(false, false, false); }
+#undef MTBC_AP
+            MTBC_CHECK_LAUNCH();
+            return MTBC_OK;
+        }
         const dim3 g(cdiv(p.HW, AP_THREADS * AP_PPT), p.items);
         if (a->stats_slots <= 64) {          // few subsets per plane: every workgroup finalizes its own 8 channels (one launch)
             if (p.f16) hipLaunchKernelGGL((in_apply_fwd_c8_kernel<true, true, true>), g, dim3(AP_THREADS), 0, st, p, a->stats_partial, a->stats_slots);

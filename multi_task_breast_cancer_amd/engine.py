@@ -37,6 +37,7 @@ _Z_BF16 = _sw.flag("MTBC_Z_BF16")
 _NO_R1 = _sw.flag("MTBC_NO_R1")
 _NO_POOLFOLD = _sw.flag("MTBC_NO_POOLFOLD")
 _NO_STEM16 = _sw.flag("MTBC_NO_STEM16")
+_NO_POOLFWD_FOLD = _sw.flag("MTBC_NO_POOLFWD_FOLD")
 _NO_DEFER_DPARAM = _sw.flag("MTBC_NO_DEFER_DPARAM")
 _DPARAM_BATCH = int(_sw.get("MTBC_DPARAM_BATCH"))
 _SPLIT_FANIN = _sw.flag("MTBC_SPLIT_FANIN")
@@ -758,11 +759,17 @@ class StepPlan:
                 a.y, a.y_batch_stride = y.data.data_ptr(), y.bstride
             return op
 
-        op = base()
-        op.kind = L.OP_POOL_FWD
-        if fold:
-            op.u.pool.argmax = arg.data_ptr()
-        self.fwd_ops.append(op)
+        if c8 and x.in_op is not None and x.in_op.u.inorm.stats_slots > 0 and not x.in_op.u.inorm.pool_y8 and not _NO_POOLFWD_FOLD:
+            # x's InstanceNorm forward is the streaming pass: it writes the pooled tensor (and the argmax codes) while it has the window
+            # in registers -- no pool launch, no second read of x (mtbc_instnorm_args.pool_y8)
+            x.in_op.u.inorm.pool_y8 = y.c8.data_ptr()
+            x.in_op.u.inorm.pool_arg = arg.data_ptr() if fold else None
+        else:
+            op = base()
+            op.kind = L.OP_POOL_FWD
+            if fold:
+                op.u.pool.argmax = arg.data_ptr()
+            self.fwd_ops.append(op)
 
         def emit_bwd() -> None:
             if not y.grad_written or not x.needs_grad:

@@ -349,7 +349,7 @@ def coop_state(dev) -> torch.Tensor:
 
 
 def instnorm_lrelu_fwd_c8(z, gamma=None, beta=None, eps=1e-5, slope=0.01, compute: Optional[int] = None, want_planar: bool = False,
-                          stats: Optional[torch.Tensor] = None):
+                          stats: Optional[torch.Tensor] = None, want_pool: bool = False):
     """InstanceNorm + LeakyReLU straight into the 16-bit channel-blocked layout (y8 of the C-ABI).  z: fp32 planes, or a
     C8 tensor (z_layout = C8: the conv output of the 16-bit modes)."""
     z8 = z if isinstance(z, C8) else None
@@ -373,9 +373,16 @@ def instnorm_lrelu_fwd_c8(z, gamma=None, beta=None, eps=1e-5, slope=0.01, comput
     a.y8, a.out16_type, a.coop_state = y8.data_ptr(), compute, coop_state(dev).data_ptr()
     if stats is not None:       # [N][slots][C][2] from conv3x3_fwd_c8(stats=True)
         a.stats_partial, a.stats_slots = stats.data_ptr(), stats.shape[1]
+    yp8 = parg = None
+    if want_pool:               # the streaming pass also writes the activation's 2x2 max-pool + argmax codes (pool_y8 / pool_arg)
+        yp8 = torch.empty(N, Cc // 8, (H // 2) * (W // 2), 8, dtype=torch.int16, device=dev)
+        parg = torch.empty(N, Cc // 8, (H // 2) * (W // 2), dtype=torch.int16, device=dev)
+        a.pool_y8, a.pool_arg = yp8.data_ptr(), parg.data_ptr()
     if not L.load().mtbc_instnorm_c8_supported(C.byref(a), 0):
         raise L.MtbcError("instnorm_fwd: shape not supported with a channel-blocked output")
     L.check(L.load().mtbc_instnorm_lrelu_fwd(C.byref(a), _s()), "instnorm_fwd(c8)")
+    if want_pool:
+        return C8(y8, z.shape, compute), mean, rstd, y, C8(yp8, (N, Cc, H // 2, W // 2), compute), parg
     return C8(y8, z.shape, compute), mean, rstd, y
 
 

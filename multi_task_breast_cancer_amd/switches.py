@@ -36,6 +36,7 @@ PLAN_SWITCHES: Dict[str, tuple] = {
     "MTBC_NO_STEM16": ("0", "the stem cell (Cin = 1) keeps fp32 conv outputs / fp32 dz (cooperative InstanceNorm forward, fp32 weight-gradient kernel)"),
     "MTBC_NO_DEFER_DPARAM": ("0", "every InstanceNorm backward reduces its parameter-gradient partials right away (one 5 us launch per cell) instead of in batches"),
     "MTBC_DPARAM_BATCH": ("12", "cells per batched InstanceNorm parameter-gradient reduction"),
+    "MTBC_NO_POOLFWD_FOLD": ("0", "the 2x2 max-pool forward is its own launch reading the activation back instead of being written by the streaming InstanceNorm pass"),
     "MTBC_BWD_OVERLAP": ("0", "weight gradient and input gradient of a layer run side by side on two streams (measured slower: DESIGN.md)"),
     "MTBC_BWD_OVERLAP_MAX_HW": ("1024", "with MTBC_BWD_OVERLAP=1: largest map (pixels) whose weight / input gradient launches are overlapped"),
     "MTBC_COOP_RESERVE_CUS": ("64", "CUs kept out of the cooperative InstanceNorm grids under data parallel"),

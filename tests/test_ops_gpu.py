@@ -1075,3 +1075,22 @@ def test_deferred_instnorm_parameter_gradients_equal_the_immediate_ones(N, C, H,
     a_, dga, dba = ops.instnorm_lrelu_bwd_c8(z, dy, mean, rstd, gamma, beta, slope=0.1, compute=1, dbias_pre=b1)
     b_, dgb, dbb = ops.instnorm_lrelu_bwd_c8(z, dy, mean, rstd, gamma, beta, slope=0.1, compute=1, dbias_pre=b2, defer_dparams=True)
     assert torch.equal(a_.data, b_.data) and torch.equal(dga, dgb) and torch.equal(dba, dbb) and torch.equal(b1, b2)
+
+
+@pytest.mark.parametrize("compute", [1, 2])
+@pytest.mark.parametrize("N,segs,Cout,H,W", [(2, [24], 24, 256, 256), (2, [48], 48, 128, 128), (3, [96], 96, 64, 64), (2, [32], 16, 16, 24)])
+def test_streaming_instnorm_also_writes_the_maxpool(N, segs, Cout, H, W, compute):
+    """mtbc_instnorm_args.pool_y8 / pool_arg: the streaming normalisation (statistics from the conv epilogue) writes the 2x2
+    max-pool of the activation it stores and the pool's argmax codes = the pool kernel run on that activation, bit for bit."""
+    g = _g(N * 31 + Cout + H + compute)
+    Cin = sum(segs)
+    xs = [(torch.randn(N, c, H, W, generator=g) + 0.3).to(DEV) for c in segs]
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (9 * Cin)) ** 0.5).to(DEV)
+    gamma, beta = (torch.rand(Cout, generator=g) + 0.5).to(DEV), (torch.randn(Cout, generator=g) * 0.1).to(DEV)
+    pf, _ = ops.conv3x3_pack_lp(w, compute)
+    z8, part = ops.conv3x3_fwd_c8([ops.C8.pack(x, compute) for x in xs], w, None, pf, out_c8=True, stats=True)
+    y_a, mean_a, rstd_a, yp_a = ops.instnorm_lrelu_fwd_c8(z8, gamma, beta, slope=0.1, stats=part, want_planar=True)
+    y_b, mean_b, rstd_b, yp_b, pool8, parg = ops.instnorm_lrelu_fwd_c8(z8, gamma, beta, slope=0.1, stats=part, want_planar=True, want_pool=True)
+    assert torch.equal(y_a.data, y_b.data) and torch.equal(yp_a, yp_b) and torch.equal(mean_a, mean_b) and torch.equal(rstd_a, rstd_b)
+    ref8, refarg = ops.maxpool2_fwd_c8(y_b, want_argmax=True)
+    assert torch.equal(pool8.data, ref8.data) and torch.equal(parg, refarg)
