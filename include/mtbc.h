@@ -6,9 +6,9 @@
  * entry point below names the reference call it replaces (file:line, relative to the
  * upstream repository).  All tensors are fp32, NCHW, plane-contiguous (channel stride =
  * H*W) device pointers BORROWED from the caller until the stream operation completes; the
- * 16-bit compute modes may additionally hand the MFMA kernels their operand tensors in the
- * matrix pipe's own format (MTBC_LAYOUT_C8: bf16 / fp16, [N][C/8][H*W][8]) -- every such field
- * says so where it is declared, and what the reference would see (parameters, gradients of
+ * 16-bit compute modes may additionally hand the MFMA kernels their operand tensors -- and take
+ * the conv outputs between a convolution and its norm -- in the matrix pipe's own format
+ * (MTBC_LAYOUT_C8: bf16 / fp16, [N][C/8][H*W][8]) -- every such field says so where it is declared, and what the reference would see (parameters, gradients of
  * parameters, losses, logits) is fp32 in every mode.
  *
  * Conventions: return 0 (MTBC_OK) or a negative MTBC_E_* code; never throws, never
@@ -90,7 +90,7 @@ typedef struct {
                                               passed through the float* / const float* fields, batch strides count
                                               16-bit elements, every segment holds a multiple of 8 channels and is
                                               16-byte aligned.  What the kernels WRITE (z, dx segments, dw, dbias)
-                                              stays fp32 planar.  No fallback: shapes the MFMA kernels do not take
+                                              stays fp32 planar unless out_layout / a segment mode says otherwise.  No fallback: shapes the MFMA kernels do not take
                                               (W % 4 != 0, H or W < 8) return MTBC_E_UNSUPPORTED.                 */
     int32_t out_accumulate;          /* fwd with operand_layout C8 only: 1 = add the result to `out` instead of overwriting
                                         it.  A forward launch over the dz of ALL 3x3 consumers of a tensor, with
