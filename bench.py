@@ -232,7 +232,7 @@ def run_mode(args, dtype, dev, rank, world, dist, want_roofline):
             op = prog.array[i]
             if op.kind == L.OP_IN_FWD:
                 a = op.u.inorm; e = a.N * a.C * a.H * a.W
-                ob = (2 + (4 if a.y else 0)) if a.y8 else (2 if a.y16 else 4)        # channel-blocked (+ fp32 planes) / 16-bit planes / fp32 planes
+                ob = (2 + (2 if a.y16 else 4 if a.y else 0)) if a.y8 else (2 if a.y16 else 4)        # channel-blocked (+ 16-bit / fp32 planes) / 16-bit planes / fp32 planes
                 zb = 2 if a.z_layout == L.LAYOUT_C8 else 4                                      # conv output stored in 16 bits (channel-blocked) or fp32 planes
                 h = hb["in_fwd"]; h[0] += e * (zb + ob); h[1] += time_op(prog, i); h[2] += 1      # read z, write y
             elif op.kind == L.OP_IN_BWD:
@@ -241,9 +241,10 @@ def run_mode(args, dtype, dev, rank, world, dist, want_roofline):
                 h = hb["in_bwd"]; h[0] += e * (rb + (2 if (a.dz16 or a.dz8) else 4)); h[1] += time_op(prog, i); h[2] += 1     # read z, dy (+ fp32 partial); write dz
             elif op.kind in (L.OP_CONVT_FWD, L.OP_CONVT_DGRAD, L.OP_CONVT_WGRAD):
                 a = op.u.convT; px = a.N * a.H * a.W
-                ob = 2 if (op.kind == L.OP_CONVT_FWD and a.y_layout == L.LAYOUT_C8) else 4
+                # bytes per element of the large tensor (y / dy) and of the small one (x / dx): 16-bit where the launch stores them so
+                ob = 2 if ((op.kind == L.OP_CONVT_FWD and a.y_layout == L.LAYOUT_C8) or (op.kind != L.OP_CONVT_FWD and a.dy_type16)) else 4
                 h = hb[{L.OP_CONVT_FWD: "convT_fwd", L.OP_CONVT_DGRAD: "convT_dgrad", L.OP_CONVT_WGRAD: "convT_wgrad"}[op.kind]]
-                xb = 2 if (op.kind == L.OP_CONVT_FWD and a.x_layout == L.LAYOUT_C8) else 4
+                xb = 2 if ((op.kind == L.OP_CONVT_FWD and a.x_layout == L.LAYOUT_C8) or (op.kind == L.OP_CONVT_WGRAD and a.x_type16)) else 4
                 h[0] += px * (a.Cin * xb + a.Cout * a.k * a.k * ob); h[1] += time_op(prog, i); h[2] += 1
             elif op.kind in (L.OP_C8_PACK, L.OP_C8_PACK16):                               # fp32 / 16-bit planes -> channel-blocked 16-bit
                 a = op.u.c8pack; e = a.N * a.C * a.HW

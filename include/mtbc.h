@@ -226,7 +226,10 @@ typedef struct {
        cooperative kernel (csrc/norm_coop.hip: teams of resident workgroups exchange per-channel partials through
        coop_state).  coop_state: mtbc_instnorm_coop_state_bytes() of device memory, ZEROED once by the caller, kept
        for the lifetime of the stream's launches and never used from two streams at once.  C % 8 == 0, no dy_extra;
-       shapes: ask mtbc_instnorm_c8_supported.  Statistics are combined with Chan's formula (fixed order).        */
+       shapes: ask mtbc_instnorm_c8_supported.  Statistics are combined with Chan's formula (fixed order).
+       y8 together with y16 (forward with stats_partial only, H*W % 8 == 0; otherwise MTBC_E_UNSUPPORTED): the PLANAR copy is
+       the 16-bit one -- the same rounded values as y8, for a reader that wants planes of the MFMA type
+       (mtbc_convT_args.x_type16) -- and y is not touched; y_batch_stride then counts 16-bit elements of y16 (% 8 == 0).  */
     void* y8;
     void* dz8;
     void* coop_state;
@@ -360,6 +363,10 @@ typedef struct {
                                         written by mtbc_conv3x3_dgrad into a segment with accumulate = 2; the MFMAs read it
                                         as is (what they did to an fp32 dy while loading it), the bias gradient is the
                                         sum of the stored values.  Shapes the direct kernels do not take: MTBC_E_UNSUPPORTED */
+    int32_t x_type16;                /* wgrad, with dy_type16 only: non-zero (= compute) says x is a 16-BIT planar (N,Cin,H,W) tensor of
+                                        that type too (batch stride in 16-bit elements, % 8 == 0), as written by
+                                        mtbc_instnorm_lrelu_fwd into y16 beside y8: 8 pixels of a channel are one 16-byte load that
+                                        is the MFMA fragment -- the operands the fp32 x gave after rounding, bit for bit      */
 } mtbc_convT_args;
 /* 1 if mtbc_convT_fwd takes these arguments with y_layout = MTBC_LAYOUT_C8 (fp32 x: k == 2, Cin <= 64, Cout <= 48,
  * Cout % 8 == 0, H*W % 32 == 0; x_layout C8: k == 2, channel counts % 8 == 0, H*W % 32 == 0), else 0: the caller then

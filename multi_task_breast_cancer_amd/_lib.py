@@ -80,7 +80,7 @@ class ConvTArgs(C.Structure):
                 ("accumulate_dx", C.c_int32),
                 ("dw", C.c_void_p), ("dbias", C.c_void_p), ("accumulate_dw", C.c_int32),
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("compute", C.c_int32),
-                ("y_layout", C.c_int32), ("y_type", C.c_int32), ("x_layout", C.c_int32), ("dy_type16", C.c_int32)]
+                ("y_layout", C.c_int32), ("y_type", C.c_int32), ("x_layout", C.c_int32), ("dy_type16", C.c_int32), ("x_type16", C.c_int32)]
 
 
 class Conv1x1Args(C.Structure):

@@ -206,9 +206,12 @@ __global__ __launch_bounds__(256) void convT2_dgrad_kernel(const Ct2P p) {
 // odd elements of the same 64 bytes.  Lane group kg owns pixels 8kg .. 8kg+7 of the step.
 // DY16: the 16 consecutive values of an output row (8 pixels x b) are 32 bytes; fragment word m of the b = 0 tile is
 // (low half of dword 2m) | (low half of dword 2m+1) << 16, of the b = 1 tile the two high halves: two v_perm per word.
-template <int LP, bool DY16 = false>
+// X16: x is a 16-bit planar tensor of the MFMA's own type too (the InstanceNorm forward writes it beside the channel-blocked copy
+// for exactly this reader): 8 consecutive pixels of a channel are ONE 16-byte load that IS the fragment -- half the bytes of the fp32
+// planes written by the norm and read here, no conversion, same MFMA operands.
+template <int LP, bool DY16 = false, bool X16 = false>
 __global__ __launch_bounds__(256) void convT2_wgrad_kernel(const Ct2P p) {
-    static_assert(!DY16 || LP != 0, "a 16-bit dY feeds the 16-bit MFMA");
+    static_assert((!DY16 && !X16) || LP != 0, "16-bit tensors feed the 16-bit MFMA");
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int j = lane & 15, kg = lane >> 4;
     const long long task = (long long)blockIdx.x * 4 + wv;
@@ -229,6 +232,7 @@ __global__ __launch_bounds__(256) void convT2_wgrad_kernel(const Ct2P p) {
         rok[m] = ci < p.Cin;
         xrow[m] = p.x + (size_t)(rok[m] ? ci : 0) * HW + 8 * kg;
     }
+    const unsigned short* x16base = reinterpret_cast<const unsigned short*>(p.x);
     const int co = ct * 8 + (j >> 1);
     const bool cok = co < p.Cout;
     const float* dcol = p.dy + (size_t)(cok ? co : 0) * 4 * HW + (size_t)(j & 1) * oW;
@@ -240,7 +244,8 @@ __global__ __launch_bounds__(256) void convT2_wgrad_kernel(const Ct2P p) {
 
     const bool want_bias = p.dbias_part != nullptr && mb == 0;      // uniform
     float bsum = 0.f;
-    float4 ra[2][MT][2], rb[2][4];
+    float4 ra[2][X16 ? 1 : MT][2], rb[2][4];
+    ct_u32x4 rx[2][X16 ? MT : 1];            // X16: 4 dwords = 8 consecutive pixels of one channel = the A fragment
     ct_u32x4 rh[2][2];                       // DY16: 8 dwords = 8 pixels, each {b0, b1}
     auto load = [&](int g, auto SL) {
         constexpr int slot = decltype(SL)::value;
@@ -249,8 +254,14 @@ __global__ __launch_bounds__(256) void convT2_wgrad_kernel(const Ct2P p) {
         const int i = pix / p.W, jx = pix % p.W;
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
-            const float* q = xrow[m] + (size_t)n * p.xbs + st * 32;
-            ra[slot][m][0] = ld4(q); ra[slot][m][1] = ld4(q + 4);
+            if constexpr (X16) {
+                const int ci = mb * 48 + m * 16 + j;
+                const unsigned short* q = x16base + (size_t)n * p.xbs + (size_t)(rok[m] ? ci : 0) * HW + st * 32 + 8 * kg;
+                rx[slot][m] = *reinterpret_cast<const ct_u32x4*>(q);
+            } else {
+                const float* q = xrow[m] + (size_t)n * p.xbs + st * 32;
+                ra[slot][m][0] = ld4(q); ra[slot][m][1] = ld4(q + 4);
+            }
         }
         if constexpr (DY16) {
             const unsigned short* q = dcol16 + (size_t)n * p.dybs + (size_t)(2 * i) * oW + 2 * jx;
@@ -294,6 +305,13 @@ __global__ __launch_bounds__(256) void convT2_wgrad_kernel(const Ct2P p) {
         }
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
+            if constexpr (X16) {
+                Frag<LP> fa;
+                const ct_u32x4 w = rx[cur][m];
+                frag_from_words<LP>(fa, rok[m] ? w[0] : 0u, rok[m] ? w[1] : 0u, rok[m] ? w[2] : 0u, rok[m] ? w[3] : 0u);
+                acc[m][0] = Frag<LP>::mma(fa, f0, acc[m][0]);
+                acc[m][1] = Frag<LP>::mma(fa, f1, acc[m][1]);
+            } else {
             float a[8];
             a[0] = rok[m] ? ra[cur][m][0].x : 0.f; a[1] = rok[m] ? ra[cur][m][0].y : 0.f; a[2] = rok[m] ? ra[cur][m][0].z : 0.f; a[3] = rok[m] ? ra[cur][m][0].w : 0.f;
             a[4] = rok[m] ? ra[cur][m][1].x : 0.f; a[5] = rok[m] ? ra[cur][m][1].y : 0.f; a[6] = rok[m] ? ra[cur][m][1].z : 0.f; a[7] = rok[m] ? ra[cur][m][1].w : 0.f;
@@ -301,6 +319,7 @@ __global__ __launch_bounds__(256) void convT2_wgrad_kernel(const Ct2P p) {
             fa.set(a);
             acc[m][0] = Frag<LP>::mma(fa, f0, acc[m][0]);
             acc[m][1] = Frag<LP>::mma(fa, f1, acc[m][1]);
+            }
         }
     };
     if (g0 < g1) load(g0, S0{});
@@ -626,12 +645,14 @@ void fill(const mtbc_convT_args* a, Ct2P* p) {
 bool mtbc_i_convT2_dgrad_ok(const mtbc_convT_args* a) {
     const int HW = a->H * a->W;
     if (a->dy_type16 && (a->dy_type16 != a->compute || a->dy_batch_stride % 8 != 0)) return false;
+    if (a->x_type16 && (a->x_type16 != a->compute || !a->dy_type16 || a->x_batch_stride % 8 != 0)) return false;
     return a->k == 2 && HW % 32 == 0 && a->W % 2 == 0 && a->Cout % 2 == 0 && al16(a->dy) && al16(a->w) && al16(a->dx) &&
            a->dy_batch_stride % 4 == 0 && a->dx_batch_stride % 2 == 0;
 }
 bool mtbc_i_convT2_wgrad_ok(const mtbc_convT_args* a) {
     const int HW = a->H * a->W;
     if (a->dy_type16 && (a->dy_type16 != a->compute || a->dy_batch_stride % 8 != 0)) return false;
+    if (a->x_type16 && (a->x_type16 != a->compute || !a->dy_type16 || a->x_batch_stride % 8 != 0)) return false;
     return a->k == 2 && HW % 32 == 0 && a->W % 8 == 0 && al16(a->dy) && al16(a->x) && a->dy_batch_stride % 4 == 0 &&
            a->x_batch_stride % 4 == 0;
 }
@@ -766,7 +787,11 @@ int mtbc_i_convT2_wgrad(const mtbc_convT_args* a, int compute, float* partial, f
     p.partial = partial; p.dbias_part = dbias_part; p.steps_per_split = steps_per_split; p.nsplit = nsplit;
     p.ntasks = (long long)p.mblocks * p.ctiles * nsplit;
     const unsigned blocks = (unsigned)cdiv64(p.ntasks, 4);
-    if (a->dy_type16) {
+    if (a->x_type16) {          // 16-bit planar x (and dy): both operands arrive as fragments
+        if (!a->dy_type16 || a->x_type16 != compute) return MTBC_E_UNSUPPORTED;
+        if (compute == 1) hipLaunchKernelGGL((convT2_wgrad_kernel<1, true, true>), dim3(blocks), dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((convT2_wgrad_kernel<2, true, true>), dim3(blocks), dim3(256), 0, st, p);
+    } else if (a->dy_type16) {
         if (compute == 1) hipLaunchKernelGGL((convT2_wgrad_kernel<1, true>), dim3(blocks), dim3(256), 0, st, p);
         else hipLaunchKernelGGL((convT2_wgrad_kernel<2, true>), dim3(blocks), dim3(256), 0, st, p);
     } else if (compute == 1) hipLaunchKernelGGL(convT2_wgrad_kernel<1>, dim3(blocks), dim3(256), 0, st, p);

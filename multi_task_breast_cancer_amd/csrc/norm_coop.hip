@@ -53,6 +53,7 @@ struct CoP {
     float* r1dw; float* r1db;                // ... and the head's own weight / bias gradient partials: [N*C][T], [N][T], or nullptr
     const float* pg; const unsigned short* pa; int W;      // backward: gradient of a 2 x 2 max-pool of this activation (pooled fp32 planes + argmax codes), or nullptr
     unsigned short* py8; unsigned short* parg;             // forward (streaming pass): the 2 x 2 max-pool of the activation + its argmax codes, or nullptr
+    unsigned short* y16;                     // forward (streaming pass): the planar copy as 16-bit planes (N,C,H,W) of the output type instead of `y`, or nullptr
 };
 
 typedef float co_f32x2 __attribute__((ext_vector_type(2)));
@@ -524,6 +525,8 @@ __global__ __launch_bounds__(AP_THREADS) void in_apply_fwd_c8_kernel(const CoP p
     const unsigned short* zg = p.z8 + ((size_t)n * p.G8 + g) * p.HW * 8;
     unsigned short* ob = p.y8 + ((size_t)n * p.G8 + g) * p.HW * 8;
     float* yb = p.y ? p.y + (size_t)n * p.ybs + (size_t)(8 * g) * p.HW : nullptr;
+    // 16-bit planes: a thread owns two ADJACENT pixels, so that a channel's two values are one 4-byte store (uniform branch)
+    unsigned short* yh = p.y16 ? p.y16 + (size_t)n * p.ybs + (size_t)(8 * g) * p.HW : nullptr;
     if constexpr (POOL) {
         const int oW = p.W >> 1, oHW = p.HW >> 2;
         unsigned short* pb = p.py8 + ((size_t)n * p.G8 + g) * oHW * 8;
@@ -536,6 +539,7 @@ __global__ __launch_bounds__(AP_THREADS) void in_apply_fwd_c8_kernel(const CoP p
             for (int e = 0; e < 4; ++e) wz[e] = *reinterpret_cast<const co_u32x4*>(zg + pos[e] * 8);
             float best[8];
             unsigned code = 0;
+            co_u32x4 oprev = {0u, 0u, 0u, 0u};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 float v[8];
@@ -549,6 +553,15 @@ __global__ __launch_bounds__(AP_THREADS) void in_apply_fwd_c8_kernel(const CoP p
                 if (yb) {
 #pragma unroll
                     for (int c = 0; c < 8; ++c) yb[(size_t)c * p.HW + pos[e]] = v[c];
+                }
+                if (yh) {           // pieces 0|1 and 2|3 are neighbours in a row: halves c of the two pieces -> one dword
+                    if (e & 1) {
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) {
+                            const unsigned lo = (oprev[c >> 1] >> (16 * (c & 1))) & 0xffffu, hi = (o[c >> 1] >> (16 * (c & 1))) & 0xffffu;
+                            *reinterpret_cast<unsigned*>(yh + (size_t)c * p.HW + pos[e - 1]) = lo | (hi << 16);
+                        }
+                    } else oprev = o;
                 }
                 float r[8];
                 co_unpk<F16>(o, r);              // the stored values: what the pool compares
@@ -566,16 +579,18 @@ __global__ __launch_bounds__(AP_THREADS) void in_apply_fwd_c8_kernel(const CoP p
         }
         return;
     }
-    const int px0 = blockIdx.x * (AP_THREADS * AP_PPT) + threadIdx.x;
-    co_u32x4 w[AP_PPT];
+    static_assert(AP_PPT == 2, "the 16-bit planes pair a thread's two pixels");
+    const int pxb = blockIdx.x * (AP_THREADS * AP_PPT), pstep = yh ? 1 : AP_THREADS;
+    const int px0 = pxb + (yh ? 2 * (int)threadIdx.x : (int)threadIdx.x);
+    co_u32x4 w[AP_PPT], okeep = {0u, 0u, 0u, 0u};
 #pragma unroll
     for (int k = 0; k < AP_PPT; ++k) {
-        const int px = px0 + AP_THREADS * k;
+        const int px = px0 + pstep * k;
         if (px < p.HW) w[k] = *reinterpret_cast<const co_u32x4*>(zg + (size_t)px * 8);
     }
 #pragma unroll
     for (int k = 0; k < AP_PPT; ++k) {
-        const int px = px0 + AP_THREADS * k;
+        const int px = px0 + pstep * k;
         if (px >= p.HW) continue;
         float v[8];
         co_unpk<ZF16>(w[k], v);
@@ -588,6 +603,15 @@ __global__ __launch_bounds__(AP_THREADS) void in_apply_fwd_c8_kernel(const CoP p
         if (yb) {
 #pragma unroll
             for (int c = 0; c < 8; ++c) yb[(size_t)c * p.HW + px] = v[c];
+        }
+        if (yh) {           // H*W is even: both pixels of the pair are inside the plane
+            if (k == 1) {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const unsigned lo = (okeep[c >> 1] >> (16 * (c & 1))) & 0xffffu, hi = (o[c >> 1] >> (16 * (c & 1))) & 0xffffu;
+                    *reinterpret_cast<unsigned*>(yh + (size_t)c * p.HW + px - 1) = lo | (hi << 16);
+                }
+            } else okeep = o;
         }
     }
 }
@@ -723,6 +747,8 @@ int fill_coop(const mtbc_instnorm_args* a, CoP* p) {
     if ((p->r1 == nullptr) != (p->r1w == nullptr)) return MTBC_E_BADARG;
     p->pg = a->dy_pool; p->pa = reinterpret_cast<const unsigned short*>(a->dy_pool_arg); p->W = a->W;
     p->py8 = reinterpret_cast<unsigned short*>(a->pool_y8); p->parg = reinterpret_cast<unsigned short*>(a->pool_arg);
+    p->y16 = reinterpret_cast<unsigned short*>(a->y16);
+    if (p->y16) { p->y = nullptr; if ((a->H * a->W) % 8 || a->y_batch_stride % 8 || (reinterpret_cast<uintptr_t>(a->y16) & 15)) return MTBC_E_BADARG; }
     if ((p->pg == nullptr) != (p->pa == nullptr) || (p->pg && ((a->H | a->W) & 1))) return MTBC_E_BADARG;
     if (a->z_layout == MTBC_LAYOUT_C8) {
         if (reinterpret_cast<uintptr_t>(a->z) & 15) return MTBC_E_BADARG;
@@ -802,6 +828,7 @@ int mtbc_instnorm_c8_supported(const mtbc_instnorm_args* a, int32_t backward) {
 int mtbc_i_instnorm_fwd_c8(const mtbc_instnorm_args* a, hipStream_t st) {
     CoP p; int rc = fill_coop(a, &p); if (rc) return rc;
     if ((!p.z && !p.z8) || !p.y8 || !p.mean || !p.rstd || (reinterpret_cast<uintptr_t>(p.y8) & 15)) return MTBC_E_BADARG;
+    if (p.y16 && !a->stats_partial) return MTBC_E_UNSUPPORTED;       // 16-bit planes beside y8: the streaming pass only
     if (a->stats_partial) {         // statistics from the conv epilogue: finalize (one wave per plane) + one streaming pass
         if (!p.z8 || a->stats_slots <= 0) return MTBC_E_BADARG;
         const int planes = a->N * a->C;

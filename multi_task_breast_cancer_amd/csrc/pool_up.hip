@@ -390,7 +390,7 @@ int mtbc_convT_wgrad(const mtbc_convT_args* a, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     static const bool generic = mtbc_probe_set("MTBC_CONVT_GENERIC");      // A/B switch
     bool bias_done = false;
-    if (a->dy_type16 && !((a->compute == 1 || a->compute == 2) && mtbc_i_convT2_wgrad_ok(a))) return MTBC_E_UNSUPPORTED;      // 16-bit dY: the direct kernel or nothing
+    if ((a->dy_type16 || a->x_type16) && !((a->compute == 1 || a->compute == 2) && mtbc_i_convT2_wgrad_ok(a))) return MTBC_E_UNSUPPORTED;      // 16-bit dY / x: the direct kernel or nothing
     if ((!generic || a->dy_type16) && mtbc_i_convT2_wgrad_ok(a)) {
         int sps; mtbc_i_convT2_wgrad_plan(a, &sps, &nsplit);
         float* bpart = a->dbias ? p.partial + (size_t)nsplit * a->Cin * p.M : nullptr;

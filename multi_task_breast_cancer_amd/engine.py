@@ -29,6 +29,7 @@ _NO_P16 = _sw.flag("MTBC_NO_P16")
 _FANIN = _sw.flag("MTBC_FANIN")
 _NO_C8_SMALL = _sw.flag("MTBC_NO_C8_SMALL_OPS")
 _NO_G16 = _sw.flag("MTBC_NO_G16")
+_NO_X16 = _sw.flag("MTBC_NO_X16")
 _NO_Z16 = _sw.flag("MTBC_NO_Z16")
 _DA16 = _sw.flag("MTBC_DA16")
 _NO_EPI_STATS = _sw.flag("MTBC_NO_EPI_STATS")
@@ -62,6 +63,7 @@ class Act:
     c8: Optional[torch.Tensor] = None  # 16-bit channel-blocked copy [N][C/8][H*W][8] read by the 3x3 convs' MFMAs
     planar_valid: bool = True          # False: the producer wrote only `c8` (ConvT forward in the 16-bit modes)
     planar_used: bool = False          # some op reads `data` (pool, ConvT, 1x1 heads, GAP, a planar-staged conv)
+    p16_users: list = field(default_factory=list)      # ConvT weight-gradient ops that take 16-bit planes if nobody needs the fp32 ones
     c8_used: bool = False              # some 3x3 conv reads `c8`
     conv_consumers: int = 0            # 3x3 conv cells (16-bit, channel-blocked backward) that read this activation
     no_gather: bool = False            # ... and one that cannot take part in a gathered dgrad
@@ -794,17 +796,17 @@ class StepPlan:
         x.readers += 1
         y = self.new_act(out_name, cout, x.H * k, x.W * k)
 
-        def base() -> L.Op:
+        def base(reads_x: bool = True) -> L.Op:
             op = _mk(0)
             a = op.u.convT
             a.N, a.H, a.W, a.Cin, a.Cout, a.k = self.N, x.H, x.W, x.C, cout, k
-            a.x, a.x_batch_stride = self._rd(x), x.bstride
+            a.x, a.x_batch_stride = (self._rd(x) if reads_x else x.data.data_ptr()), x.bstride
             a.w = w.data_ptr()
             a.bias = _ptr(self.pv(bname)) if bname else None
             a.y, a.y_batch_stride = y.data.data_ptr(), y.bstride
             return op
 
-        op = base()
+        op = base(reads_x=False)
         op.kind = L.OP_CONVT_FWD
         if self.compute and not _NO_C8 and cout % 8 == 0:
             # 16-bit modes: the up-sampled tensor feeds 3x3 convs only -- write it straight into their channel-blocked
@@ -823,6 +825,8 @@ class StepPlan:
                     y.c8 = None
                     a.y, a.y_layout, a.y_type = y.data.data_ptr(), L.LAYOUT_PLANAR, 0
             y.planar_valid = y.c8 is None
+        if op.u.convT.x_layout != L.LAYOUT_C8:
+            op.u.convT.x = self._rd(x)
         self.fwd_ops.append(op)
         # 16-bit modes: the backward MFMAs of the k = 2 up-convolutions take rounded operands too (they are fp32-MFMA
         # bound otherwise); only where BOTH direct-to-fragment kernels of convt2.hip take the shape
@@ -839,7 +843,13 @@ class StepPlan:
             forked = x.needs_grad and self._overlap_ok(x.H * x.W)
             if forked:
                 self.fork_side()
-            op = base()
+            # x as 16-bit planes too, where the streaming InstanceNorm pass can write them beside the channel-blocked copy and
+            # nothing else wants fp32 planes of x (decided in _narrow_activations, once every reader is known)
+            x16 = (g16 and not _NO_X16 and x.in_op is not None and bool(x.in_op.u.inorm.y8) and x.in_op.u.inorm.stats_slots > 0
+                   and (x.H * x.W) % 8 == 0 and x.bstride % 8 == 0)
+            op = base(reads_x=not x16)
+            if x16:
+                x.p16_users.append(op)
             op.kind = L.OP_CONVT_WGRAD
             a = op.u.convT
             a.compute = lp
@@ -854,7 +864,7 @@ class StepPlan:
             if forked:
                 self.back_to_main()
             if x.needs_grad:
-                op = base()
+                op = base(reads_x=False)
                 op.kind = L.OP_CONVT_DGRAD
                 a = op.u.convT
                 a.compute = lp
@@ -1136,6 +1146,17 @@ class StepPlan:
             return
         for a in self.acts.values():
             hw = a.H * a.W
+            if a.p16_users:           # ConvT weight gradients that can take 16-bit planes: only if nobody reads the fp32 ones
+                if a.planar_used:
+                    for op in a.p16_users:
+                        op.u.convT.x = a.data.data_ptr()
+                else:
+                    y16 = self.alloc(a.N, a.C, a.H, a.W, dtype=torch.int16)
+                    a.in_op.u.inorm.y16, a.in_op.u.inorm.y = y16.data_ptr(), None
+                    for op in a.p16_users:
+                        op.u.convT.x, op.u.convT.x_type16 = y16.data_ptr(), self.compute
+                    a.planar_valid = False
+                    continue
             if a.in_op is not None and a.in_op.u.inorm.y8:          # cooperative kernel: drop the output nobody reads
                 if not a.c8_used and a.in_op.u.inorm.z_layout != L.LAYOUT_C8:      # (a channel-blocked z is read by the channel-group kernels only: they keep their output)
                     a.in_op.u.inorm.y8 = None

@@ -349,9 +349,10 @@ def coop_state(dev) -> torch.Tensor:
 
 
 def instnorm_lrelu_fwd_c8(z, gamma=None, beta=None, eps=1e-5, slope=0.01, compute: Optional[int] = None, want_planar: bool = False,
-                          stats: Optional[torch.Tensor] = None, want_pool: bool = False):
+                          stats: Optional[torch.Tensor] = None, want_pool: bool = False, planar16: bool = False):
     """InstanceNorm + LeakyReLU straight into the 16-bit channel-blocked layout (y8 of the C-ABI).  z: fp32 planes, or a
-    C8 tensor (z_layout = C8: the conv output of the 16-bit modes)."""
+    C8 tensor (z_layout = C8: the conv output of the 16-bit modes).  planar16 (with stats): the planar copy is an int16
+    (N,C,H,W) tensor of the output type (y16 beside y8)."""
     z8 = z if isinstance(z, C8) else None
     if compute is None:         # output type: given, else the type of a channel-blocked z, else bf16
         compute = z8.compute if z8 is not None else 1
@@ -360,12 +361,14 @@ def instnorm_lrelu_fwd_c8(z, gamma=None, beta=None, eps=1e-5, slope=0.01, comput
     N, Cc, H, W = z.shape
     dev = zt.device
     y8 = torch.empty(N, Cc // 8, H * W, 8, dtype=torch.int16, device=dev)
-    y = torch.empty(N, Cc, H, W, dtype=torch.float32, device=dev) if want_planar else None
+    y = torch.empty(N, Cc, H, W, dtype=torch.int16 if planar16 else torch.float32, device=dev) if (want_planar or planar16) else None
     mean = torch.empty(N * Cc, dtype=torch.float32, device=dev)
     rstd = torch.empty_like(mean)
     a = L.InstNormArgs()
     a.N, a.C, a.H, a.W, a.eps, a.slope = N, Cc, H, W, eps, slope
-    a.z, a.gamma, a.beta, a.y, a.y_batch_stride = zt.data_ptr(), _p(gamma), _p(beta), _p(y), Cc * H * W
+    a.z, a.gamma, a.beta, a.y, a.y_batch_stride = zt.data_ptr(), _p(gamma), _p(beta), (None if planar16 else _p(y)), Cc * H * W
+    if planar16:
+        a.y16 = y.data_ptr()
     a.z_layout = L.LAYOUT_C8 if z8 is not None else L.LAYOUT_PLANAR
     if z8 is not None and z8.compute != compute:
         a.z_type = z8.compute           # fp16 z with bf16 outputs
@@ -568,13 +571,15 @@ def convT_dgrad(x, w, dy, k, dx=None, accumulate=False, compute=0, dy16=False):
     return dx
 
 
-def convT_wgrad(x, w, dy, k, want_bias=True, compute=0, dy16=False):
-    _chk(x, w, None if dy16 else dy)
+def convT_wgrad(x, w, dy, k, want_bias=True, compute=0, dy16=False, x16=False):
+    """x16 (with dy16): x is an int16 (N,Cin,H,W) tensor of 16-bit planar values of the type of `compute` too."""
+    _chk(None if x16 else x, w, None if dy16 else dy)
     dw = torch.empty_like(w)
     db = torch.empty(w.shape[1], dtype=torch.float32, device=x.device) if want_bias else None
     a = _ct_args(x, w, k)
     a.compute = compute
     a.dy_type16 = compute if dy16 else 0
+    a.x_type16 = compute if x16 else 0
     a.dy, a.dy_batch_stride, a.dw, a.dbias = dy.data_ptr(), dy[0].numel(), dw.data_ptr(), _p(db)
     ws = _ws(L.load().mtbc_convT_wgrad_workspace(C.byref(a)), x.device)
     a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel() * 4

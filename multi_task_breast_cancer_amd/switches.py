@@ -24,6 +24,7 @@ PLAN_SWITCHES: Dict[str, tuple] = {
     "MTBC_FANIN": ("0", "private gradient fan-in buffers summed by InstanceNorm backward"),
     "MTBC_NOFUSE_HEADS": ("0", "MTnnUNet deep-supervision heads as ConvT + 1x1 (the reference's two layers) instead of one combined ConvT"),
     "MTBC_NO_C8_SMALL_OPS": ("0", "max-pool and the 1x1 heads keep reading fp32 planes in the 16-bit modes (InstanceNorm then writes them too)"),
+    "MTBC_NO_X16": ("0", "the input of a k = 2 ConvT stays available as fp32 planes for its weight gradient (else 16-bit planes written by the streaming InstanceNorm pass)"),
     "MTBC_NO_G16": ("0", "the gradient of an up-sampled (ConvT) tensor stays fp32 between the 3x3 conv's dgrad and the ConvT backward"),
     "MTBC_NO_Z16": ("0", "16-bit modes keep the conv outputs z as fp32 planes (InstanceNorm reads 4 bytes per element in both directions)"),
     "MTBC_DA16": ("0", "the gradient a conv-cell activation gets from ALL its 3x3 consumers is one gathered launch writing a 16-bit channel-blocked tensor instead of fp32 planar fan-in (no faster on this workload -- the norm backward that reads it is latency-bound -- and about 1 pt of held-out Dice in the 3000-step sweep: off)"),

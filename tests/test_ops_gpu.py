@@ -1094,3 +1094,57 @@ def test_streaming_instnorm_also_writes_the_maxpool(N, segs, Cout, H, W, compute
     assert torch.equal(y_a.data, y_b.data) and torch.equal(yp_a, yp_b) and torch.equal(mean_a, mean_b) and torch.equal(rstd_a, rstd_b)
     ref8, refarg = ops.maxpool2_fwd_c8(y_b, want_argmax=True)
     assert torch.equal(pool8.data, ref8.data) and torch.equal(parg, refarg)
+
+
+@pytest.mark.parametrize("compute", [1, 2])
+@pytest.mark.parametrize("pool", [False, True])
+@pytest.mark.parametrize("N,segs,Cout,H,W", [(2, [24], 24, 256, 256), (2, [48], 48, 128, 128), (3, [96], 96, 64, 64), (2, [32], 16, 16, 24),
+                                             (2, [192], 192, 8, 8)])
+def test_streaming_instnorm_writes_16bit_planes(N, segs, Cout, H, W, compute, pool):
+    """mtbc_instnorm_args.y16 beside y8: the planar copy of the activation as 16-bit planes of the output type = the fp32
+    planes rounded once (RNE) = the values of the channel-blocked copy, bit for bit; y8 / statistics / pooled outputs as
+    without it."""
+    g = _g(N * 37 + Cout + H + compute)
+    Cin = sum(segs)
+    dt = torch.bfloat16 if compute == 1 else torch.float16
+    xs = [(torch.randn(N, c, H, W, generator=g) + 0.3).to(DEV) for c in segs]
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (9 * Cin)) ** 0.5).to(DEV)
+    gamma, beta = (torch.rand(Cout, generator=g) + 0.5).to(DEV), (torch.randn(Cout, generator=g) * 0.1).to(DEV)
+    pf, _ = ops.conv3x3_pack_lp(w, compute)
+    z8, part = ops.conv3x3_fwd_c8([ops.C8.pack(x, compute) for x in xs], w, None, pf, out_c8=True, stats=True)
+    ref = ops.instnorm_lrelu_fwd_c8(z8, gamma, beta, slope=0.1, stats=part, want_planar=True, want_pool=pool)
+    got = ops.instnorm_lrelu_fwd_c8(z8, gamma, beta, slope=0.1, stats=part, planar16=True, want_pool=pool)
+    assert torch.equal(got[0].data, ref[0].data) and torch.equal(got[1], ref[1]) and torch.equal(got[2], ref[2])
+    assert got[3].dtype == torch.int16 and torch.equal(got[3].view(dt), ref[3].to(dt))
+    assert torch.equal(got[3].view(dt).float(), got[0].unpack())
+    if pool:
+        assert torch.equal(got[4].data, ref[4].data) and torch.equal(got[5], ref[5])
+
+
+def test_instnorm_16bit_planes_need_the_streaming_pass():
+    """y16 beside y8 without conv-epilogue statistics is refused (MTBC_E_UNSUPPORTED), not silently ignored."""
+    from multi_task_breast_cancer_amd import _lib as L
+    z = torch.randn(2, 16, 16, 16, generator=_g(5)).to(DEV)
+    with pytest.raises(L.MtbcError):
+        ops.instnorm_lrelu_fwd_c8(z, compute=1, planar16=True)
+
+
+@pytest.mark.parametrize("compute", [1, 2])
+@pytest.mark.parametrize("N,Cin,Cout,H,W", [(2, 48, 48, 32, 32), (3, 96, 48, 8, 16), (1, 384, 192, 8, 8), (2, 40, 24, 16, 8), (32, 96, 48, 64, 64)])
+def test_convT_wgrad_reads_16bit_planar_x(N, Cin, Cout, H, W, compute):
+    """x_type16: the k = 2 ConvT weight gradient on 16-bit planes of x (and dy) = the same kernel fed the fp32 tensors with the
+    same (representable) values, bit for bit; fp32 x that is NOT representable gives the same result as its rounded planes."""
+    from multi_task_breast_cancer_amd import _lib as L
+    g = _g(N + Cin + Cout + H + compute)
+    dt = torch.bfloat16 if compute == 1 else torch.float16
+    x = torch.randn(N, Cin, H, W, generator=g).to(DEV)
+    w = (torch.randn(Cin, Cout, 2, 2, generator=g) * 0.1).to(DEV)
+    dy16 = torch.randn(N, Cout, 2 * H, 2 * W, generator=g).to(DEV).to(dt)
+    x16 = x.to(dt)
+    dw_ref, db_ref = ops.convT_wgrad(x, w, dy16.view(torch.int16), 2, compute=compute, dy16=True)
+    dw, db = ops.convT_wgrad(x16.view(torch.int16), w, dy16.view(torch.int16), 2, compute=compute, dy16=True, x16=True)
+    assert torch.equal(dw, dw_ref) and torch.equal(db, db_ref)
+    want = torch.einsum("nchw,ndhawb->cdab", x16.double().cpu(), dy16.double().cpu().view(N, Cout, H, 2, W, 2))
+    assert (dw.cpu().double() - want).abs().max().item() <= 1e-4 * max(1.0, want.abs().max().item())
+    with pytest.raises(L.MtbcError):        # 16-bit x with an fp32 dy: no kernel, refused
+        ops.convT_wgrad(x16.view(torch.int16), w, dy16.float(), 2, compute=compute, x16=True)
