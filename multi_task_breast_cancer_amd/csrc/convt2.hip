@@ -19,6 +19,7 @@
 // while the current step is multiplied.  (The generic 64x64 LDS GEMM in pool_up.hip gathered dY 8 bytes at a time:
 // 26 TF on wgrad, 41 TF on dgrad.)  That kernel remains the fallback for k = 4, 8 and for odd shapes.
 #include "common.h"
+#include <utility>
 
 namespace {
 
@@ -87,6 +88,10 @@ struct Ct2P {
 
 struct S0 { static constexpr int value = 0; };
 struct S1 { static constexpr int value = 1; };
+// compile-time loop: f(slot constant) for 0 .. N-1 (register-set indices must be constants, see below)
+template <int I> struct SC { static constexpr int value = I; };
+template <typename F, int... Is> __device__ __forceinline__ void sfor_impl(F&& f, std::integer_sequence<int, Is...>) { (f(SC<Is>{}), ...); }
+template <int N, typename F> __device__ __forceinline__ void sfor(F&& f) { sfor_impl(f, std::make_integer_sequence<int, N>{}); }
 constexpr int MT = 3;                  // 16-row tiles of input channels per wave (48 = the U-Net++ channel quantum)
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
@@ -98,10 +103,12 @@ __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast
 // DY16: dY is a 16-bit planar tensor of the MFMA's own type (written by the 3x3 conv's dgrad, mtbc_seg.accumulate = 2): the
 // four values of an output row that the fp32 form loads as one float4 and converts are ONE 8-byte load whose two dwords
 // are the fragment words of the even / odd pixel as they stand -- half the bytes, no conversion, same MFMA operands.
-template <int LP, bool DY16 = false>
+// D register sets = D - 1 steps of loads in flight: the deep levels have a few waves per SIMD, each with a long chain of steps
+// (Cout / 8 = 12 .. 24), and one step of prefetch leaves every step waiting for the L2.
+template <int LP, bool DY16 = false, int D = 2>
 __global__ __launch_bounds__(256) void convT2_dgrad_kernel(const Ct2P p) {
     static_assert(!DY16 || LP != 0, "a 16-bit dY feeds the 16-bit MFMA");
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // (scalar: the task's indices and branches are wave-uniform)
     const int j = lane & 15, kg = lane >> 4;
     const long long task = (long long)blockIdx.x * 4 + wv;
     if (task >= p.ntasks) return;
@@ -128,8 +135,8 @@ __global__ __launch_bounds__(256) void convT2_dgrad_kernel(const Ct2P p) {
 
     const int nsteps = (p.Cout + 7) / 8;
     // two register sets with COMPILE-TIME slot numbers (a runtime slot index would put the arrays in scratch)
-    float4 ra[2][MT][2], rb[2][4];
-    uint2 rh[2][4];                          // DY16: (row a, channel c) -> {even pixel (b0,b1), odd pixel (b0,b1)}
+    float4 ra[D][MT][2], rb[DY16 ? 1 : D][4];
+    uint2 rh[DY16 ? D : 1][4];               // DY16: (row a, channel c) -> {even pixel (b0,b1), odd pixel (b0,b1)}
     auto load = [&](int s, auto SL) {       // issue only; masking happens at use
         constexpr int slot = decltype(SL)::value;
         const int c0 = 8 * s + 2 * kg;
@@ -154,11 +161,12 @@ __global__ __launch_bounds__(256) void convT2_dgrad_kernel(const Ct2P p) {
         constexpr int cur = decltype(SL)::value;
         const int c0 = 8 * s + 2 * kg;
         const bool ok0 = c0 < p.Cout, ok1 = c0 + 1 < p.Cout;
+        constexpr int cb = DY16 ? 0 : cur;       // (the fp32 registers do not exist with a 16-bit dY)
         float e[8], o[8];
-        e[0] = ok0 ? rb[cur][0].x : 0.f; e[1] = ok0 ? rb[cur][0].y : 0.f; e[2] = ok0 ? rb[cur][1].x : 0.f; e[3] = ok0 ? rb[cur][1].y : 0.f;
-        e[4] = ok1 ? rb[cur][2].x : 0.f; e[5] = ok1 ? rb[cur][2].y : 0.f; e[6] = ok1 ? rb[cur][3].x : 0.f; e[7] = ok1 ? rb[cur][3].y : 0.f;
-        o[0] = ok0 ? rb[cur][0].z : 0.f; o[1] = ok0 ? rb[cur][0].w : 0.f; o[2] = ok0 ? rb[cur][1].z : 0.f; o[3] = ok0 ? rb[cur][1].w : 0.f;
-        o[4] = ok1 ? rb[cur][2].z : 0.f; o[5] = ok1 ? rb[cur][2].w : 0.f; o[6] = ok1 ? rb[cur][3].z : 0.f; o[7] = ok1 ? rb[cur][3].w : 0.f;
+        e[0] = ok0 ? rb[cb][0].x : 0.f; e[1] = ok0 ? rb[cb][0].y : 0.f; e[2] = ok0 ? rb[cb][1].x : 0.f; e[3] = ok0 ? rb[cb][1].y : 0.f;
+        e[4] = ok1 ? rb[cb][2].x : 0.f; e[5] = ok1 ? rb[cb][2].y : 0.f; e[6] = ok1 ? rb[cb][3].x : 0.f; e[7] = ok1 ? rb[cb][3].y : 0.f;
+        o[0] = ok0 ? rb[cb][0].z : 0.f; o[1] = ok0 ? rb[cb][0].w : 0.f; o[2] = ok0 ? rb[cb][1].z : 0.f; o[3] = ok0 ? rb[cb][1].w : 0.f;
+        o[4] = ok1 ? rb[cb][2].z : 0.f; o[5] = ok1 ? rb[cb][2].w : 0.f; o[6] = ok1 ? rb[cb][3].z : 0.f; o[7] = ok1 ? rb[cb][3].w : 0.f;
         Frag<LP> fe, fo;
         if constexpr (DY16) {
             frag_from_words<LP>(fe, ok0 ? rh[cur][0].x : 0u, ok0 ? rh[cur][1].x : 0u, ok1 ? rh[cur][2].x : 0u, ok1 ? rh[cur][3].x : 0u);
@@ -176,17 +184,30 @@ __global__ __launch_bounds__(256) void convT2_dgrad_kernel(const Ct2P p) {
             acc[m][1] = Frag<LP>::mma(fa, fo, acc[m][1]);
         }
     };
-    load(0, S0{});
-    for (int s = 0; s < nsteps; s += 2) {
-        if (s + 1 < nsteps) load(s + 1, S1{});
-        compute(s, S0{});
-        if (s + 1 < nsteps) {
-            if (s + 2 < nsteps) load(s + 2, S0{});
-            compute(s + 1, S1{});
-        }
-    }
+    // Step t lives in register set t % D.  The main loop has NO branch around a load (past the end it re-loads the last step into a
+    // set nobody reads): with conditional loads the compiler's wait-count pass gave up and waited for ALL loads, the ones just issued
+    // included, before the first MFMA of every round -- there was no prefetch at all.
+    const int last = nsteps - 1;
+    sfor<D - 1>([&](auto U) { load(min((int)U.value, last), U); });
+    int s = 0;
+    for (; s + D <= nsteps; s += D)
+        sfor<D>([&](auto U) {
+            constexpr int u = decltype(U)::value;
+            load(min(s + u + D - 1, last), SC<(u + D - 1) % D>{});
+            __builtin_amdgcn_sched_barrier(0);        // (the scheduler otherwise sinks the loads below the MFMAs that do not depend on them)
+            compute(s + u, U);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    sfor<D - 1>([&](auto U) { if (s + U.value < nsteps) compute(s + U.value, U); });      // the loads of the last < D steps are in flight
     // rows kg*4 + r of tile m, column j -> pixels (2j, 2j+1): one float2 per row
     float* dxn = p.dx + (size_t)n * p.dxbs + g * 32 + 2 * j;
+    float2 old[MT][4];
+    if (p.acc_dx) {         // all twelve loads of the read-modify-write in flight at once (rows past Cin re-read the last row)
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) old[m][r] = *reinterpret_cast<const float2*>(dxn + (size_t)min(mb * 48 + m * 16 + kg * 4 + r, p.Cin - 1) * HW);
+    }
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -195,7 +216,7 @@ __global__ __launch_bounds__(256) void convT2_dgrad_kernel(const Ct2P p) {
             if (ci >= p.Cin) continue;
             float2* d = reinterpret_cast<float2*>(dxn + (size_t)ci * HW);
             float2 v = make_float2(acc[m][0][r], acc[m][1][r]);
-            if (p.acc_dx) { const float2 old = *d; v.x += old.x; v.y += old.y; }
+            if (p.acc_dx) { v.x += old[m][r].x; v.y += old[m][r].y; }
             *d = v;
         }
 }
@@ -209,10 +230,10 @@ __global__ __launch_bounds__(256) void convT2_dgrad_kernel(const Ct2P p) {
 // X16: x is a 16-bit planar tensor of the MFMA's own type too (the InstanceNorm forward writes it beside the channel-blocked copy
 // for exactly this reader): 8 consecutive pixels of a channel are ONE 16-byte load that IS the fragment -- half the bytes of the fp32
 // planes written by the norm and read here, no conversion, same MFMA operands.
-template <int LP, bool DY16 = false, bool X16 = false>
+template <int LP, bool DY16 = false, bool X16 = false, int D = 2>
 __global__ __launch_bounds__(256) void convT2_wgrad_kernel(const Ct2P p) {
     static_assert((!DY16 && !X16) || LP != 0, "16-bit tensors feed the 16-bit MFMA");
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // (scalar: the task's indices and branches are wave-uniform)
     const int j = lane & 15, kg = lane >> 4;
     const long long task = (long long)blockIdx.x * 4 + wv;
     if (task >= p.ntasks) return;
@@ -244,9 +265,9 @@ __global__ __launch_bounds__(256) void convT2_wgrad_kernel(const Ct2P p) {
 
     const bool want_bias = p.dbias_part != nullptr && mb == 0;      // uniform
     float bsum = 0.f;
-    float4 ra[2][X16 ? 1 : MT][2], rb[2][4];
-    ct_u32x4 rx[2][X16 ? MT : 1];            // X16: 4 dwords = 8 consecutive pixels of one channel = the A fragment
-    ct_u32x4 rh[2][2];                       // DY16: 8 dwords = 8 pixels, each {b0, b1}
+    float4 ra[X16 ? 1 : D][X16 ? 1 : MT][2], rb[DY16 ? 1 : D][4];
+    ct_u32x4 rx[X16 ? D : 1][X16 ? MT : 1];  // X16: 4 dwords = 8 consecutive pixels of one channel = the A fragment
+    ct_u32x4 rh[DY16 ? D : 1][2];            // DY16: 8 dwords = 8 pixels, each {b0, b1}
     auto load = [&](int g, auto SL) {
         constexpr int slot = decltype(SL)::value;
         const int n = g / steps_per_img, st = g % steps_per_img;
@@ -322,14 +343,19 @@ __global__ __launch_bounds__(256) void convT2_wgrad_kernel(const Ct2P p) {
             }
         }
     };
-    if (g0 < g1) load(g0, S0{});
-    for (int g = g0; g < g1; g += 2) {
-        if (g + 1 < g1) load(g + 1, S1{});
-        compute(S0{});
-        if (g + 1 < g1) {
-            if (g + 2 < g1) load(g + 2, S0{});
-            compute(S1{});
-        }
+    if (g0 < g1) {          // (as in the dgrad: no branch around a load; step g0 + t lives in register set t % D)
+        const int last = g1 - 1;
+        sfor<D - 1>([&](auto U) { load(min(g0 + (int)U.value, last), U); });
+        int g = g0;
+        for (; g + D <= g1; g += D)
+            sfor<D>([&](auto U) {
+                constexpr int u = decltype(U)::value;
+                load(min(g + u + D - 1, last), SC<(u + D - 1) % D>{});
+                __builtin_amdgcn_sched_barrier(0);
+                compute(U);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        sfor<D - 1>([&](auto U) { if (g + U.value < g1) compute(U); });
     }
     if (want_bias) {                       // lanes (co, a) x 4 pixel groups -> one value per channel, fixed shuffle tree
         bsum += __shfl_xor(bsum, 16);
@@ -347,6 +373,132 @@ __global__ __launch_bounds__(256) void convT2_wgrad_kernel(const Ct2P p) {
             if (ci >= p.Cin) continue;
             *reinterpret_cast<float2*>(part + ((size_t)ci * p.Cout + co) * 4 + 2 * (j & 1)) = make_float2(acc[m][0][r], acc[m][1][r]);
         }
+}
+
+// The weight gradient with BOTH tensors as 16-bit planes (the 16-bit modes' product path), CT tiles of 8 output channels per wave:
+// every x fragment a wave loads is multiplied with 2 CT dY fragments instead of 2, i.e. x travels L2 -> registers Cout / (8 CT)
+// times instead of Cout / 8 (with CT = 1 this is convT2_wgrad_kernel<LP, true, true, D>, and the results are the same bit for
+// bit: the same products are summed in the same order, only on another wave).  No branch around a load, D register sets.
+template <int LP, int CT, int D>
+__global__ __launch_bounds__(256) void convT2_wgrad16_kernel(const Ct2P p) {
+    static_assert(LP != 0, "16-bit operands");
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 15, kg = lane >> 4;
+    const long long task = (long long)blockIdx.x * 4 + wv;
+    if (task >= p.ntasks) return;
+    const int HW = p.H * p.W, oW = 2 * p.W;
+    const int steps_per_img = HW / 32;
+    const int ctw = (p.ctiles + CT - 1) / CT;                 // wave tiles along the output channels
+    const int ct = (int)(task % ctw);
+    const long long t = task / ctw;
+    const int mb = (int)(t % p.mblocks), split = (int)(t / p.mblocks);
+    const int total_steps = p.N * steps_per_img;
+    const int g0 = split * p.steps_per_split, g1 = min(total_steps, g0 + p.steps_per_split);
+    bool rok[MT];
+    const unsigned short* xrow[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int ci = mb * 48 + m * 16 + j;
+        rok[m] = ci < p.Cin;
+        xrow[m] = reinterpret_cast<const unsigned short*>(p.x) + (size_t)(rok[m] ? ci : 0) * HW + 8 * kg;
+    }
+    int co[CT]; bool cok[CT];
+    const unsigned short* dcol[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+        co[c] = (ct * CT + c) * 8 + (j >> 1);
+        cok[c] = co[c] < p.Cout;
+        dcol[c] = reinterpret_cast<const unsigned short*>(p.dy) + (size_t)(cok[c] ? co[c] : 0) * 4 * HW + (size_t)(j & 1) * oW;
+    }
+    f32x4 acc[CT][MT][2];
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) { acc[c][m][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[c][m][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    const bool want_bias = p.dbias_part != nullptr && mb == 0;      // uniform
+    float bsum[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) bsum[c] = 0.f;
+    ct_u32x4 rx[D][MT], rh[D][CT][2];
+    auto load = [&](int g, auto SL) {
+        constexpr int slot = decltype(SL)::value;
+        const int n = g / steps_per_img, st = g % steps_per_img;
+        const int pix = st * 32 + 8 * kg;
+        const int i = pix / p.W, jx = pix % p.W;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) rx[slot][m] = *reinterpret_cast<const ct_u32x4*>(xrow[m] + (size_t)n * p.xbs + st * 32);
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            const unsigned short* q = dcol[c] + (size_t)n * p.dybs + (size_t)(2 * i) * oW + 2 * jx;
+            rh[slot][c][0] = *reinterpret_cast<const ct_u32x4*>(q); rh[slot][c][1] = *reinterpret_cast<const ct_u32x4*>(q + 8);
+        }
+    };
+    auto compute = [&](auto SL) {
+        constexpr int cur = decltype(SL)::value;
+        Frag<LP> fa[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const ct_u32x4 w = rx[cur][m];
+            frag_from_words<LP>(fa[m], rok[m] ? w[0] : 0u, rok[m] ? w[1] : 0u, rok[m] ? w[2] : 0u, rok[m] ? w[3] : 0u);
+        }
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            unsigned d[8], w0[4], w1[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { d[k] = cok[c] ? rh[cur][c][0][k] : 0u; d[4 + k] = cok[c] ? rh[cur][c][1][k] : 0u; }
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                w0[m] = (d[2 * m] & 0xffffu) | (d[2 * m + 1] << 16);
+                w1[m] = (d[2 * m] >> 16) | (d[2 * m + 1] & 0xffff0000u);
+            }
+            if (want_bias) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) bsum[c] += sum2_16<LP>(d[k]);
+            }
+            Frag<LP> f0, f1;
+            frag_from_words<LP>(f0, w0[0], w0[1], w0[2], w0[3]);
+            frag_from_words<LP>(f1, w1[0], w1[1], w1[2], w1[3]);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                acc[c][m][0] = Frag<LP>::mma(fa[m], f0, acc[c][m][0]);
+                acc[c][m][1] = Frag<LP>::mma(fa[m], f1, acc[c][m][1]);
+            }
+        }
+    };
+    if (g0 < g1) {
+        const int last = g1 - 1;
+        sfor<D - 1>([&](auto U) { load(min(g0 + (int)U.value, last), U); });
+        int g = g0;
+        for (; g + D <= g1; g += D)
+            sfor<D>([&](auto U) {
+                constexpr int u = decltype(U)::value;
+                load(min(g + u + D - 1, last), SC<(u + D - 1) % D>{});
+                __builtin_amdgcn_sched_barrier(0);
+                compute(U);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        sfor<D - 1>([&](auto U) { if (g + U.value < g1) compute(U); });
+    }
+    float* part = p.partial + (size_t)split * p.Cin * p.Cout * 4;
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+        if (want_bias) {                   // lanes (co, a) x 4 pixel groups -> one value per channel, fixed shuffle tree
+            float b = bsum[c];
+            b += __shfl_xor(b, 16);
+            b += __shfl_xor(b, 32);
+            b += __shfl_xor(b, 1);
+            if (kg == 0 && (j & 1) == 0 && cok[c]) p.dbias_part[(size_t)split * p.Cout + co[c]] = b;
+        }
+        if (!cok[c]) continue;
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ci = mb * 48 + m * 16 + kg * 4 + r;
+                if (ci >= p.Cin) continue;
+                *reinterpret_cast<float2*>(part + ((size_t)ci * p.Cout + co[c]) * 4 + 2 * (j & 1)) = make_float2(acc[c][m][0][r], acc[c][m][1][r]);
+            }
+    }
 }
 
 // ------------------------------------------------------------------ forward, weights resident in LDS (small Cin)
@@ -550,12 +702,29 @@ __global__ __launch_bounds__(256, 2) void convT2_fwd_lp_c8_kernel(const Ct2P p, 
     // order (consecutive threads = consecutive floats), scatter the 16-bit values into the LDS rows.  (Reading it in LDS
     // order -- ci fastest -- made every load a 4-byte access at a stride of 4 * Cout floats: 40 us of the 65 us the
     // 384 -> 192 up-convolution took.)
-    for (int idx = tid; idx < 4 * CB * kpad; idx += 256) {
-        const int r = idx % (4 * CB), ci = idx / (4 * CB), c = r >> 2, pos = r & 3, co = cb0 + c;
-        const float w = (ci < p.Cin && co < p.Cout) ? p.w[((size_t)ci * p.Cout + co) * 4 + pos] : 0.f;
-        unsigned short h;
-        if constexpr (F16) h = __builtin_bit_cast(unsigned short, (_Float16)w); else h = __builtin_bit_cast(unsigned short, (__bf16)w);
-        Wl[(pos * CB + c) * wrow + ci] = h;
+    // One (ci, channel) pair = the 4 positions = one 16-byte load and four 16-bit LDS stores, 8 loads in flight per thread: a block
+    // has only a handful of pixel tasks on the deep levels, so a prologue of 96 dependent {4-byte load, convert, store} rounds WAS the
+    // launch (43 us for 2 us of MFMA work).
+    const int npairs = CB * kpad;
+    for (int base = tid; base < npairs; base += 256 * 8) {
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int idx = base + 256 * u, c = idx % CB, ci = idx / CB, co = cb0 + c;
+            v[u] = (idx < npairs && ci < p.Cin && co < p.Cout) ? ld4(p.w + ((size_t)ci * p.Cout + co) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int idx = base + 256 * u, c = idx % CB, ci = idx / CB;
+            if (idx >= npairs) continue;
+            const float e[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+            for (int pos = 0; pos < 4; ++pos) {
+                unsigned short h;
+                if constexpr (F16) h = __builtin_bit_cast(unsigned short, (_Float16)e[pos]); else h = __builtin_bit_cast(unsigned short, (__bf16)e[pos]);
+                Wl[(pos * CB + c) * wrow + ci] = h;
+            }
+        }
     }
     for (int c = tid; c < CB; c += 256) bias_s[c] = (bias && cb0 + c < p.Cout) ? bias[cb0 + c] : 0.f;
     __syncthreads();
@@ -627,6 +796,110 @@ __global__ __launch_bounds__(256, 2) void convT2_fwd_lp_c8_kernel(const Ct2P p, 
                 }
             }
         }
+    }
+}
+
+// Input gradient with the weights of the block's 48 input channels resident in LDS (16-bit dY only).  convT2_dgrad_kernel above
+// re-loads every weight it multiplies from L2 -- 48 x 4Cout fp32 values per 32-pixel task, three times the bytes of the dY the task
+// reads, as fragment-shaped loads (16 rows x 128 bytes per instruction) -- and on the deep levels (a few thousand pixels, hundreds of
+// channels) that load path was the whole launch: 48 us for 4 us of MFMA work, the same at every level because pixels x Cin x Cout
+// is.  Here a block converts its slice [48][4Cout] once (memory order = LDS row order: two 16-byte loads, one ds_write_b128 per
+// piece; row stride = 2 mod 4 pieces, conflict-free ds_read_b128), then its waves walk pixel tasks: A fragments from LDS, dY
+// straight into B fragments as before, D register sets of dY in flight.  Same MFMA operands in the same order as the kernel above:
+// bit-identical results.
+template <int LP, int D>
+__global__ __launch_bounds__(256, 2) void convT2_dgrad_lds_kernel(const Ct2P p, const int wrow) {
+    static_assert(LP != 0, "16-bit operands");
+    extern __shared__ __attribute__((aligned(16))) unsigned short Wd[];          // [48][wrow]
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 15, kg = lane >> 4;
+    const int mb = blockIdx.y;
+    const int HW = p.H * p.W, oW = 2 * p.W, M4 = 4 * p.Cout;
+    const int ppr = M4 / 8, npieces = 48 * ppr;
+    for (int base = tid; base < npieces; base += 256 * 4) {
+        float4 v[4][2];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int idx = min(base + 256 * u, npieces - 1), r = idx / ppr, q = idx - r * ppr;
+            const float* src = p.w + (size_t)min(mb * 48 + r, p.Cin - 1) * M4 + 8 * q;
+            v[u][0] = ld4(src); v[u][1] = ld4(src + 4);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int idx = base + 256 * u;
+            if (idx >= npieces) continue;
+            const int r = idx / ppr, q = idx - r * ppr;
+            ct_u32x4 o = {cvt_pk16<LP == 2>(v[u][0].x, v[u][0].y), cvt_pk16<LP == 2>(v[u][0].z, v[u][0].w),
+                          cvt_pk16<LP == 2>(v[u][1].x, v[u][1].y), cvt_pk16<LP == 2>(v[u][1].z, v[u][1].w)};
+            if (mb * 48 + r >= p.Cin) o = (ct_u32x4){0u, 0u, 0u, 0u};
+            *reinterpret_cast<ct_u32x4*>(Wd + (size_t)r * wrow + 8 * q) = o;
+        }
+    }
+    __syncthreads();
+    const int groups = HW / 32, nsteps = p.Cout / 8, last = nsteps - 1;
+    const long long ntasks = (long long)p.N * groups;
+    const unsigned short* arow = Wd + (size_t)j * wrow + 8 * kg;
+    for (long long gi = (long long)blockIdx.x * 4 + wv; gi < ntasks; gi += (long long)gridDim.x * 4) {
+        const int n = (int)(gi / groups), g = (int)(gi % groups);
+        const int pix = g * 32 + 2 * j;
+        const int i = pix / p.W, jx = pix % p.W;
+        const unsigned short* dyn16 = reinterpret_cast<const unsigned short*>(p.dy) + (size_t)n * p.dybs + (size_t)(2 * i) * oW + 2 * jx +
+                                      (size_t)(2 * kg) * 4 * HW;
+        f32x4 acc[MT][2];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) { acc[m][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[m][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+        uint2 rh[D][4];                       // (channel c, row a) -> {even pixel (b0,b1), odd pixel (b0,b1)}
+        auto load = [&](int s, auto SL) {
+            constexpr int slot = decltype(SL)::value;
+            const unsigned short* q = dyn16 + (size_t)(8 * s) * 4 * HW;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                rh[slot][2 * c] = *reinterpret_cast<const uint2*>(q + (size_t)c * 4 * HW);
+                rh[slot][2 * c + 1] = *reinterpret_cast<const uint2*>(q + (size_t)c * 4 * HW + oW);
+            }
+        };
+        auto compute = [&](int s, auto SL) {
+            constexpr int cur = decltype(SL)::value;
+            Frag<LP> fe, fo;
+            frag_from_words<LP>(fe, rh[cur][0].x, rh[cur][1].x, rh[cur][2].x, rh[cur][3].x);
+            frag_from_words<LP>(fo, rh[cur][0].y, rh[cur][1].y, rh[cur][2].y, rh[cur][3].y);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                Frag<LP> fa;
+                fa.v = __builtin_bit_cast(decltype(fa.v), *reinterpret_cast<const ct_u32x4*>(arow + (size_t)(m * 16) * wrow + 32 * s));
+                acc[m][0] = Frag<LP>::mma(fa, fe, acc[m][0]);
+                acc[m][1] = Frag<LP>::mma(fa, fo, acc[m][1]);
+            }
+        };
+        sfor<D - 1>([&](auto U) { load(min((int)U.value, last), U); });
+        int s = 0;
+        for (; s + D <= nsteps; s += D)
+            sfor<D>([&](auto U) {
+                constexpr int u = decltype(U)::value;
+                load(min(s + u + D - 1, last), SC<(u + D - 1) % D>{});
+                __builtin_amdgcn_sched_barrier(0);
+                compute(s + u, U);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        sfor<D - 1>([&](auto U) { if (s + U.value < nsteps) compute(s + U.value, U); });
+        float* dxn = p.dx + (size_t)n * p.dxbs + g * 32 + 2 * j;
+        float2 old[MT][4];
+        if (p.acc_dx) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) old[m][r] = *reinterpret_cast<const float2*>(dxn + (size_t)min(mb * 48 + m * 16 + kg * 4 + r, p.Cin - 1) * HW);
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ci = mb * 48 + m * 16 + kg * 4 + r;
+                if (ci >= p.Cin) continue;
+                float2 v = make_float2(acc[m][0][r], acc[m][1][r]);
+                if (p.acc_dx) { v.x += old[m][r].x; v.y += old[m][r].y; }
+                *reinterpret_cast<float2*>(dxn + (size_t)ci * HW) = v;
+            }
     }
 }
 
@@ -740,7 +1013,7 @@ static int lp_c8_mtc(const mtbc_convT_args* a, int* kpad, int* wrow, size_t* lds
 bool mtbc_i_convT2_fwd_lp_c8_ok(const mtbc_convT_args* a) {
     int kpad, wrow; size_t lds;
     return a->k == 2 && (a->H * a->W) % 32 == 0 && a->Cin % 8 == 0 && a->Cout % 8 == 0 && (a->y_type == 1 || a->y_type == 2) &&
-           al16(a->y) && al16(a->x) && a->y_batch_stride % 8 == 0 && a->x_batch_stride % 8 == 0 && lp_c8_mtc(a, &kpad, &wrow, &lds) > 0;
+           al16(a->y) && al16(a->x) && al16(a->w) && a->y_batch_stride % 8 == 0 && a->x_batch_stride % 8 == 0 && lp_c8_mtc(a, &kpad, &wrow, &lds) > 0;
 }
 int mtbc_i_convT2_fwd_lp_c8(const mtbc_convT_args* a, hipStream_t st) {
     Ct2P p; fill(a, &p);
@@ -772,9 +1045,31 @@ int mtbc_i_convT2_dgrad(const mtbc_convT_args* a, int compute, hipStream_t st) {
     Ct2P p; fill(a, &p);
     p.ntasks = (long long)p.mblocks * a->N * (a->H * a->W / 32);
     const unsigned blocks = (unsigned)cdiv64(p.ntasks, 4);
+    static const bool no_lds = mtbc_probe_set("MTBC_CT_DGRAD_DIRECT");      // A/B: the direct kernel for every shape
+    const int wrow = 4 * a->Cout + 16;
+    const size_t lds = (size_t)48 * wrow * 2;
+    if (a->dy_type16 && !no_lds && a->Cout % 8 == 0 && lds <= 80 * 1024) {      // weights of the block's 48 input channels in LDS
+        const long long tasks = (long long)a->N * (a->H * a->W / 32);
+        int gx = 512 / p.mblocks; if (gx < 1) gx = 1;
+        if ((long long)gx * 4 > tasks) gx = (int)cdiv64(tasks, 4);
+        const dim3 grid(gx, p.mblocks);
+#define MTBC_CT2DG(LP_, D_)                                                                                              \
+        do {                                                                                                             \
+            static bool attr = false;                                                                                    \
+            if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&convT2_dgrad_lds_kernel<LP_, D_>),     \
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); attr = true; } \
+            hipLaunchKernelGGL((convT2_dgrad_lds_kernel<LP_, D_>), grid, dim3(256), lds, st, p, wrow);                   \
+        } while (0)
+        if (compute == 1) MTBC_CT2DG(1, 4); else MTBC_CT2DG(2, 4);
+#undef MTBC_CT2DG
+        MTBC_CHECK_LAUNCH();
+        return MTBC_OK;
+    }
+    static const int depth_env = mtbc_probe_int("MTBC_CT_DEPTH", 0);      // A/B: register sets (2 | 4), 0 = by shape
+    const bool deep = depth_env ? depth_env >= 4 : a->Cout >= 96;          // long step chains, few waves: three steps of loads in flight
     if (a->dy_type16) {
-        if (compute == 1) hipLaunchKernelGGL((convT2_dgrad_kernel<1, true>), dim3(blocks), dim3(256), 0, st, p);
-        else hipLaunchKernelGGL((convT2_dgrad_kernel<2, true>), dim3(blocks), dim3(256), 0, st, p);
+        if (compute == 1) { if (deep) hipLaunchKernelGGL((convT2_dgrad_kernel<1, true, 4>), dim3(blocks), dim3(256), 0, st, p); else hipLaunchKernelGGL((convT2_dgrad_kernel<1, true>), dim3(blocks), dim3(256), 0, st, p); }
+        else { if (deep) hipLaunchKernelGGL((convT2_dgrad_kernel<2, true, 4>), dim3(blocks), dim3(256), 0, st, p); else hipLaunchKernelGGL((convT2_dgrad_kernel<2, true>), dim3(blocks), dim3(256), 0, st, p); }
     } else if (compute == 1) hipLaunchKernelGGL(convT2_dgrad_kernel<1>, dim3(blocks), dim3(256), 0, st, p);
     else if (compute == 2) hipLaunchKernelGGL(convT2_dgrad_kernel<2>, dim3(blocks), dim3(256), 0, st, p);
     else hipLaunchKernelGGL(convT2_dgrad_kernel<0>, dim3(blocks), dim3(256), 0, st, p);
@@ -789,8 +1084,21 @@ int mtbc_i_convT2_wgrad(const mtbc_convT_args* a, int compute, float* partial, f
     const unsigned blocks = (unsigned)cdiv64(p.ntasks, 4);
     if (a->x_type16) {          // 16-bit planar x (and dy): both operands arrive as fragments
         if (!a->dy_type16 || a->x_type16 != compute) return MTBC_E_UNSUPPORTED;
-        if (compute == 1) hipLaunchKernelGGL((convT2_wgrad_kernel<1, true, true>), dim3(blocks), dim3(256), 0, st, p);
-        else hipLaunchKernelGGL((convT2_wgrad_kernel<2, true, true>), dim3(blocks), dim3(256), 0, st, p);
+        static const int ct_env = mtbc_probe_int("MTBC_CT_WG_CT", 0);      // A/B: tiles of 8 output channels per wave (1 | 2), 0 = by shape
+        const int ctn = ct_env ? ct_env : (p.ctiles % 2 == 0 ? 2 : 1);
+        if (ctn == 2) {
+            p.ntasks = (long long)p.mblocks * ((p.ctiles + 1) / 2) * nsplit;
+            const unsigned b2 = (unsigned)cdiv64(p.ntasks, 4);
+            static const int depth_env = mtbc_probe_int("MTBC_CT_DEPTH", 2);      // A/B: register sets (2 | 4); measured 0.59 vs 0.62 ms per step
+            if (depth_env == 2) {
+                if (compute == 1) hipLaunchKernelGGL((convT2_wgrad16_kernel<1, 2, 2>), dim3(b2), dim3(256), 0, st, p);
+                else hipLaunchKernelGGL((convT2_wgrad16_kernel<2, 2, 2>), dim3(b2), dim3(256), 0, st, p);
+            } else if (compute == 1) hipLaunchKernelGGL((convT2_wgrad16_kernel<1, 2, 4>), dim3(b2), dim3(256), 0, st, p);
+            else hipLaunchKernelGGL((convT2_wgrad16_kernel<2, 2, 4>), dim3(b2), dim3(256), 0, st, p);
+        } else {
+            if (compute == 1) hipLaunchKernelGGL((convT2_wgrad16_kernel<1, 1, 4>), dim3(blocks), dim3(256), 0, st, p);
+            else hipLaunchKernelGGL((convT2_wgrad16_kernel<2, 1, 4>), dim3(blocks), dim3(256), 0, st, p);
+        }
     } else if (a->dy_type16) {
         if (compute == 1) hipLaunchKernelGGL((convT2_wgrad_kernel<1, true>), dim3(blocks), dim3(256), 0, st, p);
         else hipLaunchKernelGGL((convT2_wgrad_kernel<2, true>), dim3(blocks), dim3(256), 0, st, p);
