@@ -929,12 +929,15 @@ bool mtbc_i_convT2_wgrad_ok(const mtbc_convT_args* a) {
     return a->k == 2 && HW % 32 == 0 && a->W % 8 == 0 && al16(a->dy) && al16(a->x) && a->dy_batch_stride % 4 == 0 &&
            a->x_batch_stride % 4 == 0;
 }
-// 32-pixel steps per split: ~4096 wave tasks in flight, at least 8 steps each (the partial sums are real traffic)
+// 32-pixel steps per split: ~4096 wave tasks in flight, at least 8 steps each (the partial sums are real traffic).  With both tensors
+// as 16-bit planes (convT2_wgrad16_kernel) the inputs are half the bytes and the partials weigh twice as much: 1536 tasks
+// (sweep 512 .. 16384 per step of the bench: 1.16 / 0.65 / 0.50 / 0.52 / 0.55 / 0.67 / 0.75 ms at 512 / 1024 / 1536 / 2048 / 4096 / 8192 / 16384).
+// (A workspace sized before x_type16 was set is sized for 4096: never too small.)
 void mtbc_i_convT2_wgrad_plan(const mtbc_convT_args* a, int* steps_per_split, int* nsplit) {
     const long long total_steps = (long long)a->N * (a->H * a->W / 32);
     const long long per_split_tasks = (long long)cdiv(a->Cin, 48) * cdiv(a->Cout, 8);
     static const int tasks_env = mtbc_probe_int("MTBC_CT_WG_TASKS", 0);      // A/B
-    long long want = cdiv64(tasks_env > 0 ? tasks_env : 4096, per_split_tasks);
+    long long want = cdiv64(tasks_env > 0 ? tasks_env : (a->x_type16 ? 1536 : 4096), per_split_tasks);
     if (want < 1) want = 1;
     long long sps = cdiv64(total_steps, want);
     if (sps < 8) sps = 8;
@@ -1048,7 +1051,7 @@ int mtbc_i_convT2_dgrad(const mtbc_convT_args* a, int compute, hipStream_t st) {
     static const bool no_lds = mtbc_probe_set("MTBC_CT_DGRAD_DIRECT");      // A/B: the direct kernel for every shape
     const int wrow = 4 * a->Cout + 16;
     const size_t lds = (size_t)48 * wrow * 2;
-    if (a->dy_type16 && !no_lds && a->Cout % 8 == 0 && lds <= 80 * 1024) {      // weights of the block's 48 input channels in LDS
+    if (a->dy_type16 && !no_lds && a->Cout % 8 == 0 && lds <= 104 * 1024) {      // (Cout <= 256; one block per CU above 192)      // weights of the block's 48 input channels in LDS
         const long long tasks = (long long)a->N * (a->H * a->W / 32);
         int gx = 512 / p.mblocks; if (gx < 1) gx = 1;
         if ((long long)gx * 4 > tasks) gx = (int)cdiv64(tasks, 4);
@@ -1057,7 +1060,7 @@ int mtbc_i_convT2_dgrad(const mtbc_convT_args* a, int compute, hipStream_t st) {
         do {                                                                                                             \
             static bool attr = false;                                                                                    \
             if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&convT2_dgrad_lds_kernel<LP_, D_>),     \
-                                                    hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); attr = true; } \
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, 104 * 1024); attr = true; } \
             hipLaunchKernelGGL((convT2_dgrad_lds_kernel<LP_, D_>), grid, dim3(256), lds, st, p, wrow);                   \
         } while (0)
         if (compute == 1) MTBC_CT2DG(1, 4); else MTBC_CT2DG(2, 4);

@@ -728,7 +728,8 @@ def test_conv3x3_dgrad_into_16bit_planar_segment(N, segs, Cout, H, W, compute):
 
 
 @pytest.mark.parametrize("compute", [1, 2])
-@pytest.mark.parametrize("N,Cin,Cout,H,W", [(2, 48, 48, 32, 32), (3, 96, 48, 8, 16), (1, 384, 192, 8, 8), (2, 48, 24, 16, 8)])
+@pytest.mark.parametrize("N,Cin,Cout,H,W", [(2, 48, 48, 32, 32), (3, 96, 48, 8, 16), (1, 384, 192, 8, 8), (2, 48, 24, 16, 8), (2, 56, 40, 16, 16),
+                                            (2, 512, 256, 8, 8), (32, 96, 48, 64, 64), (2, 24, 12, 16, 16)])
 def test_convT_backward_reads_16bit_planar_dy(N, Cin, Cout, H, W, compute):
     """dy_type16: the k = 2 ConvT dgrad / wgrad on a 16-bit planar dy must equal the same kernels fed the fp32 tensor with
     the same (representable) values, bit for bit -- they rounded an fp32 dy to exactly these operands while loading it."""
@@ -1143,7 +1144,11 @@ def test_convT_wgrad_reads_16bit_planar_x(N, Cin, Cout, H, W, compute):
     x16 = x.to(dt)
     dw_ref, db_ref = ops.convT_wgrad(x, w, dy16.view(torch.int16), 2, compute=compute, dy16=True)
     dw, db = ops.convT_wgrad(x16.view(torch.int16), w, dy16.view(torch.int16), 2, compute=compute, dy16=True, x16=True)
-    assert torch.equal(dw, dw_ref) and torch.equal(db, db_ref)
+    if N * H * W <= 4096:       # both launches split the pixels the same way (8 steps per split): the same sums in the same order
+        assert torch.equal(dw, dw_ref) and torch.equal(db, db_ref)
+    else:                       # the 16-bit-planes launch takes fewer, longer splits: fp32 re-association of the split sums
+        assert (dw - dw_ref).abs().max().item() <= 1e-5 * dw_ref.abs().max().item()
+        assert (db - db_ref).abs().max().item() <= 1e-5 * db_ref.abs().max().item()
     want = torch.einsum("nchw,ndhawb->cdab", x16.double().cpu(), dy16.double().cpu().view(N, Cout, H, 2, W, 2))
     assert (dw.cpu().double() - want).abs().max().item() <= 1e-4 * max(1.0, want.abs().max().item())
     with pytest.raises(L.MtbcError):        # 16-bit x with an fp32 dy: no kernel, refused
