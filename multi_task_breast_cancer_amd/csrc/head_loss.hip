@@ -45,7 +45,15 @@ __global__ void linear_dx_kernel(const float* __restrict__ g, const float* __res
     if (idx >= N * In) return;
     const int n = idx / In, i = idx % In;
     float s = 0.f;
-    for (int o = 0; o < Out; ++o) s = fmaf(g[(size_t)n * Out + o], w[(size_t)o * In + i], s);
+    int o = 0;
+    for (; o + 8 <= Out; o += 8) {           // sixteen loads in flight, the fma chain in the plain loop's order (one round trip per o otherwise)
+        float gv[8], wv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { gv[u] = g[(size_t)n * Out + o + u]; wv[u] = w[(size_t)(o + u) * In + i]; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s = fmaf(gv[u], wv[u], s);
+    }
+    for (; o < Out; ++o) s = fmaf(g[(size_t)n * Out + o], w[(size_t)o * In + i], s);
     dx[idx] = s;
 }
 __global__ void linear_dw_kernel(const float* __restrict__ g, const float* __restrict__ x, float* __restrict__ dw,
@@ -54,7 +62,15 @@ __global__ void linear_dw_kernel(const float* __restrict__ g, const float* __res
     if (idx < Out * In) {
         const int o = idx / In, i = idx % In;
         float s = 0.f;
-        for (int n = 0; n < N; ++n) s = fmaf(g[(size_t)n * Out + o], x[(size_t)n * In + i], s);
+        int n = 0;
+        for (; n + 8 <= N; n += 8) {
+            float gv[8], xv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { gv[u] = g[(size_t)(n + u) * Out + o]; xv[u] = x[(size_t)(n + u) * In + i]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s = fmaf(gv[u], xv[u], s);
+        }
+        for (; n < N; ++n) s = fmaf(g[(size_t)n * Out + o], x[(size_t)n * In + i], s);
         dw[idx] = accumulate ? dw[idx] + s : s;
     }
     if (db && idx < Out) {

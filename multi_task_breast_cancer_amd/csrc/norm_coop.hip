@@ -279,13 +279,18 @@ __global__ __launch_bounds__(THREADS, THREADS >= 512 ? 4 : 2) void in_bwd_c8_ker
         const int n = item / p.G8, g = item % p.G8;
         const size_t plane0 = (size_t)n * p.C + 8 * g;
         const int plane_b = p.HW * 4;
+        // (the pixel offsets are recomputed per item from an opaque copy of the thread index: hoisted out of this loop they lived across the
+        //  team exchange, were spilled, and every reload -- a scratch load, counted by vmcnt -- sat between the z loads of the next item, which
+        //  then went out one memory round trip at a time)
+        int tl = tid;
+        asm volatile("" : "+v"(tl));
         float xh[8][PPT], gy[8][PPT];
         // out-of-slab lanes: offsets past the buffer, the bounds check returns 0
         if constexpr (ZC8 != 0) {
             const __amdgpu_buffer_rsrc_t zr = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.z8 + ((size_t)n * p.G8 + g) * p.HW * 8), 0, p.HW * 16, 0x00020000);
 #pragma unroll
             for (int k = 0; k < PPT; ++k) {
-                const int px = tid + THREADS * k;
+                const int px = tl + THREADS * k;
                 const int off = px < slab ? (member * slab + px) * 16 : 0x7ffffff0;
                 float o[8];
                 co_unpk<ZF16>(__builtin_bit_cast(co_u32x4, __builtin_amdgcn_raw_buffer_load_b128(zr, off, 0, 0)), o);
@@ -296,7 +301,7 @@ __global__ __launch_bounds__(THREADS, THREADS >= 512 ? 4 : 2) void in_bwd_c8_ker
             const __amdgpu_buffer_rsrc_t zr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.z + plane0 * p.HW), 0, 8 * p.HW * 4, 0x00020000);
 #pragma unroll
             for (int k = 0; k < PPT; ++k) {
-                const int px = tid + THREADS * k;
+                const int px = tl + THREADS * k;
                 const int off = px < slab ? (member * slab + px) * 4 : 0x7ffffff0;
 #pragma unroll
                 for (int c = 0; c < 8; ++c) xh[c][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(zr, off, c * plane_b, 0));
@@ -306,7 +311,7 @@ __global__ __launch_bounds__(THREADS, THREADS >= 512 ? 4 : 2) void in_bwd_c8_ker
             const __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.dy8 + (size_t)n * p.dy8bs + (size_t)g * p.HW * 8), 0, p.HW * 16, 0x00020000);
 #pragma unroll
             for (int k = 0; k < PPT; ++k) {
-                const int px = tid + THREADS * k;
+                const int px = tl + THREADS * k;
                 const int off = px < slab ? (member * slab + px) * 16 : 0x7ffffff0;
                 float o[8];
                 co_unpk<F16>(__builtin_bit_cast(co_u32x4, __builtin_amdgcn_raw_buffer_load_b128(gr, off, 0, 0)), o);
@@ -317,7 +322,7 @@ __global__ __launch_bounds__(THREADS, THREADS >= 512 ? 4 : 2) void in_bwd_c8_ker
                 const __amdgpu_buffer_rsrc_t er = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dyx + plane0 * p.HW), 0, 8 * p.HW * 4, 0x00020000);
 #pragma unroll
                 for (int k = 0; k < PPT; ++k) {
-                    const int px = tid + THREADS * k;
+                    const int px = tl + THREADS * k;
                     const int off = px < slab ? (member * slab + px) * 4 : 0x7ffffff0;
 #pragma unroll
                     for (int c = 0; c < 8; ++c) gy[c][k] += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(er, off, c * plane_b, 0));
@@ -327,7 +332,7 @@ __global__ __launch_bounds__(THREADS, THREADS >= 512 ? 4 : 2) void in_bwd_c8_ker
             const __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dy + (size_t)n * p.dybs + (size_t)(8 * g) * p.HW), 0, 8 * p.HW * 4, 0x00020000);
 #pragma unroll
             for (int k = 0; k < PPT; ++k) {
-                const int px = tid + THREADS * k;
+                const int px = tl + THREADS * k;
                 const int off = px < slab ? (member * slab + px) * 4 : 0x7ffffff0;
 #pragma unroll
                 for (int c = 0; c < 8; ++c) gy[c][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(gr, off, c * plane_b, 0));
@@ -336,7 +341,7 @@ __global__ __launch_bounds__(THREADS, THREADS >= 512 ? 4 : 2) void in_bwd_c8_ker
                 const __amdgpu_buffer_rsrc_t er = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dyx + plane0 * p.HW), 0, 8 * p.HW * 4, 0x00020000);
 #pragma unroll
                 for (int k = 0; k < PPT; ++k) {
-                    const int px = tid + THREADS * k;
+                    const int px = tl + THREADS * k;
                     const int off = px < slab ? (member * slab + px) * 4 : 0x7ffffff0;
 #pragma unroll
                     for (int c = 0; c < 8; ++c) gy[c][k] += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(er, off, c * plane_b, 0));
@@ -358,7 +363,7 @@ __global__ __launch_bounds__(THREADS, THREADS >= 512 ? 4 : 2) void in_bwd_c8_ker
             const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.r1 + (size_t)n * p.HW), 0, p.HW * 4, 0x00020000);
 #pragma unroll
             for (int k = 0; k < PPT; ++k) {
-                const int px = tid + THREADS * k;
+                const int px = tl + THREADS * k;
                 hv[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr, px < slab ? (member * slab + px) * 4 : 0x7ffffff0, 0, 0));
             }
 #pragma unroll
@@ -376,7 +381,7 @@ __global__ __launch_bounds__(THREADS, THREADS >= 512 ? 4 : 2) void in_bwd_c8_ker
             const unsigned short* pa = p.pa + ((size_t)n * p.G8 + g) * oHW;
 #pragma unroll
             for (int k = 0; k < PPT; ++k) {
-                const int px = tid + THREADS * k;
+                const int px = tl + THREADS * k;
                 const bool ok = px < slab;
                 const int q = ok ? member * slab + px : 0;
                 const int yy = q / p.W, xx = q - yy * p.W;
@@ -399,7 +404,7 @@ __global__ __launch_bounds__(THREADS, THREADS >= 512 ? 4 : 2) void in_bwd_c8_ker
             float s1 = 0.f, s2 = 0.f, s4 = 0.f;
 #pragma unroll
             for (int k = 0; k < PPT; ++k) {
-                const bool ok = tid + THREADS * k < slab;
+                const bool ok = tl + THREADS * k < slab;
                 const float x = ok ? (xh[c][k] - mean) * rstd : 0.f;
                 const float pre = x * ga + be;
                 const float y = gy[c][k] * (pre > 0.f ? 1.f : p.slope);
@@ -440,7 +445,7 @@ __global__ __launch_bounds__(THREADS, THREADS >= 512 ? 4 : 2) void in_bwd_c8_ker
             float t = 0.f;
 #pragma unroll
             for (int k = 0; k < PPT; ++k) {
-                const float o = (tid + THREADS * k < slab) ? kk * (gy[c][k] - m1 - xh[c][k] * m2) : 0.f;
+                const float o = (tl + THREADS * k < slab) ? kk * (gy[c][k] - m1 - xh[c][k] * m2) : 0.f;
                 gy[c][k] = o; t += o;
             }
             s3[c] = t;
@@ -448,7 +453,7 @@ __global__ __launch_bounds__(THREADS, THREADS >= 512 ? 4 : 2) void in_bwd_c8_ker
         unsigned short* ob = p.dz8 + (((size_t)n * p.G8 + g) * p.HW + (size_t)member * slab) * 8;
 #pragma unroll
         for (int k = 0; k < PPT; ++k) {
-            const int px = tid + THREADS * k;
+            const int px = tl + THREADS * k;
             if (px < slab) {
                 co_u32x4 w;
 #pragma unroll
@@ -477,7 +482,15 @@ __global__ void in_stats_finalize_kernel(const float* __restrict__ part, int slo
     const int n = plane / C, c = plane % C;
     const float* q = part + ((size_t)n * slots * C + c) * 2;
     double s = 0.0, qq = 0.0;
-    for (int t = lane; t < slots; t += 64) { const float2 v = *reinterpret_cast<const float2*>(q + (size_t)t * C * 2); s += (double)v.x; qq += (double)v.y; }
+    int t = lane;
+    for (; t + 192 < slots; t += 256) {          // four loads in flight, added in the order of the plain loop below (one load per round = a memory round trip per 64 subsets)
+        float2 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float2*>(q + (size_t)(t + 64 * u) * C * 2);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { s += (double)v[u].x; qq += (double)v[u].y; }
+    }
+    for (; t < slots; t += 64) { const float2 v = *reinterpret_cast<const float2*>(q + (size_t)t * C * 2); s += (double)v.x; qq += (double)v.y; }
     s = wave_sum_d(s); qq = wave_sum_d(qq);
     if (lane == 0) {
         const double m = s / (double)HW, var = fmax(qq / (double)HW - m * m, 0.0);

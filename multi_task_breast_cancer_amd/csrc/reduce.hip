@@ -15,6 +15,15 @@ __global__ void splitk_reduce_k(const float* __restrict__ partial, float* __rest
     float s0 = 0.f, s1 = 0.f;               // two independent chains per thread, combined in a fixed order
     if (i < elems) {
         int k = g;
+        // eight rows in flight per round (the two-row loop below waited for its loads every round: a memory round trip per two rows);
+        // the adds keep the order of that loop -- chain 0 takes rows g, g + 2G, ..., chain 1 rows g + G, g + 3G, ... -- bit-identical sums
+        for (; k + 7 * G < nsplit; k += 8 * G) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = partial[(size_t)(k + u * G) * elems + i];
+#pragma unroll
+            for (int u = 0; u < 8; u += 2) { s0 += v[u]; s1 += v[u + 1]; }
+        }
         for (; k + G < nsplit; k += 2 * G) { s0 += partial[(size_t)k * elems + i]; s1 += partial[(size_t)(k + G) * elems + i]; }
         if (k < nsplit) s0 += partial[(size_t)k * elems + i];
     }
