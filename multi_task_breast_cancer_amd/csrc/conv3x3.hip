@@ -1033,6 +1033,9 @@ __device__ __forceinline__ void c8_epilogue(const ConvP& p, f32x4 (&acc)[MT][4],
     }
 }
 
+// halo-pixel offset of pixel group g from group 0 of the same lane (GEO 0: 2 rows x two 16-column halves; 1: 4 rows; 2: 4 row pairs of an 8 x 8 map)
+template <int GEO> __device__ __forceinline__ constexpr int c8_goff(int g, int HC) { return GEO == 0 ? (g >> 1) * HC + 16 * (g & 1) : GEO == 1 ? g * HC : 2 * g * HC; }
+
 // O8 = the OUTPUT is 16-bit channel-blocked as well (conv outputs z / single-writer gradients of the 16-bit modes): the MFMAs
 // run as D = W X (channels on the rows), so a lane holds 4 consecutive channels of ONE pixel = half a 16-byte piece; the 16
 // lanes of a row group write 16 consecutive pixels, and the lane groups kg = 2q, 2q + 1 the two halves of the same pieces
@@ -1066,15 +1069,15 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 4) void conv3x3_igemm_c8_ker
 
     const int nchunks = (p.Cin + LPKC - 1) / LPKC;
     const int j = lane & 15, kg = lane >> 4;
-    int bpix[4];                      // halo-pixel index of this lane's output pixel in group g, tap (0,0)
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        int img = 0, y, x;
-        if (GEO == 0) { y = 2 * wv + (g >> 1); x = 16 * (g & 1) + j; }
-        else if (GEO == 1) { y = 4 * wv + g; x = j; }
-        else { img = wv; y = 2 * g + (j >> 3); x = j & 7; }
-        bpix[g] = (img * HR + y) * HC + x;
-    }
+    // Halo-pixel index of this lane's output pixel in group 0, tap (0,0); group g and tap t sit at COMPILE-TIME offsets from it
+    // (c8_goff), so the 36 fragment reads of a chunk are one address register + the ds_read immediate.  (Written as an array bpix[g]
+    // the compiler kept 36 separate address registers, ran out of the 128 this occupancy allows, and spilled the per-tile halo
+    // constants: every tile then began with scratch reloads whose vmcnt(0) also drained the previous tile's output stores.)
+    int bpix0;
+    if (GEO == 0) bpix0 = (2 * wv) * HC + j;
+    else if (GEO == 1) bpix0 = (4 * wv) * HC + j;
+    else bpix0 = (wv * HR + (j >> 3)) * HC + (j & 7);
+    const unsigned short* const xlane = Xs + (kg * HPP + bpix0) * 8;
     int w_have = -1;
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(p.wp), 0, (int)((size_t)p.mtiles * nchunks * (9 * 16 * WROW) * 2), 0x00020000);
@@ -1179,7 +1182,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 4) void conv3x3_igemm_c8_ker
                     a[m] = *reinterpret_cast<const typename T::frag*>(Ws + ((m * 9 + tap) * 16 + j) * WROW + 8 * (kg ^ ((j >> 1) & 3)));
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
-                    b[g] = *reinterpret_cast<const typename T::frag*>(Xs + (kg * HPP + bpix[g] + toff) * 8);
+                    b[g] = *reinterpret_cast<const typename T::frag*>(xlane + (c8_goff<GEO>(g, HC) + toff) * 8);
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -1270,14 +1273,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_igemm_c8_ring_kernel(const Con
 
     const int nchunks = (p.Cin + LPKC - 1) / LPKC;
     const int j = lane & 15, kg = lane >> 4;
-    int bpix[4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        int y, x;
-        if (GEO == 0) { y = 2 * wv + (g >> 1); x = 16 * (g & 1) + j; }
-        else { y = 4 * wv + g; x = j; }
-        bpix[g] = y * HC + x;
-    }
+    const int bpix0 = (GEO == 0 ? 2 * wv : 4 * wv) * HC + j;      // group g / tap t at compile-time offsets (c8_goff), as in the kernel above
     for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
         int t = tile;
         const int tx = t % p.tiles_x; t /= p.tiles_x;
@@ -1319,7 +1315,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_igemm_c8_ring_kernel(const Con
                     a[m] = *reinterpret_cast<const typename T::frag*>(Ws + ((m * 9 + tap) * 16 + j) * WROW + 8 * (kg ^ ((j >> 1) & 3)));
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
-                    b[g] = *reinterpret_cast<const typename T::frag*>(Xs + (kg * HPP + bpix[g] + toff) * 8);
+                    b[g] = *reinterpret_cast<const typename T::frag*>(Xs + (kg * HPP + bpix0) * 8 + (c8_goff<GEO>(g, HC) + toff) * 8);
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
 #pragma unroll
