@@ -187,7 +187,7 @@ def run_mode(args, dtype, dev, rank, world, dist, want_roofline):
     # from the committed summary of the separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same command
     # (tools/profile_round.sh); `traffic_source` names the file, and the field is null when no summary fits the build
     traffic, traffic_source = None, None
-    for tag in ("r02b", "r02", "r01"):
+    for tag in ("r02c", "r02b", "r02", "r01"):
         tpath = os.path.join(ROOT, "profiles", f"{tag}_hbm_traffic_{dtype}.json")
         if not os.path.exists(tpath):
             continue
@@ -307,8 +307,8 @@ def main() -> None:
         "config": {"workload": f"{args.arch} seg+cls deep-supervision step (Dice+Focal, alpha=0.5, Adam eps 1e-4), "
                                f"per-GPU batch {args.batch}, 1x{args.size}x{args.size}, "
                                + ("fp32 MFMA (parity mode)" if args.dtype == "f32" else
-                                  f"{args.dtype} MFMA operands (3x3 convs, ConvT backward) / fp32 conv outputs, gradient sums, "
-                                  f"statistics, accumulation and optimizer") +
+                                  f"{args.dtype} MFMA operands (3x3 convs, ConvT) and 16-bit stored conv outputs / activations; fp32 accumulation, "
+                                  f"gradient sums, statistics, losses, parameters and optimizer") +
                                ", random-init weights (BASELINE.json configs[1])",
                    "global_batch": args.batch * world, "parallelism": f"dp{world}"},
         "final_loss": main_res["final_loss"],

@@ -6,12 +6,14 @@ namespace {
 // g, g+G, ... (coalesced 256-B rows), the G partial sums are combined by a fixed pairwise tree -> deterministic.
 // G = 16 for the many-split partials of the wide maps (a level-0 wgrad has 512 splits of only ~5k elements: with 4
 // lanes each thread walked 128 dependent rows and the launch took 18 us for 10 MB).
-template <int G>
+// E = elements per block: 64, or 16 for the SMALL many-split partials (a 24 -> 24 level-0 wgrad: 1024 splits of 5184 elements = 81 blocks of
+// 64 elements on 256 CUs, each pulling 260 KB through one CU; with 16 elements x 64 split lanes it is 324 blocks and 16 rows per thread).
+template <int G, int E = 64>
 __global__ void splitk_reduce_k(const float* __restrict__ partial, float* __restrict__ out, int nsplit, size_t elems,
                                 int accumulate) {
-    __shared__ float red[G][64];
-    const int e = threadIdx.x & 63, g = threadIdx.x >> 6;
-    const size_t i = (size_t)blockIdx.x * 64 + e;
+    __shared__ float red[G][E];
+    const int e = threadIdx.x % E, g = threadIdx.x / E;
+    const size_t i = (size_t)blockIdx.x * E + e;
     float s0 = 0.f, s1 = 0.f;               // two independent chains per thread, combined in a fixed order
     if (i < elems) {
         int k = g;
@@ -59,7 +61,8 @@ __global__ void sum_over_n_k(const float* __restrict__ planes, float* __restrict
 }  // namespace
 
 int mtbc_i_splitk_reduce(const float* partial, float* out, int nsplit, size_t elems, int accumulate, hipStream_t st) {
-    if (nsplit > 32) hipLaunchKernelGGL(splitk_reduce_k<16>, dim3((unsigned)cdiv64(elems, 64)), dim3(1024), 0, st, partial, out, nsplit, elems, accumulate);
+    if (nsplit >= 256 && elems <= 16384) hipLaunchKernelGGL((splitk_reduce_k<64, 16>), dim3((unsigned)cdiv64(elems, 16)), dim3(1024), 0, st, partial, out, nsplit, elems, accumulate);
+    else if (nsplit > 32) hipLaunchKernelGGL(splitk_reduce_k<16>, dim3((unsigned)cdiv64(elems, 64)), dim3(1024), 0, st, partial, out, nsplit, elems, accumulate);
     else hipLaunchKernelGGL(splitk_reduce_k<4>, dim3((unsigned)cdiv64(elems, 64)), dim3(256), 0, st, partial, out, nsplit, elems, accumulate);
     MTBC_CHECK_LAUNCH();
     return MTBC_OK;
