@@ -918,7 +918,6 @@ void fill(const mtbc_convT_args* a, Ct2P* p) {
 bool mtbc_i_convT2_dgrad_ok(const mtbc_convT_args* a) {
     const int HW = a->H * a->W;
     if (a->dy_type16 && (a->dy_type16 != a->compute || a->dy_batch_stride % 8 != 0)) return false;
-    if (a->x_type16 && (a->x_type16 != a->compute || !a->dy_type16 || a->x_batch_stride % 8 != 0)) return false;
     return a->k == 2 && HW % 32 == 0 && a->W % 2 == 0 && a->Cout % 2 == 0 && al16(a->dy) && al16(a->w) && al16(a->dx) &&
            a->dy_batch_stride % 4 == 0 && a->dx_batch_stride % 2 == 0;
 }
