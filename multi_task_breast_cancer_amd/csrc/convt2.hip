@@ -227,12 +227,10 @@ __global__ __launch_bounds__(256) void convT2_dgrad_kernel(const Ct2P p) {
 // odd elements of the same 64 bytes.  Lane group kg owns pixels 8kg .. 8kg+7 of the step.
 // DY16: the 16 consecutive values of an output row (8 pixels x b) are 32 bytes; fragment word m of the b = 0 tile is
 // (low half of dword 2m) | (low half of dword 2m+1) << 16, of the b = 1 tile the two high halves: two v_perm per word.
-// X16: x is a 16-bit planar tensor of the MFMA's own type too (the InstanceNorm forward writes it beside the channel-blocked copy
-// for exactly this reader): 8 consecutive pixels of a channel are ONE 16-byte load that IS the fragment -- half the bytes of the fp32
-// planes written by the norm and read here, no conversion, same MFMA operands.
-template <int LP, bool DY16 = false, bool X16 = false, int D = 2>
+// (16-bit planes of x as well: convT2_wgrad16_kernel below.)
+template <int LP, bool DY16 = false, int D = 2>
 __global__ __launch_bounds__(256) void convT2_wgrad_kernel(const Ct2P p) {
-    static_assert((!DY16 && !X16) || LP != 0, "16-bit tensors feed the 16-bit MFMA");
+    static_assert(!DY16 || LP != 0, "a 16-bit dY feeds the 16-bit MFMA");
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // (scalar: the task's indices and branches are wave-uniform)
     const int j = lane & 15, kg = lane >> 4;
     const long long task = (long long)blockIdx.x * 4 + wv;
@@ -253,7 +251,6 @@ __global__ __launch_bounds__(256) void convT2_wgrad_kernel(const Ct2P p) {
         rok[m] = ci < p.Cin;
         xrow[m] = p.x + (size_t)(rok[m] ? ci : 0) * HW + 8 * kg;
     }
-    const unsigned short* x16base = reinterpret_cast<const unsigned short*>(p.x);
     const int co = ct * 8 + (j >> 1);
     const bool cok = co < p.Cout;
     const float* dcol = p.dy + (size_t)(cok ? co : 0) * 4 * HW + (size_t)(j & 1) * oW;
@@ -265,8 +262,7 @@ __global__ __launch_bounds__(256) void convT2_wgrad_kernel(const Ct2P p) {
 
     const bool want_bias = p.dbias_part != nullptr && mb == 0;      // uniform
     float bsum = 0.f;
-    float4 ra[X16 ? 1 : D][X16 ? 1 : MT][2], rb[DY16 ? 1 : D][4];
-    ct_u32x4 rx[X16 ? D : 1][X16 ? MT : 1];  // X16: 4 dwords = 8 consecutive pixels of one channel = the A fragment
+    float4 ra[D][MT][2], rb[DY16 ? 1 : D][4];
     ct_u32x4 rh[DY16 ? D : 1][2];            // DY16: 8 dwords = 8 pixels, each {b0, b1}
     auto load = [&](int g, auto SL) {
         constexpr int slot = decltype(SL)::value;
@@ -275,14 +271,8 @@ __global__ __launch_bounds__(256) void convT2_wgrad_kernel(const Ct2P p) {
         const int i = pix / p.W, jx = pix % p.W;
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
-            if constexpr (X16) {
-                const int ci = mb * 48 + m * 16 + j;
-                const unsigned short* q = x16base + (size_t)n * p.xbs + (size_t)(rok[m] ? ci : 0) * HW + st * 32 + 8 * kg;
-                rx[slot][m] = *reinterpret_cast<const ct_u32x4*>(q);
-            } else {
-                const float* q = xrow[m] + (size_t)n * p.xbs + st * 32;
-                ra[slot][m][0] = ld4(q); ra[slot][m][1] = ld4(q + 4);
-            }
+            const float* q = xrow[m] + (size_t)n * p.xbs + st * 32;
+            ra[slot][m][0] = ld4(q); ra[slot][m][1] = ld4(q + 4);
         }
         if constexpr (DY16) {
             const unsigned short* q = dcol16 + (size_t)n * p.dybs + (size_t)(2 * i) * oW + 2 * jx;
@@ -326,13 +316,6 @@ __global__ __launch_bounds__(256) void convT2_wgrad_kernel(const Ct2P p) {
         }
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
-            if constexpr (X16) {
-                Frag<LP> fa;
-                const ct_u32x4 w = rx[cur][m];
-                frag_from_words<LP>(fa, rok[m] ? w[0] : 0u, rok[m] ? w[1] : 0u, rok[m] ? w[2] : 0u, rok[m] ? w[3] : 0u);
-                acc[m][0] = Frag<LP>::mma(fa, f0, acc[m][0]);
-                acc[m][1] = Frag<LP>::mma(fa, f1, acc[m][1]);
-            } else {
             float a[8];
             a[0] = rok[m] ? ra[cur][m][0].x : 0.f; a[1] = rok[m] ? ra[cur][m][0].y : 0.f; a[2] = rok[m] ? ra[cur][m][0].z : 0.f; a[3] = rok[m] ? ra[cur][m][0].w : 0.f;
             a[4] = rok[m] ? ra[cur][m][1].x : 0.f; a[5] = rok[m] ? ra[cur][m][1].y : 0.f; a[6] = rok[m] ? ra[cur][m][1].z : 0.f; a[7] = rok[m] ? ra[cur][m][1].w : 0.f;
@@ -340,7 +323,6 @@ __global__ __launch_bounds__(256) void convT2_wgrad_kernel(const Ct2P p) {
             fa.set(a);
             acc[m][0] = Frag<LP>::mma(fa, f0, acc[m][0]);
             acc[m][1] = Frag<LP>::mma(fa, f1, acc[m][1]);
-            }
         }
     };
     if (g0 < g1) {          // (as in the dgrad: no branch around a load; step g0 + t lives in register set t % D)
@@ -377,7 +359,7 @@ __global__ __launch_bounds__(256) void convT2_wgrad_kernel(const Ct2P p) {
 
 // The weight gradient with BOTH tensors as 16-bit planes (the 16-bit modes' product path), CT tiles of 8 output channels per wave:
 // every x fragment a wave loads is multiplied with 2 CT dY fragments instead of 2, i.e. x travels L2 -> registers Cout / (8 CT)
-// times instead of Cout / 8 (with CT = 1 this is convT2_wgrad_kernel<LP, true, true, D>, and the results are the same bit for
+// times instead of Cout / 8 (with CT = 1 this is convT2_wgrad_kernel<LP, true> fed the same values, and the results are the same bit for
 // bit: the same products are summed in the same order, only on another wave).  No branch around a load, D register sets.
 template <int LP, int CT, int D>
 __global__ __launch_bounds__(256) void convT2_wgrad16_kernel(const Ct2P p) {

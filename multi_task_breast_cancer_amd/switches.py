@@ -45,7 +45,8 @@ PLAN_SWITCHES: Dict[str, tuple] = {
 # variables that only the probes build of the library (or removed timing hacks) ever honoured: results are wrong or
 # timings are not the product's when one of them takes effect
 RESULT_ALTERING = ("MTBC_DBG", "MTBC_NOACC", "MTBC_LOWP", "MTBC_LP_MT", "MTBC_RING", "MTBC_NODMA", "MTBC_C8_BLOCKS_PER_CU",
-                   "MTBC_WGRAD_LP1", "MTBC_CT_WG_TASKS", "MTBC_IN_BWD_STREAM", "MTBC_CONVT_GENERIC", "MTBC_C8_NW", "MTBC_C8_RING")
+                   "MTBC_WGRAD_LP1", "MTBC_CT_WG_TASKS", "MTBC_IN_BWD_STREAM", "MTBC_CONVT_GENERIC", "MTBC_C8_NW", "MTBC_C8_RING",
+                   "MTBC_CT_DEPTH", "MTBC_CT_WG_CT", "MTBC_CT_DGRAD_DIRECT")
 
 
 def get(name: str) -> str:
