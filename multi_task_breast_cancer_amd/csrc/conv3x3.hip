@@ -2342,13 +2342,26 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_stem_c8_kernel(const float*
                 for (int t = 0; t < 9; ++t) acc[c][t] = fmaf(ge[c], xv[t / 3][e + t % 3], acc[c][t]);
         }
     }
+    // 72 sums per block: every wave reduces all of its own first, ONE barrier, then 72 threads add the four wave sums in wave order (72
+    // block_sum calls = 144 barriers before)
+    __shared__ float wsum[4][72];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
 #pragma unroll
     for (int c = 0; c < 8; ++c)
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
-            const float tsum = block_sum(acc[c][t], red);
-            if (threadIdx.x == 0) partial[(((size_t)n * S + band) * Cout + 8 * g + c) * 9 + t] = tsum;
+            // wave sum on the VALU: DPP row sums (lanes 15 / 31 / 47 / 63), four lane reads.  (wave_sum's six ds_bpermute rounds per value
+            // -- 432 dependent LDS round trips for the 72 values -- took longer than the accumulation itself.)
+            const int r = __builtin_bit_cast(int, row16_sum(acc[c][t]));
+            const float v = ((__builtin_bit_cast(float, __builtin_amdgcn_readlane(r, 15)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(r, 31))) +
+                             __builtin_bit_cast(float, __builtin_amdgcn_readlane(r, 47))) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(r, 63));
+            if (lane == 0) wsum[wid][c * 9 + t] = v;
         }
+    __syncthreads();
+    if (threadIdx.x < 72) {
+        const float tsum = ((wsum[0][threadIdx.x] + wsum[1][threadIdx.x]) + wsum[2][threadIdx.x]) + wsum[3][threadIdx.x];
+        partial[(((size_t)n * S + band) * Cout + 8 * g) * 9 + threadIdx.x] = tsum;
+    }
 }
 
 // wgrad direct: block = (co, ci, split over n); 9 sums per thread, block-reduced.  partial[split][co][ci][9]
@@ -2701,7 +2714,9 @@ bool c8_segs_ok(const mtbc_seg* segs, int nseg) {
 WgPlan plan_wgrad(const mtbc_conv3x3_args* a) {
     WgPlan w{};
     if (a->operand_layout == MTBC_LAYOUT_C8 && a->Cin == 1) {      // conv3x3_wgrad_stem_c8_kernel: (image, band) splits
-        const int bands = (a->H * a->W >= 16384) ? 4 : 1;
+        // (image, 8-channel group, band) blocks: 16 bands on 256 x 256 planes -- with 4 a step's stem launch was 384 blocks = 1.5 waves per SIMD,
+        // each walking 16 iterations of {load, wait, 288 FMAs}: nobody to run while a wave waits (87 us for 110 MB)
+        const int bands = (a->H * a->W >= 65536) ? 16 : (a->H * a->W >= 16384) ? 4 : 1;
         w.nsplit = a->N * bands;
         w.partial_elems = (size_t)w.nsplit * a->Cout * 9;
         w.dbias_elems = 0;
