@@ -119,11 +119,23 @@ __device__ __forceinline__ void team_exchange(float mine, unsigned long long* mb
 // Sums of NV per-thread values over the workgroup -> tot[0..NV) in LDS (fixed order: deterministic).  The per-channel
 // quantities stay in LDS and are read back (broadcast) where they are used: 8 channels x {pivot, sums, mean, scale,
 // shift, ...} as registers cost 60+ VGPRs (or as many spilled SGPRs) and with them the second resident workgroup.
+// Wave sum on the VALU: four DPP row-shift adds leave each 16-lane row's sum in its last lane, four lane reads add the rows (fixed order).
+// The ds_bpermute butterfly of wave_sum is six dependent LDS round trips per value -- with 16 .. 25 values per reduction that was
+// ~200 of them per item in the backward kernel.
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x118, 0xf, 0xf, true));      // row_shr:8
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x114, 0xf, 0xf, true));      // row_shr:4
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x112, 0xf, 0xf, true));      // row_shr:2
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, true));      // row_shr:1
+    const int r = __builtin_bit_cast(int, v);
+    return ((__builtin_bit_cast(float, __builtin_amdgcn_readlane(r, 15)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(r, 31))) +
+            __builtin_bit_cast(float, __builtin_amdgcn_readlane(r, 47))) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(r, 63));
+}
 template <int NV, int THREADS>
 __device__ __forceinline__ void block_reduce_lds(float (&a)[NV], float (*red)[16], float* tot) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
-    for (int i = 0; i < NV; ++i) a[i] = wave_sum(a[i]);
+    for (int i = 0; i < NV; ++i) a[i] = wave_sum_dpp(a[i]);
     __syncthreads();
     if (lane == 0) {
 #pragma unroll
