@@ -889,6 +889,13 @@ __device__ __forceinline__ float row16_sum(float v) {
     return v;
 }
 
+// sum over the wave, on the VALU: DPP row sums, then the four rows' last lanes (fixed order); every lane gets the result
+__device__ __forceinline__ float wave_sum_rows(float v) {
+    const int r = __builtin_bit_cast(int, row16_sum(v));
+    return ((__builtin_bit_cast(float, __builtin_amdgcn_readlane(r, 15)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(r, 31))) +
+            __builtin_bit_cast(float, __builtin_amdgcn_readlane(r, 47))) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(r, 63));
+}
+
 // Epilogue of the channel-blocked igemm kernels (one pixel tile's accumulators -> HBM), shared by the single-buffer kernel and
 // the ring kernel of the deep levels.  O8 = 0: fp32 planar segments (store / read-modify-write / 16-bit planes); 1: 16-bit
 // channel-blocked (+ forward InstanceNorm statistics); 2: that + the norm-backward reductions (zpre = the tensor's z, prefetched).
@@ -2280,7 +2287,7 @@ __global__ __launch_bounds__(128) void conv3x3_stem_fwd_c8_kernel(const float* _
     }
     if (stats) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { ss[i] = wave_sum(ss[i]); sq[i] = wave_sum(sq[i]); }
+        for (int i = 0; i < 8; ++i) { ss[i] = wave_sum_rows(ss[i]); sq[i] = wave_sum_rows(sq[i]); }      // (16 butterflies = 96 ds_bpermute round trips: more than the convolution)
         const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
         if (lane == 0) {
 #pragma unroll
@@ -2352,9 +2359,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_stem_c8_kernel(const float*
         for (int t = 0; t < 9; ++t) {
             // wave sum on the VALU: DPP row sums (lanes 15 / 31 / 47 / 63), four lane reads.  (wave_sum's six ds_bpermute rounds per value
             // -- 432 dependent LDS round trips for the 72 values -- took longer than the accumulation itself.)
-            const int r = __builtin_bit_cast(int, row16_sum(acc[c][t]));
-            const float v = ((__builtin_bit_cast(float, __builtin_amdgcn_readlane(r, 15)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(r, 31))) +
-                             __builtin_bit_cast(float, __builtin_amdgcn_readlane(r, 47))) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(r, 63));
+            const float v = wave_sum_rows(acc[c][t]);
             if (lane == 0) wsum[wid][c * 9 + t] = v;
         }
     __syncthreads();
