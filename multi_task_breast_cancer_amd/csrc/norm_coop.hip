@@ -278,6 +278,7 @@ __global__ __launch_bounds__(THREADS, THREADS >= 512 ? 4 : 2) void in_bwd_c8_ker
     __shared__ float xch[COOP ? CO_MAXT : 1][CO_NV];
     __shared__ float tot[16];
     __shared__ float cst[3][8];              // k = rstd * gamma, m1 = S1 / HW, m2 = S2 / HW
+    __shared__ float4 cq[8];                 // {mean, rstd, gamma, beta} of the item's 8 channels
     const int tid = threadIdx.x;
     CoopHdr* hdr = COOP ? reinterpret_cast<CoopHdr*>(p.state) : nullptr;
     unsigned epoch = 0;
@@ -296,6 +297,12 @@ __global__ __launch_bounds__(THREADS, THREADS >= 512 ? 4 : 2) void in_bwd_c8_ker
         //  then went out one memory round trip at a time)
         int tl = tid;
         asm volatile("" : "+v"(tl));
+        // The per-channel constants: thread c < 8 requests channel c's NOW, in front of the tensor loads, and publishes them through LDS.
+        // (Read where they are used -- `p.mean[plane0 + c]` inside the channel loop below -- they were 8 x 4 vector loads with a wait per
+        //  channel: eight dependent memory round trips per item AFTER the tensor data had arrived, and one more for rstd * gamma behind
+        //  the team exchange.  The compiler cannot use scalar loads here: the kernel stores through other pointers.)
+        float4 myc = make_float4(0.f, 1.f, 1.f, 0.f);
+        if (tid < 8) myc = make_float4(p.mean[plane0 + tid], p.rstd[plane0 + tid], p.gamma ? p.gamma[8 * g + tid] : 1.f, p.beta ? p.beta[8 * g + tid] : 0.f);
         float xh[8][PPT], gy[8][PPT];
         // out-of-slab lanes: offsets past the buffer, the bounds check returns 0
         if constexpr (ZC8 != 0) {
@@ -408,11 +415,13 @@ __global__ __launch_bounds__(THREADS, THREADS >= 512 ? 4 : 2) void in_bwd_c8_ker
                 }
             }
         }
+        if (tid < 8) cq[tid] = myc;
+        __syncthreads();
         float ss[16], sw[9];
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
-            const float mean = p.mean[plane0 + c], rstd = p.rstd[plane0 + c];
-            const float ga = p.gamma ? p.gamma[8 * g + c] : 1.f, be = p.beta ? p.beta[8 * g + c] : 0.f;
+            const float4 qc = cq[c];
+            const float mean = qc.x, rstd = qc.y, ga = qc.z, be = qc.w;
             float s1 = 0.f, s2 = 0.f, s4 = 0.f;
 #pragma unroll
             for (int k = 0; k < PPT; ++k) {
@@ -445,7 +454,7 @@ __global__ __launch_bounds__(THREADS, THREADS >= 512 ? 4 : 2) void in_bwd_c8_ker
         block_reduce_lds<16, THREADS>(ss, red, tot);
         if constexpr (COOP) team_sum<16, THREADS>(tot, mb, member, p.T, seq, epoch, hdr, xch);
         if (tid < 8) {
-            cst[0][tid] = p.rstd[plane0 + tid] * (p.gamma ? p.gamma[8 * g + tid] : 1.f);
+            cst[0][tid] = myc.y * myc.z;
             cst[1][tid] = tot[tid] * inv; cst[2][tid] = tot[8 + tid] * inv;
             if (p.part && member == 0) { float* q = p.part + 3 * (plane0 + tid); q[0] = tot[tid]; q[1] = tot[8 + tid]; q[2] = 0.f; }
         }
