@@ -25,7 +25,8 @@
 extern "C" {
 #endif
 
-#define MTBC_VERSION 100            /* 0.1.0 */
+#define MTBC_VERSION 200            /* 0.2.0: the argument structs grew in round 2 (fields appended); a binding compiled against
+                                       another version must refuse the library (mtbc_version()) -- layouts are not negotiated */
 #define MTBC_MAX_SEGS 6
 
 enum {

@@ -227,6 +227,7 @@ EXPORTS = [
     "mtbc_program_run_ms", "mtbc_event_create", "mtbc_event_destroy",
 ]
 
+ABI_VERSION = 200          # MTBC_VERSION of include/mtbc.h these mirrors follow
 _lib: Optional[C.CDLL] = None
 
 
@@ -241,6 +242,9 @@ def load() -> C.CDLL:
             f"g.build()'` (or `make -C multi_task_breast_cancer_amd/csrc`). There is no CPU fallback.")
     lib = C.CDLL(LIB_PATH)
     lib.mtbc_version.restype = C.c_int
+    if lib.mtbc_version() != ABI_VERSION:        # the ctypes mirrors below are one struct layout: a stale library would read garbage
+        raise MtbcError(f"{LIB_PATH} reports ABI version {lib.mtbc_version()}, this binding is written for {ABI_VERSION}: rebuild "
+                        f"(`make -C multi_task_breast_cancer_amd/csrc`)")
     lib.mtbc_strerror.restype = C.c_char_p
     lib.mtbc_strerror.argtypes = [C.c_int]
     lib.mtbc_arch.restype = C.c_char_p

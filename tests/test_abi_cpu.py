@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol(lib):
     assert declared == set(L.EXPORTS), declared ^ set(L.EXPORTS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.mtbc_version() == 100
+    assert lib.mtbc_version() == 200
     assert lib.mtbc_arch() == b"gfx950"
     assert lib.mtbc_strerror(0) == b"ok" and b"workspace" in lib.mtbc_strerror(-3)
 
