@@ -29,6 +29,8 @@ def test_library_exports_every_declared_symbol(lib):
     for name in declared:
         assert hasattr(lib, name), name
     assert lib.mtbc_version() == 200
+    # header, library and binding agree on the layout version (the binding refuses any other library at load time)
+    assert int(re.search(r"#define\s+MTBC_VERSION\s+(\d+)", src).group(1)) == lib.mtbc_version() == L.ABI_VERSION
     assert lib.mtbc_arch() == b"gfx950"
     assert lib.mtbc_strerror(0) == b"ok" and b"workspace" in lib.mtbc_strerror(-3)
 
