@@ -240,6 +240,11 @@ def load() -> C.CDLL:
         raise MtbcError(
             f"{LIB_PATH} not found: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; "
             f"g.build()'` (or `make -C multi_task_breast_cancer_amd/csrc`). There is no CPU fallback.")
+    # torch FIRST: it ships its own HIP runtime (torch/lib/libamdhip64.so) and the device memory / streams handed to this library come
+    # from it.  Loaded before torch, libmtbc_hip.so would pull in the system runtime (/opt/rocm/lib) instead and the process would hold
+    # two of them: kernels registered with one, streams created by the other -> every launch fails (seen as "kernel launch failed"
+    # on the first op when __graft_entry__.build() and smoke() ran in one process).
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     lib.mtbc_version.restype = C.c_int
     if lib.mtbc_version() != ABI_VERSION:        # the ctypes mirrors below are one struct layout: a stale library would read garbage
