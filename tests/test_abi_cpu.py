@@ -99,3 +99,16 @@ def test_product_path_fails_loudly_without_gpu():
         DiceLoss()(torch.zeros(1, 1, 8, 8), torch.zeros(1, 1, 8, 8))
     with pytest.raises(L.MtbcError):
         FocalLoss()(torch.zeros(2, 3), torch.zeros(2, 3))
+
+
+def test_library_is_loaded_after_torch():
+    """_lib.load() must import torch before dlopen: libmtbc_hip.so has to bind to the HIP runtime torch ships, not bring the system one in
+    beside it (two runtimes in one process: every launch fails) -- also when the package is imported first, as __graft_entry__.build() does."""
+    import subprocess, sys
+    code = ("import sys\n"
+            "from multi_task_breast_cancer_amd import _lib\n"
+            "assert 'torch' not in sys.modules, 'the package import itself stays light'\n"
+            "_lib.load()\n"
+            "assert 'torch' in sys.modules\n")
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
