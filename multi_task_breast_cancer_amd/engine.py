@@ -169,8 +169,9 @@ class StepPlan:
 
     def __init__(self, device: torch.device, N: int, param_view: Callable[[str], torch.Tensor],
                  grad_view: Callable[[str], torch.Tensor], slots: Dict[str, ParamSlot], force_direct: bool = False,
-                 compute: int = 0, coop_reserve_cus: int = 0):
+                 compute: int = 0, coop_reserve_cus: int = 0, coop_state: Optional[Callable[[], torch.Tensor]] = None):
         self.dev = device
+        self._shared_coop = coop_state   # the model's ONE mailbox / error-word block, shared by all of its step plans
         self.coop_reserve_cus = int(coop_reserve_cus)    # CUs the cooperative InstanceNorm grids leave to other streams (data parallel)
         self.compute = int(compute)      # MFMA operand type of the 3x3 convs: 0 fp32 (parity path), 1 bf16, 2 fp16
         self.N = N
@@ -252,9 +253,15 @@ class StepPlan:
         return a.c8
 
     def _coop_state(self) -> int:
-        """The zeroed mailbox block of the cooperative InstanceNorm kernels (one per plan: its programs share a stream)."""
+        """The zeroed mailbox block of the cooperative InstanceNorm kernels.  ONE per model, shared by every step plan the
+        model compiles (training batch, short last batch, evaluation batch: they run one after the other on one stream),
+        so that the sticky error word any of them sets is the word `check_nan()` / `result()` read, whichever plan ran
+        last.  A plan built without a model (op tests) owns a block of its own."""
         if getattr(self, "_coop_buf", None) is None:
-            self._coop_buf = torch.zeros(self.lib.mtbc_instnorm_coop_state_bytes() // 4, dtype=torch.int32, device=self.dev)
+            if self._shared_coop is not None:
+                self._coop_buf = self._shared_coop()
+            else:
+                self._coop_buf = torch.zeros(self.lib.mtbc_instnorm_coop_state_bytes() // 4, dtype=torch.int32, device=self.dev)
             self.keep.append(self._coop_buf)
         return self._coop_buf.data_ptr()
 

@@ -250,7 +250,7 @@ class CompiledStep:
         dev = net.flat_p.device
         self.N, self.H, self.W = N, H, W
         plan = StepPlan(dev, N, net._param_view, net._grad_view, net.slots, force_direct=net.force_direct,
-                        compute=net.compute, coop_reserve_cus=net.coop_reserve_cus)
+                        compute=net.compute, coop_reserve_cus=net.coop_reserve_cus, coop_state=net._coop_state)
         self.x = Act("input", plan.alloc(N, net.in_channels, H, W), needs_grad=False)
         self.logits, self.segs = net._graph(plan, self.x)
         self.mask = self.onehot = None
@@ -372,6 +372,25 @@ class HipMultiTaskNet(nn.Module):
         params = self._named()
         for name in self._order:
             params[name].grad = self._grad_view(name)
+
+    def _coop_state(self) -> torch.Tensor:
+        """The cooperative InstanceNorm kernels' mailbox / error-word block of THIS model on its current device: every
+        compiled step shares it, so a mailbox timeout in any of them (the short last batch, an evaluation batch of
+        another size) is seen by the next `FusedTrainStep.check_nan()` / `FusedEvalStep.result()` whatever ran since."""
+        dev = self.flat_p.device
+        buf = getattr(self, "_coop_buf", None)
+        if buf is None or buf.device != dev:
+            buf = torch.zeros(L.load().mtbc_instnorm_coop_state_bytes() // 4, dtype=torch.int32, device=dev)
+            self._coop_buf = buf
+        return buf
+
+    def coop_error_word(self) -> Optional[torch.Tensor]:
+        """Device view (1 x int32) of the model's sticky cooperative-kernel error word (None: no plan has used one)."""
+        buf = getattr(self, "_coop_buf", None)
+        if buf is None:
+            return None
+        i = L.load().mtbc_instnorm_coop_error_offset() // 4
+        return buf[i:i + 1]
 
     # ---- compiled steps ---------------------------------------------------------------------
     def compiled(self, N: int, H: int, W: int, fused_loss: Optional[dict] = None) -> CompiledStep:

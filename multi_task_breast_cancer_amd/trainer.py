@@ -99,6 +99,8 @@ class FusedTrainStep:
             # reference trains it with BCEWithLogits (experiment_init.py:241-246) -- that loss is not in the fused program
             raise NotImplementedError("FusedTrainStep covers the multi-class head (Focal / one-hot labels); for n_classes == 2 "
                                       "use the drop-in loop (model(x), criterions.apply_criterion_..., optimizer.step())")
+        if n_classes > 3:
+            raise NotImplementedError("the fused step covers the reference's label set {0, 1, 2} (n_classes <= 3)")
         self.model, self.opt = model, optimizer
         self.alpha, self.iw, self.n_classes = float(alpha), bool(inversely_weighted), n_classes
         self.focal_weight = focal_weight
@@ -179,7 +181,7 @@ class FusedTrainStep:
         self.opt.grad_scale = (1.0 / self.world) / getattr(st, "loss_scale", 1.0)
         self.opt.step(grads_in_flat=True)
         self.losses = st.plan.loss_out
-        self._coop_err = st.plan.coop_error_word()
+        self._coop_err = self.model.coop_error_word()      # ONE word per model: every compiled step's kernels set it
         return self.losses
 
     def run_empty(self) -> None:
@@ -251,6 +253,8 @@ class FusedEvalStep:
                  focal_weight: Optional[torch.Tensor] = None):
         self.model, self.alpha, self.iw, self.n_classes = model, float(alpha), bool(inversely_weighted), n_classes
         self.binary = n_classes == 2
+        if n_classes > 3:       # the confusion matrix is the reference's 3 x 3 (f1_score(labels=[0, 1, 2]), training_multitask.py:155)
+            raise NotImplementedError("FusedEvalStep covers the reference's label set {0, 1, 2} (n_classes <= 3)")
         if self.binary != (getattr(model, "n_classes", n_classes) == 1):
             raise ValueError("n_classes does not match the model's classification head")
         self.focal_weight = None if self.binary else focal_weight
@@ -277,7 +281,7 @@ class FusedEvalStep:
         P["pack"].run()
         P["fwd"].run()
         P["loss"].run()
-        self._coop_err = st.plan.coop_error_word()
+        self._coop_err = self.model.coop_error_word()
         if self._acc is None:
             self._acc = torch.zeros(5, dtype=torch.float64, device=dev)
             self._conf = torch.zeros(3, 3, dtype=torch.int64, device=dev)
@@ -304,6 +308,8 @@ class FusedEvalStep:
         self._conf.view(-1).index_add_(0, gt * 3 + pred, torch.ones_like(gt))
 
     def result(self):
+        if self._acc is None:
+            raise L.MtbcError("FusedEvalStep.result() before any batch was evaluated")
         err = self._coop_err
         if err is not None and int(err.item()) != 0:
             raise L.MtbcError("cooperative InstanceNorm: a mailbox poll timed out (team members were not co-resident): the "

@@ -116,6 +116,32 @@ def test_cooperative_error_word_reaches_the_host():
     assert len(ev.result()) == 6
 
 
+def test_error_word_of_one_step_program_is_seen_after_a_step_of_another():
+    """ONE error word per model: a timeout in the plan of the short last batch (or of an evaluation batch of another
+    size) must still raise when `check_nan()` runs after a later step on a DIFFERENT plan (the INTEGRATION.md recipe
+    checks every 50 steps)."""
+    m = _model("bf16", 0)
+    step = FusedTrainStep(m, FusedAdam(m, lr=1e-4, eps=1e-4), alpha=0.5)
+    full = tuple(t.to(DEV) for t in O.synthetic_batch(2, 256, 256, seed=3))
+    short = tuple(t.to(DEV) for t in O.synthetic_batch(1, 256, 256, seed=4))
+    step(*short)
+    st_short = step._st
+    step(*full)
+    assert step._st is not st_short
+    assert st_short.plan.coop_error_word().data_ptr() == step._st.plan.coop_error_word().data_ptr() == m.coop_error_word().data_ptr()
+    step.check_nan()
+    step(*short)
+    st_short.plan.coop_error_word().fill_(1)           # what a timed-out kernel of the short-batch plan leaves
+    step(*full)
+    with pytest.raises(L.MtbcError, match="cooperative InstanceNorm"):
+        step.check_nan()
+    ev = FusedEvalStep(m, alpha=0.5)
+    ev(*short)
+    with pytest.raises(L.MtbcError, match="cooperative InstanceNorm"):
+        ev.result()
+    m.coop_error_word().zero_()
+
+
 def test_reserve_is_a_property_of_the_step_program_not_of_the_process():
     """Two models in one process, one planned with 64 CUs reserved and one with none: neither changes the other's
     cooperative grids (the library keeps no process-wide setting), and both reproduce themselves bit for bit."""

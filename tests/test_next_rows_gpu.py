@@ -249,94 +249,6 @@ def test_fused_step_without_inverse_weighting_matches_oracle(arch):
         assert (a.cpu() - b).abs().max().item() < 2.0e-4, k
 
 
-def test_factory_torch_optimizers_step_the_flat_parameters():
-    """experiment_init.py:186-195: SGD / AdamW are torch optimizers over the HIP model's parameters (views of the flat
-    buffer): one drop-in step moves the weights exactly as the same optimizer moves the oracle's."""
-    from multi_task_breast_cancer_amd import criterions as CR
-    from multi_task_breast_cancer_amd.experiment_init import init_optimizer
-    for name, make_ref in (("SGD", lambda ps: torch.optim.SGD(ps, lr=1e-3, momentum=0.9, nesterov=True)),
-                           ("AdamW", lambda ps: torch.optim.AdamW(ps, lr=1e-3))):
-        seed_everything(4)
-        prod = MTnnUNet(1, 1, 3)
-        ref = O.build_oracle_model("MTnnUNet", 1, 1, 3, True)
-        ref.load_state_dict(prod.state_dict())
-        prod = prod.to(DEV)
-        opt = init_optimizer(prod, name, 1e-3)
-        assert type(opt).__name__ == name
-        img, mask, label = O.synthetic_batch(2, 64, 64, seed=2)
-        onehot = torch.nn.functional.one_hot(label.flatten().long(), 3).float()
-        opt.zero_grad(set_to_none=True)
-        logits, outs = prod(img.to(DEV))
-        seg, cls = CR.apply_criterion_multitask_segmentation_classification(CR.DiceLoss(), mask.to(DEV), outs, CR.FocalLoss(), onehot.to(DEV), logits, True)
-        (0.5 * seg + 0.5 * cls).backward()
-        opt.step()
-        ropt = make_ref(ref.parameters())
-        rl, ro = ref(img)
-        rseg, rcls = O.multitask_losses(ro, mask, rl, onehot, True)
-        ropt.zero_grad()
-        (0.5 * rseg + 0.5 * rcls).backward()
-        ropt.step()
-        for (k, a), (_, b) in zip(prod.state_dict().items(), ref.state_dict().items()):
-            d = (a.cpu() - b).abs()
-            if name == "SGD":                       # update = lr * (1.9 g): as exact as the gradient
-                assert d.max().item() < 5e-5, (name, k, d.max().item())
-            else:                                   # AdamW, eps 1e-8, step 1: update = lr * sign(g) -- an element whose
-                assert d.max().item() <= 2.1e-3     # gradient is rounding noise may go the other way (2 lr), few do
-                assert (d > 1e-4).float().mean().item() < 0.02, (name, k)
-        # the step landed in the flat buffer (parameters are views of it)
-        assert torch.equal(prod._param_view(prod._order[0]), dict(prod.named_parameters())[prod._order[0]].detach())
-
-
-def test_hip_criterions_reproduce_the_reference_aggregation_goldens(golden_dir):
-    """tests/golden/criterion_aggregation.npz holds the reference's apply_criterion_multitask_segmentation_classification
-    (criterions.py:52-76) results for lists (inversely_weighted True AND False) and for the tensor branch; here the HIP
-    DiceLoss / FocalLoss modules go through the package's mirror of that function -- forward values and, by autograd,
-    the gradients of the weighted sum against the oracle's."""
-    import os
-    from multi_task_breast_cancer_amd import criterions as CR
-    g = np.load(os.path.join(golden_dir, "criterion_aggregation.npz"))
-    t = lambda k: torch.from_numpy(g[k]).to(DEV)
-    segs = [t(f"seg{i}").requires_grad_(True) for i in range(4)]
-    cls0, gt, onehot = t("cls0").requires_grad_(True), t("gt"), t("onehot")
-    dice, focal = CR.DiceLoss(), CR.FocalLoss(alpha=1, gamma=2)
-    for iw in (True, False):
-        s, c = CR.apply_criterion_multitask_segmentation_classification(dice, gt, segs, focal, onehot, [cls0], iw)
-        assert abs(s.item() - float(g[f"seg_iw{int(iw)}"])) < 1e-5, (iw, s.item())
-        assert abs(c.item() - float(g[f"cls_iw{int(iw)}"])) < 1e-5, (iw, c.item())
-        for x in segs + [cls0]:
-            x.grad = None
-        (0.35 * s + 0.65 * c).backward()
-        rs = [x.detach().cpu().clone().requires_grad_(True) for x in segs]
-        rc = cls0.detach().cpu().clone().requires_grad_(True)
-        so, co = O.multitask_losses(rs, gt.cpu(), [rc], onehot.cpu(), iw)
-        (0.35 * so + 0.65 * co).backward()
-        for a, b in zip(segs + [cls0], rs + [rc]):
-            assert (a.grad.cpu() - b.grad).abs().max().item() < 1e-7 + 1e-4 * b.grad.abs().max().item()
-    s, c = CR.apply_criterion_multitask_segmentation_classification(dice, gt, segs[3], focal, onehot, cls0, True)
-    assert abs(s.item() - float(g["seg_tensor"])) < 1e-5 and abs(c.item() - float(g["cls_tensor"])) < 1e-5
-
-
-@pytest.mark.parametrize("arch", ["MTnnUNet", "MTUNetPlusPlus"])
-def test_fused_step_without_inverse_weighting_matches_oracle(arch):
-    """config.yaml `loss.inversely_weighted: False` (criterions.py:64-66: every deep-supervision head weighs 1) on the
-    fused HIP step against the oracle's step."""
-    seed_everything(3)
-    prod = MTnnUNet(1, 1, 3) if arch == "MTnnUNet" else MTUNetPlusPlus(in_channels=1, out_channels=1, n_classes=3, deep_supervision=True)
-    O.seed_everything(3)
-    ref = O.build_oracle_model(arch, 1, 1, 3, True)
-    ref.load_state_dict(prod.state_dict())
-    prod = prod.to(DEV)
-    img, mask, label = O.synthetic_batch(2, 64, 64, seed=8)
-    step = FusedTrainStep(prod, FusedAdam(prod, lr=1e-4, eps=1e-4), alpha=0.35, inversely_weighted=False)
-    got = step(img.to(DEV), mask.to(DEV), label.to(DEV)).cpu()
-    total, seg, cls, _, _ = O.train_step(ref, O.make_adam(ref, 1e-4), img, mask, label, 0.35, False, 3)
-    assert abs(got[0].item() - total.item()) < 1e-4 and abs(got[1].item() - seg.item()) < 1e-4 and abs(got[2].item() - cls.item()) < 1e-4
-    # un-weighted heads: the segmentation term is larger than the weighted one would be (4 heads of ~1 vs 1 + 1/2 + 1/3 + 1/4)
-    _, seg_w = O.multitask_losses(ref(img)[1], mask, ref(img)[0], torch.nn.functional.one_hot(label.flatten().long(), 3).float(), True)[0], None
-    for (k, a), (_, b) in zip(prod.state_dict().items(), ref.state_dict().items()):
-        assert (a.cpu() - b).abs().max().item() < 2.0e-4, k
-
-
 def test_validation_epoch_with_the_binary_head_matches_oracle():
     """n_classes == 2: ONE logit, BCEWithLogits (experiment_init.py:242), predictions sigmoid > .5 against the {0,1} label
     (training_multitask.py:53-61), f1 still asked for labels [0,1,2] (:155)."""
