@@ -5,12 +5,15 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
         bench.py --gpus N --steps K --warmup W
 
+`python bench.py --gpus N` from a bare interpreter (no WORLD_SIZE in the environment) starts the N ranks itself -- as child
+processes of `torch.distributed.run`, BEFORE anything in this process touches the GPU -- and relays rank 0's JSON line.
+
 One "step" = one optimisation step (pack -> fwd -> Dice+Focal -> bwd -> [all-reduce] -> Adam) on a per-GPU batch
 of 32 synthetic images already resident in HBM (BASELINE.json configs[1]; weak scaling: global batch = 32*N).
-Default compute mode is the one configs[1] names: bf16 MFMA operands (3x3 convs, k=2 ConvT backward), everything an
-MFMA does not read -- conv outputs, gradient sums, norm statistics, accumulators, losses, Adam -- in fp32; the operand
-tensors are stored once in the MFMA's 16-bit channel-blocked layout.  At N=1 the same step is also timed in the fp32
-parity mode (`fp32_parity_mode`).
+Default compute mode is the one configs[1] names: bf16 MFMA operands (3x3 convs, k=2 ConvT), stored once in the MFMA's
+16-bit channel-blocked layout; the conv outputs in front of InstanceNorm are stored in 16 bits too (fp16, 11 significant
+bits); accumulators, gradient sums, norm statistics, parameters, losses and Adam are fp32.  At N=1 the same step is also
+timed in the fp32 parity mode (`fp32_parity_mode`: the reference's arithmetic, the mode the 1e-4 parity tests run in).
 Rank 0 prints ONE JSON line; `roofline` is measured live with HIP events around the dominant kernel family (the
 implicit-GEMM conv3x3, forward + dgrad launches) and priced against the roof the kernel's arithmetic intensity puts it
 under (fp32: MFMA; bf16: HBM); `cpu_baseline` times the CPU oracle on the host cores.
@@ -187,7 +190,7 @@ def run_mode(args, dtype, dev, rank, world, dist, want_roofline):
     # from the committed summary of the separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same command
     # (tools/profile_round.sh); `traffic_source` names the file, and the field is null when no summary fits the build
     traffic, traffic_source = None, None
-    for tag in ("r02c", "r02b", "r02", "r01"):
+    for tag in ("r03", "r02c", "r02b", "r02", "r01"):
         tpath = os.path.join(ROOT, "profiles", f"{tag}_hbm_traffic_{dtype}.json")
         if not os.path.exists(tpath):
             continue
@@ -256,6 +259,80 @@ def run_mode(args, dtype, dev, rank, world, dist, want_roofline):
     return res
 
 
+def spawn_ranks(n: int) -> int:
+    """Start `n` ranks of this script under torch.distributed.run (127.0.0.1 rendezvous, a free port) and wait."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    note(f"no WORLD_SIZE in the environment: starting {n} ranks: {' '.join(cmd[1:8])} ...")
+    return subprocess.call(cmd, env=env)
+
+
+def workload_labels(args, world: int):
+    """(metric, workload tail, BASELINE.json configs index or None) for what was actually run."""
+    arch_label = {"MTUNetPlusPlus": "U-Net++ MT", "MTnnUNet": "nnU-Net MT"}.get(args.arch, args.arch)
+    metric = f"training images/sec (1-ch {args.size}x{args.size}, {arch_label})"
+    idx = None
+    if args.arch == "MTUNetPlusPlus" and args.size == 256 and args.batch == 32 and args.dtype == "bf16":
+        idx = 1 if world == 1 else (3 if world == 8 else None)
+        tail = ("BASELINE.json configs[1]" if world == 1 else
+                f"BASELINE.json configs[3] (global batch 256 on 8 GPUs){'' if world == 8 else f' at {world} GPUs: per-GPU shape of configs[1]'}")
+    elif args.arch == "MTnnUNet" and args.size == 256 and args.batch == 64 and world == 1:
+        idx, tail = 2, "BASELINE.json configs[2]"
+    elif args.size == 512 and args.dtype == "f16" and args.batch == 16:
+        idx = 4 if world == 8 else None
+        tail = "BASELINE.json configs[4]" + ("" if world == 8 else f": its per-GPU shape (global batch 128 on 8 GPUs) at {world} GPU(s)")
+    else:
+        tail = "not a BASELINE.json configuration"
+    return metric, tail, idx
+
+
+def stub_main(args, rank: int, world: int) -> None:
+    """`--cpu-stub`: the launcher and the one-line contract on CPU ranks (gloo), with a stand-in for the step."""
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("gloo")
+    g = torch.Generator().manual_seed(rank)
+    w = torch.randn(64, 64, generator=g)
+
+    def step():
+        y = (w @ w).sum().reshape(1)
+        if world > 1:
+            dist.all_reduce(y)
+        return y
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    if world > 1:
+        dist.barrier()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    metric, tail, idx = workload_labels(args, world)
+    if rank == 0:
+        print(json.dumps({"metric": metric, "value": round(args.batch * world * args.steps / dt, 2), "unit": "images/sec", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+                          "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+                          "config": {"workload": f"CPU stand-in step (launcher rehearsal), {tail}", "baseline_config_index": idx,
+                                     "global_batch": args.batch * world, "parallelism": f"dp{world}"},
+                          "env": {"not_reportable": ["--cpu-stub"]}}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -265,8 +342,9 @@ def main() -> None:
     ap.add_argument("--batch", type=int, default=32, help="per-GPU batch")
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--dtype", default="bf16", choices=["f32", "bf16", "f16"],
-                    help="MFMA operand type of the 3x3 convs (BASELINE.json configs[1] names bf16); storage, "
-                         "accumulation, norm statistics, losses and Adam are fp32 in every mode; f32 = the parity mode")
+                    help="MFMA operand type of the 3x3 convs / k=2 ConvT (BASELINE.json configs[1] names bf16); in the 16-bit modes "
+                         "operand tensors and conv outputs are STORED in 16 bits, accumulation, norm statistics, gradient sums, "
+                         "losses and Adam stay fp32; f32 = the reference-arithmetic parity mode")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-parity-mode", action="store_true", help="skip the extra fp32 (parity mode) measurement at N=1")
@@ -275,14 +353,23 @@ def main() -> None:
     ap.add_argument("--allow-probes", action="store_true",
                     help="A/B experiments only: run although probe variables / MTBC_LIB are set; the JSON line is then marked "
                          "not_reportable and must never be quoted as a result")
+    ap.add_argument("--cpu-stub", action="store_true",
+                    help="launcher / contract rehearsal WITHOUT a GPU: gloo backend and a stand-in step (tests/test_bench_cli_cpu.py); "
+                         "the line is marked not_reportable")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # bare `python bench.py --gpus N`: one fresh process per GPU through torch.distributed.run, started before this
+        # process has made any GPU call (a process that has initialised the GPU must never be replaced or forked from);
+        # the children inherit stdout, so rank 0's JSON line is this command's output; exit with the launcher's code
+        raise SystemExit(spawn_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if args.gpus != 1 or world != 1:
-            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's --nproc-per-node must equal --gpus")
+    if args.cpu_stub:
+        return stub_main(args, rank, world)
     from multi_task_breast_cancer_amd import _lib as L
     from multi_task_breast_cancer_amd import switches
     bad = switches.result_altering()
@@ -299,8 +386,9 @@ def main() -> None:
         dist.init_process_group("nccl", device_id=dev)
 
     main_res = run_mode(args, args.dtype, dev, rank, world, dist, rank == 0 and not args.no_roofline)
+    metric, tail, cfg_idx = workload_labels(args, world)
     out = {
-        "metric": "training images/sec (1-ch 256x256, U-Net++ MT)", "value": main_res["value"],
+        "metric": metric, "value": main_res["value"],
         "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": main_res["ms_per_step"], "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": args.dtype, "data": "synthetic" + (" (pinned host batches, H2D inside the step)" if args.host_input else ""),
@@ -309,7 +397,10 @@ def main() -> None:
                                + ("fp32 MFMA (parity mode)" if args.dtype == "f32" else
                                   f"{args.dtype} MFMA operands (3x3 convs, ConvT) and 16-bit stored conv outputs / activations; fp32 accumulation, "
                                   f"gradient sums, statistics, losses, parameters and optimizer") +
-                               ", random-init weights (BASELINE.json configs[1])",
+                               f", random-init weights ({tail})",
+                   "baseline_config_index": cfg_idx,
+                   "storage": ({"operands": "f32", "conv_outputs": "f32"} if args.dtype == "f32" else
+                               {"mfma_operands": args.dtype, "conv_outputs_before_norm": "f16", "accumulators_gradsums_stats_params_adam": "f32"}),
                    "global_batch": args.batch * world, "parallelism": f"dp{world}"},
         "final_loss": main_res["final_loss"],
         "env": {"mtbc_variables_set": switches.active(), "library": os.path.relpath(L.LIB_PATH, ROOT),

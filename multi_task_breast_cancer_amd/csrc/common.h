@@ -119,6 +119,8 @@ size_t mtbc_i_conv1x1_c8_wgrad_workspace(const mtbc_conv1x1_args* a);
 int mtbc_i_conv1x1_c8_wgrad(const mtbc_conv1x1_args* a, hipStream_t st);
 // internal (C++) helpers implemented in reduce.hip
 int mtbc_i_splitk_reduce(const float* partial, float* out, int nsplit, size_t elems, int accumulate, hipStream_t st);
+// rows of elems1 + elems2 floats per split: [0, elems1) summed into out, the rest into out2
+int mtbc_i_splitk_reduce2(const float* partial, float* out, float* out2, int nsplit, size_t elems1, size_t elems2, int accumulate, hipStream_t st);
 // convt2.hip: ConvTranspose k == s == 2 backward, operands straight from HBM into MFMA fragments
 bool mtbc_i_convT2_fwd_ok(const mtbc_convT_args* a);
 int mtbc_i_convT2_fwd(const mtbc_convT_args* a, hipStream_t st);

@@ -8,6 +8,7 @@
 // packed weight image is already the LDS image ([mtile][ci][tap][16]) so its staging is a copy.
 // Replaces nn.Conv2d(k=3,padding=1) of MTnnUNet.py:12-16 and MONAI Convolution (MTUNetPlusPlus.py:47-81).
 #include "common.h"
+#include <type_traits>
 #include <cstdlib>
 
 namespace {
@@ -1890,9 +1891,12 @@ struct WgC8P {
     int N, H, W, Cin, Cout;
     SegTable in;                       // ptr = 16-bit base, bstride in 16-bit elements, channels % 8 == 0
     const unsigned short* dz;          // [N][Cout/8][HW][8]
-    float* partial;                    // [nsplit][Cout][Cin][9]
-    float* dbias_partial;              // [nsplit][Cout] or nullptr
+    float* partial;                    // [nsplit] rows of `prow` floats: [Cout][Cin][9], then [Cout] bias-gradient partials when asked for
+    long long prow;
+    int want_bias;
     int tiles_x, tiles_y, total_tiles, tiles_per_split, ciblocks;
+    int hack;
+    int coblocks, cit, segs, seg_tiles, depth;   // conv3x3_wgrad_c8w_kernel: input-channel tiles of 16 per block; row segments per strip, steps (4 rows) per segment
 };
 template <bool F16, int GEO>
 __global__ __launch_bounds__(256, 4) void conv3x3_wgrad_c8_kernel(const WgC8P p) {
@@ -1952,7 +1956,7 @@ __global__ __launch_bounds__(256, 4) void conv3x3_wgrad_c8_kernel(const WgC8P p)
     const int lrow = GEO == 0 ? 0 : (kg >> 1), lcol = GEO == 0 ? 8 * kg : 8 * (kg & 1);      // this lane group's place in a K-step
     const int zoff = ZBASE + ((pp >> 1) * ZG + lrow * TW + lcol + q) * 8 + 4 * (pp & 1);     // + c*2*ZG*8 + (step*32 + 4*blk)*8
     const int xoff = ((2 * it + (pp >> 1)) * XG + lrow * LW + lcol + q) * 8 + 4 * (pp & 1);  // + ((row0+r)*LW + 4*blk)*8
-    const bool do_bias = p.dbias_partial != nullptr && cib == 0 && it == 0;         // wave-uniform
+    const bool do_bias = p.want_bias && cib == 0 && it == 0;         // wave-uniform
 
     f32x4 acc[2][9], accb[2];
 #pragma unroll
@@ -2031,7 +2035,7 @@ __global__ __launch_bounds__(256, 4) void conv3x3_wgrad_c8_kernel(const WgC8P p)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int co = co0 + c * 16 + kg * 4 + r;
-                if (co < p.Cout) p.dbias_partial[(size_t)split * p.Cout + co] = accb[c][r] + red[(36 + c) * 64 + lane][r];
+                if (co < p.Cout) p.partial[(size_t)split * p.prow + (size_t)p.Cout * p.Cin * 9 + co] = accb[c][r] + red[(36 + c) * 64 + lane][r];
             }
     }
     const int ci = ci0 + it * 16 + j;
@@ -2042,10 +2046,323 @@ __global__ __launch_bounds__(256, 4) void conv3x3_wgrad_c8_kernel(const WgC8P p)
         for (int r = 0; r < 4; ++r) {
             const int co = co0 + c * 16 + kg * 4 + r;
             if (co >= p.Cout) continue;
-            float* dst = p.partial + (((size_t)split * p.Cout + co) * p.Cin + ci) * 9;
+            float* dst = p.partial + (size_t)split * p.prow + ((size_t)co * p.Cin + ci) * 9;
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) dst[tap] = acc[c][tap][r] + red[(it * 18 + c * 9 + tap) * 64 + lane][r];
         }
+}
+
+// ------------------------------------------------------------------ wgrad on channel-blocked operands, wide blocks + rolling rows ("c8w", round 3)
+// conv3x3_wgrad_c8_kernel stages (L2 -> LDS, by DMA) 1.59 x 32 input channels + 32 output channels per 128-pixel tile and
+// (32 co x 32 ci) block: dz once per 32 input channels (five times for the 144 -> 24 conv), X once per 32 output channels
+// (twice for Cout = 48, with 64 x 64 MFMA padding around 48 x 48), and a third of every X tile is halo that was staged before.
+// Its measured HBM traffic is 2.2x the algorithmic bytes (profiles/r02c_hbm_traffic_bf16.json) at a byte rate that is already
+// what this code base reaches, so the lever is bytes.  This kernel:
+//   * a block owns ALL output channels of a 24 / 48-channel conv (COT = 2 or 3 tiles of 16; wider outputs in blocks of 48 or 32)
+//     and up to 5 input-channel tiles (80 channels);
+//   * it walks DOWN a 32-column strip of one image and keeps the rows it has already staged: per group an LDS ring of 10 halo
+//     rows x 34 columns; a step multiplies 4 rows x 32 pixels (4 K-steps, 6 live ring rows) while the DMA of the NEXT 4 rows
+//     (and of the next step's dz, second stage) is in flight -- every X row is staged once (34 / 32 = 1.06x), nothing waits for
+//     a load that was not issued a whole step earlier, ONE barrier per step;
+//   * 8 waves; the work items are (ci tile, tap row) PAIRS dealt round-robin to the waves (at most U = 2 per wave): a pair is
+//     one set of three shifted X windows (three transposed reads + v_alignbit, as before) times all COT dz fragments, which a
+//     wave reads once per K-step for both of its pairs -- (2 COT + 6) LDS reads for 6 COT MFMAs;
+//   * every accumulator has ONE owner (no row-half split): no end-of-block LDS reduction, the partial is stored straight from
+//     the accumulators.  2 blocks (16 waves) per CU, one wave of <= 512 blocks; a block = (strip, row segment, channel block).
+// Same LDS piece layout, transposed reads, MFMA operand order as conv3x3_wgrad_c8_kernel; the K order and the split-K
+// partition differ, so results agree to fp32 re-association, not bit for bit.
+// Depth D = 1 .. 3 steps of DMA in flight per block (ring of 6 + 4 D rows, D + 1 dz stages, counted vmcnt): the plan takes the
+// (blocks per CU, D) that puts the most bytes in flight within the 160 KB of LDS -- a 24 -> 24 step is only 12.7 KB.
+// LDS-DMA by hand (round 3).  hipcc knows that `buffer_load ... lds` stores to LDS and cannot tell WHICH part of a dynamic LDS block a
+// later ds_read touches, so behind the builtin it puts `s_waitcnt vmcnt(0)` in front of the next LDS read -- the DMA of step t + 1,
+// issued before the MFMAs of step t precisely to run under them, was waited for before the first fragment read of step t
+// (ISA: `[vmcnt(0)] r14 ...` at the top of the step body; ablation: DMA-only 107 us + compute-only 123 us = full 235 us).  Issued from
+// inline assembly the load is an opaque instruction: no alias tracking, no inserted wait; the kernel's own counted `s_waitcnt vmcnt`
+// + barrier are the ordering (they were all along).  The descriptor is the four dwords make_buffer_rsrc builds.
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ i32x4 dma_rsrc(const void* base, unsigned bytes) {
+    const unsigned long long a = reinterpret_cast<unsigned long long>(base);
+    return (i32x4){(int)(unsigned)a, (int)((unsigned)(a >> 32) & 0xffffu), (int)bytes, 0x00020000};
+}
+__device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(unsigned long long)(__attribute__((address_space(3))) const void*)p; }
+// 64 lanes x 16 B: lane l's piece lands at LDS byte address `lds` + 16 l; out-of-range `voff` -> zeros
+__device__ __forceinline__ void dma16(const i32x4 rsrc, unsigned lds, unsigned voff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds), "v"(voff), "s"(rsrc) : "memory", "m0");
+}
+#ifdef MTBC_PROBES
+#define MTBC_DBG_HACK(p) ((p).hack)
+#else
+#define MTBC_DBG_HACK(p) (0)
+#endif
+#define MTBC_C8W_ADVANCE() do { b4 = b4 + 4 >= RING ? b4 + 4 - RING : b4 + 4; bn = bn + 4 >= RING ? bn + 4 - RING : bn + 4; zs = zs == D ? 0 : zs + 1; zn = zn == D ? 0 : zn + 1; } while (0)
+constexpr int C8WW_TH = 4, C8WW_TW = 32, C8WW_LW = 34, C8WW_ZG = C8WW_TH * C8WW_TW + 4;
+constexpr int C8WW_MAXCIT = 5;            // ci tiles of 16 per block: 3 * 5 = 15 pairs <= 8 waves x 2
+static inline int c8w_ring(int depth) { return 6 + 4 * depth; }
+static_assert((10 * C8WW_LW * 16) % 256 == 64 && (14 * C8WW_LW * 16) % 256 == 192 && (18 * C8WW_LW * 16) % 256 == 64 && (C8WW_ZG * 16) % 256 == 64,
+              "group strides: 64 / 192 mod 256 B keep the transposed reads conflict-free");
+// X ring of every input-channel group, 16 pieces of pad, D + 1 stages of dz
+static inline size_t c8w_lds_bytes(int cit, int cot, int depth) { return (size_t)(2 * cit * c8w_ring(depth) * C8WW_LW + 16 + (depth + 1) * 2 * cot * C8WW_ZG) * 16; }
+static inline size_t c8w_step_bytes(int cit, int cot) { return (size_t)(2 * cit * C8WW_TH * C8WW_LW + 2 * cot * C8WW_TH * C8WW_TW) * 16; }
+__device__ __forceinline__ void c8w_wait_vm(int c) {       // s_waitcnt vmcnt(c), c wave-uniform and even, <= 20
+    switch (c) {
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+    case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+    case 14: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
+    case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+    case 18: asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
+    }
+}
+template <bool F16, int COT, bool BIAS>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void conv3x3_wgrad_c8w_kernel(const WgC8P p) {
+    using T = LP<F16>;
+    typedef short s16x4 __attribute__((ext_vector_type(4)));
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) s16x4* lds_s16x4_t;
+    constexpr int TW = C8WW_TW, TH = C8WW_TH, LW = C8WW_LW, ZG = C8WW_ZG, U = 2;
+    const int D = p.depth, RING = 6 + 4 * D, XG = RING * LW;      // steps in flight, ring rows, pieces per input-channel group
+    extern __shared__ __attribute__((aligned(16))) unsigned short smemw[];
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int HW = p.H * p.W;
+    // block id -> (image, row segment, strip, channel block).  Workgroups go to the 8 XCDs round-robin by linear id: with N % 8 == 0
+    // image n is handled by XCD n % 8 alone, and there the channel blocks of one (strip, segment) and then the strips of one segment
+    // are neighbours in dispatch order -- what they share (dz between input-channel blocks, X between output-channel blocks, the
+    // cache lines a strip's halo columns have in common with the next strip) is fetched into ONE L2, by blocks that run side by side
+    int yb, seg, tx, n;
+    {
+        const int ny = p.ciblocks * p.coblocks;
+        int k = blockIdx.x;
+        int img0 = 0, imgs = 1;
+        if (p.N % 8 == 0) { img0 = k & 7; imgs = 8; k >>= 3; }
+        yb = k % ny; k /= ny;
+        tx = k % p.tiles_x; k /= p.tiles_x;
+        seg = k % p.segs; k /= p.segs;
+        n = k * imgs + img0;
+    }
+    const int cib = yb % p.ciblocks, co0 = (yb / p.ciblocks) * 16 * COT;
+    const int cit0 = cib * p.cit, ncit = min(p.cit, ((p.Cin + 15) >> 4) - cit0), ci0 = cit0 * 16;
+    const int ZBASE = (2 * p.cit * XG + 16) * 8;           // 16-bit elements
+    constexpr int ZSTAGE = 2 * COT * ZG * 8;
+    // this block's share of the pixels: rows [y0, y0 + 4 nt) of the 32-column strip x0 of image n
+    const int split = (n * p.tiles_x + tx) * p.segs + seg;
+    const int x0 = tx * TW;
+    const int ty0 = seg * p.seg_tiles, nt = min(p.seg_tiles, p.tiles_y - ty0), y0 = ty0 * TH;
+
+    // DMA: wave w brings input-channel groups w and w + 8 of the block and output-channel group 7 - w; one image, so the
+    // buffer descriptors are built once
+    i32x4 xr[2]; bool xok[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int gx = wv + 8 * k, c = ci0 + 8 * gx;
+        xok[k] = gx < 2 * ncit && c < p.Cin;             // (an absent group's LDS image is never read into a stored result)
+        const SegRef sr = seg_ref(p.in, xok[k] ? c : 0);
+        const unsigned short* base = reinterpret_cast<const unsigned short*>(sr.ptr) + (size_t)((xok[k] ? c : 0) - sr.cb) * HW + (size_t)n * sr.bs;
+        xr[k] = dma_rsrc(base, HW * 16);
+    }
+    const int gz = 7 - wv, cz = co0 + 8 * gz;
+    const bool zok = gz < 2 * COT && cz < p.Cout;
+    const i32x4 zr = dma_rsrc(p.dz + ((size_t)n * p.Cout + (zok ? cz : 0)) * HW, HW * 16);
+    const unsigned lds0 = lds_addr(smemw);
+    // X rows: one instruction per (group, halo row), lanes 0..33 = halo columns x0 - 1 .. x0 + 32; row `rel` counts from y0 - 1
+    // and lives in ring slot rel % 10
+    auto issue_x = [&](int rel_first, int slot_first, int count) {
+        int ln = lane;
+        asm volatile("" : "+v"(ln));                       // (keeps the per-lane offsets out of the registers that live across the loop)
+        const int x = x0 - 1 + ln;
+        const bool colok = ln < LW && x >= 0 && x < p.W;
+#ifdef MTBC_PROBES
+        if (p.hack & 1) {      // TIMING ONLY (wrong results): the same rows as aligned 2-row x 32-column instructions of a full 1 KiB, no halo columns
+            const int xx = x0 + (ln & 31);
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                if (!xok[k]) continue;
+                for (int rr = 0; rr < count; rr += 2) {
+                    const int y = y0 - 1 + rel_first + rr + (ln >> 5);
+                    const unsigned voff = (xx < p.W && y >= 0 && y < p.H) ? 16u * (unsigned)(y * p.W + xx) : 0xfffffff0u;
+                    dma16(xr[k], lds0 + 2u * (unsigned)(((wv + 8 * k) * XG + ((slot_first + rr) % (RING - 2)) * LW) * 8), voff);
+                }
+            }
+            return;
+        }
+#endif
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            if (!xok[k]) continue;                         // wave-uniform
+            int slot = slot_first;
+            for (int rr = 0; rr < count; ++rr) {
+                const int y = y0 - 1 + rel_first + rr;
+                const unsigned voff = (colok && y >= 0 && y < p.H) ? 16u * (unsigned)(y * p.W + x) : 0xfffffff0u;
+                if (ln < LW)
+                    dma16(xr[k], lds0 + 2u * (unsigned)(((wv + 8 * k) * XG + slot * LW) * 8), voff);
+                slot = slot + 1 == RING ? 0 : slot + 1;
+            }
+        }
+    };
+    auto issue_z = [&](int t, int stg) {                   // dz of step t: 4 rows x 32 pixels into stage t % (D + 1)
+        if (!zok) return;
+        const int x = x0 + (lane & 31);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int y = y0 + TH * t + 2 * i + (lane >> 5);
+            const unsigned voff = (y < p.H && x < p.W) ? 16u * (unsigned)(y * p.W + x) : 0xfffffff0u;
+            dma16(zr, lds0 + 2u * (unsigned)(ZBASE + stg * ZSTAGE + (gz * ZG + 64 * i) * 8), voff);
+        }
+    };
+
+    const int j = lane & 15, kg = lane >> 4, q = j >> 2, pp = j & 3;
+    // transposed-read addresses (see conv3x3_wgrad_c8_kernel): a K-step is one row of 32 pixels, lane group kg owns columns 8kg .. 8kg + 7
+    const int zoff = ZBASE + ((pp >> 1) * ZG + 8 * kg + q) * 8 + 4 * (pp & 1);        // + stage + c * 2 * ZG * 8 + (step * 32 + 4 * half) * 8
+    int xoff[U], pcit[U], prow[U]; bool pok[U];
+#pragma unroll
+    for (int i = 0; i < U; ++i) {
+        const int pi = wv + 8 * i;                          // pair = (ci tile, tap row)
+        pok[i] = pi < 3 * ncit;
+        pcit[i] = pi / 3; prow[i] = pi - 3 * pcit[i];
+        xoff[i] = ((2 * pcit[i] + (pp >> 1)) * XG + 8 * kg + q) * 8 + 4 * (pp & 1);   // + ring slot * LW * 8 + 4 * blk * 8
+    }
+    // BIAS (dz x ones on the matrix pipe; the training step never asks: its conv-bias gradient comes out of the InstanceNorm backward): every
+    // wave of the input-channel block 0 carries the sums, wave 7 stores them
+    const bool do_bias = BIAS && cib == 0 && wv == 7;
+
+    f32x4 acc[U][COT][3], accb[COT];
+#pragma unroll
+    for (int c = 0; c < COT; ++c) {
+        accb[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < U; ++i)
+#pragma unroll
+            for (int s_ = 0; s_ < 3; ++s_) acc[i][c][s_] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    typename T::frag ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = 1.0f;
+
+    // step t multiplies rows rel 4t .. 4t + 5 (ring slots (4t + k) % RING) while the rows of steps t + 1 .. t + D arrive in the slots
+    // step t does not read.  ONE barrier per step: behind it every wave's share of step t has landed (each wave waited until at most
+    // the instructions of the later batches were outstanding: vmcnt counts down in issue order) and every wave has finished step
+    // t - 1, whose four oldest rows / dz stage the batch issued next overwrites.
+    const int nw = ((p.hack & 1) ? 2 : 4) * ((xok[0] ? 1 : 0) + (xok[1] ? 1 : 0)) + (zok ? 2 : 0);       // DMA instructions of this wave per steady batch
+    issue_x(0, 0, 6);
+    issue_z(0, 0);
+    for (int k = 1; k < D && k < nt; ++k) { issue_x(TH * k + 2, TH * k + 2, 4); issue_z(k, k); }       // (4k + 2 + 3 < RING for k < D)
+    int b4 = 0, bn = (TH * D + 2) % RING, zs = 0, zn = D % (D + 1);     // (4 t) % RING, slot of the first row of batch t + D, dz stage of t / of t + D
+    for (int t = 0; t < nt; ++t) {
+        const int later = min(nt - 1 - t, D - 1);
+        c8w_wait_vm(later * nw);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (t + D < nt && !(MTBC_DBG_HACK(p) & 4)) {
+            issue_x(TH * (t + D) + 2, bn, 4);
+            issue_z(t + D, zn);
+        }
+        const unsigned short* smz = smemw + zs * ZSTAGE;
+        if (MTBC_DBG_HACK(p) & 2) { MTBC_C8W_ADVANCE(); continue; }        // TIMING ONLY: no fragment reads, no MFMAs
+        // The four K-steps of a step as ONE straight-line body per (valid pair slots of this wave, bias wave or not): a wave-uniform
+        // branch inside the body ends the scheduler's view, and each K-step then runs read -> wait -> align -> MFMA back to back
+        // (measured: 3.5x the MFMA time at 4 waves per SIMD); chosen once per step.
+        auto body = [&](auto ns_) {
+            constexpr int NS = decltype(ns_)::value;
+            // Software pipeline in the source, fenced with sched_barriers (left alone the scheduler hoists ALL LDS reads of the step to
+            // the top and spills ~300 registers): the dz fragments of K-step s + 1 are read into a second set before the MFMAs of
+            // K-step s; the X windows of pair slot i for K-step s + 1 are read right behind that slot's MFMAs of K-step s, into
+            // the registers those MFMAs have just consumed (the other slot's MFMAs cover the latency).
+            s16x4 ra[2][COT][2], rb[NS][3];
+            auto load_a = [&](int step, int set) {
+#pragma unroll
+                for (int c = 0; c < COT; ++c) {
+                    ra[set][c][0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(smz + zoff + c * 2 * ZG * 8 + (step * 32) * 8));
+                    ra[set][c][1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(smz + zoff + c * 2 * ZG * 8 + (step * 32 + 4) * 8));
+                }
+            };
+            auto load_b = [&](int step, int i) {
+                const int v = b4 + step + prow[i];                       // ring slot of halo row (step + tap row): scalar
+                const unsigned short* smx = smemw + (v >= RING ? v - RING : v) * (LW * 8) + xoff[i];
+#pragma unroll
+                for (int b = 0; b < 3; ++b) rb[i][b] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(smx + 4 * b * 8));
+            };
+            load_a(0, 0);
+#pragma unroll
+            for (int i = 0; i < NS; ++i) load_b(0, i);
+#pragma unroll
+            for (int step = 0; step < TH; ++step) {
+                const int set = step & 1;
+                if (step + 1 < TH) load_a(step + 1, set ^ 1);
+                __builtin_amdgcn_sched_barrier(0);
+                typename T::frag a[COT];
+#pragma unroll
+                for (int c = 0; c < COT; ++c) {
+                    const s16x4 lo = ra[set][c][0], hi = ra[set][c][1];
+                    const short e[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    a[c] = __builtin_bit_cast(typename T::frag, e);
+                }
+                if constexpr (BIAS) {
+#pragma unroll
+                    for (int c = 0; c < COT; ++c) accb[c] = T::mfma(a[c], ones, accb[c]);
+                }
+#pragma unroll
+                for (int i = 0; i < NS; ++i) {
+                    unsigned d[6];
+#pragma unroll
+                    for (int b = 0; b < 3; ++b) {
+                        const uint2 u = __builtin_bit_cast(uint2, rb[i][b]);
+                        d[2 * b] = u.x; d[2 * b + 1] = u.y;
+                    }
+                    u32x4 w0, w1, w2;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        w0[k] = d[k];
+                        w1[k] = __builtin_amdgcn_alignbit(d[k + 1], d[k], 16);
+                        w2[k] = d[k + 1];
+                    }
+                    const typename T::frag b0 = __builtin_bit_cast(typename T::frag, w0);
+                    const typename T::frag b1 = __builtin_bit_cast(typename T::frag, w1);
+                    const typename T::frag b2 = __builtin_bit_cast(typename T::frag, w2);
+#pragma unroll
+                    for (int c = 0; c < COT; ++c) {
+                        acc[i][c][0] = T::mfma(a[c], b0, acc[i][c][0]);
+                        acc[i][c][1] = T::mfma(a[c], b1, acc[i][c][1]);
+                        acc[i][c][2] = T::mfma(a[c], b2, acc[i][c][2]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (step + 1 < TH) load_b(step + 1, i);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        };
+        using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+        // (pair slots this wave does not own are multiplied too -- their accumulators are never stored: one straight-line body
+        //  per kernel keeps the register allocation within 128; COT = 2 affords a second body for the waves with ONE pair)
+        if (COT == 2 && !pok[1]) body(I1{}); else body(I2{});
+        MTBC_C8W_ADVANCE();
+    }
+    float* prow_base = p.partial + (size_t)split * p.prow;
+    if (do_bias && j == 0) {
+#pragma unroll
+        for (int c = 0; c < COT; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = co0 + c * 16 + kg * 4 + r;
+                if (co < p.Cout) prow_base[(size_t)p.Cout * p.Cin * 9 + co] = accb[c][r];
+            }
+    }
+#pragma unroll
+    for (int i = 0; i < U; ++i) {
+        const int ci = ci0 + pcit[i] * 16 + j;
+        if (!pok[i] || ci >= p.Cin) continue;
+#pragma unroll
+        for (int c = 0; c < COT; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = co0 + c * 16 + kg * 4 + r;
+                if (co >= p.Cout) continue;
+                float* dst = prow_base + ((size_t)co * p.Cin + ci) * 9 + 3 * prow[i];
+                dst[0] = acc[i][c][0][r]; dst[1] = acc[i][c][1][r]; dst[2] = acc[i][c][2][r];
+            }
+    }
 }
 
 // fp32 planar (N,C,H,W) <-> 16-bit channel-blocked [N][C/8][H*W][8]; one thread = one 16-byte piece
@@ -2709,7 +3026,18 @@ int run_igemm(int N, int H, int W, int red, int rows, const SegTable& in, const 
     return launch_igemm_mt<2>(MT, p, mblocks, st);
 }
 
-struct WgPlan { bool mfma; bool smallcin; int cot; int geo, tiles_x, tiles_y, total_tiles, nsplit, tiles_per_split, coblocks, ciblocks; size_t partial_elems, dbias_elems; };
+struct WgPlan { bool mfma; bool smallcin; int cot; int geo, tiles_x, tiles_y, total_tiles, nsplit, tiles_per_split, coblocks, ciblocks; size_t partial_elems, dbias_elems; bool c8w; int cit, segs, seg_tiles, depth; };
+// channel-blocked weight gradient: which launches take the wide-block kernel (conv3x3_wgrad_c8w_kernel)
+bool c8w_wanted(const mtbc_conv3x3_args* a) {
+    if (a->Cin == 1 || a->W <= 16 || a->Cin % 8 || a->Cout % 8) return false;
+    static const int probe = mtbc_probe_int("MTBC_WGRAD_C8W", -1);      // probes build only: 0 = never, 1 = wherever the kernel can run
+    if (probe >= 0) return probe != 0;
+    // measured per layer of the U-Net++ step (tools/wgrad_probe.py, profiles/r03_wgrad_probe.txt): the wide blocks win where dz was
+    // staged three or more times and the maps are large (72 .. 144 -> 24 @256x256: -2 .. -30 us, 96 .. 192 -> 48 @128x128: -1 .. -25 us);
+    // on single-input convs (Cin <= 48: both kernels stage everything once) and on maps <= 64 wide (few steps per block) the
+    // 32 x 32 kernel's four small blocks per CU are as fast or faster
+    return a->Cin >= 64 && a->W >= 128;
+}
 // operand_layout = MTBC_LAYOUT_C8: are the 16-bit channel-blocked operands well-formed?
 bool c8_segs_ok(const mtbc_seg* segs, int nseg) {
     for (int i = 0; i < nseg; ++i)
@@ -2725,6 +3053,38 @@ WgPlan plan_wgrad(const mtbc_conv3x3_args* a) {
         w.nsplit = a->N * bands;
         w.partial_elems = (size_t)w.nsplit * a->Cout * 9;
         w.dbias_elems = 0;
+        return w;
+    }
+    if (a->operand_layout == MTBC_LAYOUT_C8 && c8w_wanted(a)) {
+        // conv3x3_wgrad_c8w_kernel: (all of a 24 / 48-channel output | 32 / 48 of a wider one) x <= 80 input channels per block; a block
+        // walks down a row segment of a 32-column strip of one image; 2 blocks of 8 waves per CU, one wave of <= 512 blocks
+        w.mfma = true; w.geo = 0; w.c8w = true;
+        w.cot = a->Cout % 48 == 0 ? 3 : 2;
+        w.tiles_x = cdiv(a->W, C8WW_TW); w.tiles_y = cdiv(a->H, C8WW_TH);
+        const int T = cdiv(a->Cin, 16);
+        w.coblocks = cdiv(a->Cout, 16 * w.cot); w.ciblocks = cdiv(T, C8WW_MAXCIT); w.cit = cdiv(T, w.ciblocks);
+        // (blocks per CU, depth): the most DMA bytes in flight that the LDS holds -- beyond ~96 KB per CU nothing is gained
+        static const int bpc_probe = mtbc_probe_int("MTBC_C8W_BPC", 0), d_probe = mtbc_probe_int("MTBC_C8W_DEPTH", 0);
+        int bpc = 2; w.depth = 1; size_t best = 0;
+        for (int b = 2; b >= 2; --b)
+            for (int d = 1; d <= 1; ++d) {
+                if (c8w_lds_bytes(w.cit, w.cot, d) * b > 160 * 1024) continue;
+                size_t fl = c8w_step_bytes(w.cit, w.cot) * b * d;
+                if (fl > 96 * 1024) fl = 96 * 1024;
+                if (fl > best) { best = fl; bpc = b; w.depth = d; }
+            }
+        if (bpc_probe && d_probe && c8w_lds_bytes(w.cit, w.cot, d_probe) * bpc_probe <= 160 * 1024) { bpc = bpc_probe; w.depth = d_probe; }
+        const int strips = w.tiles_x * a->N, budget = 256 * bpc / (w.coblocks * w.ciblocks);
+        int segs = budget / strips;                        // row segments per strip: as many as the block budget allows ...
+        if (segs < 1) segs = 1;
+        if (segs > w.tiles_y) segs = w.tiles_y;
+        w.seg_tiles = cdiv(w.tiles_y, segs);
+        if (w.seg_tiles < 2 && w.tiles_y >= 2) w.seg_tiles = 2;        // ... but a segment re-stages two halo rows: at least 8 rows of its own
+        w.segs = cdiv(w.tiles_y, w.seg_tiles);
+        w.nsplit = strips * w.segs;
+        w.total_tiles = w.nsplit; w.tiles_per_split = 1;
+        w.partial_elems = (size_t)w.nsplit * a->Cout * a->Cin * 9;
+        w.dbias_elems = a->dbias ? (size_t)w.nsplit * a->Cout : 0;
         return w;
     }
     if (a->operand_layout == MTBC_LAYOUT_C8) {      // conv3x3_wgrad_c8_kernel: 32 x 32 channel blocks, 4 x 32 pixel tiles, 4 blocks per CU
@@ -2991,11 +3351,33 @@ int mtbc_conv3x3_wgrad(const mtbc_conv3x3_args* a, void* stream) {
         if ((a->compute != 1 && a->compute != 2) || !c8_segs_ok(a->in, a->n_in) || !c8_segs_ok(&g, 1)) return MTBC_E_BADARG;
         WgC8P p; p.N = a->N; p.H = a->H; p.W = a->W; p.Cin = a->Cin; p.Cout = a->Cout; p.in = in;
         p.dz = reinterpret_cast<const unsigned short*>(a->dout); p.partial = partial;
-        p.dbias_partial = a->dbias ? partial + w.partial_elems : nullptr;
+        p.want_bias = a->dbias ? 1 : 0; p.prow = (long long)wel + (a->dbias ? a->Cout : 0);
         p.tiles_x = w.tiles_x; p.tiles_y = w.tiles_y; p.total_tiles = w.total_tiles; p.tiles_per_split = w.tiles_per_split;
-        p.ciblocks = w.ciblocks;
-        const dim3 grid(w.nsplit, w.coblocks * w.ciblocks);
-        if (w.geo == 1) {
+        p.ciblocks = w.ciblocks; p.coblocks = w.coblocks; p.cit = w.cit; p.segs = w.segs; p.seg_tiles = w.seg_tiles; p.depth = w.depth;
+        { static const int hk = mtbc_probe_int("MTBC_C8W_HACK", 0); p.hack = hk; }
+        const dim3 grid = w.c8w ? dim3(w.nsplit * w.coblocks * w.ciblocks) : dim3(w.nsplit, w.coblocks * w.ciblocks);
+        if (w.c8w) {
+            const size_t lds = c8w_lds_bytes(w.cit, w.cot, w.depth);
+#define MTBC_C8W_LAUNCH(F16_, COT_, BIAS_)                                                                                             \
+            do {                                                                                                                       \
+                static bool attr = false;      /* up to 160 KB of dynamic LDS */                                                      \
+                if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wgrad_c8w_kernel<F16_, COT_, BIAS_>),    \
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }         \
+                hipLaunchKernelGGL((conv3x3_wgrad_c8w_kernel<F16_, COT_, BIAS_>), grid, dim3(512), lds, st, p);                       \
+            } while (0)
+            const int sel = (a->compute == 2 ? 4 : 0) + (w.cot == 3 ? 2 : 0) + (a->dbias ? 1 : 0);
+            switch (sel) {
+            case 0: MTBC_C8W_LAUNCH(false, 2, false); break;
+            case 1: MTBC_C8W_LAUNCH(false, 2, true); break;
+            case 2: MTBC_C8W_LAUNCH(false, 3, false); break;
+            case 3: MTBC_C8W_LAUNCH(false, 3, true); break;
+            case 4: MTBC_C8W_LAUNCH(true, 2, false); break;
+            case 5: MTBC_C8W_LAUNCH(true, 2, true); break;
+            case 6: MTBC_C8W_LAUNCH(true, 3, false); break;
+            default: MTBC_C8W_LAUNCH(true, 3, true); break;
+            }
+#undef MTBC_C8W_LAUNCH
+        } else if (w.geo == 1) {
             if (a->compute == 2) hipLaunchKernelGGL((conv3x3_wgrad_c8_kernel<true, 1>), grid, dim3(256), C8W_LDS, st, p);
             else hipLaunchKernelGGL((conv3x3_wgrad_c8_kernel<false, 1>), grid, dim3(256), C8W_LDS, st, p);
         } else {
@@ -3003,9 +3385,8 @@ int mtbc_conv3x3_wgrad(const mtbc_conv3x3_args* a, void* stream) {
             else hipLaunchKernelGGL((conv3x3_wgrad_c8_kernel<false, 0>), grid, dim3(256), C8W_LDS, st, p);
         }
         MTBC_CHECK_LAUNCH();
-        rc = mtbc_i_splitk_reduce(partial, a->dw, w.nsplit, wel, a->accumulate_dw, st); if (rc) return rc;
-        if (a->dbias) { rc = mtbc_i_splitk_reduce(p.dbias_partial, a->dbias, w.nsplit, (size_t)a->Cout, a->accumulate_dw, st); if (rc) return rc; }
-        return MTBC_OK;
+        // one row per split = the weight-gradient partial followed by the bias-gradient partial: ONE reduction launch for both
+        return mtbc_i_splitk_reduce2(partial, a->dw, a->dbias, w.nsplit, wel, a->dbias ? (size_t)a->Cout : 0, a->accumulate_dw, st);
     }
     if (a->operand_layout != MTBC_LAYOUT_PLANAR) return MTBC_E_BADARG;
     if (w.mfma) {

@@ -8,9 +8,12 @@ namespace {
 // lanes each thread walked 128 dependent rows and the launch took 18 us for 10 MB).
 // E = elements per block: 64, or 16 for the SMALL many-split partials (a 24 -> 24 level-0 wgrad: 1024 splits of 5184 elements = 81 blocks of
 // 64 elements on 256 CUs, each pulling 260 KB through one CU; with 16 elements x 64 split lanes it is 324 blocks and 16 rows per thread).
+// Two destinations (round 3): elements [0, elems1) of a row go to out, [elems1, elems) to out2 -- a weight gradient's split-K partials
+// and its bias-gradient partials are ONE row per split, reduced by one launch (the separate bias launch took 4.8 us for a few
+// hundred floats, 35 times per step).
 template <int G, int E = 64>
 __global__ void splitk_reduce_k(const float* __restrict__ partial, float* __restrict__ out, int nsplit, size_t elems,
-                                int accumulate) {
+                                int accumulate, float* __restrict__ out2, size_t elems1) {
     __shared__ float red[G][E];
     const int e = threadIdx.x % E, g = threadIdx.x / E;
     const size_t i = (size_t)blockIdx.x * E + e;
@@ -36,7 +39,10 @@ __global__ void splitk_reduce_k(const float* __restrict__ partial, float* __rest
         if (g < w) red[g][e] += red[g + w][e];
         __syncthreads();
     }
-    if (g == 0 && i < elems) out[i] = accumulate ? out[i] + red[0][e] : red[0][e];
+    if (g == 0 && i < elems) {
+        float* dst = i < elems1 ? out + i : out2 + (i - elems1);
+        *dst = accumulate ? *dst + red[0][e] : red[0][e];
+    }
 }
 __global__ void plane_sum_k(const float* __restrict__ x, float* __restrict__ out, int HW) {
     __shared__ float red[32];
@@ -60,12 +66,16 @@ __global__ void sum_over_n_k(const float* __restrict__ planes, float* __restrict
 }
 }  // namespace
 
-int mtbc_i_splitk_reduce(const float* partial, float* out, int nsplit, size_t elems, int accumulate, hipStream_t st) {
-    if (nsplit >= 256 && elems <= 16384) hipLaunchKernelGGL((splitk_reduce_k<64, 16>), dim3((unsigned)cdiv64(elems, 16)), dim3(1024), 0, st, partial, out, nsplit, elems, accumulate);
-    else if (nsplit > 32) hipLaunchKernelGGL(splitk_reduce_k<16>, dim3((unsigned)cdiv64(elems, 64)), dim3(1024), 0, st, partial, out, nsplit, elems, accumulate);
-    else hipLaunchKernelGGL(splitk_reduce_k<4>, dim3((unsigned)cdiv64(elems, 64)), dim3(256), 0, st, partial, out, nsplit, elems, accumulate);
+int mtbc_i_splitk_reduce2(const float* partial, float* out, float* out2, int nsplit, size_t elems1, size_t elems2, int accumulate, hipStream_t st) {
+    const size_t elems = elems1 + elems2;
+    if (nsplit >= 256 && elems <= 16384) hipLaunchKernelGGL((splitk_reduce_k<64, 16>), dim3((unsigned)cdiv64(elems, 16)), dim3(1024), 0, st, partial, out, nsplit, elems, accumulate, out2, elems1);
+    else if (nsplit > 32) hipLaunchKernelGGL(splitk_reduce_k<16>, dim3((unsigned)cdiv64(elems, 64)), dim3(1024), 0, st, partial, out, nsplit, elems, accumulate, out2, elems1);
+    else hipLaunchKernelGGL(splitk_reduce_k<4>, dim3((unsigned)cdiv64(elems, 64)), dim3(256), 0, st, partial, out, nsplit, elems, accumulate, out2, elems1);
     MTBC_CHECK_LAUNCH();
     return MTBC_OK;
+}
+int mtbc_i_splitk_reduce(const float* partial, float* out, int nsplit, size_t elems, int accumulate, hipStream_t st) {
+    return mtbc_i_splitk_reduce2(partial, out, nullptr, nsplit, elems, 0, accumulate, st);
 }
 // out[c] (+)= sum over n and the HW plane of x[n][c][:]; planes_ws holds N*C floats
 int mtbc_i_channel_sums(const float* x, float* planes_ws, float* out, int N, int C, int HW, int accumulate, hipStream_t st) {

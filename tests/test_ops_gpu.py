@@ -489,6 +489,45 @@ def test_conv3x3_c8_operands(N, segs, Cout, H, W, compute):
     _close(dw2, 2 * wref.grad.float(), 1e-5, 4e-5 * scale, "wgrad c8 accumulate")
 
 
+# shapes that take the wide-block / rolling-row weight-gradient kernel (conv3x3_wgrad_c8w_kernel: Cin >= 64 on maps >= 128 wide)
+C8W_CASES = [
+    (8, [24, 24, 24], 24, 20, 128),            # image -> XCD block mapping (N % 8 == 0); Cin = 72: a half-empty last input tile; 5 row steps
+    (2, [24, 24, 24, 24, 48], 24, 256, 256),   # 144 -> 24 @256x256: two input-channel blocks (5 + 4 tiles), 64 steps per strip
+    (1, [48, 48], 48, 130, 128),               # 48 outputs = 3 tiles in one block; H not a multiple of the 4-row step; one image
+    (2, [96, 96], 96, 32, 160),                # 2 output-channel blocks x 3 input-channel blocks; 5 strips
+    (2, [64], 40, 36, 144),                    # Cout = 40: blocks of 32 + 8 channels; W not a multiple of the 32-column strip
+    (3, [96, 48, 48], 48, 12, 256),            # 192 -> 48: three input-channel blocks; rows < one ring (3 steps); N % 8 != 0
+]
+
+
+@pytest.mark.parametrize("compute", [1, 2])
+@pytest.mark.parametrize("N,segs,Cout,H,W", C8W_CASES)
+def test_conv3x3_wgrad_c8_wide_blocks(N, segs, Cout, H, W, compute):
+    """conv3x3_wgrad_c8w_kernel (all output channels x <= 80 input channels per block, rows staged once in an LDS ring, DMA of the
+    next rows under the MFMAs) against fp64 on the rounded operands: weight and bias gradient, the no-bias kernel instance,
+    accumulation into dw -- ragged rows / columns / channel tiles / batch."""
+    g = _g(N * 31 + Cout + H + W + compute)
+    Cin = sum(segs)
+    xs = [torch.randn(N, c, H, W, generator=g) for c in segs]
+    dz = torch.randn(N, Cout, H, W, generator=g)
+    x8 = [ops.C8.pack(x.to(DEV), compute) for x in xs]
+    dz8 = ops.C8.pack(dz.to(DEV), compute)
+    xr = _round16(torch.cat(xs, 1), compute).double()
+    dzr = _round16(dz, compute).double()
+    ref = torch.nn.grad.conv2d_weight(xr, (Cout, Cin, 3, 3), dzr, padding=1).float()
+    dbr = dzr.sum((0, 2, 3)).float()
+    scale = max(1.0, ref.abs().max().item())
+    dw, db = ops.conv3x3_wgrad_c8(x8, dz8, (Cout, Cin, 3, 3), want_bias=True)
+    _close(dw, ref, 1e-5, 2e-5 * scale, "wgrad c8w")
+    _close(db, dbr, 1e-5, 2e-5 * max(1.0, dbr.abs().max().item()), "dbias c8w")
+    dw1, _ = ops.conv3x3_wgrad_c8(x8, dz8, (Cout, Cin, 3, 3), want_bias=False)
+    _close(dw1, ref, 1e-5, 2e-5 * scale, "wgrad c8w (no-bias instance)")
+    dw2, _ = ops.conv3x3_wgrad_c8(x8, dz8, (Cout, Cin, 3, 3), want_bias=False, dw=dw1.clone(), accumulate=True)
+    _close(dw2, 2 * ref, 1e-5, 4e-5 * scale, "wgrad c8w accumulate")
+    again, _ = ops.conv3x3_wgrad_c8(x8, dz8, (Cout, Cin, 3, 3), want_bias=False)
+    assert torch.equal(again, dw1), "not deterministic"
+
+
 @pytest.mark.parametrize("compute", [1, 2])
 @pytest.mark.parametrize("N,segs,Cout,H,W", C8_CASES + [(2, [24, 24, 24, 24, 24, 24], 24, 256, 256),   # 144->24 @256x256: the bench's widest level-0 node
                                                         (1, [384, 384, 384], 512, 16, 16),                 # K = 1152 x 9: the longest accumulation of the step
