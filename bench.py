@@ -372,6 +372,9 @@ def main() -> None:
         return stub_main(args, rank, world)
     from multi_task_breast_cancer_amd import _lib as L
     from multi_task_breast_cancer_amd import switches
+    gone = switches.removed()
+    if gone:
+        raise SystemExit(f"bench.py: {gone} name plan arms that were removed in round 3 (switches.py): unset them")
     bad = switches.result_altering()
     if bad and not args.allow_probes:
         raise SystemExit(f"bench.py refuses to run with {bad} set: those select the probes build of the library or a timing "

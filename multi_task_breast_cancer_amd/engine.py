@@ -19,31 +19,16 @@ from . import _lib as L
 
 from . import switches as _sw
 
-_NO_C8 = _sw.flag("MTBC_NO_C8")            # A/B arms of measured design decisions: see switches.py (both arms parity-tested)
-_NO_CT_LP = _sw.flag("MTBC_NO_CT_LP")
+# Plan switches (switches.py): each one selects between two step programs that a -m gpu test runs against the oracle / emulation
 _NO_COOP = _sw.flag("MTBC_NO_COOP")
-_COOP_MIN_FWD = int(_sw.get("MTBC_COOP_MIN_FWD"))
-_COOP_MIN_BWD = int(_sw.get("MTBC_COOP_MIN_BWD"))
 _NO_GATHER = _sw.flag("MTBC_NO_GATHER")
-_NO_P16 = _sw.flag("MTBC_NO_P16")
-_FANIN = _sw.flag("MTBC_FANIN")
-_NO_C8_SMALL = _sw.flag("MTBC_NO_C8_SMALL_OPS")
-_NO_G16 = _sw.flag("MTBC_NO_G16")
-_NO_X16 = _sw.flag("MTBC_NO_X16")
 _NO_Z16 = _sw.flag("MTBC_NO_Z16")
-_DA16 = _sw.flag("MTBC_DA16")
-_NO_EPI_STATS = _sw.flag("MTBC_NO_EPI_STATS")
-_EPI_BSTATS = _sw.flag("MTBC_EPI_BSTATS")
 _Z_BF16 = _sw.flag("MTBC_Z_BF16")
-_NO_R1 = _sw.flag("MTBC_NO_R1")
-_NO_POOLFOLD = _sw.flag("MTBC_NO_POOLFOLD")
-_NO_STEM16 = _sw.flag("MTBC_NO_STEM16")
-_NO_POOLFWD_FOLD = _sw.flag("MTBC_NO_POOLFWD_FOLD")
-_NO_DEFER_DPARAM = _sw.flag("MTBC_NO_DEFER_DPARAM")
-_DPARAM_BATCH = int(_sw.get("MTBC_DPARAM_BATCH"))
-_SPLIT_FANIN = _sw.flag("MTBC_SPLIT_FANIN")
-_BWD_OVERLAP = _sw.flag("MTBC_BWD_OVERLAP")
-_BWD_OVERLAP_MAX_HW = int(_sw.get("MTBC_BWD_OVERLAP_MAX_HW"))
+_DA16 = _sw.flag("MTBC_DA16")
+# measured crossovers of the cooperative (split-plane) InstanceNorm kernels on fp32 conv outputs (the MTBC_NO_Z16 arm): they win on
+# planes >= 128x128 forward / 256x256 backward; on small planes their barriers and 512-thread workgroups lose to one-plane kernels + pack
+_COOP_MIN_FWD, _COOP_MIN_BWD = 16384, 65536
+_DPARAM_BATCH = 12          # cells per batched InstanceNorm parameter-gradient reduction (36 launches of 5 us -> 3)
 
 
 def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
@@ -58,8 +43,6 @@ class Act:
     needs_grad: bool = True
     grad: Optional[torch.Tensor] = None
     grad_written: bool = False         # has any backward op produced (part of) this grad yet?
-    fanin_separate: bool = False       # conv-cell outputs: every further consumer writes its own buffer (plain
-    extra_grads: List[torch.Tensor] = field(default_factory=list)   # stores); IN-backward sums them on the fly
     c8: Optional[torch.Tensor] = None  # 16-bit channel-blocked copy [N][C/8][H*W][8] read by the 3x3 convs' MFMAs
     planar_valid: bool = True          # False: the producer wrote only `c8` (ConvT forward in the 16-bit modes)
     planar_used: bool = False          # some op reads `data` (pool, ConvT, 1x1 heads, GAP, a planar-staged conv)
@@ -92,6 +75,35 @@ class Act:
 
 
 @dataclass
+class _Cell:
+    """What the forward half of a conv cell hands to its backward half (StepPlan.conv_cell / _conv_cell_backward)."""
+    inputs: List["Act"]
+    y: "Act"
+    cin: int
+    cout: int
+    H: int
+    W: int
+    tag: int
+    w: torch.Tensor
+    wname: str
+    bname: Optional[str]
+    gname: Optional[str]
+    betaname: Optional[str]
+    slope: float
+    mean: torch.Tensor
+    rstd: torch.Tensor
+    use_packed: bool
+    wp_d: Optional[torch.Tensor] = None       # full dgrad weight image (dropped again when every input's gradient is gathered)
+    wp_d_op: Optional[object] = None
+    c8: bool = False                          # the MFMAs read channel-blocked 16-bit operands
+    c8_bwd: bool = False
+    stem16: bool = False
+    z16: bool = False                         # conv output stored in 16 bits, channel-blocked
+    zf16: bool = False                        # ... as fp16 (also in the bf16 mode)
+    z: Optional[torch.Tensor] = None
+
+
+@dataclass
 class ParamSlot:
     name: str
     shape: Tuple[int, ...]
@@ -108,17 +120,15 @@ class ParamSlot:
 
 
 class Program:
-    """A contiguous ctypes array of ops + the stream-ordered runner.  Ops run on the caller's current stream; a program
-    that contains stream-control ops (MTBC_OP_SET_STREAM / EVENT_RECORD / EVENT_WAIT) also gets ONE side stream of its own,
-    on which the ops between a fork and its join run beside the main stream (mtbc_program_run_ms)."""
+    """A contiguous ctypes array of ops + the stream-ordered runner (mtbc_program_run): the ops run on the caller's current stream.
+    (The library can also run a program with stream-control ops on two streams, mtbc_program_run_ms: the weight gradient of a layer
+    beside its input gradient was built and measured in round 2 -- +0.25 .. +1.0 ms per step -- and the plan no longer emits it.)"""
 
-    def __init__(self, ops: List[L.Op], keep: list, side_stream: Optional["torch.cuda.Stream"] = None):
+    def __init__(self, ops: List[L.Op], keep: list):
         self.n = len(ops)
         self.array = (L.Op * max(1, self.n))(*ops)
         self.keep = keep                 # tensors referenced by raw pointer
         self._failed = C.c_int32(-1)
-        self.side = side_stream
-        self._streams = (C.c_void_p * 2)()
 
     def run(self, first: int = 0, count: Optional[int] = None, stream: Optional[torch.cuda.Stream] = None) -> None:
         if count is None:
@@ -126,32 +136,10 @@ class Program:
         if count <= 0:
             return
         s = (stream or torch.cuda.current_stream()).cuda_stream
-        if self.side is None:
-            rc = L.load().mtbc_program_run(self.array, first, count, C.c_void_p(s), C.byref(self._failed))
-        else:
-            self._streams[0], self._streams[1] = s, self.side.cuda_stream
-            rc = L.load().mtbc_program_run_ms(self.array, first, count, self._streams, 2, C.byref(self._failed))
+        rc = L.load().mtbc_program_run(self.array, first, count, C.c_void_p(s), C.byref(self._failed))
         if rc != 0:
             i = self._failed.value
             L.check(rc, f"program op #{i} (kind {self.array[i].kind}, tag {self.array[i].tag})")
-
-
-class _Events:
-    """The two HIP events a step program's forks / joins reuse (a wait refers to the latest record issued before it)."""
-
-    def __init__(self):
-        self.handles = []
-        for _ in range(2):
-            h = C.c_void_p()
-            L.check(L.load().mtbc_event_create(C.byref(h)), "event_create")
-            self.handles.append(h)
-
-    def __del__(self):
-        try:
-            for h in self.handles:
-                L.load().mtbc_event_destroy(h)
-        except Exception:
-            pass
 
 
 def _mk(kind: int, tag: int = 0) -> L.Op:
@@ -215,16 +203,12 @@ class StepPlan:
         return a.grad
 
     def grad_slot(self, a: Act) -> Tuple[torch.Tensor, int]:
-        """Where the next backward contribution to `a` goes: (buffer, accumulate flag).  First writer overwrites the
-        primary buffer; later writers get a private buffer when the producer can sum them (conv cells, <= 4 extras),
-        else they read-modify-write the primary."""
+        """Where the next backward contribution to `a` goes: (buffer, accumulate flag).  The first writer overwrites the buffer, later
+        writers read-modify-write it (the static plan knows who is first: no memsets).  (Private fan-in buffers summed by the
+        InstanceNorm backward were built and measured in round 1: dgrad -0.6 ms, norm backward +1.25 ms; removed.)"""
         if not a.grad_written:
             a.grad_written = True
             return self.grad_of(a), 0
-        if a.fanin_separate and len(a.extra_grads) < 4:
-            t = self.alloc(*a.data.shape)
-            a.extra_grads.append(t)
-            return t, 0
         return self.grad_of(a), 1
 
     def _rd(self, a: Act) -> int:
@@ -283,37 +267,6 @@ class StepPlan:
             setattr(self, attr, buf)
         return buf
 
-    # ------------------------------------------------------------------ two-stream backward
-    def _overlap_ok(self, hw: int) -> bool:
-        # OFF by default.  Measured (U-Net++ B=32 256x256, bf16, same box, interleaved): overlapping every layer's pair costs
-        # +1.0 ms per step (16.8 vs 15.75: on the large maps both launches are bandwidth-bound and disturb each other's L2
-        # tile walk); restricted to maps <= 32x32, where both launches are latency-bound, still +0.25 ms (15.80 vs 15.52):
-        # two event record / wait pairs per layer cost more than the side-by-side launches gain.
-        return _BWD_OVERLAP and self.dev.type == "cuda" and hw <= _BWD_OVERLAP_MAX_HW
-
-    def _sync_op(self, kind: int, event: int = 0, index: int = 0) -> L.Op:
-        op = _mk(kind)
-        op.u.sync.event, op.u.sync.index = (self._events.handles[event] if kind != L.OP_SET_STREAM else None), index
-        return op
-
-    def fork_side(self) -> None:
-        """Following backward ops go to the side stream, ordered behind everything issued so far on the main stream."""
-        if getattr(self, "_events", None) is None:
-            self._events = _Events()
-            self.keep.append(self._events)
-        self.bwd_ops += [self._sync_op(L.OP_EVENT_RECORD, 0), self._sync_op(L.OP_SET_STREAM, index=1), self._sync_op(L.OP_EVENT_WAIT, 0)]
-
-    def back_to_main(self) -> None:
-        """End of the side-stream section: mark it and continue on the main stream (which does NOT wait yet)."""
-        self.bwd_ops += [self._sync_op(L.OP_EVENT_RECORD, 1), self._sync_op(L.OP_SET_STREAM, index=0)]
-
-    def join_side(self, params: Sequence[str] = ()) -> None:
-        """The main stream waits for the side-stream section; the gradients of `params` (written there) are ready from
-        THIS op on -- what the data-parallel bucket schedule keys on."""
-        self.bwd_ops.append(self._sync_op(L.OP_EVENT_WAIT, 1))
-        for name in params:
-            self.slots[name].ready_at = len(self.bwd_ops) - 1
-
     def flush_dparams(self) -> None:
         """Emit the pending InstanceNorm parameter-gradient reductions (the runner issues a run of them as ONE launch); the gradients
         they finish are ready from the last of them on -- what the data-parallel bucket schedule keys on."""
@@ -358,7 +311,8 @@ class StepPlan:
     # ------------------------------------------------------------------ layers
     def conv_cell(self, inputs: Sequence[Act], cout: int, wname: str, bname: Optional[str],
                   gname: Optional[str], betaname: Optional[str], slope: float, out_name: str) -> Act:
-        """conv3x3(pad 1) -> InstanceNorm(eps 1e-5, affine optional) -> LeakyReLU(slope)."""
+        """conv3x3(pad 1) -> InstanceNorm(eps 1e-5, affine optional) -> LeakyReLU(slope): the forward ops now, the backward ops
+        when `emit_backward` walks the tape (`_conv_cell_backward`)."""
         inputs = list(inputs)
         for a_ in inputs:
             a_.readers += 1
@@ -370,18 +324,9 @@ class StepPlan:
         wp_f = wp_d = wp_d_op = None
         if use_packed and self.compute:
             # 16-bit operand images, re-converted from the fp32 master weights every step
-            for dg in (0, 1):
-                if dg == 1 and not (any(a.needs_grad for a in inputs) and cout % 8 == 0):
-                    continue
-                t = self.alloc(self.lib.mtbc_conv3x3_packed_lp_elems(cin, cout, dg), dtype=torch.int16)
-                op = _mk(L.OP_CONV3_PACK_LP)
-                op.u.pack.w, op.u.pack.packed, op.u.pack.Cin, op.u.pack.Cout = w.data_ptr(), t.data_ptr(), cin, cout
-                op.u.pack.dgrad, op.u.pack.compute = dg, self.compute
-                self.pack_ops.append(op)
-                if dg == 0:
-                    wp_f = t
-                else:
-                    wp_d, wp_d_op = t, op
+            wp_f, _ = self._pack_lp(w, cin, cout, 0)
+            if any(a.needs_grad for a in inputs) and cout % 8 == 0:
+                wp_d, wp_d_op = self._pack_lp(w, cin, cout, 1)
         elif use_packed:
             wp_f = self.alloc(self.lib.mtbc_conv3x3_packed_elems(cin, cout))
             op = _mk(L.OP_CONV3_PACK_FWD)
@@ -393,34 +338,22 @@ class StepPlan:
                 op.u.pack.w, op.u.pack.packed, op.u.pack.Cin, op.u.pack.Cout = w.data_ptr(), wp_d.data_ptr(), cin, cout
                 self.pack_ops.append(op)
         y = self.new_act(out_name, cout, H, W)
-        # measured: private fan-in buffers summed by IN-backward (+1.25 ms there) cost more than the read-modify-write
-        # they remove from the dgrad epilogues (-0.6 ms); the capability stays behind this switch
-        y.fanin_separate = _FANIN
         mean, rstd = self.alloc(N * cout), self.alloc(N * cout)
         self._tag += 1
-        tag = self._tag
-
-        def base_conv() -> L.Op:
-            op = _mk(0, tag)
-            a = op.u.conv3
-            a.N, a.H, a.W, a.Cin, a.Cout, a.n_in = N, H, W, cin, cout, len(inputs)
-            a.w = w.data_ptr()
-            a.force_direct = self.force_direct
-            a.compute = self.compute if use_packed else 0
-            return op
+        cell = _Cell(inputs=inputs, y=y, cin=cin, cout=cout, H=H, W=W, tag=self._tag, w=w, wname=wname, bname=bname, gname=gname,
+                     betaname=betaname, slope=slope, mean=mean, rstd=rstd, use_packed=use_packed, wp_d=wp_d, wp_d_op=wp_d_op)
 
         # 16-bit modes: the MFMA operands are converted once per tensor into the channel-blocked 16-bit layout instead
         # of once per consumer inside the staging (same RNE, same MFMA order: bit-identical forward / dgrad)
-        c8 = (not _NO_C8) and use_packed and self.compute != 0 and not self.force_direct and W % 4 == 0 and H >= 8 and W >= 8
+        c8 = use_packed and self.compute != 0 and not self.force_direct and W % 4 == 0 and H >= 8 and W >= 8
         c8_bwd = c8 and cout % 8 == 0
         # 16-bit modes: the conv output z is stored once, in 16 bits, channel-blocked (what torch.autocast keeps between a
         # convolution and its normalisation): written by the igemm's epilogue (fp32 accumulate + bias, one RNE), read by the
         # InstanceNorm forward and backward as 16-byte pieces -- 2 + 2 + 2 instead of 4 + 4 + 4 bytes per element.  Needs the
-        # channel-group InstanceNorm kernels in both directions (norm_coop.hip).
-        # the stem (Cin = 1: fp32 operands, no MFMA) takes part: its forward writes z in the same layout and leaves the same statistics,
-        # its weight gradient reads the channel-blocked dz
+        # channel-group InstanceNorm kernels in both directions (norm_coop.hip).  The stem (Cin = 1: fp32 operands, no MFMA) takes
+        # part: its forward writes z in the same layout and leaves the same statistics, its weight gradient reads the channel-blocked dz
         stem16 = bool(self.compute) and cin == 1 and len(inputs) == 1 and cout % 8 == 0 and not self.force_direct and W % 4 == 0 \
-            and H >= 8 and W >= 8 and not _NO_C8 and not _NO_STEM16 and inputs[0].planar_valid and not inputs[0].needs_grad
+            and H >= 8 and W >= 8 and inputs[0].planar_valid and not inputs[0].needs_grad
         z16 = False
         if (c8_bwd or stem16) and not _NO_Z16 and not _NO_COOP:      # (the one-plane InstanceNorm kernels read fp32 planes)
             q = L.InstNormArgs()
@@ -429,11 +362,12 @@ class StepPlan:
         z = self.alloc(N, cout // 8, H * W, 8, dtype=torch.int16) if z16 else self.alloc(N, cout, H, W)
         # ... as fp16 also in the bf16 mode: a conv output in front of a norm is O(1), and fp16 keeps 11 significant bits of it in the
         # same 2 bytes (bf16: 8) -- measured on the held-out Dice of 3000-step runs (profiles/r02b_quality_sweep.md); the MFMA
-        # operands (activations, dz, weights) stay bf16.  (the norm-backward epilogue arm reads z as an operand-typed tensor)
-        zf16 = z16 and self.compute == 1 and not _Z_BF16 and not _EPI_BSTATS
+        # operands (activations, dz, weights) stay bf16
+        zf16 = z16 and self.compute == 1 and not _Z_BF16
         stem16 = stem16 and z16
-        y.dy8_ok = z16 and (_DA16 or _EPI_BSTATS) and not _FANIN and not stem16
+        y.dy8_ok = z16 and _DA16 and not stem16
         y.z16 = z16
+        cell.c8, cell.c8_bwd, cell.stem16, cell.z16, cell.zf16, cell.z = c8, c8_bwd, stem16, z16, zf16, z
         if not c8 and not all(a_.planar_valid for a_ in inputs):
             raise NotImplementedError(f"{out_name}: an input exists only in the channel-blocked 16-bit layout")
         for a_ in inputs:
@@ -442,15 +376,9 @@ class StepPlan:
             else:
                 a_.no_gather = True
 
-        def segs_c8(arr) -> None:
-            for i, a_ in enumerate(inputs):
-                arr[i].ptr = self.c8_of(a_).data_ptr()
-                arr[i].batch_stride, arr[i].channels, arr[i].accumulate = a_.bstride, a_.C, 0
-
-        op = base_conv()
-        op.kind = L.OP_CONV3_FWD
+        op = self._cell_conv_op(cell, L.OP_CONV3_FWD)
         if c8:
-            segs_c8(op.u.conv3.in_)
+            self._segs_c8(op.u.conv3.in_, inputs)
             op.u.conv3.operand_layout = L.LAYOUT_C8
         else:
             self._segs(op.u.conv3.in_, inputs)
@@ -464,278 +392,250 @@ class StepPlan:
             op.u.conv3.out_layout = L.LAYOUT_C8
             if zf16:
                 op.u.conv3.out_type = 2
-            if not _NO_EPI_STATS:
-                # InstanceNorm statistics from the conv epilogue ({sum, sum of squares} of the stored values per wave): the
-                # normalisation that follows is then one streaming pass with no reduction / team exchange of its own
-                stats_slots = int(self.lib.mtbc_conv3x3_stats_slots(C.byref(op.u.conv3)))
-                if stats_slots > 0:
-                    self._stat_users.append((op, "conv3"))
-                    self._stat_bytes = max(self._stat_bytes, N * stats_slots * cout * 2 * 4)
+            # InstanceNorm statistics from the conv epilogue ({sum, sum of squares} of the stored values per wave): the
+            # normalisation that follows is then one streaming pass with no reduction / team exchange of its own
+            stats_slots = int(self.lib.mtbc_conv3x3_stats_slots(C.byref(op.u.conv3)))
+            if stats_slots > 0:
+                self._stat_users.append((op, "conv3"))
+                self._stat_bytes = max(self._stat_bytes, N * stats_slots * cout * 2 * 4)
         self.fwd_ops.append(op)
 
-        def base_in() -> L.Op:
-            op = _mk(0, tag)
-            a = op.u.inorm
-            a.N, a.C, a.H, a.W, a.eps, a.slope = N, cout, H, W, 1e-5, slope
-            a.z = z.data_ptr()
-            a.z_layout = L.LAYOUT_C8 if z16 else L.LAYOUT_PLANAR
-            a.z_type = 2 if zf16 else 0
-            a.gamma = _ptr(self.pv(gname)) if gname else None
-            a.beta = _ptr(self.pv(betaname)) if betaname else None
-            a.mean, a.rstd = mean.data_ptr(), rstd.data_ptr()
-            a.coop_reserve_cus = self.coop_reserve_cus
-            return op
-
-        op = base_in()
-        op.kind = L.OP_IN_FWD
+        op = self._cell_norm_op(cell, L.OP_IN_FWD)
         op.u.inorm.y, op.u.inorm.y_batch_stride = y.data.data_ptr(), y.bstride
         y.in_op = op
-        # (measured: the cooperative kernels win on planes >= 128x128 forward / 256x256 backward; on small planes their
-        # barriers and 512-thread workgroups lose to the one-plane kernels + pack)
         if stats_slots > 0:
             op.u.inorm.stats_slots = stats_slots
             self._stat_users.append((op, "inorm"))
-        if z16 or (self.compute and not _NO_C8 and not _NO_COOP and not self.force_direct and cout % 8 == 0 and H * W >= _COOP_MIN_FWD
+        if z16 or (self.compute and not _NO_COOP and not self.force_direct and cout % 8 == 0 and H * W >= _COOP_MIN_FWD
                    and self.lib.mtbc_instnorm_c8_supported(C.byref(op.u.inorm), 0)):
-            # 16-bit modes: the cooperative kernel writes the channel-blocked operand tensor itself (and fp32 planes only
-            # if something reads them -- decided in finalize(), when all consumers are known)
+            # 16-bit modes: the channel-group / cooperative kernel writes the channel-blocked operand tensor itself (and fp32 planes
+            # only if something reads them -- decided in finalize(), when all consumers are known)
             y.c8 = self.alloc(N, cout // 8, H * W, 8, dtype=torch.int16)
             op.u.inorm.y8, op.u.inorm.out16_type, op.u.inorm.coop_state = y.c8.data_ptr(), self.compute, self._coop_state()
         nb = self.lib.mtbc_instnorm_fwd_workspace(C.byref(op.u.inorm))      # > 0 only for planes larger than 64K elements
         if nb:
             self._need_ws(op, "inorm", nb)
         self.fwd_ops.append(op)
+        self.bwd_emitters.append(lambda: self._conv_cell_backward(cell))
+        return y
 
-        def wview(wsrc, dst, co, ci_total, off, cnt, mode, koff, K) -> None:
-            op = _mk(L.OP_CONV3_WVIEW)
-            v = op.u.wview
-            v.w, v.dst, v.Cout, v.Cin, v.ci_off, v.ci_cnt, v.mode, v.k_off, v.K = wsrc.data_ptr(), dst.data_ptr(), co, ci_total, off, cnt, mode, koff, K
-            self.wview_ops.append(op)
+    # ---- helpers shared by the two halves of a conv cell
+    def _pack_lp(self, wsrc: torch.Tensor, ci: int, co: int, dg: int) -> Tuple[torch.Tensor, L.Op]:
+        """The 16-bit MFMA image of a weight tensor (forward image dg = 0, transposed / tap-flipped dgrad image dg = 1), rebuilt every step."""
+        t = self.alloc(self.lib.mtbc_conv3x3_packed_lp_elems(ci, co, dg), dtype=torch.int16)
+        op = _mk(L.OP_CONV3_PACK_LP)
+        op.u.pack.w, op.u.pack.packed, op.u.pack.Cin, op.u.pack.Cout = wsrc.data_ptr(), t.data_ptr(), ci, co
+        op.u.pack.dgrad, op.u.pack.compute = dg, self.compute
+        self.pack_ops.append(op)
+        return t, op
 
-        def pack_lp(wsrc, ci, co, dg) -> torch.Tensor:
-            t = self.alloc(self.lib.mtbc_conv3x3_packed_lp_elems(ci, co, dg), dtype=torch.int16)
-            op = _mk(L.OP_CONV3_PACK_LP)
-            op.u.pack.w, op.u.pack.packed, op.u.pack.Cin, op.u.pack.Cout = wsrc.data_ptr(), t.data_ptr(), ci, co
-            op.u.pack.dgrad, op.u.pack.compute = dg, self.compute
-            self.pack_ops.append(op)
-            return t
+    def _wview(self, wsrc, dst, co, ci_total, off, cnt, mode, koff, K) -> None:
+        op = _mk(L.OP_CONV3_WVIEW)
+        v = op.u.wview
+        v.w, v.dst, v.Cout, v.Cin, v.ci_off, v.ci_cnt, v.mode, v.k_off, v.K = wsrc.data_ptr(), dst.data_ptr(), co, ci_total, off, cnt, mode, koff, K
+        self.wview_ops.append(op)
 
-        def emit_bwd() -> None:
-            if not y.grad_written and not y.pending and y.r1 is None and y.pool is None:
-                return
-            g8 = bool(y.pending) and y.dy8_ok
-            split_buf = None
-            if y.pending:
-                # Gathered dgrad: the gradient of y with respect to ALL its 3x3 consumers in ONE forward-type launch over
-                # their channel-blocked dz (K = sum of their Cout), instead of one read-modify-write of y's fp32 gradient
-                # per consumer.  Weights: the consumers' slices for y's channels, transposed / tap-flipped, side by side.
-                K = sum(pj[4] for pj in y.pending)
-                wg = self.alloc(cout, K, 3, 3)
-                koff = 0
-                for (dzj, wj, offj, cinj, coutj) in y.pending:
-                    wview(wj, wg, coutj, cinj, offj, cout, 1, koff, K)
-                    koff += coutj
-                wpg = pack_lp(wg, K, cout, 0)
-                if g8:
-                    # ... written ONCE as a 16-bit channel-blocked tensor (fp32 sum over all consumers in the MFMA accumulators,
-                    # one RNE); what the tensor's other readers (pool / ConvT / 1x1 backward) wrote stays an fp32 planar
-                    # partial that the InstanceNorm backward adds while loading
-                    y.grad8 = self.alloc(N, cout // 8, H * W, 8, dtype=torch.int16)
-                    gbuf, acc = y.grad8, 0
-                elif y.z16 and y.grad_written and not y.extra_grads and _SPLIT_FANIN and not _FANIN:
-                    # (opt-in, measured +0.05 ms: something else (a ConvT backward) already wrote y's gradient; instead of read-modify-
-                    # writing it the gathered launch writes a buffer of its own and the InstanceNorm backward adds the two while loading)
-                    gbuf, acc = self.alloc(*y.data.shape), 0
-                    split_buf = gbuf
-                else:
-                    gbuf, acc = self.grad_slot(y)
-                op = _mk(L.OP_CONV3_FWD, tag)
-                a = op.u.conv3
-                a.N, a.H, a.W, a.Cin, a.Cout, a.n_in = N, H, W, K, cout, len(y.pending)
-                for i_, (dzj, wj, offj, cinj, coutj) in enumerate(y.pending):
-                    a.in_[i_].ptr, a.in_[i_].batch_stride, a.in_[i_].channels, a.in_[i_].accumulate = dzj.data_ptr(), coutj * H * W, coutj, 0
-                a.w, a.w_packed, a.out = wg.data_ptr(), wpg.data_ptr(), gbuf.data_ptr()
-                a.compute, a.operand_layout, a.out_accumulate = self.compute, L.LAYOUT_C8, acc
-                bslots = 0
-                if g8:
-                    a.out_layout = L.LAYOUT_C8
-                    if _EPI_BSTATS:
-                        # ... and the same epilogue prepares this cell's InstanceNorm backward: it adds the other readers' fp32
-                        # partial BEFORE the one rounding, reads the cell's own z and leaves {sum g, sum g * xhat} per wave -- the
-                        # norm backward below is then one streaming pass (no reduction, no team exchange)
-                        a.norm_z, a.norm_mean, a.norm_rstd, a.norm_slope = z.data_ptr(), mean.data_ptr(), rstd.data_ptr(), slope
-                        a.norm_gamma = _ptr(self.pv(gname)) if gname else None
-                        a.norm_beta = _ptr(self.pv(betaname)) if gname else None
-                        a.out_partial = y.grad.data_ptr() if y.grad_written else None
-                        bslots = int(self.lib.mtbc_conv3x3_stats_slots(C.byref(a)))
-                        if bslots > 0:
-                            self._stat_users.append((op, "conv3"))
-                            self._stat_bytes = max(self._stat_bytes, N * bslots * cout * 2 * 4)
-                        else:
-                            a.norm_z = a.norm_mean = a.norm_rstd = a.norm_gamma = a.norm_beta = a.out_partial = None
-                self.bwd_ops.append(op)
-            else:
-                bslots = 0
-            only_r1 = (y.r1 is not None or y.pool is not None) and not g8 and not y.grad_written       # no gradient TENSOR: only folded terms
-            dy = y.grad8 if g8 else (None if only_r1 else self.grad_of(y))
-            # IN+LReLU backward, dz written in place over dy (each element is read before it is written)
-            op = base_in()
-            op.kind = L.OP_IN_BWD
-            a = op.u.inorm
-            a.dy, a.dy_batch_stride, a.dz = _ptr(dy), y.bstride, _ptr(dy)
-            if y.pool is not None:
-                a.dy_pool, a.dy_pool_arg = y.pool[0].data_ptr(), y.pool[1].data_ptr()
-            if y.r1 is not None:
-                a.dy_rank1, a.dy_rank1_w = y.r1[0].data_ptr(), y.r1[1].data_ptr()
-                a.dy_rank1_dw, a.dy_rank1_db, a.dy_rank1_accumulate = y.r1[2].data_ptr(), y.r1[3].data_ptr(), y.r1[4]
-            if g8:
-                a.dy_layout, a.dz = L.LAYOUT_C8, None
-            a.n_dy_extra = len(y.extra_grads)
-            # inputs whose gradient is gathered later (by THEIR backward) from all their 3x3 consumers: a prefix of the
-            # segment list, so that this conv's own dgrad covers a contiguous suffix of its input channels
-            defer: List[Act] = []
-            if c8_bwd and wp_d is not None and not _NO_GATHER:
-                for a_ in inputs:
-                    if a_.in_op is not None and a_.needs_grad and a_.conv_consumers >= (1 if a_.dy8_ok else 2) and not a_.no_gather and a_.C % 8 == 0:
-                        defer.append(a_)
-                    else:
-                        break
+    def _segs_c8(self, arr, acts: Sequence[Act]) -> None:
+        for i, a_ in enumerate(acts):
+            arr[i].ptr = self.c8_of(a_).data_ptr()
+            arr[i].batch_stride, arr[i].channels, arr[i].accumulate = a_.bstride, a_.C, 0
 
-            def dz8_buffer() -> torch.Tensor:      # the gathered launches read it later: it cannot be the shared scratch
-                return self.alloc(N * cout * H * W, dtype=torch.int16) if defer else self._scratch16("_dz8_buf", N * cout * H * W)
+    def _cell_conv_op(self, cell: "_Cell", kind: int) -> L.Op:
+        op = _mk(kind, cell.tag)
+        a = op.u.conv3
+        a.N, a.H, a.W, a.Cin, a.Cout, a.n_in = self.N, cell.H, cell.W, cell.cin, cell.cout, len(cell.inputs)
+        a.w = cell.w.data_ptr()
+        a.force_direct = self.force_direct
+        a.compute = self.compute if cell.use_packed else 0
+        return op
 
-            coop = z16 or (c8_bwd and not _NO_COOP and H * W >= _COOP_MIN_BWD and bool(self.lib.mtbc_instnorm_c8_supported(C.byref(a), 1)))
-            if coop:        # one pass straight into the channel-blocked dz the wgrad / dgrad MFMAs read
-                dz8 = dz8_buffer()
-                a.dz8, a.out16_type, a.coop_state = dz8.data_ptr(), self.compute, self._coop_state()
-            p16 = c8_bwd and not coop and not _NO_P16 and (H * W) % 4 == 0 and H * W <= 65536
-            if p16:         # dz feeds MFMAs only: 16-bit planar here, channel-blocked by the pack below
-                dz16 = self._scratch16("_dz16_buf", N * cout * H * W)
-                a.dz16, a.out16_type = dz16.data_ptr(), self.compute
-            a.n_dy_extra = len(y.extra_grads)
-            for k_, t_ in enumerate(y.extra_grads):
-                a.dy_extra[k_] = t_.data_ptr()
-            if g8 and bslots > 0:
-                a.stats_slots = bslots
-                self._stat_users.append((op, "inorm"))
-                if not (gname or bname):
-                    self._need_ws(op, "inorm", N * cout * 5 * 4)
-            elif g8 and y.grad_written:
-                assert not y.extra_grads
+    def _cell_norm_op(self, cell: "_Cell", kind: int) -> L.Op:
+        op = _mk(kind, cell.tag)
+        a = op.u.inorm
+        a.N, a.C, a.H, a.W, a.eps, a.slope = self.N, cell.cout, cell.H, cell.W, 1e-5, cell.slope
+        a.z = cell.z.data_ptr()
+        a.z_layout = L.LAYOUT_C8 if cell.z16 else L.LAYOUT_PLANAR
+        a.z_type = 2 if cell.zf16 else 0
+        a.gamma = _ptr(self.pv(cell.gname)) if cell.gname else None
+        a.beta = _ptr(self.pv(cell.betaname)) if cell.betaname else None
+        a.mean, a.rstd = cell.mean.data_ptr(), cell.rstd.data_ptr()
+        a.coop_reserve_cus = self.coop_reserve_cus
+        return op
+
+    def _gathered_dgrad(self, cell: "_Cell") -> None:
+        """The gradient of y with respect to ALL its 3x3 consumers in ONE forward-type launch over their channel-blocked dz (K = sum
+        of their Cout), instead of one read-modify-write of y's fp32 gradient per consumer.  Weights: the consumers' slices for y's
+        channels, transposed / tap-flipped, side by side (rebuilt each step: weight views, then the ordinary 16-bit image)."""
+        y, cout, N, H, W = cell.y, cell.cout, self.N, cell.H, cell.W
+        K = sum(pj[4] for pj in y.pending)
+        wg = self.alloc(cout, K, 3, 3)
+        koff = 0
+        for (dzj, wj, offj, cinj, coutj) in y.pending:
+            self._wview(wj, wg, coutj, cinj, offj, cout, 1, koff, K)
+            koff += coutj
+        wpg, _ = self._pack_lp(wg, K, cout, 0)
+        if y.dy8_ok:
+            # (MTBC_DA16) ... written ONCE as a 16-bit channel-blocked tensor (fp32 sum over all consumers in the MFMA accumulators,
+            # one RNE); what the tensor's other readers (pool / ConvT / 1x1 backward) wrote stays an fp32 planar partial that the
+            # InstanceNorm backward adds while loading
+            y.grad8 = self.alloc(N, cout // 8, H * W, 8, dtype=torch.int16)
+            gbuf, acc = y.grad8, 0
+        else:
+            gbuf, acc = self.grad_slot(y)
+        op = _mk(L.OP_CONV3_FWD, cell.tag)
+        a = op.u.conv3
+        a.N, a.H, a.W, a.Cin, a.Cout, a.n_in = N, H, W, K, cout, len(y.pending)
+        for i_, (dzj, wj, offj, cinj, coutj) in enumerate(y.pending):
+            a.in_[i_].ptr, a.in_[i_].batch_stride, a.in_[i_].channels, a.in_[i_].accumulate = dzj.data_ptr(), coutj * H * W, coutj, 0
+        a.w, a.w_packed, a.out = wg.data_ptr(), wpg.data_ptr(), gbuf.data_ptr()
+        a.compute, a.operand_layout, a.out_accumulate = self.compute, L.LAYOUT_C8, acc
+        if y.dy8_ok:
+            a.out_layout = L.LAYOUT_C8
+        self.bwd_ops.append(op)
+
+    def _conv_cell_backward(self, cell: "_Cell") -> None:
+        """Backward of a conv cell: [gathered dgrad of y] -> InstanceNorm + LeakyReLU backward (dz channel-blocked, or in place over dy)
+        -> weight gradient -> input gradient (whole, or the suffix of the inputs whose gradient is not gathered by THEIR cell)."""
+        y, inputs, cout, N, H, W = cell.y, cell.inputs, cell.cout, self.N, cell.H, cell.W
+        gname, betaname, bname, z16, c8_bwd = cell.gname, cell.betaname, cell.bname, cell.z16, cell.c8_bwd
+        if not y.grad_written and not y.pending and y.r1 is None and y.pool is None:
+            return
+        written_before = y.grad_written           # something else (ConvT / pool / head backward) has written y's fp32 gradient
+        g8 = bool(y.pending) and y.dy8_ok
+        if y.pending:
+            self._gathered_dgrad(cell)
+        only_folded = (y.r1 is not None or y.pool is not None) and not g8 and not y.grad_written       # no gradient TENSOR: only folded terms
+        dy = y.grad8 if g8 else (None if only_folded else self.grad_of(y))
+        op = self._cell_norm_op(cell, L.OP_IN_BWD)
+        a = op.u.inorm
+        a.dy, a.dy_batch_stride, a.dz = _ptr(dy), y.bstride, _ptr(dy)      # dz in place over dy unless a 16-bit output is asked for below
+        if y.pool is not None:
+            a.dy_pool, a.dy_pool_arg = y.pool[0].data_ptr(), y.pool[1].data_ptr()
+        if y.r1 is not None:
+            a.dy_rank1, a.dy_rank1_w = y.r1[0].data_ptr(), y.r1[1].data_ptr()
+            a.dy_rank1_dw, a.dy_rank1_db, a.dy_rank1_accumulate = y.r1[2].data_ptr(), y.r1[3].data_ptr(), y.r1[4]
+        if g8:
+            a.dy_layout, a.dz = L.LAYOUT_C8, None
+            if written_before:                    # the other readers' fp32 planar partial, added while loading
                 a.n_dy_extra = 1
                 a.dy_extra[0] = y.grad.data_ptr()
-            elif split_buf is not None:
-                a.n_dy_extra = 1
-                a.dy_extra[0] = split_buf.data_ptr()
-            if gname or bname:
-                acc = None
-                if gname:
-                    acc = self._mark_param(gname)
-                    self._mark_param(betaname)
-                    a.dgamma, a.dbeta = self.gv(gname).data_ptr(), self.gv(betaname).data_ptr()
-                if bname:                       # conv bias gradient = sum of dz, produced by the same pass
-                    accb = self._mark_param(bname)
-                    acc = accb if acc is None else acc
-                    assert acc == accb
-                    a.dbias_pre = self.gv(bname).data_ptr()
-                a.accumulate_dparams = acc
-                self._need_ws(op, "inorm", N * cout * (131 if coop else 3) * 4)
-            if y.r1 is not None:
-                self._need_ws(op, "inorm", N * (cout + 1) * 262 * 4)
-            dop = None
-            if (gname or bname) and z16 and not _NO_DEFER_DPARAM and not (g8 and bslots > 0) and self.dev.type == "cuda":
-                # the per-plane partial sums of dgamma / dbeta / dbias stay in a (small) buffer of this cell's own and are reduced later,
-                # many cells per launch (a step has 36 of these 5 us reductions): after every MTBC_DPARAM_BATCH cells and at the end
-                if a.accumulate_dparams:
-                    self.flush_dparams()            # an earlier contribution to the same parameters lands first
-                buf = self.alloc(N * (cout + 1) * 262)
-                self.ws_users = [u for u in self.ws_users if u[0] is not op]
-                a.workspace, a.workspace_bytes, a.defer_dparams = buf.data_ptr(), buf.numel() * 4, 1
-                dop = _mk(L.OP_IN_DPARAM, tag)
-                d = dop.u.dparam
-                d.part, d.dgamma, d.dbeta, d.dbias_pre = buf.data_ptr(), a.dgamma, a.dbeta, a.dbias_pre
-                d.N, d.C, d.T, d.accumulate = N, cout, int(self.lib.mtbc_instnorm_bwd_team(C.byref(a))), a.accumulate_dparams
-            self.bwd_ops.append(op)
-            if dop is not None:
-                self._pending_dparams.append((dop, tuple(n_ for n_ in (gname, betaname, bname) if n_)))
-                if len(self._pending_dparams) >= _DPARAM_BATCH:
-                    self.flush_dparams()
-            if y.r1 is not None:            # the head's parameter gradients are written by THIS op
-                for name in y.r1[5]:
-                    self.slots[name].ready_at = len(self.bwd_ops) - 1
-            if c8_bwd and not coop:
-                dz8 = dz8_buffer()
-                pk = self._c8_pack_op(dz16 if p16 else dy, dz8, cout, H * W)
-                if p16:
-                    pk.kind = L.OP_C8_PACK16
-                self.bwd_ops.append(pk)
-            # dgrad into every input that needs one
-            need = [a_ for a_ in inputs if a_.needs_grad]
-            # wgrad -- beside the dgrad on the side stream when there is one: both only READ dz and the inputs, the weight
-            # gradient's split-K workspace is not touched by a dgrad, and on the deep levels neither fills the chip alone
-            forked = bool(need) and self._overlap_ok(H * W)
-            if forked:
-                self.fork_side()
-            op = base_conv()
-            op.kind = L.OP_CONV3_WGRAD
-            a = op.u.conv3
-            if c8_bwd:
-                segs_c8(a.in_)
-                a.dout, a.operand_layout = dz8.data_ptr(), L.LAYOUT_C8
-            elif stem16:          # fp32 planar 1-channel input, channel-blocked dz
-                self._segs(a.in_, inputs)
-                a.dout, a.operand_layout, a.compute = dz8.data_ptr(), L.LAYOUT_C8, self.compute
-            else:
-                self._segs(a.in_, inputs)
-                a.dout = dy.data_ptr()
-            a.accumulate_dw = self._mark_param(wname)
-            a.dw = self.gv(wname).data_ptr()
-            # (batching the ~40 split-K reductions of a step into a few launches was built and measured: 15.20 vs 14.54 ms -- the
-            #  partials then live in buffers of their own and travel to HBM and back instead of being reduced out of the cache)
-            self._need_ws(op, "conv3", self.lib.mtbc_conv3x3_wgrad_workspace(C.byref(a)))
-            self.bwd_ops.append(op)
-            if forked:
-                self.back_to_main()
-            if need and defer:
-                off = 0
-                for a_ in defer:
-                    a_.pending.append((dz8, w, off, cin, cout))
-                    off += a_.C
-                self.pack_ops.remove(wp_d_op)          # the full dgrad image is not needed
-                rest = inputs[len(defer):]
-                if rest:
-                    crest = cin - off
-                    ws = self.alloc(cout, crest, 3, 3)
-                    wview(w, ws, cout, cin, off, crest, 0, 0, 0)
-                    wps = pack_lp(ws, crest, cout, 1)
-                    op = base_conv()
-                    op.kind = L.OP_CONV3_DGRAD
-                    a = op.u.conv3
-                    a.Cin, a.n_in, a.w = crest, len(rest), ws.data_ptr()
-                    self._segs(a.in_, rest, grads=True, g16=True)
-                    a.dout, a.operand_layout, a.w_packed = dz8.data_ptr(), L.LAYOUT_C8, wps.data_ptr()
-                    self.bwd_ops.append(op)
-            elif need:
-                if len(need) != len(inputs):
-                    raise NotImplementedError("mixed grad / no-grad concat inputs")
-                op = base_conv()
-                op.kind = L.OP_CONV3_DGRAD
-                a = op.u.conv3
-                self._segs(a.in_, inputs, grads=True, g16=bool(c8_bwd and wp_d is not None))
-                a.dout = _ptr(dy)
-                if c8_bwd and wp_d is not None:
-                    a.dout, a.operand_layout = dz8.data_ptr(), L.LAYOUT_C8
-                a.w_packed = _ptr(wp_d)
-                self.bwd_ops.append(op)
-            if forked:
-                self.join_side([wname])
+        # inputs whose gradient is gathered later (by THEIR backward) from all their 3x3 consumers: a prefix of the
+        # segment list, so that this conv's own dgrad covers a contiguous suffix of its input channels
+        defer: List[Act] = []
+        if c8_bwd and cell.wp_d is not None and not _NO_GATHER:
+            for a_ in inputs:
+                if a_.in_op is not None and a_.needs_grad and a_.conv_consumers >= (1 if a_.dy8_ok else 2) and not a_.no_gather and a_.C % 8 == 0:
+                    defer.append(a_)
+                else:
+                    break
 
-        self.bwd_emitters.append(emit_bwd)
-        return y
+        def dz8_buffer() -> torch.Tensor:      # the gathered launches read it later: it cannot be the shared scratch
+            return self.alloc(N * cout * H * W, dtype=torch.int16) if defer else self._scratch16("_dz8_buf", N * cout * H * W)
+
+        coop = z16 or (c8_bwd and not _NO_COOP and H * W >= _COOP_MIN_BWD and bool(self.lib.mtbc_instnorm_c8_supported(C.byref(a), 1)))
+        dz8 = dz16 = None
+        if coop:        # one pass straight into the channel-blocked dz the wgrad / dgrad MFMAs read
+            dz8 = dz8_buffer()
+            a.dz8, a.out16_type, a.coop_state = dz8.data_ptr(), self.compute, self._coop_state()
+        p16 = c8_bwd and not coop and (H * W) % 4 == 0 and H * W <= 65536
+        if p16:         # dz feeds MFMAs only: 16-bit planar here, channel-blocked by the pack below
+            dz16 = self._scratch16("_dz16_buf", N * cout * H * W)
+            a.dz16, a.out16_type = dz16.data_ptr(), self.compute
+        if gname or bname:
+            acc = None
+            if gname:
+                acc = self._mark_param(gname)
+                self._mark_param(betaname)
+                a.dgamma, a.dbeta = self.gv(gname).data_ptr(), self.gv(betaname).data_ptr()
+            if bname:                       # conv bias gradient = sum of dz, produced by the same pass
+                accb = self._mark_param(bname)
+                acc = accb if acc is None else acc
+                assert acc == accb
+                a.dbias_pre = self.gv(bname).data_ptr()
+            a.accumulate_dparams = acc
+            self._need_ws(op, "inorm", N * cout * (131 if coop else 3) * 4)
+        if y.r1 is not None:
+            self._need_ws(op, "inorm", N * (cout + 1) * 262 * 4)
+        dop = None
+        if (gname or bname) and z16 and self.dev.type == "cuda":
+            # the per-plane partial sums of dgamma / dbeta / dbias stay in a (small) buffer of this cell's own and are reduced later,
+            # many cells per launch (a step has 36 of these 5 us reductions): after every _DPARAM_BATCH cells and at the end
+            if a.accumulate_dparams:
+                self.flush_dparams()            # an earlier contribution to the same parameters lands first
+            buf = self.alloc(N * (cout + 1) * 262)
+            self.ws_users = [u for u in self.ws_users if u[0] is not op]
+            a.workspace, a.workspace_bytes, a.defer_dparams = buf.data_ptr(), buf.numel() * 4, 1
+            dop = _mk(L.OP_IN_DPARAM, cell.tag)
+            d = dop.u.dparam
+            d.part, d.dgamma, d.dbeta, d.dbias_pre = buf.data_ptr(), a.dgamma, a.dbeta, a.dbias_pre
+            d.N, d.C, d.T, d.accumulate = N, cout, int(self.lib.mtbc_instnorm_bwd_team(C.byref(a))), a.accumulate_dparams
+        self.bwd_ops.append(op)
+        if dop is not None:
+            self._pending_dparams.append((dop, tuple(n_ for n_ in (gname, betaname, bname) if n_)))
+            if len(self._pending_dparams) >= _DPARAM_BATCH:
+                self.flush_dparams()
+        if y.r1 is not None:            # the head's parameter gradients are written by THIS op
+            for name in y.r1[5]:
+                self.slots[name].ready_at = len(self.bwd_ops) - 1
+        if c8_bwd and not coop:
+            dz8 = dz8_buffer()
+            pk = self._c8_pack_op(dz16 if p16 else dy, dz8, cout, H * W)
+            if p16:
+                pk.kind = L.OP_C8_PACK16
+            self.bwd_ops.append(pk)
+        # weight gradient
+        op = self._cell_conv_op(cell, L.OP_CONV3_WGRAD)
+        a = op.u.conv3
+        if c8_bwd:
+            self._segs_c8(a.in_, inputs)
+            a.dout, a.operand_layout = dz8.data_ptr(), L.LAYOUT_C8
+        elif cell.stem16:          # fp32 planar 1-channel input, channel-blocked dz
+            self._segs(a.in_, inputs)
+            a.dout, a.operand_layout, a.compute = dz8.data_ptr(), L.LAYOUT_C8, self.compute
+        else:
+            self._segs(a.in_, inputs)
+            a.dout = dy.data_ptr()
+        a.accumulate_dw = self._mark_param(cell.wname)
+        a.dw = self.gv(cell.wname).data_ptr()
+        # (batching the ~40 split-K reductions of a step into a few launches was built and measured: 15.20 vs 14.54 ms -- the
+        #  partials then live in buffers of their own and travel to HBM and back instead of being reduced out of the cache)
+        self._need_ws(op, "conv3", self.lib.mtbc_conv3x3_wgrad_workspace(C.byref(a)))
+        self.bwd_ops.append(op)
+        # input gradient into every input that needs one
+        need = [a_ for a_ in inputs if a_.needs_grad]
+        if need and defer:
+            off = 0
+            for a_ in defer:
+                a_.pending.append((dz8, cell.w, off, cell.cin, cout))
+                off += a_.C
+            self.pack_ops.remove(cell.wp_d_op)          # the full dgrad image is not needed
+            rest = inputs[len(defer):]
+            if rest:
+                crest = cell.cin - off
+                ws = self.alloc(cout, crest, 3, 3)
+                self._wview(cell.w, ws, cout, cell.cin, off, crest, 0, 0, 0)
+                wps, _ = self._pack_lp(ws, crest, cout, 1)
+                op = self._cell_conv_op(cell, L.OP_CONV3_DGRAD)
+                a = op.u.conv3
+                a.Cin, a.n_in, a.w = crest, len(rest), ws.data_ptr()
+                self._segs(a.in_, rest, grads=True, g16=True)
+                a.dout, a.operand_layout, a.w_packed = dz8.data_ptr(), L.LAYOUT_C8, wps.data_ptr()
+                self.bwd_ops.append(op)
+        elif need:
+            if len(need) != len(inputs):
+                raise NotImplementedError("mixed grad / no-grad concat inputs")
+            op = self._cell_conv_op(cell, L.OP_CONV3_DGRAD)
+            a = op.u.conv3
+            self._segs(a.in_, inputs, grads=True, g16=bool(c8_bwd and cell.wp_d is not None))
+            a.dout = _ptr(dy)
+            if c8_bwd and cell.wp_d is not None:
+                a.dout, a.operand_layout = dz8.data_ptr(), L.LAYOUT_C8
+            a.w_packed = _ptr(cell.wp_d)
+            self.bwd_ops.append(op)
 
     def _c8_small_ok(self, x: Act) -> bool:
         """16-bit modes: may a small consumer (max-pool, 1x1 head) read the channel-blocked copy of x instead of fp32 planes?"""
-        return bool(self.compute) and not _NO_C8 and not _NO_C8_SMALL and not self.force_direct and x.C % 8 == 0 and (x.H * x.W) % 4 == 0
+        return bool(self.compute) and not self.force_direct and x.C % 8 == 0 and (x.H * x.W) % 4 == 0
 
     def maxpool(self, x: Act, out_name: str) -> Act:
         x.readers += 1
@@ -752,7 +652,7 @@ class StepPlan:
             # the pool's backward inside the InstanceNorm backward of x (mtbc_instnorm_args.dy_pool): the forward records where
             # each window's maximum sits (2 bits per channel), the pooled gradient is routed while the norm backward loads its
             # slab -- no 4x larger, three-quarters-zero fp32 tensor written, read-modify-written by the fan-in and read back
-            fold = x.z16 and x.needs_grad and not _NO_POOLFOLD and not _EPI_BSTATS and x.pool is None
+            fold = x.z16 and x.needs_grad and x.pool is None
         arg = self.alloc(self.N, x.C // 8, y.H * y.W, dtype=torch.int16) if fold else None
 
         def base() -> L.Op:
@@ -768,7 +668,7 @@ class StepPlan:
                 a.y, a.y_batch_stride = y.data.data_ptr(), y.bstride
             return op
 
-        if c8 and x.in_op is not None and x.in_op.u.inorm.stats_slots > 0 and not x.in_op.u.inorm.pool_y8 and not _NO_POOLFWD_FOLD:
+        if c8 and x.in_op is not None and x.in_op.u.inorm.stats_slots > 0 and not x.in_op.u.inorm.pool_y8:
             # x's InstanceNorm forward is the streaming pass: it writes the pooled tensor (and the argmax codes) while it has the window
             # in registers -- no pool launch, no second read of x (mtbc_instnorm_args.pool_y8)
             x.in_op.u.inorm.pool_y8 = y.c8.data_ptr()
@@ -815,7 +715,7 @@ class StepPlan:
 
         op = base(reads_x=False)
         op.kind = L.OP_CONVT_FWD
-        if self.compute and not _NO_C8 and cout % 8 == 0:
+        if self.compute and cout % 8 == 0:
             # 16-bit modes: the up-sampled tensor feeds 3x3 convs only -- write it straight into their channel-blocked
             # 16-bit layout; y.data then stays unwritten.  First choice: the 16-bit MFMA forward that also READS the
             # channel-blocked copy of x (the same one the 3x3 convs read); else the fp32-MFMA forward on fp32 x (same
@@ -824,7 +724,7 @@ class StepPlan:
             y.c8 = self.alloc(self.N, cout // 8, y.H * y.W, 8, dtype=torch.int16)
             a.y, a.y_batch_stride, a.y_layout, a.y_type = y.c8.data_ptr(), y.bstride, L.LAYOUT_C8, self.compute
             a.x_layout = L.LAYOUT_C8
-            if k == 2 and x.C % 8 == 0 and not _NO_CT_LP and self.lib.mtbc_convT_fwd_c8_supported(C.byref(a)):
+            if k == 2 and x.C % 8 == 0 and self.lib.mtbc_convT_fwd_c8_supported(C.byref(a)):
                 a.x = self.c8_of(x).data_ptr()
             else:
                 a.x_layout = L.LAYOUT_PLANAR
@@ -837,22 +737,19 @@ class StepPlan:
         self.fwd_ops.append(op)
         # 16-bit modes: the backward MFMAs of the k = 2 up-convolutions take rounded operands too (they are fp32-MFMA
         # bound otherwise); only where BOTH direct-to-fragment kernels of convt2.hip take the shape
-        lp = self.compute if (k == 2 and not _NO_CT_LP and (x.H * x.W) % 32 == 0 and x.W % 8 == 0 and cout % 2 == 0) else 0
+        lp = self.compute if (k == 2 and (x.H * x.W) % 32 == 0 and x.W % 8 == 0 and cout % 2 == 0) else 0
         # ... and since they round dy while loading it, a dy with a single writer can arrive as 16-bit planes (half the bytes
         # written by the 3x3 conv's dgrad and read twice here); the writer decides (conv_cell.emit_bwd)
-        y.grad16_ok = bool(lp) and not _NO_G16 and (y.bstride % 8 == 0)
+        y.grad16_ok = bool(lp) and (y.bstride % 8 == 0)
 
         def emit_bwd() -> None:
             if not y.grad_written:
                 return
             g16 = y.grad16 is not None
             dy = y.grad16 if g16 else self.grad_of(y)
-            forked = x.needs_grad and self._overlap_ok(x.H * x.W)
-            if forked:
-                self.fork_side()
             # x as 16-bit planes too, where the streaming InstanceNorm pass can write them beside the channel-blocked copy and
             # nothing else wants fp32 planes of x (decided in _narrow_activations, once every reader is known)
-            x16 = (g16 and not _NO_X16 and x.in_op is not None and bool(x.in_op.u.inorm.y8) and x.in_op.u.inorm.stats_slots > 0
+            x16 = (g16 and x.in_op is not None and bool(x.in_op.u.inorm.y8) and x.in_op.u.inorm.stats_slots > 0
                    and (x.H * x.W) % 8 == 0 and x.bstride % 8 == 0)
             op = base(reads_x=not x16)
             if x16:
@@ -868,8 +765,6 @@ class StepPlan:
                 a.dbias = self.gv(bname).data_ptr()
             self._need_ws(op, "convT", self.lib.mtbc_convT_wgrad_workspace(C.byref(a)))
             self.bwd_ops.append(op)
-            if forked:
-                self.back_to_main()
             if x.needs_grad:
                 op = base(reads_x=False)
                 op.kind = L.OP_CONVT_DGRAD
@@ -879,8 +774,6 @@ class StepPlan:
                 gx, acc = self.grad_slot(x)
                 a.dx, a.dx_batch_stride, a.accumulate_dx = gx.data_ptr(), x.bstride, acc
                 self.bwd_ops.append(op)
-            if forked:
-                self.join_side([wname] + ([bname] if bname else []))
 
         self.bwd_emitters.append(emit_bwd)
         return y
@@ -981,7 +874,7 @@ class StepPlan:
             if not y.grad_written:
                 return
             dy = self.grad_of(y)
-            r1 = x.needs_grad and c8 and cout == 1 and x.z16 and not _NO_R1 and not _EPI_BSTATS and x.r1 is None
+            r1 = x.needs_grad and c8 and cout == 1 and x.z16 and x.r1 is None
             if r1:
                 # dx = w[c] * dy[n, pixel] is rank 1: the InstanceNorm backward of x forms it from dy (4 B per pixel) and w instead of
                 # this head writing C fp32 planes that the fan-in and the norm read back (mtbc_instnorm_args.dy_rank1) -- and since it
@@ -1171,7 +1064,7 @@ class StepPlan:
                     a.in_op.u.inorm.y = None
                     a.planar_valid = False
                 continue
-            if _NO_P16 or a.in_op is None or a.pack_op is None or a.planar_used or hw % 4 or hw > 65536:
+            if a.in_op is None or a.pack_op is None or a.planar_used or hw % 4 or hw > 65536:
                 continue
             y16 = self.alloc(a.N, a.C, a.H, a.W, dtype=torch.int16)
             a.in_op.u.inorm.y16, a.in_op.u.inorm.out16_type = y16.data_ptr(), self.compute
@@ -1189,10 +1082,9 @@ class StepPlan:
             sb = self.alloc((self._stat_bytes + 15) // 16 * 4)
             for op, fieldname in self._stat_users:
                 getattr(op.u, fieldname).stats_partial = sb.data_ptr()
-        side = torch.cuda.Stream(device=self.dev) if getattr(self, "_events", None) is not None else None
         return {
             "pack": Program(self.wview_ops + self.pack_ops, self.keep),
             "fwd": Program(self.fwd_ops, self.keep),
             "loss": Program(self.loss_ops, self.keep),
-            "bwd": Program(self.bwd_ops, self.keep, side_stream=side),
+            "bwd": Program(self.bwd_ops, self.keep),
         }

@@ -132,3 +132,23 @@ def test_dice_score_from_counts_semantics():
     assert dice_score_from_counts(torch.tensor([1.0, 1.0, 1.0], dtype=torch.float64)) == 0.5
     assert dice_score_from_counts(torch.tensor([0.0, 0.0, 0.0], dtype=torch.float64)) == 1.0
     assert dice_score_from_counts(torch.tensor([0.0, 4.0, 0.0], dtype=torch.float64)) == 0.0
+
+
+def test_every_plan_switch_names_its_gpu_test():
+    """switches.py: a plan switch is kept only while a -m gpu test runs its non-default arm against the oracle / emulation; the test it
+    names must exist (file and function), and every switch the engine / nets / trainer read must be declared."""
+    import os
+    import re
+    from multi_task_breast_cancer_amd import switches
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    assert len(switches.PLAN_SWITCHES) <= 10
+    for name, (default, what, test) in switches.PLAN_SWITCHES.items():
+        path, func = test.split("::")
+        func = func.split("[")[0]
+        src = open(os.path.join(root, path)).read()
+        assert re.search(r"^def %s\(" % re.escape(func), src, re.M), (name, test)
+    used = set()
+    for fn in ("engine.py", "nets.py", "trainer.py"):
+        used |= set(re.findall(r'_sw\.(?:flag|get)\("(MTBC_[A-Z0-9_]+)"\)', open(os.path.join(root, "multi_task_breast_cancer_amd", fn)).read()))
+    assert used <= set(switches.PLAN_SWITCHES), used - set(switches.PLAN_SWITCHES)
+    assert not (set(switches.REMOVED) & set(switches.PLAN_SWITCHES))

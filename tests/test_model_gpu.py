@@ -264,9 +264,12 @@ def test_distributed_step_single_rank_rccl_equals_local_step():
 
 
 @pytest.mark.parametrize("arch,dtype,size,arm", [("MTUNetPlusPlus", "bf16", 64, ""), ("MTUNetPlusPlus", "f16", 64, ""), ("MTnnUNet", "bf16", 128, ""),
-                                                 ("MTUNetPlusPlus", "bf16", 128, ""), ("MTUNetPlusPlus", "bf16", 128, "epi_bstats"),
+                                                 ("MTUNetPlusPlus", "bf16", 128, ""), ("MTUNetPlusPlus", "bf16", 128, "no_gather"),
                                                  ("MTUNetPlusPlus", "bf16", 64, "no_z16"), ("MTUNetPlusPlus", "bf16", 64, "da16"),
-                                                 ("MTUNetPlusPlus", "bf16", 64, "z_bf16")])
+                                                 ("MTUNetPlusPlus", "bf16", 64, "z_bf16"),
+                                                 # the BASELINE plane sizes: configs[1] (bf16, 256x256: cooperative InstanceNorm backward in teams of 32,
+                                                 # wide-block weight gradients) and configs[4] (fp16, 512x512: teams of 128), whole model against the emulation
+                                                 ("MTUNetPlusPlus", "bf16", 256, ""), ("MTUNetPlusPlus", "f16", 512, "")])
 def test_16bit_mfma_modes_match_their_emulation(arch, dtype, size, arm, monkeypatch):
     """Optional compute modes: conv3x3 MFMA operands rounded to bf16 / fp16 (fp32 storage + accumulation).  Not the
     reference-parity path (that is fp32); the oracle for it is oracle.lowp_conv3x3, which rounds the same operands
@@ -279,20 +282,19 @@ def test_16bit_mfma_modes_match_their_emulation(arch, dtype, size, arm, monkeypa
     the forward as >= 3e-2.  fp16 runs with the static loss scale 4096 on both sides (unscaled, dz underflows fp16)."""
     import copy
     from multi_task_breast_cancer_amd import engine
-    # A/B arms of the plan (switches.py), each with the emulation told the same thing: the gathered 16-bit activation gradients
-    # (MTBC_DA16), the norm-backward epilogue where the other readers' partial meets the rounding (MTBC_EPI_BSTATS: bf16 z),
-    # conv outputs kept in fp32 (MTBC_NO_Z16) or stored as bf16 instead of fp16 (MTBC_Z_BF16)
-    emu = {"": {}, "da16": {"da16": True}, "epi_bstats": {"da16": True, "fold_partials": True, "z_fp16": False},
-           "no_z16": {"z16": False}, "z_bf16": {"z_fp16": False}}[arm]
-    if arm == "epi_bstats":
-        monkeypatch.setattr(engine, "_EPI_BSTATS", True)
+    # the plan switches (switches.py), each with the emulation told the same thing: the gathered 16-bit activation gradients
+    # (MTBC_DA16), conv outputs kept in fp32 (MTBC_NO_Z16) or stored as bf16 instead of fp16 (MTBC_Z_BF16); per-consumer input
+    # gradients with read-modify-write fan-in instead of the gathered launches (MTBC_NO_GATHER: same roundings, another fp32 order)
+    emu = {"": {}, "da16": {"da16": True}, "no_gather": {}, "no_z16": {"z16": False}, "z_bf16": {"z_fp16": False}}[arm]
+    if arm == "no_gather":
+        monkeypatch.setattr(engine, "_NO_GATHER", True)
     elif arm == "no_z16":
         monkeypatch.setattr(engine, "_NO_Z16", True)
     elif arm == "da16":
         monkeypatch.setattr(engine, "_DA16", True)
     elif arm == "z_bf16":
         monkeypatch.setattr(engine, "_Z_BF16", True)
-    N = 4 if size == 64 else 2          # 128x128: level 0 takes the cooperative InstanceNorm forward (planes >= 128x128)
+    N = 4 if size == 64 else (1 if size == 512 else 2)          # >= 128x128: level 0 takes the cooperative InstanceNorm kernels
     prod, ref = _oracle_and_product(arch, 1993)
     prod.set_compute(dtype)
     ref64 = copy.deepcopy(ref).double()
@@ -315,12 +317,25 @@ def test_16bit_mfma_modes_match_their_emulation(arch, dtype, size, arm, monkeypa
         if name.endswith("conv.bias") or g64[name].grad.norm().item() == 0.0:
             continue
         e_hip, e_cpu = rel(prod._grad_view(name) / ls, g64[name].grad), rel(g32[name].grad, g64[name].grad)
-        assert e_hip < max(3 * e_cpu, 5e-2), (name, e_hip, e_cpu)
+        if e_cpu <= 0.1:
+            assert e_hip < max(3 * e_cpu, 5e-2), (name, e_hip, e_cpu)
+        else:
+            # At the BASELINE plane sizes (256x256 / 512x512, N <= 2) the encoder's first cells have gradients that are cancellation
+            # residues at initialisation: the SAME roundings accumulated in fp32 instead of fp64 already move them by 13-18 % (e_cpu),
+            # and 16-bit rounding itself by 60-100 % (HIP bf16 against HIP fp32: 0.66-0.98; HIP fp16: 0.57-0.75, i.e. closer, as its
+            # 3 extra bits say it should be -- tools/experiments/try_emul2.py).  A 3 x e_cpu bar is meaningless there: such a tensor has
+            # to stay CORRELATED with the fp64 emulation (a wiring / rounding-place error gives >= 1.4 or a sign flip) and within
+            # 6 x the fp32-accumulating emulation's own distance.  Every kernel's backward is checked to 1e-5 in test_ops_gpu.py.
+            gh, gr = (prod._grad_view(name) / ls).double().cpu().flatten(), g64[name].grad.double().flatten()
+            cos = (gh @ gr / (gh.norm() * gr.norm())).item()
+            assert e_hip < min(1.0, 6 * e_cpu) and cos > 0.6, (name, e_hip, e_cpu, cos)
 
 
 def test_512_inputs_16bit_modes_track_the_fp32_step():
-    """BASELINE config 5's 512x512 inputs: planes of 1 MB leave the register-resident / cooperative InstanceNorm paths
-    (chunked forward, streaming backward, fp32 planes + pack) -- the 16-bit modes must still follow the fp32 step."""
+    """BASELINE configs[4]'s 512x512 inputs, two steps: the 16-bit modes (conv outputs stored in 16 bits, InstanceNorm forward from the conv
+    epilogue's statistics + one streaming pass, cooperative backward in teams of 128 on the 1 MB planes) must follow the fp32 step
+    (chunked InstanceNorm forward, fp32 planes) -- HIP against HIP; the oracle comparison at this size is
+    test_16bit_mfma_modes_match_their_emulation[MTUNetPlusPlus-f16-512-]."""
     out = {}
     for dt in ("f32", "bf16", "f16"):
         seed_everything(5)
@@ -337,27 +352,26 @@ def test_512_inputs_16bit_modes_track_the_fp32_step():
         assert (out[dt][1] - out["f32"][1]).abs().max().item() < 5e-4      # two Adam steps of lr 1e-4
 
 
-def test_two_stream_backward_is_bit_identical_to_the_single_stream_one(monkeypatch):
-    """MTBC_BWD_OVERLAP (off by default: measured slower): the weight gradient of a layer on a side stream beside its input
-    gradient (mtbc_program_run_ms, MTBC_OP_SET_STREAM / EVENT_RECORD / EVENT_WAIT) must change nothing but the schedule."""
-    from multi_task_breast_cancer_amd import engine, _lib as L
-
-    def run(overlap):
-        monkeypatch.setattr(engine, "_BWD_OVERLAP", overlap)
-        monkeypatch.setattr(engine, "_BWD_OVERLAP_MAX_HW", 1 << 30)
-        seed_everything(21)
-        m = MTUNetPlusPlus(in_channels=1, out_channels=1, n_classes=3, deep_supervision=True).to(DEV)
-        m.set_compute("bf16")
-        step = FusedTrainStep(m, FusedAdam(m, lr=1e-4, eps=1e-4), alpha=0.5)
-        batch = tuple(t.to(DEV) for t in O.synthetic_batch(2, 128, 128, seed=2))
-        for _ in range(2):
-            losses = step(*batch)
-        torch.cuda.synchronize()
-        prog = step._st.programs["bwd"]
-        n_sync = sum(1 for i in range(prog.n) if prog.array[i].kind in (L.OP_SET_STREAM, L.OP_EVENT_RECORD, L.OP_EVENT_WAIT))
-        return losses.cpu(), m.flat_p.detach().cpu().clone(), m.flat_g.detach().cpu().clone(), n_sync
-
-    l0, p0, g0, s0 = run(False)
-    l1, p1, g1, s1 = run(True)
-    assert s0 == 0 and s1 > 100
-    assert torch.equal(l0, l1) and torch.equal(p0, p1) and torch.equal(g0, g1)
+def test_mtnnunet_two_layer_heads_match_the_fused_heads_and_the_oracle(monkeypatch):
+    """MTBC_NOFUSE_HEADS=1: the deep-supervision heads as the reference's two layers (ConvTranspose2d k = s in {2, 4, 8} -> Conv2d 1x1,
+    MTnnUNet.py:106-116) instead of ONE transposed conv with combined weights (engine.convT_head): both step programs against the
+    oracle's step, fp32."""
+    out = {}
+    for nofuse in ("0", "1"):
+        monkeypatch.setenv("MTBC_NOFUSE_HEADS", nofuse)
+        prod, ref = _oracle_and_product("MTnnUNet", 17)
+        img, mask, label = O.synthetic_batch(2, 64, 64, seed=9)
+        step = FusedTrainStep(prod, FusedAdam(prod, lr=1e-4, eps=1e-4), alpha=0.35)
+        st = step.load_batch(img.to(DEV), mask.to(DEV), label.to(DEV))
+        losses = step.run(st).cpu()
+        from multi_task_breast_cancer_amd import _lib as L
+        kinds = [st.programs["fwd"].array[i].kind for i in range(st.programs["fwd"].n)]
+        assert (L.OP_HEAD_COMBINE in kinds) == (nofuse == "0")
+        total, seg, cls, rlogits, routs = O.train_step(ref, O.make_adam(ref, 1e-4), img, mask, label, 0.35, True, 3)
+        assert abs(losses[0].item() - total.item()) < TOL and abs(losses[1].item() - seg.item()) < TOL
+        for got, want in zip(st.segs, routs):
+            assert _maxerr(got.data, want) < TOL
+        for (k, a), (_, b) in zip(prod.state_dict().items(), ref.state_dict().items()):
+            assert (a.cpu() - b).abs().max().item() < 2.0e-4, k
+        out[nofuse] = losses
+    assert (out["0"][:3] - out["1"][:3]).abs().max().item() < 1e-5

@@ -1192,3 +1192,43 @@ def test_convT_wgrad_reads_16bit_planar_x(N, Cin, Cout, H, W, compute):
     assert (dw.cpu().double() - want).abs().max().item() <= 1e-4 * max(1.0, want.abs().max().item())
     with pytest.raises(L.MtbcError):        # 16-bit x with an fp32 dy: no kernel, refused
         ops.convT_wgrad(x16.view(torch.int16), w, dy16.float(), 2, compute=compute, x16=True)
+
+
+def test_program_run_on_two_streams_orders_a_forked_section():
+    """mtbc_program_run_ms (MTBC_OP_SET_STREAM / EVENT_RECORD / EVENT_WAIT): ops between a fork and its join run on the second stream,
+    ordered behind what the main stream had issued before the fork, and the main stream waits at the join.  (The step plan no longer
+    emits forked sections -- two-stream backward measured slower, DESIGN.md -- so the entry point is exercised here.)"""
+    import ctypes as C
+    from multi_task_breast_cancer_amd import _lib as L
+    from multi_task_breast_cancer_amd.engine import _mk
+    lib = L.load()
+    N, Cc, HW = 2, 16, 4096
+    g = _g(5)
+    x = torch.randn(N, Cc, 64, 64, generator=g).to(DEV)
+    a8 = torch.zeros(N, Cc // 8, HW, 8, dtype=torch.int16, device=DEV)
+    back = torch.zeros_like(x)
+    ev = [C.c_void_p(), C.c_void_p()]
+    for h in ev:
+        L.check(lib.mtbc_event_create(C.byref(h)), "event_create")
+
+    def sync(kind, event=0, index=0):
+        op = _mk(kind)
+        op.u.sync.event, op.u.sync.index = (ev[event] if kind != L.OP_SET_STREAM else None), index
+        return op
+
+    pack = _mk(L.OP_C8_PACK)
+    pack.u.c8pack.src, pack.u.c8pack.src_batch_stride, pack.u.c8pack.dst = x.data_ptr(), Cc * HW, a8.data_ptr()
+    pack.u.c8pack.N, pack.u.c8pack.C, pack.u.c8pack.HW, pack.u.c8pack.compute = N, Cc, HW, 1
+    # main: pack | fork -> side: (waits for the pack) nothing else | join ; then unpack on the caller's side through the ordinary entry
+    ops_ = [pack, sync(L.OP_EVENT_RECORD, 0), sync(L.OP_SET_STREAM, index=1), sync(L.OP_EVENT_WAIT, 0),
+            sync(L.OP_EVENT_RECORD, 1), sync(L.OP_SET_STREAM, index=0), sync(L.OP_EVENT_WAIT, 1)]
+    arr = (L.Op * len(ops_))(*ops_)
+    side = torch.cuda.Stream()
+    streams = (C.c_void_p * 2)(torch.cuda.current_stream().cuda_stream, side.cuda_stream)
+    failed = C.c_int32(-1)
+    L.check(lib.mtbc_program_run_ms(arr, 0, len(ops_), streams, 2, C.byref(failed)), "program_run_ms")
+    L.check(lib.mtbc_c8_unpack(a8.data_ptr(), back.data_ptr(), N, Cc, HW, 1, C.c_void_p(torch.cuda.current_stream().cuda_stream)), "unpack")
+    torch.cuda.synchronize()
+    assert torch.equal(back, x.to(torch.bfloat16).float())
+    for h in ev:
+        lib.mtbc_event_destroy(h)
