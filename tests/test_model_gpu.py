@@ -317,7 +317,7 @@ def test_16bit_mfma_modes_match_their_emulation(arch, dtype, size, arm, monkeypa
         if name.endswith("conv.bias") or g64[name].grad.norm().item() == 0.0:
             continue
         e_hip, e_cpu = rel(prod._grad_view(name) / ls, g64[name].grad), rel(g32[name].grad, g64[name].grad)
-        if e_cpu <= 0.1:
+        if e_cpu <= 0.1 or e_hip < 3 * e_cpu:
             assert e_hip < max(3 * e_cpu, 5e-2), (name, e_hip, e_cpu)
         else:
             # At the BASELINE plane sizes (256x256 / 512x512, N <= 2) the encoder's first cells have gradients that are cancellation
