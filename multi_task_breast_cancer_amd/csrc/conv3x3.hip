@@ -1314,23 +1314,33 @@ __global__ __launch_bounds__(256, 1) void conv3x3_igemm_c8_ring_kernel(const Con
             if (ch + R - 1 < nchunks) ring_issue<MT, GEO>(p, smem16, seg_in, pixo, ch + R - 1, (ch + R - 1) % R, wvu, lane, n0, mt0, nchunks, HW);
             const unsigned short* Xs = smem16 + (ch % R) * RG::SLOT;
             const unsigned short* Ws = Xs + XB;
-#pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
+            // ONE wave per SIMD: nobody else covers a fragment read's latency.  Left to the scheduler the taps ran as `2 reads, wait for
+            // the first, 4 MFMAs, ...` (ISA: `r2 [lgkmcnt(1)] M4 r2 [lgkmcnt(1)] M4`), the matrix pipe a third busy; here the fragments of
+            // tap t + 1 are read into a second register set BEFORE the 4 MT MFMAs of tap t (56 VGPRs of fragments; the block has 512).
+            typename T::frag fa[2][MT], fb[2][4];
+            auto load_tap = [&](int tap, int set) {
                 const int toff = (tap / 3) * HC + tap % 3;
-                typename T::frag a[MT], b[4];
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
-                    a[m] = *reinterpret_cast<const typename T::frag*>(Ws + ((m * 9 + tap) * 16 + j) * WROW + 8 * (kg ^ ((j >> 1) & 3)));
+                    fa[set][m] = *reinterpret_cast<const typename T::frag*>(Ws + ((m * 9 + tap) * 16 + j) * WROW + 8 * (kg ^ ((j >> 1) & 3)));
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
-                    b[g] = *reinterpret_cast<const typename T::frag*>(Xs + (kg * HPP + bpix0) * 8 + (c8_goff<GEO>(g, HC) + toff) * 8);
+                    fb[set][g] = *reinterpret_cast<const typename T::frag*>(Xs + (kg * HPP + bpix0) * 8 + (c8_goff<GEO>(g, HC) + toff) * 8);
+            };
+            load_tap(0, 0);
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int set = tap & 1;
+                if (tap + 1 < 9) load_tap(tap + 1, set ^ 1);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
-                        if constexpr (O8 != 0) acc[m][g] = T::mfma(a[m], b[g], acc[m][g]);
-                        else acc[m][g] = T::mfma(b[g], a[m], acc[m][g]);
+                        if constexpr (O8 != 0) acc[m][g] = T::mfma(fa[set][m], fb[set][g], acc[m][g]);
+                        else acc[m][g] = T::mfma(fb[set][g], fa[set][m], acc[m][g]);
                     }
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         int zpre = 0;
@@ -1356,9 +1366,14 @@ struct WgP {
     int dbg;      // timing probes (env MTBC_DBG): 1 = no global loads, 4 = no LDS commits
 };
 
-// COT = output-channel tiles per block (2 or 3): 128*COT threads, wave w = (co-tile w/2, ci-tile w%2).  COT = 3 serves
+// COT = output-channel tiles per block (2 or 3): 128*COT threads, wave w = (co-tile w/2, half w%2 of the column tiles).  COT = 3 serves
 // Cout = 48 (U-Net++ level 1) without padding the second 32-channel block half empty.
-template <int GEO, int COT>
+// Columns (round 3): the N dimension of the MFMA is the (tap, ci) PAIR, 9 * cib columns per block in tiles of 16, instead of one 16-channel
+// tile per tap.  With 32 input channels per block that is the same 18 tiles; with 24 (PACK: every level-0 / level-1 conv of the U-Net++ has
+// Cin = 24 k, which blocks of 32 cut into 32 + 32 + 8 or pad 24 -> 32) it is 13.5 -> 14 tiles, 7 per wave instead of 9: -22 % MFMAs on
+// 60 % of the weight-gradient FLOPs.  A lane's column decides its channel AND its tap, so its LDS offset is per lane and per tile
+// (`boff`); a tile that straddles two taps reads 2-way conflicted (the LDS is not what bounds this kernel).
+template <int GEO, int COT, bool PACK>
 __global__ __launch_bounds__(128 * COT, 3) void conv3x3_wgrad_mfma_kernel(const WgP p) {
     using G = WGeo<GEO>;
     constexpr int XS = 32 * G::PSX;
@@ -1370,7 +1385,8 @@ __global__ __launch_bounds__(128 * COT, 3) void conv3x3_wgrad_mfma_kernel(const 
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int HW = p.H * p.W;
-    const int co0 = (blockIdx.y / p.ciblocks) * (16 * COT), ci0 = (blockIdx.y % p.ciblocks) * 32;
+    constexpr int CIB = PACK ? 24 : 32, NTW = PACK ? 7 : 9;          // input channels per block, column tiles per wave
+    const int co0 = (blockIdx.y / p.ciblocks) * (16 * COT), ci0 = (blockIdx.y % p.ciblocks) * CIB;
     const int split = blockIdx.x;
     const int t_begin = split * p.tiles_per_split;
     const int t_end = min(p.total_tiles, t_begin + p.tiles_per_split);
@@ -1378,7 +1394,7 @@ __global__ __launch_bounds__(128 * COT, 3) void conv3x3_wgrad_mfma_kernel(const 
     // ---- staging role: thread -> (channel ch = tid/8, lane-in-channel q = tid%8), fixed for the block
     const int ch = tid >> 3, q = tid & 7;                 // ch < 16*COT; only ch < 32 stage X
     const int my_ci = ci0 + ch, my_co = co0 + ch;
-    const bool ci_ok = ch < 32 && my_ci < p.Cin, co_ok = my_co < p.Cout;
+    const bool ci_ok = ch < CIB && my_ci < p.Cin, co_ok = my_co < p.Cout;
     const SegRef sr = seg_ref(p.in, ci_ok ? my_ci : 0);
     const float* xplane = sr.ptr + (size_t)((ci_ok ? my_ci : 0) - sr.cb) * HW;       // + n*bs + y*W + x
     const long long xbs = sr.bs;
@@ -1388,21 +1404,12 @@ __global__ __launch_bounds__(128 * COT, 3) void conv3x3_wgrad_mfma_kernel(const 
     // Slot offsets relative to the tile origin are tile-invariant: computed once.  A tile that does not touch the
     // image border then costs one 64-bit add per operand and one address instruction per load (the generic path
     // below spends ~25 VALU instructions per slot on div/mod, bounds and 64-bit index math).
-    int xrel[XSLOTS], zrel[4];
     unsigned slots_ok = 0;
     if (G::IMG == 1) {
 #pragma unroll
-        for (int s = 0; s < XSLOTS; ++s) {
-            const int f = q + 8 * s, row = f / (G::LW / 4), c4 = f % (G::LW / 4);
-            xrel[s] = (row - 1) * p.W + (c4 * 4 - 4);
-            slots_ok |= (f < XF4_PER_CH && ci_ok) ? (1u << s) : 0u;
-        }
+        for (int s = 0; s < XSLOTS; ++s) slots_ok |= (q + 8 * s < XF4_PER_CH && ci_ok) ? (1u << s) : 0u;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const int px = (q + 8 * s) * 4;
-            zrel[s] = (px / G::TW) * p.W + px % G::TW;
-            slots_ok |= co_ok ? (1u << (XSLOTS + s)) : 0u;
-        }
+        for (int s = 0; s < 4; ++s) slots_ok |= co_ok ? (1u << (XSLOTS + s)) : 0u;
     }
 
     auto prefetch = [&](int tile) {
@@ -1416,10 +1423,21 @@ __global__ __launch_bounds__(128 * COT, 3) void conv3x3_wgrad_mfma_kernel(const 
                 const float* xt = xplane + ((size_t)n0 * xbs + y0 * p.W + x0);
                 const float* zt = zplane + ((size_t)n0 * p.Cout * HW + y0 * p.W + x0);
                 live = slots_ok;
+                // the slot offsets are recomputed per tile from an opaque copy of q: kept live across the MFMA loop they were spilled
+                // (the packed-column variant has 7 per-lane column offsets more), and every scratch reload between these loads waits
+                // for the loads already issued
+                int qq = q;
+                asm volatile("" : "+v"(qq));
 #pragma unroll
-                for (int s = 0; s < XSLOTS; ++s) xr[s] = *reinterpret_cast<const float4*>(((slots_ok >> s) & 1u) ? xt + xrel[s] : xplane);
+                for (int s = 0; s < XSLOTS; ++s) {
+                    const int f = qq + 8 * s, row = f / (G::LW / 4), c4 = f % (G::LW / 4);
+                    xr[s] = *reinterpret_cast<const float4*>(((slots_ok >> s) & 1u) ? xt + ((row - 1) * p.W + (c4 * 4 - 4)) : xplane);
+                }
 #pragma unroll
-                for (int s = 0; s < 4; ++s) zr[s] = *reinterpret_cast<const float4*>(co_ok ? zt + zrel[s] : zplane);
+                for (int s = 0; s < 4; ++s) {
+                    const int px = (qq + 8 * s) * 4;
+                    zr[s] = *reinterpret_cast<const float4*>(co_ok ? zt + ((px / G::TW) * p.W + px % G::TW) : zplane);
+                }
                 return;
             }
         }
@@ -1460,7 +1478,7 @@ __global__ __launch_bounds__(128 * COT, 3) void conv3x3_wgrad_mfma_kernel(const 
 #pragma unroll
         for (int s = 0; s < XSLOTS; ++s) {
             const int f = q + 8 * s;
-            if (f < XF4_PER_CH && ch < 32) {
+            if (f < XF4_PER_CH && ch < CIB) {
                 const int img = f / (G::ROWS * G::LW / 4), rem = f % (G::ROWS * G::LW / 4);
                 const int row = rem / (G::LW / 4), c4 = rem % (G::LW / 4);
                 float* d = Xs + ch * G::PSX + img * G::IMGS + row * G::LW + c4 * 4;
@@ -1478,11 +1496,23 @@ __global__ __launch_bounds__(128 * COT, 3) void conv3x3_wgrad_mfma_kernel(const 
 
     const int j = lane & 15, kk = lane >> 4;
     const int aBase = ((wv >> 1) * 16 + j) * PSZ + kk;
+    // column tile i of this wave = tile 2 i + (wv & 1); lane j's column c -> (tap, channel); columns past 9 * CIB (the second half of the
+    // 14th tile of a 24-channel block) read a valid address and are never stored
+    // (32-channel blocks: tile i IS tap i of the wave's 16-channel tile -- one base + compile-time tap offsets, as before)
     const int bBase = ((wv & 1) * 16 + j) * G::PSX + kk + 3;
-
-    f32x4 acc[9];
+    int boff[PACK ? NTW : 1];
+    if constexpr (PACK) {
 #pragma unroll
-    for (int i = 0; i < 9; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < NTW; ++i) {
+            const int c = 16 * (2 * i + (wv & 1)) + j;
+            const int tap = min(c / CIB, 8), cc = min(c - (c / CIB) * CIB, CIB - 1);
+            boff[i] = cc * G::PSX + kk + 3 + (tap / 3) * G::LW + tap % 3;
+        }
+    }
+
+    f32x4 acc[NTW];
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
 #pragma unroll
     for (int s = 0; s < XSLOTS; ++s) xr[s] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1496,7 +1526,7 @@ __global__ __launch_bounds__(128 * COT, 3) void conv3x3_wgrad_mfma_kernel(const 
         if (tile + 1 < t_end && !MTBC_DBG_BIT(p, 1)) prefetch(tile + 1);   // in flight under the MFMAs below
         // 32 k-steps of 4 pixels; fragments of step s+1 are read before the MFMAs of step s (bounded live ranges:
         // without the sched_barriers hipcc hoists all 320 LDS reads and needs >180 VGPRs, i.e. 2 waves/SIMD)
-        float fa[2], fb[2][9];
+        float fa[2], fb[2][NTW];
         auto read_step = [&](int p4, int slot) {
             const int px = p4 * 4;
             int xoff;
@@ -1505,7 +1535,10 @@ __global__ __launch_bounds__(128 * COT, 3) void conv3x3_wgrad_mfma_kernel(const 
             else xoff = (px / 64) * G::IMGS + ((px % 64) / 8) * G::LW + px % 8;
             fa[slot] = Zs[aBase + px];
 #pragma unroll
-            for (int tap = 0; tap < 9; ++tap) fb[slot][tap] = Xs[bBase + xoff + (tap / 3) * G::LW + tap % 3];
+            for (int i = 0; i < NTW; ++i) {
+                if constexpr (PACK) fb[slot][i] = Xs[boff[i] + xoff];
+                else fb[slot][i] = Xs[bBase + xoff + (i / 3) * G::LW + i % 3];
+            }
         };
         read_step(0, 0);
 #pragma unroll
@@ -1513,21 +1546,21 @@ __global__ __launch_bounds__(128 * COT, 3) void conv3x3_wgrad_mfma_kernel(const 
             if (p4 + 1 < 32) read_step(p4 + 1, (p4 + 1) & 1);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int tap = 0; tap < 9; ++tap)
-                acc[tap] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[p4 & 1], fb[p4 & 1][tap], acc[tap], 0, 0, 0);
+            for (int i = 0; i < NTW; ++i)
+                acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[p4 & 1], fb[p4 & 1][i], acc[i], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
-    // partial[split][co][ci][tap]; D row = co (kk*4+r), col = ci (j)
-    const int ci = ci0 + (wv & 1) * 16 + j;
-    if (ci < p.Cin) {
+    // partial[split][co][ci][tap]; D row = co (kk*4+r), column = (tap, ci) of tile 2 i + (wv & 1)
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) {
+        const int c = PACK ? 16 * (2 * i + (wv & 1)) + j : i * CIB + (wv & 1) * 16 + j;      // (32-channel blocks: tile i = tap i)
+        const int tap = c / CIB, ci = ci0 + c - tap * CIB;
+        if (tap >= 9 || ci >= p.Cin) continue;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int co = co0 + (wv >> 1) * 16 + kk * 4 + r;
-            if (co >= p.Cout) continue;
-            float* d = p.partial + (((size_t)split * p.Cout + co) * p.Cin + ci) * 9;
-#pragma unroll
-            for (int tap = 0; tap < 9; ++tap) d[tap] = acc[tap][r];
+            if (co < p.Cout) p.partial[(((size_t)split * p.Cout + co) * p.Cin + ci) * 9 + tap] = acc[i][r];
         }
     }
 }
@@ -2365,6 +2398,200 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     }
 }
 
+// ------------------------------------------------------------------ wgrad on channel-blocked operands, 16 x 16 maps ("c8i", round 3)
+// The deep level of the U-Net++ (16 x 16 maps, 192 .. 1152 -> 384 / 512 channels): K = 8192 pixels only, a weight gradient of 1.3 .. 5.3 M
+// elements.  conv3x3_wgrad_c8_kernel runs it as 576 .. 1024 blocks of 32 co x 32 ci that each stage the pixels in 128-pixel tiles of 21 KB
+// for 36 MFMAs per wave, single-buffered: 149 us for the 1152 -> 512 conv whose MFMAs take 35 us.  Here a block owns 32 / 48 output x
+// <= 80 input channels (the pairs / MFMA body of conv3x3_wgrad_c8w_kernel) and a range of IMAGES; a tile is one whole image with its
+// zero halo (18 x 18 pieces per input-channel group: the padding comes out of the buffer bounds check, nothing is staged twice), eight
+// K-steps of 2 rows x 16 pixels, 135 MFMAs per wave and tile; two stages, the DMA of image n + 1 (inline assembly: no compiler-inserted
+// vmcnt(0) in front of the fragment reads) under the MFMAs of image n, ONE barrier per image.  One block of 8 waves per CU (up to 154 KB
+// of LDS), <= 256 blocks; everything it reads sits in L2 / the memory-side cache.
+constexpr int C8I_LW = 18, C8I_XG = C8I_LW * C8I_LW, C8I_ZG = 256 + 4;
+static_assert((C8I_XG * 16) % 256 == 64 && (C8I_ZG * 16) % 256 == 64, "group strides: 64 / 192 mod 256 B keep the transposed reads conflict-free");
+static inline size_t c8i_lds_bytes(int cit, int cot) { return 2 * (size_t)(2 * cit * C8I_XG + 2 * cot * C8I_ZG) * 16 + 256; }
+template <bool F16, int COT, bool BIAS>
+__global__ __launch_bounds__(512) void conv3x3_wgrad_c8i_kernel(const WgC8P p) {
+    using T = LP<F16>;
+    typedef short s16x4 __attribute__((ext_vector_type(4)));
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) s16x4* lds_s16x4_t;
+    constexpr int LW = C8I_LW, XG = C8I_XG, ZG = C8I_ZG, U = 2, KS = 8, XI = (XG + 63) / 64, ZI = 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned short smemi[];
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int HW = 256;
+    // block id = split + nsplit * (channel block): with nsplit a multiple of 8 an image range is read by ONE XCD (its L2 holds it)
+    const int split = blockIdx.x % p.segs, yb = blockIdx.x / p.segs;          // (segs = number of image ranges)
+    const int cib = yb % p.ciblocks, co0 = (yb / p.ciblocks) * 16 * COT;
+    const int cit0 = cib * p.cit, ncit = min(p.cit, ((p.Cin + 15) >> 4) - cit0), ci0 = cit0 * 16;
+    const int n_begin = split * p.seg_tiles, n_end = min(p.N, n_begin + p.seg_tiles);        // (seg_tiles = images per range)
+    const int ZBASE = 2 * p.cit * XG * 8;                  // 16-bit elements, within a stage
+    const int SS = ZBASE + 2 * COT * ZG * 8;               // one stage
+
+    // DMA: wave w brings input-channel groups w and w + 8 (6 instructions each) and output-channel group 7 - w (4) of every image
+    const unsigned short* xbase[2]; long long xbs[2]; bool xok[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int gx = wv + 8 * k, c = ci0 + 8 * gx;
+        xok[k] = gx < 2 * ncit && c < p.Cin;             // (an absent group's LDS image is never read into a stored result)
+        const SegRef sr = seg_ref(p.in, xok[k] ? c : 0);
+        xbase[k] = reinterpret_cast<const unsigned short*>(sr.ptr) + (size_t)((xok[k] ? c : 0) - sr.cb) * HW;
+        xbs[k] = sr.bs;
+    }
+    const int gz = 7 - wv, cz = co0 + 8 * gz;
+    const bool zok = gz < 2 * COT && cz < p.Cout;
+    const unsigned short* zbase = p.dz + (size_t)(zok ? cz : 0) * HW;
+    const unsigned lds0 = lds_addr(smemi);
+    unsigned xvoff[XI];                                   // the same for every image: piece s of the 18 x 18 halo image <- pixel (row - 1, col - 1)
+#pragma unroll
+    for (int i = 0; i < XI; ++i) {
+        const int s_ = 64 * i + lane, row = s_ / LW - 1, col = s_ % LW - 1;
+        xvoff[i] = (s_ < XG && row >= 0 && row < 16 && col >= 0 && col < 16) ? 16u * (unsigned)(row * 16 + col) : 0xfffffff0u;
+    }
+    auto issue = [&](int n, int stg) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            if (!xok[k]) continue;                         // wave-uniform
+            const i32x4 xr = dma_rsrc(xbase[k] + (size_t)n * xbs[k], HW * 16);
+#pragma unroll
+            for (int i = 0; i < XI; ++i)
+                if (64 * i + lane < XG) dma16(xr, lds0 + 2u * (unsigned)(stg * SS + ((wv + 8 * k) * XG + 64 * i) * 8), xvoff[i]);
+        }
+        if (zok) {
+            const i32x4 zr = dma_rsrc(zbase + (size_t)n * p.Cout * HW, HW * 16);
+#pragma unroll
+            for (int i = 0; i < ZI; ++i) dma16(zr, lds0 + 2u * (unsigned)(stg * SS + ZBASE + (gz * ZG + 64 * i) * 8), 16u * (unsigned)(64 * i + lane));
+        }
+    };
+
+    const int j = lane & 15, kg = lane >> 4, q = j >> 2, pp = j & 3;
+    // a K-step = two image rows of 16 pixels: lane group kg owns row kg >> 1, columns 8 (kg & 1) .. + 7 -- in the linear dz image that is
+    // pixels 32 step + 8 kg .. + 7, in the halo image row 2 step + (kg >> 1) + tap row, columns 8 (kg & 1) + {0, 4, 8} + q
+    const int zoff = ZBASE + ((pp >> 1) * ZG + 8 * kg + q) * 8 + 4 * (pp & 1);
+    int xoff[U], pcit[U], prow[U]; bool pok[U];
+#pragma unroll
+    for (int i = 0; i < U; ++i) {
+        const int pi = wv + 8 * i;                          // pair = (ci tile, tap row)
+        pok[i] = pi < 3 * ncit;
+        pcit[i] = pi / 3; prow[i] = pi - 3 * pcit[i];
+        xoff[i] = ((2 * pcit[i] + (pp >> 1)) * XG + ((kg >> 1) + prow[i]) * LW + 8 * (kg & 1) + q) * 8 + 4 * (pp & 1);
+    }
+    const bool do_bias = BIAS && cib == 0 && wv == 7;
+
+    f32x4 acc[U][COT][3], accb[COT];
+#pragma unroll
+    for (int c = 0; c < COT; ++c) {
+        accb[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < U; ++i)
+#pragma unroll
+            for (int s_ = 0; s_ < 3; ++s_) acc[i][c][s_] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    typename T::frag ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = 1.0f;
+
+    int stage = 0;
+    if (n_begin < n_end) issue(n_begin, 0);
+    for (int n = n_begin; n < n_end; ++n) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");      // image n has landed for everybody; everybody is done with image n - 1
+        if (n + 1 < n_end) issue(n + 1, stage ^ 1);
+        const unsigned short* sm = smemi + stage * SS;
+        stage ^= 1;
+        // the eight K-steps as one straight-line, software-pipelined body (see conv3x3_wgrad_c8w_kernel): pair slots this wave does not own
+        // are multiplied too, their accumulators are never stored
+        auto body = [&](auto ns_) {
+            constexpr int NS = decltype(ns_)::value;
+            s16x4 ra[2][COT][2], rb[NS][3];
+            auto load_a = [&](int step, int set) {
+#pragma unroll
+                for (int c = 0; c < COT; ++c) {
+                    ra[set][c][0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(sm + zoff + c * 2 * ZG * 8 + (step * 32) * 8));
+                    ra[set][c][1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(sm + zoff + c * 2 * ZG * 8 + (step * 32 + 4) * 8));
+                }
+            };
+            auto load_b = [&](int step, int i) {
+#pragma unroll
+                for (int b = 0; b < 3; ++b) rb[i][b] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(sm + xoff[i] + (2 * step * LW + 4 * b) * 8));
+            };
+            load_a(0, 0);
+#pragma unroll
+            for (int i = 0; i < NS; ++i) load_b(0, i);
+#pragma unroll
+            for (int step = 0; step < KS; ++step) {
+                const int set = step & 1;
+                if (step + 1 < KS) load_a(step + 1, set ^ 1);
+                __builtin_amdgcn_sched_barrier(0);
+                typename T::frag a[COT];
+#pragma unroll
+                for (int c = 0; c < COT; ++c) {
+                    const s16x4 lo = ra[set][c][0], hi = ra[set][c][1];
+                    const short e[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    a[c] = __builtin_bit_cast(typename T::frag, e);
+                }
+                if constexpr (BIAS) {
+#pragma unroll
+                    for (int c = 0; c < COT; ++c) accb[c] = T::mfma(a[c], ones, accb[c]);
+                }
+#pragma unroll
+                for (int i = 0; i < NS; ++i) {
+                    unsigned d[6];
+#pragma unroll
+                    for (int b = 0; b < 3; ++b) {
+                        const uint2 u = __builtin_bit_cast(uint2, rb[i][b]);
+                        d[2 * b] = u.x; d[2 * b + 1] = u.y;
+                    }
+                    u32x4 w0, w1, w2;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        w0[k] = d[k];
+                        w1[k] = __builtin_amdgcn_alignbit(d[k + 1], d[k], 16);
+                        w2[k] = d[k + 1];
+                    }
+                    const typename T::frag b0 = __builtin_bit_cast(typename T::frag, w0);
+                    const typename T::frag b1 = __builtin_bit_cast(typename T::frag, w1);
+                    const typename T::frag b2 = __builtin_bit_cast(typename T::frag, w2);
+#pragma unroll
+                    for (int c = 0; c < COT; ++c) {
+                        acc[i][c][0] = T::mfma(a[c], b0, acc[i][c][0]);
+                        acc[i][c][1] = T::mfma(a[c], b1, acc[i][c][1]);
+                        acc[i][c][2] = T::mfma(a[c], b2, acc[i][c][2]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (step + 1 < KS) load_b(step + 1, i);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        };
+        using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+        if (COT == 2 && !pok[1]) body(I1{}); else body(I2{});
+    }
+    float* prow_base = p.partial + (size_t)split * p.prow;
+    if (do_bias && j == 0) {
+#pragma unroll
+        for (int c = 0; c < COT; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = co0 + c * 16 + kg * 4 + r;
+                if (co < p.Cout) prow_base[(size_t)p.Cout * p.Cin * 9 + co] = accb[c][r];
+            }
+    }
+#pragma unroll
+    for (int i = 0; i < U; ++i) {
+        const int ci = ci0 + pcit[i] * 16 + j;
+        if (!pok[i] || ci >= p.Cin) continue;
+#pragma unroll
+        for (int c = 0; c < COT; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = co0 + c * 16 + kg * 4 + r;
+                if (co >= p.Cout) continue;
+                float* dst = prow_base + ((size_t)co * p.Cin + ci) * 9 + 3 * prow[i];
+                dst[0] = acc[i][c][0][r]; dst[1] = acc[i][c][1][r]; dst[2] = acc[i][c][2][r];
+            }
+    }
+}
+
 // fp32 planar (N,C,H,W) <-> 16-bit channel-blocked [N][C/8][H*W][8]; one thread = one 16-byte piece
 template <bool F16>
 __global__ void c8_pack_kernel(const float* __restrict__ x, long long xbs, unsigned short* __restrict__ y, int C, int HW, long long total) {
@@ -3026,7 +3253,14 @@ int run_igemm(int N, int H, int W, int red, int rows, const SegTable& in, const 
     return launch_igemm_mt<2>(MT, p, mblocks, st);
 }
 
-struct WgPlan { bool mfma; bool smallcin; int cot; int geo, tiles_x, tiles_y, total_tiles, nsplit, tiles_per_split, coblocks, ciblocks; size_t partial_elems, dbias_elems; bool c8w; int cit, segs, seg_tiles, depth; };
+struct WgPlan { bool mfma; bool smallcin; int cot; int geo, tiles_x, tiles_y, total_tiles, nsplit, tiles_per_split, coblocks, ciblocks; size_t partial_elems, dbias_elems; bool c8w, c8i, pack24; int cit, segs, seg_tiles, depth; };
+// channel-blocked weight gradient on 16 x 16 maps: the image-tile kernel (conv3x3_wgrad_c8i_kernel)
+bool c8i_wanted(const mtbc_conv3x3_args* a) {
+    if (a->Cin == 1 || a->W != 16 || a->H != 16 || a->Cin % 8 || a->Cout % 8) return false;
+    static const int probe = mtbc_probe_int("MTBC_WGRAD_C8I", -1);      // probes build only: 0 = never
+    if (probe >= 0) return probe != 0;
+    return a->Cin >= 64 && a->Cout >= 32;
+}
 // channel-blocked weight gradient: which launches take the wide-block kernel (conv3x3_wgrad_c8w_kernel)
 bool c8w_wanted(const mtbc_conv3x3_args* a) {
     if (a->Cin == 1 || a->W <= 16 || a->Cin % 8 || a->Cout % 8) return false;
@@ -3053,6 +3287,24 @@ WgPlan plan_wgrad(const mtbc_conv3x3_args* a) {
         w.nsplit = a->N * bands;
         w.partial_elems = (size_t)w.nsplit * a->Cout * 9;
         w.dbias_elems = 0;
+        return w;
+    }
+    if (a->operand_layout == MTBC_LAYOUT_C8 && c8i_wanted(a)) {
+        // conv3x3_wgrad_c8i_kernel: 16 x 16 maps, a tile = one image; (32 | 48 output) x <= 80 input channels per block, image ranges as the
+        // split-K dimension (a multiple of 8 ranges where the block budget allows: one XCD per range), one block of 8 waves per CU
+        w.mfma = true; w.geo = 1; w.c8i = true;
+        w.cot = a->Cout % 48 == 0 ? 3 : 2;
+        const int T = cdiv(a->Cin, 16);
+        w.coblocks = cdiv(a->Cout, 16 * w.cot); w.ciblocks = cdiv(T, C8WW_MAXCIT); w.cit = cdiv(T, w.ciblocks);
+        int ns = 256 / (w.coblocks * w.ciblocks);
+        if (ns >= 8) ns &= ~7;
+        if (ns > a->N) ns = a->N;
+        if (ns < 1) ns = 1;
+        w.seg_tiles = cdiv(a->N, ns);                      // images per range
+        w.segs = cdiv(a->N, w.seg_tiles);
+        w.nsplit = w.segs; w.total_tiles = a->N; w.tiles_per_split = w.seg_tiles;
+        w.partial_elems = (size_t)w.nsplit * a->Cout * a->Cin * 9;
+        w.dbias_elems = a->dbias ? (size_t)w.nsplit * a->Cout : 0;
         return w;
     }
     if (a->operand_layout == MTBC_LAYOUT_C8 && c8w_wanted(a)) {
@@ -3116,6 +3368,10 @@ WgPlan plan_wgrad(const mtbc_conv3x3_args* a) {
         w.cot = pad3 < pad2 ? 3 : 2;
         if (w.geo == 0 && a->compute != 0) w.cot = 2;      // conv3x3_wgrad_lp2_kernel: 32 x 32 channel blocks
         w.coblocks = cdiv(a->Cout, 16 * w.cot); w.ciblocks = cdiv(a->Cin, 32);
+        // fp32 kernel: input-channel blocks of 24 where Cin is a multiple of 24 and not of 32 (every level-0 / level-1 conv of the U-Net++):
+        // 13.5 (tap, ci) column tiles per block instead of 18 -- conv3x3_wgrad_mfma_kernel<.., PACK>
+        w.pack24 = a->compute == 0 && a->Cin % 24 == 0 && a->Cin % 32 != 0;
+        if (w.pack24) w.ciblocks = a->Cin / 24;
         const int pairs = w.coblocks * w.ciblocks;
         // resident blocks per CU: 3 (256 threads, 50 KB LDS) or 2 (384 threads, 58 KB) -- ONE wave of blocks, a
         // block beyond that would double the launch time
@@ -3352,11 +3608,37 @@ int mtbc_conv3x3_wgrad(const mtbc_conv3x3_args* a, void* stream) {
         WgC8P p; p.N = a->N; p.H = a->H; p.W = a->W; p.Cin = a->Cin; p.Cout = a->Cout; p.in = in;
         p.dz = reinterpret_cast<const unsigned short*>(a->dout); p.partial = partial;
         p.want_bias = a->dbias ? 1 : 0; p.prow = (long long)wel + (a->dbias ? a->Cout : 0);
+        // ONE split (the 1152 -> 512 conv on 16 x 16 maps: 240 channel blocks fill the chip by themselves): the "partial" IS the gradient -- the
+        // blocks store straight into dw instead of into a 21 MB workspace that a reduction launch then copies (32 us)
+        const bool direct = w.nsplit == 1 && !a->dbias && !a->accumulate_dw;
+        if (direct) p.partial = a->dw;
         p.tiles_x = w.tiles_x; p.tiles_y = w.tiles_y; p.total_tiles = w.total_tiles; p.tiles_per_split = w.tiles_per_split;
         p.ciblocks = w.ciblocks; p.coblocks = w.coblocks; p.cit = w.cit; p.segs = w.segs; p.seg_tiles = w.seg_tiles; p.depth = w.depth;
         { static const int hk = mtbc_probe_int("MTBC_C8W_HACK", 0); p.hack = hk; }
-        const dim3 grid = w.c8w ? dim3(w.nsplit * w.coblocks * w.ciblocks) : dim3(w.nsplit, w.coblocks * w.ciblocks);
-        if (w.c8w) {
+        const dim3 grid = (w.c8w || w.c8i) ? dim3(w.nsplit * w.coblocks * w.ciblocks) : dim3(w.nsplit, w.coblocks * w.ciblocks);
+        if (w.c8i) {
+            const size_t lds = c8i_lds_bytes(w.cit, w.cot);
+            const dim3 gridi(w.nsplit * w.coblocks * w.ciblocks);
+#define MTBC_C8I_LAUNCH(F16_, COT_, BIAS_)                                                                                             \
+            do {                                                                                                                       \
+                static bool attr = false;                                                                                              \
+                if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wgrad_c8i_kernel<F16_, COT_, BIAS_>),    \
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }         \
+                hipLaunchKernelGGL((conv3x3_wgrad_c8i_kernel<F16_, COT_, BIAS_>), gridi, dim3(512), lds, st, p);                      \
+            } while (0)
+            const int sel = (a->compute == 2 ? 4 : 0) + (w.cot == 3 ? 2 : 0) + (a->dbias ? 1 : 0);
+            switch (sel) {
+            case 0: MTBC_C8I_LAUNCH(false, 2, false); break;
+            case 1: MTBC_C8I_LAUNCH(false, 2, true); break;
+            case 2: MTBC_C8I_LAUNCH(false, 3, false); break;
+            case 3: MTBC_C8I_LAUNCH(false, 3, true); break;
+            case 4: MTBC_C8I_LAUNCH(true, 2, false); break;
+            case 5: MTBC_C8I_LAUNCH(true, 2, true); break;
+            case 6: MTBC_C8I_LAUNCH(true, 3, false); break;
+            default: MTBC_C8I_LAUNCH(true, 3, true); break;
+            }
+#undef MTBC_C8I_LAUNCH
+        } else if (w.c8w) {
             const size_t lds = c8w_lds_bytes(w.cit, w.cot, w.depth);
 #define MTBC_C8W_LAUNCH(F16_, COT_, BIAS_)                                                                                             \
             do {                                                                                                                       \
@@ -3385,6 +3667,7 @@ int mtbc_conv3x3_wgrad(const mtbc_conv3x3_args* a, void* stream) {
             else hipLaunchKernelGGL((conv3x3_wgrad_c8_kernel<false, 0>), grid, dim3(256), C8W_LDS, st, p);
         }
         MTBC_CHECK_LAUNCH();
+        if (direct) return MTBC_OK;
         // one row per split = the weight-gradient partial followed by the bias-gradient partial: ONE reduction launch for both
         return mtbc_i_splitk_reduce2(partial, a->dw, a->dbias, w.nsplit, wel, a->dbias ? (size_t)a->Cout : 0, a->accumulate_dw, st);
     }
@@ -3406,7 +3689,9 @@ int mtbc_conv3x3_wgrad(const mtbc_conv3x3_args* a, void* stream) {
                                               (32 * WGeoLP<GEO_>::PSX + zch * PSZ_LP) * sizeof(float), st, p);            \
             else if (lowp == 2) hipLaunchKernelGGL((conv3x3_wgrad_lp_kernel<GEO_, COT_, true>), grid, blk,                 \
                                                    (32 * WGeoLP<GEO_>::PSX + zch * PSZ_LP) * sizeof(float), st, p);       \
-            else hipLaunchKernelGGL((conv3x3_wgrad_mfma_kernel<GEO_, COT_>), grid, blk,                                    \
+            else if (w.pack24) hipLaunchKernelGGL((conv3x3_wgrad_mfma_kernel<GEO_, COT_, true>), grid, blk,                \
+                                                  (32 * WGeo<GEO_>::PSX + zch * PSZ) * sizeof(float), st, p);              \
+            else hipLaunchKernelGGL((conv3x3_wgrad_mfma_kernel<GEO_, COT_, false>), grid, blk,                             \
                                     (32 * WGeo<GEO_>::PSX + zch * PSZ) * sizeof(float), st, p);                            \
         } while (0)
         static const bool lp1 = mtbc_probe_set("MTBC_WGRAD_LP1");      // A/B: first-generation 16-bit wgrad

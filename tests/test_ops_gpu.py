@@ -500,8 +500,18 @@ C8W_CASES = [
 ]
 
 
+# ... and the image-tile kernel of the 16 x 16 maps (conv3x3_wgrad_c8i_kernel: Cin >= 64, Cout >= 32)
+C8I_CASES = [
+    (5, [64], 40, 16, 16),                     # Cout = 40: blocks of 32 + 8 channels; 5 image ranges of one image
+    (9, [96, 48, 48], 48, 16, 16),             # three segments, 192 -> 48: three input-channel blocks of 4 tiles; 48 outputs in one block
+    (16, [264], 64, 16, 16),                   # 16.5 input tiles: four blocks, the last tile half empty; two images per range
+    (3, [72], 96, 16, 16),                     # 4.5 input tiles in one block; 2 output-channel blocks of 48
+    (1, [64], 48, 16, 16),                     # ONE image range: without bias / accumulation the blocks store straight into dw (no reduction launch)
+]
+
+
 @pytest.mark.parametrize("compute", [1, 2])
-@pytest.mark.parametrize("N,segs,Cout,H,W", C8W_CASES)
+@pytest.mark.parametrize("N,segs,Cout,H,W", C8W_CASES + C8I_CASES)
 def test_conv3x3_wgrad_c8_wide_blocks(N, segs, Cout, H, W, compute):
     """conv3x3_wgrad_c8w_kernel (all output channels x <= 80 input channels per block, rows staged once in an LDS ring, DMA of the
     next rows under the MFMAs) against fp64 on the rounded operands: weight and bias gradient, the no-bias kernel instance,
