@@ -3370,7 +3370,11 @@ WgPlan plan_wgrad(const mtbc_conv3x3_args* a) {
         w.coblocks = cdiv(a->Cout, 16 * w.cot); w.ciblocks = cdiv(a->Cin, 32);
         // fp32 kernel: input-channel blocks of 24 where Cin is a multiple of 24 and not of 32 (every level-0 / level-1 conv of the U-Net++):
         // 13.5 (tap, ci) column tiles per block instead of 18 -- conv3x3_wgrad_mfma_kernel<.., PACK>
-        w.pack24 = a->compute == 0 && a->Cin % 24 == 0 && a->Cin % 32 != 0;
+        // MEASURED (round 3, profiles/r03_f32_wgrad_pack24.txt): no faster -- 24 -> 24 @256x256 0.298 ms with 28 MFMAs per K-step and block as
+        // with 36, i.e. the matrix pipe 64 % instead of 82 % busy: the level-0 / level-1 launches of this kernel are not bound by the number
+        // of MFMAs they issue.  Kept behind the probes build (MTBC_WGRAD_PACK24=1) for the next look at what does bound them.
+        static const int pack_probe = mtbc_probe_int("MTBC_WGRAD_PACK24", 0);
+        w.pack24 = pack_probe && a->compute == 0 && a->Cin % 24 == 0 && a->Cin % 32 != 0;
         if (w.pack24) w.ciblocks = a->Cin / 24;
         const int pairs = w.coblocks * w.ciblocks;
         // resident blocks per CU: 3 (256 threads, 50 KB LDS) or 2 (384 threads, 58 KB) -- ONE wave of blocks, a
