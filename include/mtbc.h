@@ -457,7 +457,10 @@ int mtbc_dice_bwd(const mtbc_dice_args* a, void* stream);
  * replaces FocalLoss.forward (criterions.py:14-24, reduction='mean', soft/one-hot float
  * targets, optional class weight).  One launch computes the loss and d loss / d logits.
  *   ce_i = -sum_c w_c t_ic log_softmax(x_i)_c ; pt = exp(-ce_i) ;
- *   loss = mean_i alpha (1 - pt)^gamma ce_i ;  dx = gscale * (*gscale_dev) * d loss / d x    */
+ *   loss = mean_i alpha (1 - pt)^gamma ce_i ;  dx = gscale * (*gscale_dev) * d loss / d x
+ * gamma = 0 is torch.nn.CrossEntropyLoss(reduction='mean') on soft targets (experiment_init.py:257-261, criterion "CE").
+ * C == 1 is the binary head (n_classes == 2: ONE logit, MTUNetPlusPlus.py:39-41): ce_i = BCEWithLogits(x_i, t_i) =
+ *   (1 - t) x + softplus(-x), target (N,1) in {0,1}; alpha = 1, gamma = 0 = torch.nn.BCEWithLogitsLoss() (experiment_init.py:241-242). */
 typedef struct {
     int32_t N, C;
     float alpha, gamma;

@@ -151,6 +151,22 @@ __global__ void focal_kernel(const FocalP p) {
     for (int n = threadIdx.x; n < p.N; n += blockDim.x) {
         const float* xs = p.x + (size_t)n * p.C;
         const float* ts = p.t + (size_t)n * p.C;
+        if (p.C == 1) {
+            // ONE logit = the reference's binary head (n_classes == 2, MTUNetPlusPlus.py:39-41) with torch.nn.BCEWithLogitsLoss
+            // (experiment_init.py:241-242): ce = (1 - t) x + softplus(-x), the stable form torch evaluates; alpha = 1, gamma = 0 give
+            // exactly its mean; d ce / d x = sigmoid(x) - t.  (`weight`, if given, multiplies the sample's term by w[0].)
+            const float x = xs[0], t = ts[0], wc = p.w ? p.w[0] : 1.f;
+            const float ce = wc * ((1.0f - t) * x + (fmaxf(-x, 0.f) + log1pf(expf(-fabsf(x)))));
+            const float pt = expf(-ce), om = 1.0f - pt;
+            const float mod = p.gamma == 0.f ? 1.0f : powf(om, p.gamma);
+            acc += p.alpha * mod * ce;
+            if (p.dx) {
+                const float dmod = p.gamma == 0.f ? 0.f : ((om > 0.f || p.gamma >= 1.f) ? p.gamma * powf(om, p.gamma - 1.0f) : 0.f);
+                const float dfdce = p.alpha * (dmod * pt * ce + mod);
+                p.dx[n] = gs * dfdce * wc * (1.0f / (1.0f + expf(-x)) - t);
+            }
+            continue;
+        }
         float m = xs[0];
         for (int c = 1; c < p.C; ++c) m = fmaxf(m, xs[c]);
         float se = 0.f;

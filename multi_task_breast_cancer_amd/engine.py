@@ -976,7 +976,7 @@ class StepPlan:
     # ------------------------------------------------------------------ losses (fused-step path)
     def fused_losses(self, seg_heads: Sequence[Act], logits: Act, mask: torch.Tensor, onehot: torch.Tensor,
                      alpha: float, inversely_weighted: bool, focal_weight: Optional[torch.Tensor] = None,
-                     loss_scale: float = 1.0, binary: bool = False):
+                     loss_scale: float = 1.0, binary: bool = False, cls_gamma: float = 2.0):
         """criterions.py:52-76 + training_multitask.py:98 on device: Dice over the heads (weights 1/(j+1) from the
         LAST head backwards), Focal on the logits, alpha-mix, NaN flag.  Gradients land in the heads' grad buffers."""
         nh = len(seg_heads)
@@ -1010,17 +1010,13 @@ class StepPlan:
         op.u.dice.gscale_dev = self.grad_weight.data_ptr()
         op.u.dice.gscale = alpha * loss_scale      # loss_scale: fp16 mode keeps dz inside the fp16 range; Adam divides it out
         self.loss_ops.append(op)
-        if binary:
-            # ONE-logit head (n_classes == 2): the reference's BCEWithLogits (experiment_init.py:242) is applied by torch on
-            # the logit (trainer.FusedEvalStep); the program holds the Dice part only.  The backward program stays
-            # well-formed for the drop-in loop: the logits' gradient buffer is written by the caller.
-            self.grad_of(logits)
-            logits.grad_written = True
-            self.keep += [mask, onehot]
-            return
+        # classification criterion (experiment_init.py:232-262): "Focal" = FocalLoss(alpha 1, gamma 2); "CE" = CrossEntropyLoss = the same
+        # formula with gamma 0; the ONE-logit head (n_classes == 2, `binary`) = BCEWithLogitsLoss on the {0, 1} label, which the focal
+        # kernel evaluates when C == 1 (gamma 0): `onehot` then holds the (N, 1) float label itself
+        assert (logits.C == 1) == bool(binary), "one logit <=> binary head"
         op = _mk(L.OP_FOCAL)
         a = op.u.focal
-        a.N, a.C, a.alpha, a.gamma = N, logits.C, 1.0, 2.0
+        a.N, a.C, a.alpha, a.gamma = N, logits.C, 1.0, (0.0 if binary else float(cls_gamma))
         a.x, a.target, a.weight = logits.data.data_ptr(), onehot.data_ptr(), _ptr(focal_weight)
         a.loss, a.dx, a.gscale = self.focal_loss.data_ptr(), self.grad_of(logits).data_ptr(), (1.0 - alpha) * loss_scale
         a.gscale_dev = self.grad_weight.data_ptr()

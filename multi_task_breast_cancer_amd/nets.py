@@ -261,7 +261,7 @@ class CompiledStep:
             self.loss_scale = float(net.loss_scale)
             plan.fused_losses(heads, self.logits, self.mask, self.onehot, fused_loss["alpha"],
                               fused_loss["inversely_weighted"], fused_loss.get("focal_weight"), loss_scale=self.loss_scale,
-                              binary=bool(fused_loss.get("binary")))
+                              binary=bool(fused_loss.get("binary")), cls_gamma=float(fused_loss.get("cls_gamma", 2.0)))
             self.grad_weight = plan.grad_weight
         else:
             for h in (self.segs if net.deep_supervision_outputs else self.segs[-1:]):
@@ -403,7 +403,7 @@ class HipMultiTaskNet(nn.Module):
                 if fw.dtype != torch.float32 or not fw.is_contiguous() or fw.device != self.flat_p.device or fw.numel() != self.n_classes:
                     raise ValueError("focal_weight must be a contiguous float32 tensor of n_classes values on the model's device")
             fkey = (fused_loss["alpha"], fused_loss["inversely_weighted"], self.loss_scale,
-                    None if fw is None else (fw.data_ptr(), fw._version), bool(fused_loss.get("binary")))
+                    None if fw is None else (fw.data_ptr(), fw._version), bool(fused_loss.get("binary")), float(fused_loss.get("cls_gamma", 2.0)))
         key = (N, H, W, self.compute, self.coop_reserve_cus, fkey)
         st = self._steps.get(key)
         if st is None or st.param_ptr != self.flat_p.data_ptr():

@@ -92,13 +92,25 @@ def allreduce_buckets(flat_g: torch.Tensor, buckets: Sequence[Bucket], group=Non
 # the fused step (HIP)
 # ------------------------------------------------------------------------------------------------
 class FusedTrainStep:
+    """One optimisation step of training_multitask.py:87-103 as ONE stream-ordered program.  `cls_criterion`: "Focal" (config.yaml's
+    default, FocalLoss alpha 1 gamma 2), "CE" (CrossEntropyLoss = gamma 0) -- experiment_init.py:232-262; with n_classes == 2 the model has
+    ONE logit and the reference trains it with BCEWithLogitsLoss on the {0, 1} label (`:241-242`, training_multitask.py:83-84 leaves the
+    label (N, 1)): the same program with the focal kernel's one-logit form."""
+
     def __init__(self, model, optimizer, alpha: float, inversely_weighted: bool = True, n_classes: int = 3,
-                 distributed: bool = False, n_buckets: int = 4, focal_weight: Optional[torch.Tensor] = None):
-        if n_classes < 3 or getattr(model, "n_classes", n_classes) < 3:
-            # training_multitask.py:84 one-hot-encodes the label; with n_classes == 2 the head has ONE logit and the
-            # reference trains it with BCEWithLogits (experiment_init.py:241-246) -- that loss is not in the fused program
-            raise NotImplementedError("FusedTrainStep covers the multi-class head (Focal / one-hot labels); for n_classes == 2 "
-                                      "use the drop-in loop (model(x), criterions.apply_criterion_..., optimizer.step())")
+                 distributed: bool = False, n_buckets: int = 4, focal_weight: Optional[torch.Tensor] = None,
+                 cls_criterion: str = "Focal"):
+        self.binary = n_classes == 2
+        if self.binary != (getattr(model, "n_classes", n_classes) == 1):
+            raise ValueError("n_classes does not match the model's classification head (n_classes == 2 <=> ONE logit)")
+        if cls_criterion not in ("Focal", "CE"):
+            raise ValueError(f"unknown classification criterion {cls_criterion!r} (Focal | CE; the binary head always trains with BCEWithLogits)")
+        self.cls_gamma = 2.0 if cls_criterion == "Focal" else 0.0
+        if cls_criterion == "CE" and focal_weight is not None:
+            # torch.nn.CrossEntropyLoss(weight=w) divides by the sum of the samples' weights; FocalLoss (criterions.py:14-24) by N
+            raise NotImplementedError("class-weighted CrossEntropyLoss normalises by the weights' sum: use the drop-in loop for it")
+        if self.binary:
+            focal_weight = None
         if n_classes > 3:
             raise NotImplementedError("the fused step covers the reference's label set {0, 1, 2} (n_classes <= 3)")
         self.model, self.opt = model, optimizer
@@ -125,8 +137,8 @@ class FusedTrainStep:
         self.losses: Optional[torch.Tensor] = None      # device: [total, seg, cls, nan_flag]
 
     def _compiled(self, N: int, H: int, W: int):
-        st = self.model.compiled(N, H, W, fused_loss={"alpha": self.alpha, "inversely_weighted": self.iw,
-                                                      "focal_weight": self.focal_weight})
+        st = self.model.compiled(N, H, W, fused_loss={"alpha": self.alpha, "inversely_weighted": self.iw, "focal_weight": self.focal_weight,
+                                                      "binary": self.binary, "cls_gamma": self.cls_gamma})
         if st is not self._st:
             self._st = st
             self.model.grads_as_views()
@@ -144,9 +156,12 @@ class FusedTrainStep:
         st = self._compiled(N, H, W)
         st.x.data.copy_(image, non_blocking=True)
         st.mask.copy_(mask, non_blocking=True)
-        lab = label.to(st.onehot.device, non_blocking=True).flatten().to(torch.int64)
-        st.onehot.zero_()
-        st.onehot.scatter_(1, lab.view(-1, 1), 1.0)
+        lab = label.to(st.onehot.device, non_blocking=True).flatten()
+        if self.binary:             # the (N, 1) float label itself is the target of the one-logit criterion
+            st.onehot.copy_(lab.view(-1, 1).to(torch.float32))
+        else:
+            st.onehot.zero_()
+            st.onehot.scatter_(1, lab.to(torch.int64).view(-1, 1), 1.0)
         st.grad_weight.fill_(1.0 if weight is None else float(weight) * self.world)
         return st
 
@@ -274,7 +289,9 @@ class FusedEvalStep:
         st.mask.copy_(mask, non_blocking=True)
         dev = st.plan.loss_out.device
         lab = label.to(dev, non_blocking=True).flatten()
-        if not self.binary:
+        if self.binary:
+            st.onehot.copy_(lab.view(-1, 1).to(torch.float32))
+        else:
             st.onehot.zero_()
             st.onehot.scatter_(1, lab.to(torch.int64).view(-1, 1), 1.0)
         P = st.programs
@@ -291,16 +308,11 @@ class FusedEvalStep:
         dice = torch.where(empty_gt, torch.where((tp + fp) == 0, torch.ones_like(tp), torch.zeros_like(tp)),
                            2 * tp / torch.clamp(2 * tp + fp + fn, min=1.0))          # metrics.py:255-267
         logit = st.logits.data.view(N, -1)
+        self._acc[:3] += st.plan.loss_out[:3].double()
         if self.binary:
-            seg = st.plan.dice_loss[-1]
-            cls = torch.nn.functional.binary_cross_entropy_with_logits(logit, lab.float().view(N, 1))
-            self._acc[0] += (self.alpha * seg + (1.0 - self.alpha) * cls).double()
-            self._acc[1] += seg.double()
-            self._acc[2] += cls.double()
             pred = (torch.sigmoid(logit[:, 0]) > 0.5).to(torch.int64)
             gt = lab.to(torch.int64)
         else:
-            self._acc[:3] += st.plan.loss_out[:3].double()
             pred = logit.argmax(dim=1)
             gt = st.onehot.argmax(dim=1)
         self._acc[3] += dice

@@ -375,10 +375,24 @@ def train_step(model: nn.Module, optimizer, image: torch.Tensor, mask: torch.Ten
                loss_scale: float = 1.0):
     """Returns (total, seg, cls) python floats plus the raw outputs of the forward pass.  loss_scale != 1 mirrors the
     product's fp16 mode: the loss is scaled before backward and the gradients unscaled before the optimizer."""
-    onehot = F.one_hot(label.flatten().to(torch.int64), num_classes=n_classes).to(torch.float)
     optimizer.zero_grad(set_to_none=True)
     logits, outputs = model(image)
-    seg, cls = multitask_losses(outputs, mask, logits, onehot, inversely_weighted)
+    if n_classes == 2:
+        # the binary head (MTUNetPlusPlus.py:39-41: ONE logit): training_multitask.py:83-84 leaves the label (N, 1) float, the criterion is
+        # torch.nn.BCEWithLogitsLoss() (experiment_init.py:241-242), aggregated like any other (criterions.py:61-66)
+        bce = torch.nn.BCEWithLogitsLoss()
+        if isinstance(outputs, (list, tuple)):
+            seg = torch.sum(torch.stack([dice_loss_sigmoid_sq(s_, mask) / (j + 1) if inversely_weighted else dice_loss_sigmoid_sq(s_, mask)
+                                         for j, s_ in enumerate(reversed(list(outputs)))]))
+        else:
+            seg = dice_loss_sigmoid_sq(outputs, mask)
+        tgt = label.view(-1, 1).to(image.dtype)
+        cls = (torch.sum(torch.stack([bce(c, tgt) for c in reversed(list(logits))])) if isinstance(logits, (list, tuple)) else bce(logits, tgt))
+        if torch.isnan(seg) or torch.isnan(cls):
+            raise SystemExit(1)
+    else:
+        onehot = F.one_hot(label.flatten().to(torch.int64), num_classes=n_classes).to(torch.float)
+        seg, cls = multitask_losses(outputs, mask, logits, onehot, inversely_weighted)
     total = alpha * seg + (1.0 - alpha) * cls
     (total * loss_scale).backward()
     if loss_scale != 1.0:

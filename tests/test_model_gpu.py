@@ -352,6 +352,32 @@ def test_512_inputs_16bit_modes_track_the_fp32_step():
         assert (out[dt][1] - out["f32"][1]).abs().max().item() < 5e-4      # two Adam steps of lr 1e-4
 
 
+@pytest.mark.parametrize("arch", ["MTUNetPlusPlus", "MTnnUNet"])
+def test_fused_step_with_the_binary_head_matches_oracle(arch):
+    """n_classes == 2 (training_multitask.py:83-84, experiment_init.py:241-242): ONE logit trained with BCEWithLogitsLoss on the (N, 1) float
+    label, inside the fused step program (the focal kernel's one-logit form) -- losses, outputs and the weights after Adam against the oracle."""
+    seed_everything(23)
+    prod = (MTnnUNet(1, 1, 2) if arch == "MTnnUNet" else MTUNetPlusPlus(in_channels=1, out_channels=1, n_classes=2, deep_supervision=True))
+    O.seed_everything(23)
+    ref = O.build_oracle_model(arch, 1, 1, 2, True)
+    ref.load_state_dict(prod.state_dict())
+    prod = prod.to(DEV)
+    img, mask, label = O.synthetic_batch(3, 64, 64, seed=31)
+    label = (label > 0).float()                          # benign / malignant vs normal
+    step = FusedTrainStep(prod, FusedAdam(prod, lr=1e-4, eps=1e-4), alpha=0.35, n_classes=2)
+    st = step.load_batch(img.to(DEV), mask.to(DEV), label.to(DEV))
+    losses = step.run(st).cpu()
+    total, seg, cls, rlogits, routs = O.train_step(ref, O.make_adam(ref, 1e-4), img, mask, label, 0.35, True, 2)
+    assert st.logits.data.shape[1] == 1
+    assert _maxerr(st.logits.data.view(3, -1), rlogits[0]) < TOL
+    assert abs(losses[0].item() - total.item()) < TOL and abs(losses[1].item() - seg.item()) < TOL and abs(losses[2].item() - cls.item()) < TOL
+    assert losses[3].item() == 0.0
+    for (k, a), (_, b) in zip(prod.state_dict().items(), ref.state_dict().items()):
+        assert (a.cpu() - b).abs().max().item() < 2.0e-4, k
+    with pytest.raises(ValueError):
+        FusedTrainStep(prod, FusedAdam(prod, lr=1e-4, eps=1e-4), alpha=0.35, n_classes=3)
+
+
 def test_mtnnunet_two_layer_heads_match_the_fused_heads_and_the_oracle(monkeypatch):
     """MTBC_NOFUSE_HEADS=1: the deep-supervision heads as the reference's two layers (ConvTranspose2d k = s in {2, 4, 8} -> Conv2d 1x1,
     MTnnUNet.py:106-116) instead of ONE transposed conv with combined weights (engine.convT_head): both step programs against the

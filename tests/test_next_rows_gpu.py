@@ -284,4 +284,4 @@ def test_validation_epoch_with_the_binary_head_matches_oracle():
     for g_, w_ in zip(got, want):
         assert abs(g_ - w_) < 1e-4, (got, want)
     with pytest.raises(NotImplementedError):
-        FusedTrainStep(prod, FusedAdam(prod, lr=1e-4, eps=1e-4), alpha=0.35, n_classes=2)
+        FusedEvalStep(prod, alpha=0.35, n_classes=5)

@@ -1242,3 +1242,39 @@ def test_program_run_on_two_streams_orders_a_forked_section():
     assert torch.equal(back, x.to(torch.bfloat16).float())
     for h in ev:
         lib.mtbc_event_destroy(h)
+
+
+@pytest.mark.parametrize("gamma", [0.0, 2.0])
+def test_focal_one_logit_is_bce_with_logits(gamma):
+    """mtbc_focal_fwd_bwd with C == 1: the binary head's criterion.  gamma = 0, alpha = 1 = torch.nn.BCEWithLogitsLoss() (the reference's
+    choice for n_classes == 2, experiment_init.py:241-242), loss and gradient; gamma = 2 = the focal modulation of the same per-sample term."""
+    g = _g(12)
+    x = (torch.randn(37, 1, generator=g) * 4.0)
+    x[0, 0], x[1, 0] = 30.0, -30.0                      # saturated logits: the stable form
+    t = torch.randint(0, 2, (37, 1), generator=g).float()
+    xr = x.clone().double().requires_grad_(True)
+    ce = torch.nn.functional.binary_cross_entropy_with_logits(xr, t.double(), reduction="none")
+    ref = ((1.0 - torch.exp(-ce)) ** gamma * ce).mean() if gamma else torch.nn.BCEWithLogitsLoss()(xr, t.double())
+    ref.backward()
+    loss, dx = ops.focal(x.to(DEV), t.to(DEV), alpha=1.0, gamma=gamma, gscale=0.65)
+    assert abs(loss.item() - ref.item()) < 1e-6 * max(1.0, abs(ref.item()))
+    _close(dx, (0.65 * xr.grad).float(), 1e-5, 1e-7, "d BCE / d logit")
+
+
+def test_focal_gamma_zero_is_cross_entropy():
+    """`classification_criterion: CE` (experiment_init.py:257-261): torch.nn.CrossEntropyLoss(reduction='mean') on the one-hot float target =
+    the focal kernel with gamma = 0 (what FusedTrainStep(cls_criterion="CE") runs), with and without class weights."""
+    g = _g(13)
+    x = torch.randn(29, 3, generator=g) * 3.0
+    t = torch.nn.functional.one_hot(torch.randint(0, 3, (29,), generator=g), 3).float()
+    for w in (None, torch.tensor([0.2, 0.5, 0.3])):
+        xr = x.clone().double().requires_grad_(True)
+        # FocalLoss.forward's reduction (criterions.py:14-24 with gamma = 0): mean over samples of the weighted per-sample CE
+        ce = -(torch.log_softmax(xr, 1) * t.double() * (w.double() if w is not None else 1.0)).sum(1)
+        ref = ce.mean()
+        ref.backward()
+        loss, dx = ops.focal(x.to(DEV), t.to(DEV), alpha=1.0, gamma=0.0, weight=None if w is None else w.to(DEV))
+        assert abs(loss.item() - ref.item()) < 1e-6 * max(1.0, abs(ref.item()))
+        _close(dx, xr.grad.float(), 1e-5, 1e-7, "d CE / d logits")
+        if w is None:
+            assert abs(loss.item() - torch.nn.CrossEntropyLoss()(x, t).item()) < 1e-6

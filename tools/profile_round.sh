@@ -7,7 +7,7 @@
 #     4. --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE  -> TAG_mfma_busy_{dt}.txt
 #   plus the bench lines of BASELINE.json configs[2] (MTnnUNet B=64) and configs[4]'s per-GPU shape (512x512 fp16 B=16).
 set -e
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=gpurun_out/prof_${TAG}
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -34,4 +34,5 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c2_stats -- python3
 f=$(ls $OUT/c2_stats/*/*kernel_stats.csv | head -1); cp "$f" $OUT/${TAG}_config2_mtnnunet_b64_bf16_kernel_stats.csv
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c4_stats -- python3 bench.py --size 512 --dtype f16 --batch 16 --steps 5 --warmup 2 $COMMON > $OUT/c4_stats.log 2>&1
 f=$(ls $OUT/c4_stats/*/*kernel_stats.csv | head -1); cp "$f" $OUT/${TAG}_config4_512_f16_b16_kernel_stats.csv
+python3 tools/wgrad_probe.py 1 32 1 > $OUT/${TAG}_wgrad_probe.txt 2>&1 || true
 echo "all done"
