@@ -184,8 +184,8 @@ def run_mode(args, dtype, dev, rank, world, dist, want_roofline):
     balance = peak * 1e12 / PEAK_HBM_BYTES                       # FLOP per byte at which the two roofs cross
     bound = "mfma" if fl / by > balance else "hbm"
     names = {"f32": ("conv3x3_igemm_dma_kernel", "conv3x3_wgrad_mfma_kernel"),
-             "bf16": ("conv3x3_igemm_c8_kernel", "conv3x3_wgrad_c8_kernel"),
-             "f16": ("conv3x3_igemm_c8_kernel", "conv3x3_wgrad_c8_kernel")}[dtype]
+             "bf16": ("conv3x3_igemm_c8_kernel", "conv3x3_wgrad_c8 / c8w / c8i kernels"),
+             "f16": ("conv3x3_igemm_c8_kernel", "conv3x3_wgrad_c8 / c8w / c8i kernels")}[dtype]
     # HBM traffic per launch comes from PMC counters, which cannot be collected inside a timed run: the figure is read
     # from the committed summary of the separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same command
     # (tools/profile_round.sh); `traffic_source` names the file, and the field is null when no summary fits the build

@@ -62,6 +62,25 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 
 // ABL (timing ablations, results wrong): 1 = halo pixels are not loaded (centre only), 2 = no stores, 4 = no X loads, 8 = no MFMAs,
 // 16 = W loaded once per block (not per chunk), 32 = every tile reads the pixels of tiles 0..7 (X served by L2)
+// -DASM_DMA (round 3): issue the LDS-DMA from inline assembly -- behind the builtin hipcc may put `s_waitcnt vmcnt(0)` in front of the next
+// LDS read (it knows the builtin stores to LDS and cannot tell which part), which turns VAR 1 / VAR 2's prefetch into a plain load.
+#ifdef ASM_DMA
+typedef int i32x4_ __attribute__((ext_vector_type(4)));
+typedef i32x4_ rsrc_t;
+__device__ __forceinline__ rsrc_t make_rsrc(const void* base, int bytes) {
+    const unsigned long long a = reinterpret_cast<unsigned long long>(base);
+    return (i32x4_){(int)(unsigned)a, (int)((unsigned)(a >> 32) & 0xffffu), bytes, 0x00020000};
+}
+__device__ __forceinline__ void dma16_asm(rsrc_t rs, const void* lds, unsigned voff) {
+    const unsigned la = (unsigned)(unsigned long long)(__attribute__((address_space(3))) const void*)lds;
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(la), "v"(voff), "s"(rs) : "memory", "m0");
+}
+#define DMA16(rsrc, ldsp, off) dma16_asm(rsrc, ldsp, off)
+#else
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ __forceinline__ rsrc_t make_rsrc(const void* base, int bytes) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000); }
+#define DMA16(rsrc, ldsp, off) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(ldsp), 16, off, 0, 0, 0)
+#endif
 template <int MT, int NW, int VAR, int ABL = 0>
 __global__ __launch_bounds__(64 * NW, (NW == 4 ? 3 : 4)) void conv_c8_v(const P p) {
     constexpr int TH = 2 * NW, TW = 32, HR = TH + 2, HC = TW + 2, HP = HR * HC, HPP = (HP + 15) / 16 * 16;
@@ -78,7 +97,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 ? 3 : 4)) void conv_c8_v(const P 
     int bpix[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) bpix[g] = (2 * wv + (g >> 1)) * HC + 16 * (g & 1) + j;
-    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(p.wp), 0, (int)((size_t)p.mtiles * nchunks * 9 * 16 * WROW * 2), 0x00020000);
+    const rsrc_t wrsrc = make_rsrc(p.wp, (int)((size_t)p.mtiles * nchunks * 9 * 16 * WROW * 2));
     const int per = (p.ntiles + 7) >> 3, xcd = blockIdx.x & 7;
     const int tstep = gridDim.x >> 3, tend = min(p.ntiles, (xcd + 1) * per);
     const int grp_w = NW == 4 ? wv : (wv >> 1), half = NW == 4 ? 0 : (wv & 1);      // which channel group / half of it this wave brings
@@ -88,7 +107,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 ? 3 : 4)) void conv_c8_v(const P 
         const int n = t, x0 = tx * TW, y0 = ty * TH;
         const int g8 = ch * 4 + grp_w;
         const __bf16* base = p.x8 + ((size_t)n * (p.Cin / 8) + (g8 < p.Cin / 8 ? g8 : 0)) * HW * 8;
-        const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(base), 0, g8 < p.Cin / 8 ? HW * 16 : 0, 0x00020000);
+        const rsrc_t xrsrc = make_rsrc(base, g8 < p.Cin / 8 ? HW * 16 : 0);
 #pragma unroll
         for (int q = 0; q < XPW; ++q) {
             const int qi = half * XPW + q;
@@ -98,7 +117,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 ? 3 : 4)) void conv_c8_v(const P 
             if (ABL & 4) okx = false;
             const unsigned off = okx ? 16u * (unsigned)(y * p.W + x) : 0xfffffff0u;
             if (qi < XI && hp < HPP)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_ptr_t)(Xs + slot * XB + (grp_w * HPP + 64 * qi) * 8), 16, off, 0, 0, 0);
+                DMA16(xrsrc, Xs + slot * XB + (grp_w * HPP + 64 * qi) * 8, off);
         }
     };
     auto issue_w = [&](int ch) {
@@ -110,7 +129,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 ? 3 : 4)) void conv_c8_v(const P 
                 const int idx = inst * 64 + lane, mt = idx / 576, r = idx % 576;
                 const bool ok = idx < W16 && (mt0 + mt) < p.mtiles;
                 const unsigned voff = ok ? (unsigned)((((mt0 + mt) * nchunks + ch) * 576 + r) * 16) : 0xfffffff0u;
-                if (idx < W16) __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_ptr_t)(Ws + inst * 512), 16, voff, 0, 0, 0);
+                if (idx < W16) DMA16(wrsrc, Ws + inst * 512, voff);
             }
         }
     };
