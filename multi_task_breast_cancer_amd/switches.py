@@ -23,9 +23,10 @@ PLAN_SWITCHES: Dict[str, tuple] = {
                     "tests/test_model_gpu.py::test_16bit_mfma_modes_match_their_emulation[...-no_z16]"),
     "MTBC_Z_BF16": ("0", "bf16 mode stores the conv outputs as bf16 instead of fp16 (same bytes, 8 instead of 11 significant bits)",
                     "tests/test_model_gpu.py::test_16bit_mfma_modes_match_their_emulation[...-z_bf16]"),
-    "MTBC_DA16": ("0", "the gradient a conv-cell activation gets from ALL its 3x3 consumers is one gathered launch writing a 16-bit channel-blocked tensor instead of "
-                       "fp32 planar fan-in (no faster -- the norm backward that reads it is latency-bound -- and about 1 pt of held-out Dice in the 3000-step sweep: off)",
-                  "tests/test_model_gpu.py::test_16bit_mfma_modes_match_their_emulation[...-da16]"),
+    "MTBC_NO_DA16": ("0", "the gradient a conv-cell activation gets from its 3x3 consumers stays fp32 planar fan-in (read-modify-write per consumer / gathered launch "
+                          "writing fp32) instead of ONE gathered launch writing a 16-bit channel-blocked tensor (default since round 3: -0.21 ms per step, "
+                          "held-out Dice -0.010 +- 0.025 pt over 10 paired seeds x 6000 steps, profiles/r03_quality_sweep.md)",
+                     "tests/test_model_gpu.py::test_16bit_mfma_modes_match_their_emulation[...-no_da16]"),
     "MTBC_NOFUSE_HEADS": ("0", "MTnnUNet deep-supervision heads as ConvT + 1x1 (the reference's two layers) instead of one combined ConvT",
                           "tests/test_model_gpu.py::test_mtnnunet_two_layer_heads_match_the_fused_heads_and_the_oracle"),
     "MTBC_COOP_RESERVE_CUS": ("64", "CUs kept out of the cooperative InstanceNorm grids under data parallel",

@@ -559,7 +559,7 @@ class lowp_conv3x3:
     def __init__(self, mode: str, model=None, z16: bool = True, da16: bool = False, fold_partials: bool = False, z_fp16: bool = True,
                  stem16: bool = True):
         self.lp = {"bf16": torch.bfloat16, "f16": torch.float16}[mode]
-        self.z16, self.da16 = z16, z16 and da16       # (the product's MTBC_NO_Z16 / MTBC_DA16 arms)
+        self.z16, self.da16 = z16, z16 and da16       # (the product's MTBC_NO_Z16 arm / its gathered 16-bit activation gradients: da16=True is the product's default since round 3)
         # the conv outputs are stored as fp16 in BOTH modes (bf16 mode: same bytes, 11 instead of 8 significant bits; the
         # MTBC_Z_BF16 arm stores bf16)
         self.zt = torch.float16 if (z_fp16 or self.lp == torch.float16) else self.lp

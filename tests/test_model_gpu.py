@@ -265,7 +265,7 @@ def test_distributed_step_single_rank_rccl_equals_local_step():
 
 @pytest.mark.parametrize("arch,dtype,size,arm", [("MTUNetPlusPlus", "bf16", 64, ""), ("MTUNetPlusPlus", "f16", 64, ""), ("MTnnUNet", "bf16", 128, ""),
                                                  ("MTUNetPlusPlus", "bf16", 128, ""), ("MTUNetPlusPlus", "bf16", 128, "no_gather"),
-                                                 ("MTUNetPlusPlus", "bf16", 64, "no_z16"), ("MTUNetPlusPlus", "bf16", 64, "da16"),
+                                                 ("MTUNetPlusPlus", "bf16", 64, "no_z16"), ("MTUNetPlusPlus", "bf16", 64, "no_da16"),
                                                  ("MTUNetPlusPlus", "bf16", 64, "z_bf16"),
                                                  # the BASELINE plane sizes: configs[1] (bf16, 256x256: cooperative InstanceNorm backward in teams of 32,
                                                  # wide-block weight gradients) and configs[4] (fp16, 512x512: teams of 128), whole model against the emulation
@@ -282,16 +282,18 @@ def test_16bit_mfma_modes_match_their_emulation(arch, dtype, size, arm, monkeypa
     the forward as >= 3e-2.  fp16 runs with the static loss scale 4096 on both sides (unscaled, dz underflows fp16)."""
     import copy
     from multi_task_breast_cancer_amd import engine
-    # the plan switches (switches.py), each with the emulation told the same thing: the gathered 16-bit activation gradients
-    # (MTBC_DA16), conv outputs kept in fp32 (MTBC_NO_Z16) or stored as bf16 instead of fp16 (MTBC_Z_BF16); per-consumer input
+    # the plan switches (switches.py), each with the emulation told the same thing: fp32 instead of gathered 16-bit activation gradients
+    # (MTBC_NO_DA16), conv outputs kept in fp32 (MTBC_NO_Z16) or stored as bf16 instead of fp16 (MTBC_Z_BF16); per-consumer input
     # gradients with read-modify-write fan-in instead of the gathered launches (MTBC_NO_GATHER: same roundings, another fp32 order)
-    emu = {"": {}, "da16": {"da16": True}, "no_gather": {}, "no_z16": {"z16": False}, "z_bf16": {"z_fp16": False}}[arm]
+    # (default plan: the gathered activation gradients are stored in 16 bits -- da16; without gathered launches nothing is rounded there)
+    emu = {"": {"da16": True}, "no_da16": {"da16": False}, "no_gather": {"da16": False}, "no_z16": {"z16": False},
+           "z_bf16": {"z_fp16": False, "da16": True}}[arm]
     if arm == "no_gather":
         monkeypatch.setattr(engine, "_NO_GATHER", True)
     elif arm == "no_z16":
         monkeypatch.setattr(engine, "_NO_Z16", True)
-    elif arm == "da16":
-        monkeypatch.setattr(engine, "_DA16", True)
+    elif arm == "no_da16":
+        monkeypatch.setattr(engine, "_DA16", False)
     elif arm == "z_bf16":
         monkeypatch.setattr(engine, "_Z_BF16", True)
     N = 4 if size == 64 else (1 if size == 512 else 2)          # >= 128x128: level 0 takes the cooperative InstanceNorm kernels
