@@ -613,6 +613,42 @@ __device__ __forceinline__ void pack_lp_elem8(const float* __restrict__ w, unsig
     if (f16) *reinterpret_cast<f16x8*>(p + dst8 * 8) = LP<true>::pack(v);
     else *reinterpret_cast<bf16x8*>(p + dst8 * 8) = LP<false>::pack(v);
 }
+// The same image, one (16-row tile, 32-K chunk) UNIT per 256-thread block, through LDS (round 3).  pack_lp_elem8 gathers 8 floats that lie
+// 36 B (forward) or 36 Cin B (dgrad) apart: every load instruction of a wave touches 64 cache lines, and the ~70 images of a step took
+// 105 us for 120 MB.  Here the unit's slab of the weight tensor -- 16 rows x 288 contiguous floats (forward) / 32 rows x 144 (dgrad) -- is
+// read with consecutive lanes on consecutive floats, and the 576 pieces of the unit are cut from LDS.  Same values, same places.
+constexpr int PACK_UNIT_SM = 32 * 145;
+__device__ __forceinline__ void pack_lp_unit(const float* __restrict__ w, unsigned short* __restrict__ p, int Cin, int Cout, int dgrad,
+                                             int f16, int unit, float* __restrict__ sm) {
+    const int rows = dgrad ? Cin : Cout, red = dgrad ? Cout : Cin;
+    const int nch = (red + LPKC - 1) / LPKC;
+    const int cb = unit % nch, mt = unit / nch, r0 = mt * 16, k0 = cb * LPKC;
+    const int tid = threadIdx.x;
+    if (!dgrad) {          // sm[i][kk * 9 + tap] = w[r0 + i][k0 + kk][tap]
+        for (int t = tid; t < 16 * 288; t += 256) {
+            const int i = t / 288, c = t - i * 288;
+            sm[i * 289 + c] = (r0 + i < rows && k0 + c / 9 < red) ? w[((size_t)(r0 + i) * Cin + k0) * 9 + c] : 0.f;
+        }
+    } else {               // sm[kk][i * 9 + tap] = w[k0 + kk][r0 + i][tap]
+        for (int t = tid; t < 32 * 144; t += 256) {
+            const int kk = t / 144, c = t - kk * 144;
+            sm[kk * 145 + c] = (k0 + kk < red && r0 + c / 9 < rows) ? w[((size_t)(k0 + kk) * Cin + r0) * 9 + c] : 0.f;
+        }
+    }
+    __syncthreads();
+    for (int q = tid; q < 576; q += 256) {
+        const int kq = q & 3, i = (q >> 2) & 15, tap = q >> 6;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int kk = kq * 8 + e;
+            v[e] = dgrad ? sm[kk * 145 + i * 9 + (8 - tap)] : sm[i * 289 + kk * 9 + tap];
+        }
+        const long long dst8 = (long long)unit * 576 + q - kq + (kq ^ ((i >> 1) & 3));      // (the XOR placement of pack_lp_elem8)
+        if (f16) *reinterpret_cast<f16x8*>(p + dst8 * 8) = LP<true>::pack(v);
+        else *reinterpret_cast<bf16x8*>(p + dst8 * 8) = LP<false>::pack(v);
+    }
+}
 __global__ void pack_lp_kernel(const float* __restrict__ w, unsigned short* __restrict__ p, int Cin, int Cout, int dgrad,
                                int f16, long long total8) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -654,12 +690,9 @@ __global__ void pack_many_kernel(const PackManyP q) {
         }
         if (idx >= total) return;
         pack_dgrad_elem(w, static_cast<float*>(q.dst[d]), Cin, Cout, (int)idx);
-    } else {
-        const int dg = kind == 3;
-        const int rows = dg ? Cin : Cout, red = dg ? Cout : Cin;
-        const long long total8 = (long long)((rows + 15) / 16) * ((red + LPKC - 1) / LPKC) * 9 * 16 * (WROW / 8);
-        if (idx >= total8) return;
-        pack_lp_elem8(w, static_cast<unsigned short*>(q.dst[d]), Cin, Cout, dg, q.f16, idx);
+    } else {               // 16-bit images: one block per (row tile, chunk) unit
+        __shared__ float sm[PACK_UNIT_SM];
+        pack_lp_unit(w, static_cast<unsigned short*>(q.dst[d]), Cin, Cout, kind == 3, q.f16, (int)blockIdx.x - q.first_block[d], sm);
     }
 }
 
@@ -3455,7 +3488,8 @@ int mtbc_conv3x3_pack_many(const mtbc_pack_desc* descs, int32_t n, void* stream)
             const int i = q.n++;
             q.w[i] = d.w; q.dst[i] = d.packed; q.Cin[i] = d.Cin; q.Cout[i] = d.Cout; q.kind[i] = (unsigned char)d.kind;
             q.first_block[i] = blocks;
-            blocks += (int)cdiv64(total, 256);
+            if (d.kind < 2) blocks += (int)cdiv64(total, 256);
+            else blocks += (int)(total / 576);          // 16-bit images: one block per (16-row tile, 32-K chunk) unit of 9 x 16 x 4 pieces
             ++done;
         }
         q.first_block[q.n] = blocks;

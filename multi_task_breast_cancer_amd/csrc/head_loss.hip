@@ -98,9 +98,37 @@ __global__ void dice_stats_kernel(const DiceP p) {
     const float* xs = p.x[h] + (size_t)plane * p.HW;
     const float* ts = p.target + (size_t)plane * p.HW;
     float si = 0.f, sp = 0.f, stt = 0.f;
-    for (int i = threadIdx.x; i < p.HW; i += blockDim.x) {
-        const float pr = sigmoidf_(xs[i]), t = ts[i];
-        si = fmaf(pr, t, si); sp = fmaf(pr, pr, sp); stt = fmaf(t, t, stt);
+    if ((p.HW & 3) == 0 && ((reinterpret_cast<uintptr_t>(xs) | reinterpret_cast<uintptr_t>(ts)) & 15) == 0) {
+        // 16-byte loads, four rounds in flight per thread (the scalar loop below was one dependent 4-byte round trip per element pair:
+        // 40 us for the four 256 x 256 heads of a step -- 128 blocks pulling 512 KB each)
+        const float4* x4 = reinterpret_cast<const float4*>(xs);
+        const float4* t4 = reinterpret_cast<const float4*>(ts);
+        const int n4 = p.HW >> 2, B = blockDim.x;
+        int i = threadIdx.x;
+        for (; i + 3 * B < n4; i += 4 * B) {
+            float4 xv[4], tv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { xv[u] = x4[i + u * B]; tv[u] = t4[i + u * B]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float px = sigmoidf_(xv[u].x), py = sigmoidf_(xv[u].y), pz = sigmoidf_(xv[u].z), pw = sigmoidf_(xv[u].w);
+                si = fmaf(px, tv[u].x, si); si = fmaf(py, tv[u].y, si); si = fmaf(pz, tv[u].z, si); si = fmaf(pw, tv[u].w, si);
+                sp = fmaf(px, px, sp); sp = fmaf(py, py, sp); sp = fmaf(pz, pz, sp); sp = fmaf(pw, pw, sp);
+                stt = fmaf(tv[u].x, tv[u].x, stt); stt = fmaf(tv[u].y, tv[u].y, stt); stt = fmaf(tv[u].z, tv[u].z, stt); stt = fmaf(tv[u].w, tv[u].w, stt);
+            }
+        }
+        for (; i < n4; i += B) {
+            const float4 xv = x4[i], tv = t4[i];
+            const float px = sigmoidf_(xv.x), py = sigmoidf_(xv.y), pz = sigmoidf_(xv.z), pw = sigmoidf_(xv.w);
+            si = fmaf(px, tv.x, si); si = fmaf(py, tv.y, si); si = fmaf(pz, tv.z, si); si = fmaf(pw, tv.w, si);
+            sp = fmaf(px, px, sp); sp = fmaf(py, py, sp); sp = fmaf(pz, pz, sp); sp = fmaf(pw, pw, sp);
+            stt = fmaf(tv.x, tv.x, stt); stt = fmaf(tv.y, tv.y, stt); stt = fmaf(tv.z, tv.z, stt); stt = fmaf(tv.w, tv.w, stt);
+        }
+    } else {
+        for (int i = threadIdx.x; i < p.HW; i += blockDim.x) {
+            const float pr = sigmoidf_(xs[i]), t = ts[i];
+            si = fmaf(pr, t, si); sp = fmaf(pr, pr, sp); stt = fmaf(t, t, stt);
+        }
     }
     si = block_sum(si, red); sp = block_sum(sp, red); stt = block_sum(stt, red);
     if (threadIdx.x == 0) {
@@ -129,6 +157,29 @@ __global__ void dice_bwd_kernel(const DiceP p) {
     const int h = blockIdx.y;
     const size_t total = (size_t)p.planes * p.HW;
     const float scale = p.gscale * (p.gscale_dev ? *p.gscale_dev : 1.f) * p.hw[h] / (float)p.planes;
+    if ((p.HW & 3) == 0 && ((reinterpret_cast<uintptr_t>(p.x[h]) | reinterpret_cast<uintptr_t>(p.target) | reinterpret_cast<uintptr_t>(p.dx[h])) & 15) == 0) {
+        // four pixels of one plane per thread: 16-byte loads / stores, the plane's constants once per four elements (same formula per element)
+        const float4* x4 = reinterpret_cast<const float4*>(p.x[h]);
+        const float4* t4 = reinterpret_cast<const float4*>(p.target);
+        float4* d4 = reinterpret_cast<float4*>(p.dx[h]);
+        const int hw4 = p.HW >> 2;
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (total >> 2); i += (size_t)gridDim.x * blockDim.x) {
+            const int plane = (int)(i / hw4);
+            const float* st = p.stats + ((size_t)h * p.planes + plane) * 3;
+            const float den = st[1] + st[2] + p.dr, num = 2.0f * st[0] + p.nr;
+            const float4 xv = x4[i], tv = t4[i];
+            const float xe[4] = {xv.x, xv.y, xv.z, xv.w}, te[4] = {tv.x, tv.y, tv.z, tv.w};
+            float o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float pr = sigmoidf_(xe[e]);
+                const float dfdp = -(2.0f * te[e] * den - num * 2.0f * pr) / (den * den);
+                o[e] = scale * dfdp * pr * (1.0f - pr);
+            }
+            d4[i] = make_float4(o[0], o[1], o[2], o[3]);
+        }
+        return;
+    }
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int plane = i / p.HW;
         const float* st = p.stats + ((size_t)h * p.planes + plane) * 3;
