@@ -9,6 +9,7 @@
 // Replaces nn.Conv2d(k=3,padding=1) of MTnnUNet.py:12-16 and MONAI Convolution (MTUNetPlusPlus.py:47-81).
 #include "common.h"
 #include <type_traits>
+#include <utility>
 #include <cstdlib>
 
 namespace {
@@ -61,7 +62,15 @@ struct ConvP {
     const unsigned short* nz;   // the tensor's conv output z, channel-blocked like the output
     const float* nmean; const float* nrstd; const float* ngamma; const float* nbeta;
     float nslope;
+#ifdef MTBC_PROBES
+    unsigned long long* ts;     // phase timestamps of the ring kernel (MTBC_RING_TS=1): [block][16] ticks of the 100 MHz clock
+#endif
 };
+#ifdef MTBC_PROBES
+#define MTBC_TS(p, k) do { if ((p).ts && threadIdx.x == 0) (p).ts[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 16 + (k)] = wall_clock64(); } while (0)
+#else
+#define MTBC_TS(p, k) do { } while (0)
+#endif
 
 constexpr int KC = 8;           // input channels per LDS chunk
 
@@ -1120,8 +1129,19 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 4) void conv3x3_igemm_c8_ker
     else bpix0 = (wv * HR + (j >> 3)) * HC + (j & 7);
     const unsigned short* const xlane = Xs + (kg * HPP + bpix0) * 8;
     int w_have = -1;
+    // weights: what a lane loads does not depend on the chunk except through a constant stride (one chunk of one channel tile = 9216 B), so the
+    // per-instruction index arithmetic is done once per block and the chunk goes into the load's SCALAR offset (round 3, late)
+    constexpr int W16 = WB / 8, WI = (W16 + 63) / 64, WK = (WI + NW - 1) / NW;
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(p.wp), 0, (int)((size_t)p.mtiles * nchunks * (9 * 16 * WROW) * 2), 0x00020000);
+    unsigned wvoff[WK];
+#pragma unroll
+    for (int k = 0; k < WK; ++k) {
+        const int inst = wvu + NW * k, idx = inst * 64 + lane;
+        const int mt = idx / (9 * 16 * WROW / 8), r = idx % (9 * 16 * WROW / 8);
+        const bool ok = inst < WI && idx < W16 && (mt0 + mt) < p.mtiles;
+        wvoff[k] = ok ? (unsigned)(((mt0 + mt) * nchunks * (9 * 16 * WROW / 8) + r) * 16) : 0xfffffff0u;
+    }
     int tile, tstep, tend;            // XCD-aware walk, as above
     if ((gridDim.x & 7) == 0 && !MTBC_DBG_BIT(p, 16)) {
         const int per = (p.ntiles + 7) >> 3, xcd = blockIdx.x & 7;
@@ -1198,18 +1218,12 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 4) void conv3x3_igemm_c8_ker
                 }
             }
             if (w_have != ch && !MTBC_DBG_BIT(p, 8)) {   // ---- W: a single-chunk conv keeps its weights in LDS for the whole launch
-                constexpr int W16 = WB / 8, WI = (W16 + 63) / 64;
+                const int adv = ch * (9 * 16 * WROW * 2);      // (range check: voffset alone, as for the plane strides of the planar kernel)
 #pragma unroll
-                for (int k = 0; k < (WI + NW - 1) / NW; ++k) {
+                for (int k = 0; k < WK; ++k) {
                     const int inst = wvu + NW * k;
-                    if (inst < WI) {
-                        const int idx = inst * 64 + lane;
-                        const int mt = idx / (9 * 16 * WROW / 8), r = idx % (9 * 16 * WROW / 8);
-                        const bool ok = idx < W16 && (mt0 + mt) < p.mtiles;
-                        const unsigned voff = ok ? (unsigned)((((mt0 + mt) * nchunks + ch) * (9 * 16 * WROW / 8) + r) * 16) : 0xfffffff0u;
-                        if (idx < W16)
-                            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_ptr_t)(Ws + inst * 512), 16, voff, 0, 0, 0);
-                    }
+                    if (inst < WI && inst * 64 + lane < W16)
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_ptr_t)(Ws + inst * 512), 16, (int)wvoff[k], adv, 0, 0);
                 }
                 w_have = ch;
             }
@@ -1245,6 +1259,20 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 4) void conv3x3_igemm_c8_ker
 // chunk c only, one raw barrier per chunk (it publishes chunk c and retires the slot chunk c + R - 1 overwrites).  Every wave
 // issues the same number of DMA instructions per chunk (surplus weight instructions read out of range into a pad), so the count
 // is a compile-time constant.
+// LDS-DMA from inline assembly (the wait the compiler puts behind the builtin is described at conv3x3_wgrad_c8w_kernel below)
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ i32x4 dma_rsrc(const void* base, unsigned bytes) {
+    const unsigned long long a = reinterpret_cast<unsigned long long>(base);
+    return (i32x4){(int)(unsigned)a, (int)((unsigned)(a >> 32) & 0xffffu), (int)bytes, 0x00020000};
+}
+__device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(unsigned long long)(__attribute__((address_space(3))) const void*)p; }
+// 64 lanes x 16 B: lane l's piece lands at LDS byte address `lds` + 16 l; out-of-range `voff` -> zeros
+__device__ __forceinline__ void dma16(const i32x4 rsrc, unsigned lds, unsigned voff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds), "v"(voff), "s"(rsrc) : "memory", "m0");
+}
+// compile-time loop: f(std::integral_constant<int, 0>{}), ..., f(std::integral_constant<int, N - 1>{})
+template <typename F, int... I> __device__ __forceinline__ void sfor_c_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, typename F> __device__ __forceinline__ void sfor_c(F&& f) { sfor_c_impl(f, std::make_integer_sequence<int, N>{}); }
 template <int MT, int GEO> struct RingGeo {
     using G = GeoLP<GEO>;
     static constexpr int HR = G::TH + 2, HC = G::TW + 2, HP = HR * HC, HPP = (HP + 15) / 16 * 16;
@@ -1253,45 +1281,6 @@ template <int MT, int GEO> struct RingGeo {
     static constexpr int CNT = XQ + WPW;                                             // vector-memory instructions per wave and chunk
     static constexpr int SLOT = XB + WB + PAD;
 };
-// DMA of chunk `ch` into ring slot `sl`: wave w brings channel group w of X (XQ instructions) and its share of W (WPW instructions)
-template <int MT, int GEO>
-__device__ __forceinline__ void ring_issue(const ConvP& p, unsigned short* smem16, const SegL* seg_in,
-                                           const unsigned* pixo, const int ch, const int sl, const int wvu, const int lane,
-                                           const int n0, const int mt0, const int nchunks, const int HW) {
-    using RG = RingGeo<MT, GEO>;
-    constexpr int NW = 4, HPP = RG::HPP, XB = RG::XB, WB = RG::WB, XQ = RG::XQ;
-    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(p.wp), 0, (int)((size_t)p.mtiles * nchunks * (9 * 16 * WROW) * 2), 0x00020000);
-        unsigned short* Xs = smem16 + sl * RG::SLOT;
-        unsigned short* Ws = Xs + XB;
-        const int c0 = ch * LPKC + 8 * wvu;
-        const bool xgrp = c0 < p.Cin;
-        const SegL sr = segl_ref(seg_in, xgrp ? c0 : 0);
-        const unsigned long long pu = reinterpret_cast<unsigned long long>(sr.ptr);
-        const unsigned plo = __builtin_amdgcn_readfirstlane((unsigned)pu), phi = __builtin_amdgcn_readfirstlane((unsigned)(pu >> 32));
-        const unsigned blo = __builtin_amdgcn_readfirstlane((unsigned)sr.bs), bhi = __builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)sr.bs >> 32));
-        const int cb = __builtin_amdgcn_readfirstlane(sr.cb);
-        const long long bs = (long long)(((unsigned long long)bhi << 32) | blo);
-        unsigned short* base = reinterpret_cast<unsigned short*>(((unsigned long long)phi << 32) | plo) +
-                               ((size_t)n0 * bs + (size_t)((xgrp ? c0 : 0) - cb) * HW);
-        const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(base, 0, xgrp ? (int)((unsigned)HW * 16u) : 0, 0x00020000);
-#pragma unroll
-        for (int q = 0; q < XQ; ++q)      // (lanes past the padded image write into the next group's head / the weight head: rewritten by their owners? no -- masked)
-            if (lane + 64 * q < HPP)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_ptr_t)(Xs + (wvu * HPP + 64 * q) * 8), 16, pixo[q], 0, 0, 0);
-#pragma unroll
-        for (int k = 0; k < RG::WPW; ++k) {
-            const int inst = wvu + NW * k;
-            const int idx = inst * 64 + lane;
-            const int mt = idx / (9 * 16 * WROW / 8), r = idx % (9 * 16 * WROW / 8);
-            const bool ok = inst < RG::WI && idx < RG::W16 && (mt0 + mt) < p.mtiles;
-            const unsigned voff = ok ? (unsigned)((((mt0 + mt) * nchunks + ch) * (9 * 16 * WROW / 8) + r) * 16) : 0xfffffff0u;
-            // a wave without a real instruction left still issues one (zeros into the slot's pad): uniform count per wave
-            unsigned short* dst = inst < RG::WI ? Ws + inst * 512 : Ws + WB;
-            if (inst >= RG::WI || idx < RG::W16)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_ptr_t)dst, 16, voff, 0, 0, 0);
-        }
-    }
 template <int MT, int GEO, bool F16, int O8, int R>
 __global__ __launch_bounds__(256, 1) void conv3x3_igemm_c8_ring_kernel(const ConvP p) {
     using G = GeoLP<GEO>;
@@ -1303,18 +1292,45 @@ __global__ __launch_bounds__(256, 1) void conv3x3_igemm_c8_ring_kernel(const Con
     SegL* seg_in = reinterpret_cast<SegL*>(smem16 + R * RG::SLOT);
     SegL* seg_out = seg_in + MTBC_MAX_SEGS;
     float* bias_s = reinterpret_cast<float*>(seg_out + MTBC_MAX_SEGS);      // MT*16 floats
+    unsigned long long* xbase_s = reinterpret_cast<unsigned long long*>(bias_s + MT * 16);      // [chunk][channel group]: base of the group's pieces, this tile's image (0 = absent)
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int wvu = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int HW = p.H * p.W;
     const int mt0 = blockIdx.y * MT;
+    MTBC_TS(p, 0);
+    // the bias: requested now, written to LDS in front of the first tile's barrier (behind a __syncthreads() here its whole memory round trip
+    // was the kernel's first microsecond)
+    float bias_v = 0.f;
+    if (tid < MT * 16) { const int co = mt0 * 16 + tid; if (p.bias && co < p.Cout) bias_v = p.bias[co]; }
     segl_fill(seg_in, p.in);
     segl_fill(seg_out, p.out);
-    if (tid < MT * 16) { const int co = mt0 * 16 + tid; bias_s[tid] = (p.bias && co < p.Cout) ? p.bias[co] : 0.f; }
-    __syncthreads();
+    lds_barrier();
+    MTBC_TS(p, 1);
 
     const int nchunks = (p.Cin + LPKC - 1) / LPKC;
     const int j = lane & 15, kg = lane >> 4;
     const int bpix0 = (GEO == 0 ? 2 * wv : 4 * wv) * HC + j;      // group g / tap t at compile-time offsets (c8_goff), as in the kernel above
+    // ---- DMA issue (round 3, late).  Phase timestamps of this kernel (MTBC_RING_TS in the probes build; 384 -> 384 @16 x 16: 33 us) showed
+    // 2.14 us per chunk of which 1.33 are the tap loop and 0.8 the ISSUE of the 13 DMA instructions of chunk c + 2: with one wave per SIMD
+    // the segment lookup, 64-bit address arithmetic, descriptor words and per-instruction index divisions in front of the MFMAs are all
+    // exposed, and so is the 60 - 185 cycles a `buffer_load ... lds` costs the wave that issues it.  Now: what does not depend on the chunk is
+    // computed once (weight offsets per lane: the chunk only moves the descriptor's base), the X base of every (chunk, group) of the tile
+    // comes out of a small LDS table filled by 4 nchunks threads, and the 13 instructions go out ONE AT A TIME between the MFMA groups of the
+    // tap loop (inline assembly: the compiler neither waits for them nor moves them), under the matrix pipe: 1.78 us per chunk.  (Four
+    // producer waves beside four consumer waves -- tools/experiments/ring_producer_consumer.patch -- reach 1.61 us per chunk and lose it
+    // again in the prologue of a 512-thread block: 28.2 against 28.8 us for 384 -> 384, the step 0.04 ms slower than this form.)
+    constexpr int WPW = RG::WPW, CNT = RG::CNT;
+    const unsigned lds0 = lds_addr(smem16);
+    const unsigned wbytes = (unsigned)((size_t)p.mtiles * nchunks * (9 * 16 * WROW) * 2);
+    unsigned wvoff[WPW];
+#pragma unroll
+    for (int k = 0; k < WPW; ++k) {
+        const int inst = wvu + NW * k, idx = inst * 64 + lane;
+        const int mt = idx / (9 * 16 * WROW / 8), r = idx % (9 * 16 * WROW / 8);
+        const bool ok = inst < RG::WI && idx < RG::W16 && (mt0 + mt) < p.mtiles;
+        wvoff[k] = ok ? (unsigned)(((mt0 + mt) * nchunks * (9 * 16 * WROW / 8) + r) * 16) : 0xfffffff0u;      // + chunk * 9216 through the descriptor base
+    }
+    static_assert(RG::W16 % 64 == 0, "whole weight instructions: every wave issues CNT instructions per chunk");
     for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
         int t = tile;
         const int tx = t % p.tiles_x; t /= p.tiles_x;
@@ -1334,17 +1350,58 @@ __global__ __launch_bounds__(256, 1) void conv3x3_igemm_c8_ring_kernel(const Con
         for (int m = 0; m < MT; ++m)
 #pragma unroll
             for (int g = 0; g < 4; ++g) acc[m][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        lds_barrier();                            // the previous tile's fragments are consumed (its stores were waited for below)
+        if (tid < 4 * nchunks) {                  // (nchunks <= 64: the launcher's condition)
+            const int c0 = (tid >> 2) * LPKC + 8 * (tid & 3);
+            unsigned long long b = 0;
+            if (c0 < p.Cin) {
+                const SegL sr = segl_ref(seg_in, c0);
+                b = reinterpret_cast<unsigned long long>(reinterpret_cast<unsigned short*>(sr.ptr) + ((size_t)n0 * sr.bs + (size_t)(c0 - sr.cb) * HW));
+            }
+            xbase_s[tid] = b;
+        }
+        if (tid < MT * 16) bias_s[tid] = bias_v;
+        lds_barrier();                            // the table (and the bias) are there; the previous tile's fragments are consumed (its stores were waited for below)
+        // descriptors of chunk `c` for this wave: X = its channel group's pieces of the tile's image, W = the packed image moved on by c chunks
+        auto chunk_rsrc = [&](int c, i32x4& xr, i32x4& wr) {
+            const unsigned long long b = xbase_s[4 * c + wvu];
+            const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+            xr = (i32x4){(int)lo, (int)(hi & 0xffffu), (lo | hi) ? (int)((unsigned)HW * 16u) : 0, 0x00020000};
+            const unsigned adv = (unsigned)c * (unsigned)(9 * 16 * WROW * 2);
+            wr = dma_rsrc(reinterpret_cast<const char*>(p.wp) + adv, wbytes - adv);
+        };
+        // instruction i of the CNT a wave issues per chunk: the first XQ bring halo pixels 64 i .. of its channel group, the rest its share of W
+        auto piece = [&](auto i_, int sl, const i32x4& xr, const i32x4& wr) {
+            constexpr int i = decltype(i_)::value;
+            const unsigned slot0 = lds0 + 2u * (unsigned)(sl * RG::SLOT);
+            if constexpr (i < XQ) {
+                if (lane + 64 * i < HPP) dma16(xr, slot0 + 2u * (unsigned)((wvu * HPP + 64 * i) * 8), pixo[i]);
+            } else {
+                constexpr int k = i - XQ;
+                const int inst = wvu + NW * k;      // a wave without a real instruction left still issues one (zeros into the slot's pad)
+                dma16(wr, slot0 + 2u * (unsigned)(XB + (inst < RG::WI ? inst * 512 : WB)), wvoff[k]);
+            }
+        };
 #pragma unroll
         for (int s0 = 0; s0 < R - 1; ++s0)
-            if (s0 < nchunks) ring_issue<MT, GEO>(p, smem16, seg_in, pixo, s0, s0, wvu, lane, n0, mt0, nchunks, HW);
+            if (s0 < nchunks) {
+                i32x4 xr, wr;
+                chunk_rsrc(s0, xr, wr);
+                sfor_c<CNT>([&](auto I) { piece(I, s0, xr, wr); });
+            }
+        MTBC_TS(p, 2);
         for (int ch = 0; ch < nchunks; ++ch) {
             // chunks ch + 1 .. ch + R - 2 may stay in flight
             const int rem = min(R - 2, nchunks - 1 - ch);
             if (rem >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RG::CNT) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // chunk ch is in LDS for everybody; everybody is done with chunk ch - 1
-            if (ch + R - 1 < nchunks) ring_issue<MT, GEO>(p, smem16, seg_in, pixo, ch + R - 1, (ch + R - 1) % R, wvu, lane, n0, mt0, nchunks, HW);
+            if (ch == 0) MTBC_TS(p, 3);
+            if (ch == 1) MTBC_TS(p, 4);
+            if (ch == nchunks - 1) MTBC_TS(p, 5);
+            const bool more = ch + R - 1 < nchunks;      // (uniform) chunk ch + R - 1 goes out under this chunk's MFMAs
+            const int sl_next = (ch + R - 1) % R;
+            i32x4 xr_n = (i32x4){0, 0, 0, 0}, wr_n = xr_n;
+            if (more) chunk_rsrc(ch + R - 1, xr_n, wr_n);
             const unsigned short* Xs = smem16 + (ch % R) * RG::SLOT;
             const unsigned short* Ws = Xs + XB;
             // ONE wave per SIMD: nobody else covers a fragment read's latency.  Left to the scheduler the taps ran as `2 reads, wait for
@@ -1361,24 +1418,34 @@ __global__ __launch_bounds__(256, 1) void conv3x3_igemm_c8_ring_kernel(const Con
                     fb[set][g] = *reinterpret_cast<const typename T::frag*>(Xs + (kg * HPP + bpix0) * 8 + (c8_goff<GEO>(g, HC) + toff) * 8);
             };
             load_tap(0, 0);
-#pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                const int set = tap & 1;
+            constexpr int PPS = (CNT + 9 * MT - 1) / (9 * MT);      // DMA instructions per MFMA group (1 for every instantiation in use)
+            sfor_c<9>([&](auto TAP) {
+                constexpr int tap = decltype(TAP)::value, set = tap & 1;
                 if (tap + 1 < 9) load_tap(tap + 1, set ^ 1);
                 __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int m = 0; m < MT; ++m)
+                sfor_c<MT>([&](auto M) {
+                    constexpr int m = decltype(M)::value;
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         if constexpr (O8 != 0) acc[m][g] = T::mfma(fa[set][m], fb[set][g], acc[m][g]);
                         else acc[m][g] = T::mfma(fb[set][g], fa[set][m], acc[m][g]);
                     }
-                __builtin_amdgcn_sched_barrier(0);
-            }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (more)
+                        sfor_c<PPS>([&](auto U) {
+                            constexpr int i = (tap * MT + m) * PPS + decltype(U)::value;
+                            if constexpr (i < CNT) piece(std::integral_constant<int, i>{}, sl_next, xr_n, wr_n);
+                        });
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+            });
         }
         int zpre = 0;
+        MTBC_TS(p, 6);
         c8_epilogue<MT, GEO, F16, NW, O8>(p, acc, seg_out, bias_s, n0, y0, x0, tx, ty, mt0, wv, j, kg, HW, zpre);
+        MTBC_TS(p, 7);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the stores: the next tile counts its DMA instructions from zero
+        MTBC_TS(p, 8);
     }
 }
 
@@ -2145,16 +2212,7 @@ __global__ __launch_bounds__(256, 4) void conv3x3_wgrad_c8_kernel(const WgC8P p)
 // (ISA: `[vmcnt(0)] r14 ...` at the top of the step body; ablation: DMA-only 107 us + compute-only 123 us = full 235 us).  Issued from
 // inline assembly the load is an opaque instruction: no alias tracking, no inserted wait; the kernel's own counted `s_waitcnt vmcnt`
 // + barrier are the ordering (they were all along).  The descriptor is the four dwords make_buffer_rsrc builds.
-typedef int i32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ i32x4 dma_rsrc(const void* base, unsigned bytes) {
-    const unsigned long long a = reinterpret_cast<unsigned long long>(base);
-    return (i32x4){(int)(unsigned)a, (int)((unsigned)(a >> 32) & 0xffffu), (int)bytes, 0x00020000};
-}
-__device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(unsigned long long)(__attribute__((address_space(3))) const void*)p; }
-// 64 lanes x 16 B: lane l's piece lands at LDS byte address `lds` + 16 l; out-of-range `voff` -> zeros
-__device__ __forceinline__ void dma16(const i32x4 rsrc, unsigned lds, unsigned voff) {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds), "v"(voff), "s"(rsrc) : "memory", "m0");
-}
+// (dma_rsrc / lds_addr / dma16: defined in front of conv3x3_igemm_c8_ring_kernel, their first user)
 #ifdef MTBC_PROBES
 #define MTBC_DBG_HACK(p) ((p).hack)
 #else
@@ -3162,7 +3220,8 @@ template <int MT, int GEO, int O8>
 int launch_igemm_c8_ring(const ConvP& p, int mblocks, bool f16, hipStream_t st) {
     constexpr int R = 3;
     using RG = RingGeo<MT, GEO>;
-    const size_t lds = (size_t)R * RG::SLOT * 2 + (SEGL_FLOATS + MT * 16) * sizeof(float);
+    const size_t lds = (size_t)R * RG::SLOT * 2 + (SEGL_FLOATS + MT * 16) * sizeof(float) + 64 * 4 * sizeof(unsigned long long);      // + the (chunk, group) base table
+    static_assert((size_t)R * RG::SLOT * 2 + (SEGL_FLOATS + MT * 16) * sizeof(float) + 2048 <= 160 * 1024, "ring slots + tables must fit a CU's LDS");
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_igemm_c8_ring_kernel<MT, GEO, false, O8, R>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -3173,6 +3232,33 @@ int launch_igemm_c8_ring(const ConvP& p, int mblocks, bool f16, hipStream_t st) 
     if (gx < 1) gx = 1;
     if (gx > p.ntiles) gx = p.ntiles;
     const dim3 grid(gx, mblocks);
+#ifdef MTBC_PROBES
+    // MTBC_RING_TS=1: phase timestamps of every block (thread 0), printed after a synchronisation -- a timing microscope, not a product path
+    static const int ts_env = mtbc_probe_int("MTBC_RING_TS", 0);
+    if (ts_env) {
+        ConvP q = p;
+        const size_t nb = (size_t)gx * mblocks;
+        static unsigned long long* dts = nullptr;
+        if (!dts) (void)hipMalloc(&dts, 4096 * 16 * sizeof(unsigned long long));
+        (void)hipMemsetAsync(dts, 0, nb * 16 * sizeof(unsigned long long), st);
+        q.ts = dts;
+        if (f16) hipLaunchKernelGGL((conv3x3_igemm_c8_ring_kernel<MT, GEO, true, O8, R>), grid, dim3(256), lds, st, q);
+        else hipLaunchKernelGGL((conv3x3_igemm_c8_ring_kernel<MT, GEO, false, O8, R>), grid, dim3(256), lds, st, q);
+        (void)hipStreamSynchronize(st);
+        static unsigned long long hts[4096 * 16];
+        (void)hipMemcpy(hts, dts, nb * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+        unsigned long long t0 = ~0ull, t1 = 0;
+        for (size_t b = 0; b < nb; ++b) { if (hts[b * 16] < t0) t0 = hts[b * 16]; if (hts[b * 16 + 8] > t1) t1 = hts[b * 16 + 8]; }
+        double mean[9] = {0}, mx[9] = {0};
+        for (size_t b = 0; b < nb; ++b)
+            for (int k = 0; k < 9; ++k) { const double d = (double)(hts[b * 16 + k] - t0) * 0.01; mean[k] += d / nb; if (d > mx[k]) mx[k] = d; }
+        fprintf(stderr, "ring_ts %d->%d @%dx%d MT%d O8=%d blocks %zu span %.2f us | mean (max) us since the first block's entry: entry %.2f (%.2f) prologue %.2f (%.2f) issued %.2f (%.2f) "
+                        "chunk0 landed %.2f (%.2f) chunk1 %.2f (%.2f) last chunk %.2f (%.2f) mfma done %.2f (%.2f) stores issued %.2f (%.2f) stores done %.2f (%.2f)\n",
+                p.Cin, p.Cout, p.H, p.W, MT, O8, nb, (double)(t1 - t0) * 0.01, mean[0], mx[0], mean[1], mx[1], mean[2], mx[2], mean[3], mx[3], mean[4], mx[4], mean[5], mx[5],
+                mean[6], mx[6], mean[7], mx[7], mean[8], mx[8]);
+        return MTBC_OK;
+    }
+#endif
     if (f16) hipLaunchKernelGGL((conv3x3_igemm_c8_ring_kernel<MT, GEO, true, O8, R>), grid, dim3(256), lds, st, p);
     else hipLaunchKernelGGL((conv3x3_igemm_c8_ring_kernel<MT, GEO, false, O8, R>), grid, dim3(256), lds, st, p);
     MTBC_CHECK_LAUNCH();
@@ -3196,7 +3282,7 @@ IgemmPlan plan_igemm(int N, int H, int W, int rows, int compute, bool c8, bool a
     else { q.tiles_x = 1; q.tiles_y = 1; q.ntiles = cdiv(N, 4); }
     q.nw8 = false; q.ring = false;
     static const int ring_env = mtbc_probe_int("MTBC_C8_RING", -1);      // A/B
-    if (c8 && allow_nw8 && q.geo != 2 && red >= 96 && ring_env != 0) {
+    if (c8 && allow_nw8 && q.geo != 2 && red >= 96 && red <= 64 * LPKC && ring_env != 0) {      // (<= 64 chunks: the kernel's base table)
         // deep levels: a launch of at most ONE block per CU -- the ring kernel (chunks prefetched two ahead) with as many channel
         // tiles per block as divide evenly (the pixel tile is staged once per block).  Measured (U-Net++ B=32, 16 x 16 maps):
         // 192->384 29 -> 23 us, 384->384 40 -> 35 us; with two rounds of blocks (512->512: 512 blocks) it LOSES, 50 -> 60 us, and
@@ -3238,6 +3324,9 @@ int run_igemm(int N, int H, int W, int red, int rows, const SegTable& in, const 
               const float* bias, int compute, hipStream_t st, bool c8 = false, int o8 = 0, float* stats = nullptr,
               const mtbc_conv3x3_args* nb = nullptr) {
     ConvP p;
+#ifdef MTBC_PROBES
+    p.ts = nullptr;
+#endif
     p.N = N; p.H = H; p.W = W; p.Cin = red; p.Cout = rows; p.in = in; p.out = out; p.wp = wp; p.bias = bias; p.stats = stats;
     p.extra = nullptr; p.nz = nullptr; p.nmean = p.nrstd = p.ngamma = p.nbeta = nullptr; p.nslope = 0.f;
     if (o8 == 2) {
