@@ -99,6 +99,16 @@ __device__ __forceinline__ SegL segl_ref(const SegL* t, int c) {
     }
     return r;
 }
+// ... knowing the table's length n (uniform): a one-segment table -- every conv output, every single-input conv -- is ONE LDS read instead
+// of six reads and a select chain of ~60 instructions, per chunk and per channel tile of every pixel tile
+__device__ __forceinline__ SegL segl_ref_n(const SegL* t, int c, int n) {
+    SegL r = t[0];
+    for (int i = 1; i < n; ++i) {
+        const SegL e = t[i];
+        if (c >= e.cb) r = e;
+    }
+    return r;
+}
 
 // Persistent: block (bx, by) walks pixel tiles bx, bx+gridDim.x, ... for its channel block by.  The work list is the
 // flattened sequence of (tile, chunk) items; item i+1 is prefetched into registers while item i feeds the MFMAs, so a
@@ -942,7 +952,12 @@ __device__ __forceinline__ float wave_sum_rows(float v) {
 // Epilogue of the channel-blocked igemm kernels (one pixel tile's accumulators -> HBM), shared by the single-buffer kernel and
 // the ring kernel of the deep levels.  O8 = 0: fp32 planar segments (store / read-modify-write / 16-bit planes); 1: 16-bit
 // channel-blocked (+ forward InstanceNorm statistics); 2: that + the norm-backward reductions (zpre = the tensor's z, prefetched).
-template <int MT, int GEO, bool F16, int NW, int O8, typename ZPRE>
+// FULL (round 3, late): the tile lies inside the image and the batch -- no per-pixel validity, no predicated stores; `wv` is the wave index
+// as a SCALAR (readfirstlane): with it the pixel offsets, the statistics slot and their 64-bit addresses are scalar arithmetic + one vector
+// add per lane instead of vector multiplies per accumulator tile.  (Phase timestamps, MTBC_C8_TS: a 24 -> 24 tile of 7.6 us spent 2.8 us in
+// this epilogue and 2.3 us between its start and its last DMA instruction -- ~1000 vector / scalar instructions beside 72 MFMAs per wave,
+// on SIMDs that four waves share: instruction issue, not bytes and not the matrix pipe, is what the level-0 launches wait for.)
+template <int MT, int GEO, bool F16, int NW, int O8, bool FULL, typename ZPRE>
 __device__ __forceinline__ void c8_epilogue(const ConvP& p, f32x4 (&acc)[MT][4], const SegL* seg_out, const float* bias_s, const int n0,
                                             const int y0, const int x0, const int tx, const int ty, const int mt0, const int wv,
                                             const int j, const int kg, const int HW, ZPRE& zpre) {
@@ -963,14 +978,14 @@ __device__ __forceinline__ void c8_epilogue(const ConvP& p, f32x4 (&acc)[MT][4],
             if (GEO == 0) { y = y0 + 2 * wv + (g >> 1); x = x0 + 16 * (g & 1) + j; }
             else if (GEO == 1) { y = y0 + 4 * wv + g; x = x0 + j; }
             else { y = y0 + 2 * g + (j >> 3); x = x0 + (j & 7); }
-            pix[g] = (n < p.N && y < p.H && x < p.W) ? y * p.W + x : -1;
+            pix[g] = (FULL || (n < p.N && y < p.H && x < p.W)) ? y * p.W + x : -1;
         }
         const bool want_stats = O8 == 2 || p.stats != nullptr;
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
             const int co = (mt0 + m) * 16 + 4 * kg;
             if (co >= p.Cout) continue;
-            const SegL so = segl_ref(seg_out, co);
+            const SegL so = segl_ref_n(seg_out, co, p.out.n);
             // piece (n, group, pixel) of the segment's tensor; this lane owns channels (co - cb) % 8 .. + 3 of it
             const size_t poff8 = 2 * ((size_t)n * so.bs + (size_t)((co - so.cb) >> 3) * HW * 8) + 2 * ((co - so.cb) & 7);
             gchar* cb = (gchar*)so.ptr + poff8;
@@ -987,7 +1002,7 @@ __device__ __forceinline__ void c8_epilogue(const ConvP& p, f32x4 (&acc)[MT][4],
                 const float* eb = p.extra ? p.extra + plane * HW : nullptr;
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
-                    if (pix[g] >= 0) {
+                    if (FULL || pix[g] >= 0) {
                         const pre_u32x2 zw = zpre[m][g];
                         f32x4 ex = (f32x4){0.f, 0.f, 0.f, 0.f};
                         if (eb) ex = (f32x4){eb[pix[g]], eb[(size_t)HW + pix[g]], eb[2 * (size_t)HW + pix[g]], eb[3 * (size_t)HW + pix[g]]};
@@ -1007,7 +1022,7 @@ __device__ __forceinline__ void c8_epilogue(const ConvP& p, f32x4 (&acc)[MT][4],
             } else {
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
-                    if (pix[g] >= 0) {
+                    if (FULL || pix[g] >= 0) {
                         f32x4 r = acc[m][g] + bv;
                         if constexpr (O8 == 3) {          // fp16 storage of a bf16-mode conv output: saturate (an inf would poison the norm behind it)
 #pragma unroll
@@ -1027,7 +1042,7 @@ __device__ __forceinline__ void c8_epilogue(const ConvP& p, f32x4 (&acc)[MT][4],
                 // this wave's pixels: the 16 lanes of a row group hold 16 pixels of the same 4 channels -> DPP row sums
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { ss[e] = row16_sum(ss[e]); sq[e] = row16_sum(sq[e]); }
-                if (j == 15 && n < p.N) {
+                if (j == 15 && (FULL || n < p.N)) {
                     const int slots = GEO == 2 ? 1 : p.tiles_x * p.tiles_y * NW;
                     const int slot = GEO == 2 ? 0 : (ty * p.tiles_x + tx) * NW + wv;
                     float* sp = p.stats + (((size_t)n * slots + slot) * p.Cout + co) * 2;
@@ -1046,13 +1061,13 @@ __device__ __forceinline__ void c8_epilogue(const ConvP& p, f32x4 (&acc)[MT][4],
         if (GEO == 0) { y = y0 + 2 * wv + (g >> 1); x = x0 + 16 * (g & 1) + 4 * kg; }
         else if (GEO == 1) { y = y0 + 4 * wv + g; x = x0 + 4 * kg; }
         else { y = y0 + 2 * g + (kg >> 1); x = x0 + 4 * (kg & 1); }
-        poff[g] = (n < p.N && y < p.H && x < p.W) ? y * p.W + x : -1;
+        poff[g] = (FULL || (n < p.N && y < p.H && x < p.W)) ? y * p.W + x : -1;
     }
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
         const int co = (mt0 + m) * 16 + j;
         if (co >= p.Cout) continue;
-        const SegL so = segl_ref(seg_out, co);
+        const SegL so = segl_ref_n(seg_out, co, p.out.n);
         gfloat* cb = (gfloat*)so.ptr + (size_t)n * so.bs + (size_t)(co - so.cb) * HW;
         const float bv = bias_s[m * 16 + j];
         if (so.acc == 2) {          // 16-bit planar segment: the lane's 4 consecutive pixels of its channel = one 8-byte store
@@ -1062,7 +1077,7 @@ __device__ __forceinline__ void c8_epilogue(const ConvP& p, f32x4 (&acc)[MT][4],
             gchar* c16 = (gchar*)so.ptr + 2 * ((size_t)n * so.bs + (size_t)(co - so.cb) * HW);
 #pragma unroll
             for (int g = 0; g < 4; ++g)
-                if (poff[g] >= 0) {
+                if (FULL || poff[g] >= 0) {
                     const float q[8] = {acc[m][g][0] + bv, acc[m][g][1] + bv, acc[m][g][2] + bv, acc[m][g][3] + bv, 0.f, 0.f, 0.f, 0.f};
                     const typename T::frag h = T::pack(q);          // RNE, the conversion every consumer's staging would apply
                     const ep_u32x4 u = __builtin_bit_cast(ep_u32x4, h);
@@ -1071,14 +1086,14 @@ __device__ __forceinline__ void c8_epilogue(const ConvP& p, f32x4 (&acc)[MT][4],
         } else if (so.acc) {
             f32x4 old[4];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) old[g] = poff[g] >= 0 ? *(const gf32x4*)(cb + poff[g]) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int g = 0; g < 4; ++g) old[g] = (FULL || poff[g] >= 0) ? *(const gf32x4*)(cb + poff[g]) : (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int g = 0; g < 4; ++g)
-                if (poff[g] >= 0) *(gf32x4*)(cb + poff[g]) = old[g] + (acc[m][g] + bv);
+                if (FULL || poff[g] >= 0) *(gf32x4*)(cb + poff[g]) = old[g] + (acc[m][g] + bv);
         } else {
 #pragma unroll
             for (int g = 0; g < 4; ++g)
-                if (poff[g] >= 0) *(gf32x4*)(cb + poff[g]) = acc[m][g] + bv;
+                if (FULL || poff[g] >= 0) *(gf32x4*)(cb + poff[g]) = acc[m][g] + bv;
         }
     }
 }
@@ -1124,9 +1139,9 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 4) void conv3x3_igemm_c8_ker
     // the compiler kept 36 separate address registers, ran out of the 128 this occupancy allows, and spilled the per-tile halo
     // constants: every tile then began with scratch reloads whose vmcnt(0) also drained the previous tile's output stores.)
     int bpix0;
-    if (GEO == 0) bpix0 = (2 * wv) * HC + j;
-    else if (GEO == 1) bpix0 = (4 * wv) * HC + j;
-    else bpix0 = (wv * HR + (j >> 3)) * HC + (j & 7);
+    if (GEO == 0) bpix0 = (2 * wvu) * HC + j;
+    else if (GEO == 1) bpix0 = (4 * wvu) * HC + j;
+    else bpix0 = (wvu * HR + (j >> 3)) * HC + (j & 7);
     const unsigned short* const xlane = Xs + (kg * HPP + bpix0) * 8;
     int w_have = -1;
     // weights: what a lane loads does not depend on the chunk except through a constant stride (one chunk of one channel tile = 9216 B), so the
@@ -1147,21 +1162,33 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 4) void conv3x3_igemm_c8_ker
         const int per = (p.ntiles + 7) >> 3, xcd = blockIdx.x & 7;
         tile = xcd * per + (blockIdx.x >> 3); tstep = gridDim.x >> 3; tend = min(p.ntiles, (xcd + 1) * per);
     } else { tile = blockIdx.x; tstep = gridDim.x; tend = p.ntiles; }
+    // what a lane's halo pieces are does not depend on the tile: (image, row, column) of piece q inside the halo image, once per block
+    const int xgrp_w = NW == 4 ? wvu : (wvu >> 1), xq0 = NW == 4 ? 0 : (wvu & 1) * XPW;      // this wave's channel group / first piece row
+    int hrc[XPW];                     // (image << 20) | (row << 10) | column, -1 past the halo image
+#pragma unroll
+    for (int q = 0; q < XPW; ++q) {
+        const int hp = lane + 64 * (xq0 + q);
+        const int img = hp / (HR * HC), rem = hp % (HR * HC);
+        hrc[q] = (hp < HP && !MTBC_DBG_BIT(p, 1)) ? ((img << 20) | ((rem / HC) << 10) | (rem % HC)) : -1;
+    }
+    // tile index -> (column, row, image): shifts when the tile counts are powers of two (every size of the BASELINE configurations)
+    const int txs = (p.tiles_x & (p.tiles_x - 1)) == 0 ? __builtin_ctz(p.tiles_x) : -1;
+    const int tys = (p.tiles_y & (p.tiles_y - 1)) == 0 ? __builtin_ctz(p.tiles_y) : -1;
+    int tsk = 0;      // (probes: tile counter of the phase stamps)
     for (; tile < tend; tile += tstep) {
-        int t = tile;
-        const int tx = t % p.tiles_x; t /= p.tiles_x;
-        const int ty = t % p.tiles_y; t /= p.tiles_y;
+        int t = tile, tx, ty;
+        if (txs >= 0 && tys >= 0) { tx = t & (p.tiles_x - 1); t >>= txs; ty = t & (p.tiles_y - 1); t >>= tys; }
+        else { tx = t % p.tiles_x; t /= p.tiles_x; ty = t % p.tiles_y; t /= p.tiles_y; }
         const int n0 = t * G::IMG, x0 = tx * G::TW, y0 = ty * TH;
-        const int xgrp_w = NW == 4 ? wvu : (wvu >> 1), xq0 = NW == 4 ? 0 : (wvu & 1) * XPW;      // this wave's channel group / first piece row
+        if (tsk < 3) MTBC_TS(p, 4 * tsk);
         unsigned pixo[XPW];           // byte offset of the halo pixel's piece inside a channel group (out of range: reads 0)
         int pimg[XPW];
 #pragma unroll
         for (int q = 0; q < XPW; ++q) {
-            const int hp = lane + 64 * (xq0 + q);
-            const int img = hp / (HR * HC), rem = hp % (HR * HC);
-            const int row = rem / HC, col = rem % HC;
-            const int y = y0 + row - 1, x = x0 + col - 1;
-            const bool ok = hp < HP && n0 + img < p.N && y >= 0 && y < p.H && x >= 0 && x < p.W && !MTBC_DBG_BIT(p, 1);
+            const int rc = hrc[q];
+            const int img = G::IMG > 1 ? (rc >> 20) : 0;
+            const int y = y0 + ((rc >> 10) & 1023) - 1, x = x0 + (rc & 1023) - 1;
+            const bool ok = rc >= 0 && (G::IMG == 1 || n0 + img < p.N) && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
             pixo[q] = ok ? 16u * (unsigned)(y * p.W + x) : 0xfffffff0u;
             pimg[q] = ok ? img : 0;
         }
@@ -1176,12 +1203,12 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 4) void conv3x3_igemm_c8_ker
         typedef __attribute__((address_space(1))) pre_u32x2 gpre2;
         pre_u32x2 zpre[O8 == 2 ? MT : 1][4];
         if constexpr (O8 == 2) {
-            const int nn = GEO == 2 ? n0 + wv : n0;
+            const int nn = GEO == 2 ? n0 + wvu : n0;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 int y, x;
-                if (GEO == 0) { y = y0 + 2 * wv + (g >> 1); x = x0 + 16 * (g & 1) + j; }
-                else if (GEO == 1) { y = y0 + 4 * wv + g; x = x0 + j; }
+                if (GEO == 0) { y = y0 + 2 * wvu + (g >> 1); x = x0 + 16 * (g & 1) + j; }
+                else if (GEO == 1) { y = y0 + 4 * wvu + g; x = x0 + j; }
                 else { y = y0 + 2 * g + (j >> 3); x = x0 + (j & 7); }
                 const bool ok = nn < p.N && y < p.H && x < p.W;
 #pragma unroll
@@ -1199,7 +1226,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 4) void conv3x3_igemm_c8_ker
             {   // ---- X: wave w (wave pair w/2 for 8 waves) brings one channel group of the chunk, 64 halo pixels x 16 bytes per instruction
                 const int c0 = ch * LPKC + 8 * xgrp_w;
                 const bool xgrp = c0 < p.Cin;
-                const SegL sr = segl_ref(seg_in, xgrp ? c0 : 0);
+                const SegL sr = segl_ref_n(seg_in, xgrp ? c0 : 0, p.in.n);
                 const unsigned long long pu = reinterpret_cast<unsigned long long>(sr.ptr);
                 const unsigned plo = __builtin_amdgcn_readfirstlane((unsigned)pu), phi = __builtin_amdgcn_readfirstlane((unsigned)(pu >> 32));
                 const unsigned blo = __builtin_amdgcn_readfirstlane((unsigned)sr.bs), bhi = __builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)sr.bs >> 32));
@@ -1227,7 +1254,9 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 4) void conv3x3_igemm_c8_ker
                 }
                 w_have = ch;
             }
+            if (ch == 0 && tsk < 3) MTBC_TS(p, 4 * tsk + 1);
             asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+            if (ch == 0 && tsk < 3) MTBC_TS(p, 4 * tsk + 2);
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
                 const int toff = (tap / 3) * HC + tap % 3;
@@ -1247,7 +1276,11 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 4) void conv3x3_igemm_c8_ker
                     }
             }
         }
-        c8_epilogue<MT, GEO, F16, NW, O8>(p, acc, seg_out, bias_s, n0, y0, x0, tx, ty, mt0, wv, j, kg, HW, zpre);
+        if (tsk < 3) MTBC_TS(p, 4 * tsk + 3);
+        if (n0 + G::IMG <= p.N && y0 + TH <= p.H && x0 + G::TW <= p.W) c8_epilogue<MT, GEO, F16, NW, O8, true>(p, acc, seg_out, bias_s, n0, y0, x0, tx, ty, mt0, wvu, j, kg, HW, zpre);
+        else c8_epilogue<MT, GEO, F16, NW, O8, false>(p, acc, seg_out, bias_s, n0, y0, x0, tx, ty, mt0, wvu, j, kg, HW, zpre);
+        if (tsk < 3) MTBC_TS(p, 12 + tsk);
+        ++tsk;
     }
 }
 
@@ -1442,7 +1475,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_igemm_c8_ring_kernel(const Con
         }
         int zpre = 0;
         MTBC_TS(p, 6);
-        c8_epilogue<MT, GEO, F16, NW, O8>(p, acc, seg_out, bias_s, n0, y0, x0, tx, ty, mt0, wv, j, kg, HW, zpre);
+        if (y0 + TH <= p.H && x0 + G::TW <= p.W) c8_epilogue<MT, GEO, F16, NW, O8, true>(p, acc, seg_out, bias_s, n0, y0, x0, tx, ty, mt0, wvu, j, kg, HW, zpre);
+        else c8_epilogue<MT, GEO, F16, NW, O8, false>(p, acc, seg_out, bias_s, n0, y0, x0, tx, ty, mt0, wvu, j, kg, HW, zpre);
         MTBC_TS(p, 7);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the stores: the next tile counts its DMA instructions from zero
         MTBC_TS(p, 8);
@@ -3204,6 +3238,34 @@ int launch_igemm_c8(const ConvP& p, int mblocks, bool f16, hipStream_t st) {
     if (gx < 8) gx = 8;
     if (gx > p.ntiles) gx = p.ntiles;
     const dim3 grid(gx, mblocks);
+#ifdef MTBC_PROBES
+    // MTBC_C8_TS=1: phase timestamps of the first three tiles of every block (thread 0) -- a timing microscope, not a product path
+    static const int ts_env = mtbc_probe_int("MTBC_C8_TS", 0);
+    if (ts_env && (size_t)gx * mblocks <= 4096) {
+        ConvP q = p;
+        const size_t nb = (size_t)gx * mblocks;
+        static unsigned long long* dts = nullptr;
+        if (!dts) (void)hipMalloc(&dts, 4096 * 16 * sizeof(unsigned long long));
+        (void)hipMemsetAsync(dts, 0, nb * 16 * sizeof(unsigned long long), st);
+        q.ts = dts;
+        if (f16) hipLaunchKernelGGL((conv3x3_igemm_c8_kernel<MT, GEO, true, NW, O8>), grid, dim3(64 * NW), lds, st, q);
+        else hipLaunchKernelGGL((conv3x3_igemm_c8_kernel<MT, GEO, false, NW, O8>), grid, dim3(64 * NW), lds, st, q);
+        (void)hipStreamSynchronize(st);
+        static unsigned long long hts[4096 * 16];
+        (void)hipMemcpy(hts, dts, nb * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+        unsigned long long t0 = ~0ull;
+        for (size_t b = 0; b < nb; ++b) if (hts[b * 16] && hts[b * 16] < t0) t0 = hts[b * 16];
+        double mean[15] = {0}; int cnt[15] = {0};
+        for (size_t b = 0; b < nb; ++b)
+            for (int k = 0; k < 15; ++k) if (hts[b * 16 + k]) { mean[k] += (double)(hts[b * 16 + k] - t0) * 0.01; ++cnt[k]; }
+        for (int k = 0; k < 15; ++k) if (cnt[k]) mean[k] /= cnt[k];
+        fprintf(stderr, "c8_ts %d->%d @%dx%d MT%d NW%d O8=%d blocks %zu tiles %d | mean us since the first block's start:", p.Cin, p.Cout, p.H, p.W, MT, NW, O8, nb, p.ntiles);
+        for (int k = 0; k < 3; ++k)
+            fprintf(stderr, "  tile%d: start %.2f issued %.2f landed %.2f mfma done %.2f epilogue done %.2f", k, mean[4 * k], mean[4 * k + 1], mean[4 * k + 2], mean[4 * k + 3], mean[12 + k]);
+        fprintf(stderr, "\n");
+        return MTBC_OK;
+    }
+#endif
     if (f16) hipLaunchKernelGGL((conv3x3_igemm_c8_kernel<MT, GEO, true, NW, O8>), grid, dim3(64 * NW), lds, st, p);
     else hipLaunchKernelGGL((conv3x3_igemm_c8_kernel<MT, GEO, false, NW, O8>), grid, dim3(64 * NW), lds, st, p);
     MTBC_CHECK_LAUNCH();
