@@ -2064,7 +2064,15 @@ struct WgC8P {
     int tiles_x, tiles_y, total_tiles, tiles_per_split, ciblocks;
     int hack;
     int coblocks, cit, segs, seg_tiles, depth;   // conv3x3_wgrad_c8w_kernel: input-channel tiles of 16 per block; row segments per strip, steps (4 rows) per segment
+#ifdef MTBC_PROBES
+    unsigned long long* ts;            // phase timestamps (MTBC_WG_TS=1): [block][16] ticks of the 100 MHz clock
+#endif
 };
+#ifdef MTBC_PROBES
+#define MTBC_WTS(p, k) do { if ((p).ts && threadIdx.x == 0) (p).ts[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 16 + (k)] = wall_clock64(); } while (0)
+#else
+#define MTBC_WTS(p, k) do { } while (0)
+#endif
 template <bool F16, int GEO>
 __global__ __launch_bounds__(256, 4) void conv3x3_wgrad_c8_kernel(const WgC8P p) {
     using G = C8WGeo<GEO>;
@@ -2136,10 +2144,14 @@ __global__ __launch_bounds__(256, 4) void conv3x3_wgrad_c8_kernel(const WgC8P p)
 #pragma unroll
     for (int e = 0; e < 8; ++e) ones[e] = 1.0f;
 
+    MTBC_WTS(p, 0);
     for (int tile = t_begin; tile < t_end; ++tile) {
         lds_barrier();                         // everyone is done reading the previous tile
+        if (tile - t_begin < 3) MTBC_WTS(p, 1 + 3 * (tile - t_begin));
         issue(tile);
+        if (tile - t_begin < 3) MTBC_WTS(p, 2 + 3 * (tile - t_begin));
         asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        if (tile - t_begin < 3) MTBC_WTS(p, 3 + 3 * (tile - t_begin));
 #pragma unroll
         for (int ksl = 0; ksl < 2; ++ksl) {
             const int step = 2 * kh + ksl;     // 32 pixels per step: one tile row (GEO 0) or two (GEO 1)
@@ -2185,7 +2197,9 @@ __global__ __launch_bounds__(256, 4) void conv3x3_wgrad_c8_kernel(const WgC8P p)
         }
     }
     // sum the two row halves (waves 2,3 -> waves 0,1) through LDS, then one partial per block
+    MTBC_WTS(p, 10);
     __syncthreads();
+    MTBC_WTS(p, 11);
     f32x4* red = reinterpret_cast<f32x4*>(smemc8);        // [it][18][64] + [2][64] f32x4
     if (kh == 1) {
 #pragma unroll
@@ -2217,6 +2231,7 @@ __global__ __launch_bounds__(256, 4) void conv3x3_wgrad_c8_kernel(const WgC8P p)
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) dst[tap] = acc[c][tap][r] + red[(it * 18 + c * 9 + tap) * 64 + lane][r];
         }
+    MTBC_WTS(p, 12);
 }
 
 // ------------------------------------------------------------------ wgrad on channel-blocked operands, wide blocks + rolling rows ("c8w", round 3)
@@ -2405,18 +2420,22 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     // the instructions of the later batches were outstanding: vmcnt counts down in issue order) and every wave has finished step
     // t - 1, whose four oldest rows / dz stage the batch issued next overwrites.
     const int nw = ((p.hack & 1) ? 2 : 4) * ((xok[0] ? 1 : 0) + (xok[1] ? 1 : 0)) + (zok ? 2 : 0);       // DMA instructions of this wave per steady batch
+    MTBC_WTS(p, 0);
     issue_x(0, 0, 6);
     issue_z(0, 0);
     for (int k = 1; k < D && k < nt; ++k) { issue_x(TH * k + 2, TH * k + 2, 4); issue_z(k, k); }       // (4k + 2 + 3 < RING for k < D)
+    MTBC_WTS(p, 1);
     int b4 = 0, bn = (TH * D + 2) % RING, zs = 0, zn = D % (D + 1);     // (4 t) % RING, slot of the first row of batch t + D, dz stage of t / of t + D
     for (int t = 0; t < nt; ++t) {
         const int later = min(nt - 1 - t, D - 1);
         c8w_wait_vm(later * nw);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (t >= 2 && t < 5) MTBC_WTS(p, 2 + 3 * (t - 2));          // (steps 2 .. 4: the steady state)
         if (t + D < nt && !(MTBC_DBG_HACK(p) & 4)) {
             issue_x(TH * (t + D) + 2, bn, 4);
             issue_z(t + D, zn);
         }
+        if (t >= 2 && t < 5) MTBC_WTS(p, 3 + 3 * (t - 2));
         const unsigned short* smz = smemw + zs * ZSTAGE;
         if (MTBC_DBG_HACK(p) & 2) { MTBC_C8W_ADVANCE(); continue; }        // TIMING ONLY: no fragment reads, no MFMAs
         // The four K-steps of a step as ONE straight-line body per (valid pair slots of this wave, bias wave or not): a wave-uniform
@@ -2495,8 +2514,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         // (pair slots this wave does not own are multiplied too -- their accumulators are never stored: one straight-line body
         //  per kernel keeps the register allocation within 128; COT = 2 affords a second body for the waves with ONE pair)
         if (COT == 2 && !pok[1]) body(I1{}); else body(I2{});
+        if (t >= 2 && t < 5) MTBC_WTS(p, 4 + 3 * (t - 2));
         MTBC_C8W_ADVANCE();
     }
+    MTBC_WTS(p, 11);
     float* prow_base = p.partial + (size_t)split * p.prow;
     if (do_bias && j == 0) {
 #pragma unroll
@@ -2521,6 +2542,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 dst[0] = acc[i][c][0][r]; dst[1] = acc[i][c][1][r]; dst[2] = acc[i][c][2][r];
             }
     }
+    MTBC_WTS(p, 12);
 }
 
 // ------------------------------------------------------------------ wgrad on channel-blocked operands, 16 x 16 maps ("c8i", round 3)
@@ -3805,6 +3827,18 @@ int mtbc_conv3x3_wgrad(const mtbc_conv3x3_args* a, void* stream) {
         p.ciblocks = w.ciblocks; p.coblocks = w.coblocks; p.cit = w.cit; p.segs = w.segs; p.seg_tiles = w.seg_tiles; p.depth = w.depth;
         { static const int hk = mtbc_probe_int("MTBC_C8W_HACK", 0); p.hack = hk; }
         const dim3 grid = (w.c8w || w.c8i) ? dim3(w.nsplit * w.coblocks * w.ciblocks) : dim3(w.nsplit, w.coblocks * w.ciblocks);
+#ifdef MTBC_PROBES
+        // MTBC_WG_TS=1: phase timestamps of every block (thread 0) of the 32 x 32 / wide-block weight-gradient kernels, printed after the launch
+        static const int wts_env = mtbc_probe_int("MTBC_WG_TS", 0);
+        static unsigned long long* wdts = nullptr;
+        const size_t wnb = (size_t)grid.x * grid.y;
+        p.ts = nullptr;
+        if (wts_env && !w.c8i && wnb <= 4096) {
+            if (!wdts) (void)hipMalloc(&wdts, 4096 * 16 * sizeof(unsigned long long));
+            (void)hipMemsetAsync(wdts, 0, wnb * 16 * sizeof(unsigned long long), st);
+            p.ts = wdts;
+        }
+#endif
         if (w.c8i) {
             const size_t lds = c8i_lds_bytes(w.cit, w.cot);
             const dim3 gridi(w.nsplit * w.coblocks * w.ciblocks);
@@ -3856,6 +3890,28 @@ int mtbc_conv3x3_wgrad(const mtbc_conv3x3_args* a, void* stream) {
             else hipLaunchKernelGGL((conv3x3_wgrad_c8_kernel<false, 0>), grid, dim3(256), C8W_LDS, st, p);
         }
         MTBC_CHECK_LAUNCH();
+#ifdef MTBC_PROBES
+        if (p.ts) {
+            (void)hipStreamSynchronize(st);
+            static unsigned long long hts[4096 * 16];
+            (void)hipMemcpy(hts, wdts, wnb * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+            unsigned long long t0 = ~0ull;
+            for (size_t b = 0; b < wnb; ++b) if (hts[b * 16] && hts[b * 16] < t0) t0 = hts[b * 16];
+            double mean[13] = {0}; int cnt[13] = {0};
+            for (size_t b = 0; b < wnb; ++b)
+                for (int k = 0; k < 13; ++k) if (hts[b * 16 + k]) { mean[k] += (double)(hts[b * 16 + k] - t0) * 0.01; ++cnt[k]; }
+            for (int k = 0; k < 13; ++k) if (cnt[k]) mean[k] /= cnt[k];
+            fprintf(stderr, "wg_ts %s %d->%d @%dx%d blocks %zu | mean us since the first block's entry: entry %.2f", w.c8w ? "c8w" : "c8", p.Cin, p.Cout, p.H, p.W, wnb, mean[0]);
+            if (w.c8w) {
+                fprintf(stderr, " first rows issued %.2f", mean[1]);
+                for (int k = 0; k < 3; ++k) fprintf(stderr, " | step %d: landed %.2f next issued %.2f mfma done %.2f", k + 2, mean[2 + 3 * k], mean[3 + 3 * k], mean[4 + 3 * k]);
+                fprintf(stderr, " | loop done %.2f stored %.2f\n", mean[11], mean[12]);
+            } else {
+                for (int k = 0; k < 3; ++k) fprintf(stderr, " | tile %d: start %.2f issued %.2f landed %.2f", k, mean[1 + 3 * k], mean[2 + 3 * k], mean[3 + 3 * k]);
+                fprintf(stderr, " | loop done %.2f halves in LDS %.2f stored %.2f\n", mean[10], mean[11], mean[12]);
+            }
+        }
+#endif
         if (direct) return MTBC_OK;
         // one row per split = the weight-gradient partial followed by the bias-gradient partial: ONE reduction launch for both
         return mtbc_i_splitk_reduce2(partial, a->dw, a->dbias, w.nsplit, wel, a->dbias ? (size_t)a->Cout : 0, a->accumulate_dw, st);
