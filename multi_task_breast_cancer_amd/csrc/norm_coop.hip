@@ -54,7 +54,15 @@ struct CoP {
     const float* pg; const unsigned short* pa; int W;      // backward: gradient of a 2 x 2 max-pool of this activation (pooled fp32 planes + argmax codes), or nullptr
     unsigned short* py8; unsigned short* parg;             // forward (streaming pass): the 2 x 2 max-pool of the activation + its argmax codes, or nullptr
     unsigned short* y16;                     // forward (streaming pass): the planar copy as 16-bit planes (N,C,H,W) of the output type instead of `y`, or nullptr
+#ifdef MTBC_PROBES
+    unsigned long long* ts;                  // phase timestamps of the channel-group backward (MTBC_INB_TS=1): [block][16] ticks of the 100 MHz clock
+#endif
 };
+#ifdef MTBC_PROBES
+#define MTBC_NTS(p, k) do { if ((p).ts && threadIdx.x == 0) (p).ts[(size_t)blockIdx.x * 16 + (k)] = wall_clock64(); } while (0)
+#else
+#define MTBC_NTS(p, k) do { } while (0)
+#endif
 
 typedef float co_f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 co_bf16x2 __attribute__((ext_vector_type(2)));
@@ -288,10 +296,12 @@ __global__ __launch_bounds__(THREADS, THREADS >= 512 ? 4 : 2) void in_bwd_c8_ker
     const int slab = p.HW / p.T;
     const float inv = 1.0f / (float)p.HW;
     unsigned seq = 0;
-    for (int item = team; item < p.items; item += p.nteams) {
+    int itk = 0;          // (probes: item counter of the phase stamps)
+    for (int item = team; item < p.items; item += p.nteams, ++itk) {
         const int n = item / p.G8, g = item % p.G8;
         const size_t plane0 = (size_t)n * p.C + 8 * g;
         const int plane_b = p.HW * 4;
+        if (itk < 2) MTBC_NTS(p, 7 * itk);
         // (the pixel offsets are recomputed per item from an opaque copy of the thread index: hoisted out of this loop they lived across the
         //  team exchange, were spilled, and every reload -- a scratch load, counted by vmcnt -- sat between the z loads of the next item, which
         //  then went out one memory round trip at a time)
@@ -415,8 +425,10 @@ __global__ __launch_bounds__(THREADS, THREADS >= 512 ? 4 : 2) void in_bwd_c8_ker
                 }
             }
         }
+        if (itk < 2) MTBC_NTS(p, 7 * itk + 1);          // loads issued
         if (tid < 8) cq[tid] = myc;
         __syncthreads();
+        if (itk < 2) MTBC_NTS(p, 7 * itk + 2);          // constants published (their loads have landed)
         float ss[16], sw[9];
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
@@ -451,8 +463,11 @@ __global__ __launch_bounds__(THREADS, THREADS >= 512 ? 4 : 2) void in_bwd_c8_ker
             if (tid == 8 && g == 0) p.r1db[(size_t)n * p.T + member] = tot[8];
             __syncthreads();
         }
+        if (itk < 2) MTBC_NTS(p, 7 * itk + 3);          // tensor data landed, per-thread sums formed
         block_reduce_lds<16, THREADS>(ss, red, tot);
+        if (itk < 2) MTBC_NTS(p, 7 * itk + 4);          // block sums
         if constexpr (COOP) team_sum<16, THREADS>(tot, mb, member, p.T, seq, epoch, hdr, xch);
+        if (itk < 2) MTBC_NTS(p, 7 * itk + 5);          // team exchange done
         if (tid < 8) {
             cst[0][tid] = myc.y * myc.z;
             cst[1][tid] = tot[tid] * inv; cst[2][tid] = tot[8 + tid] * inv;
@@ -486,9 +501,12 @@ __global__ __launch_bounds__(THREADS, THREADS >= 512 ? 4 : 2) void in_bwd_c8_ker
             block_reduce_lds<8, THREADS>(s3, red, tot);
             if (tid < 8) p.part3[(plane0 + tid) * p.T + member] = tot[tid];
         }
+        if (itk < 2) MTBC_NTS(p, 7 * itk + 6);          // dz stored (issued), parameter partials
         __syncthreads();                     // cst / tot are rewritten by the next item
     }
+    MTBC_NTS(p, 14);
     if constexpr (COOP) coop_finish(hdr, epoch);
+    MTBC_NTS(p, 15);
 }
 
 // ---------------------------------------------------------------- statistics from the conv epilogue + streaming normalisation
@@ -823,9 +841,39 @@ template <bool BWD> CoPlan plan_team(int items, int HW, const Var& v, int reserv
 Var var_of(const mtbc_instnorm_args* a) { return Var{a->out16_type == 2, a->z_layout == MTBC_LAYOUT_C8 ? ((a->z_type == 2 && a->out16_type == 1) ? 2 : 1) : 0, a->dy_layout == MTBC_LAYOUT_C8 ? (a->n_dy_extra ? 2 : 1) : 0}; }
 
 template <bool BWD, int THREADS, int PPT, bool COOP>
-void launch_c8(const CoP& p, int grid, hipStream_t st) {
+void launch_c8(const CoP& p0, int grid, hipStream_t st) {
+    CoP p = p0;
     const Var v{p.f16 != 0, p.z8 ? (p.zf16 && !p.f16 ? 2 : 1) : 0, p.dy8 ? (p.dyx ? 2 : 1) : 0};      // (planar dy: a second planar contribution is a runtime branch)
+#ifdef MTBC_PROBES
+    // MTBC_INB_TS=1: phase timestamps of every workgroup (thread 0) of the channel-group backward, printed after the launch
+    static const int ts_env = mtbc_probe_int("MTBC_INB_TS", 0);
+    static unsigned long long* dts = nullptr;
+    p.ts = nullptr;
+    if (BWD && ts_env && grid <= 4096) {
+        if (!dts) (void)hipMalloc(&dts, 4096 * 16 * sizeof(unsigned long long));
+        (void)hipMemsetAsync(dts, 0, (size_t)grid * 16 * sizeof(unsigned long long), st);
+        p.ts = dts;
+    }
+#endif
     with_kernel<BWD, THREADS, PPT, COOP>(v, [&](auto k) { hipLaunchKernelGGL(decltype(k)::value, dim3(grid), dim3(THREADS), 0, st, p); return 0; });
+#ifdef MTBC_PROBES
+    if (p.ts) {
+        (void)hipStreamSynchronize(st);
+        static unsigned long long hts[4096 * 16];
+        (void)hipMemcpy(hts, dts, (size_t)grid * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+        unsigned long long t0 = ~0ull;
+        for (int b = 0; b < grid; ++b) if (hts[b * 16] && hts[b * 16] < t0) t0 = hts[b * 16];
+        double mean[16] = {0}; int cnt[16] = {0};
+        for (int b = 0; b < grid; ++b)
+            for (int k = 0; k < 16; ++k) if (hts[b * 16 + k]) { mean[k] += (double)(hts[b * 16 + k] - t0) * 0.01; ++cnt[k]; }
+        for (int k = 0; k < 16; ++k) if (cnt[k]) mean[k] /= cnt[k];
+        fprintf(stderr, "inb_ts C%d HW%d T%d coop%d threads%d ppt%d grid %d items %d | mean us since the first workgroup's start:", p.C, p.HW, p.T, (int)COOP, THREADS, PPT, grid, p.items);
+        for (int k = 0; k < 2; ++k)
+            fprintf(stderr, " item%d: start %.2f loads issued %.2f constants %.2f data + thread sums %.2f block sums %.2f exchange %.2f stored %.2f |", k,
+                    mean[7 * k], mean[7 * k + 1], mean[7 * k + 2], mean[7 * k + 3], mean[7 * k + 4], mean[7 * k + 5], mean[7 * k + 6]);
+        fprintf(stderr, " loop done %.2f finished %.2f\n", mean[14], mean[15]);
+    }
+#endif
 }
 // one workgroup per item, sized to the plane
 template <bool BWD> void launch_solo(CoP& p, hipStream_t st) {
