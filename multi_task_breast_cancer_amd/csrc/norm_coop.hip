@@ -314,19 +314,6 @@ __global__ __launch_bounds__(THREADS, THREADS >= 512 ? 4 : 2) void in_bwd_c8_ker
         float4 myc = make_float4(0.f, 1.f, 1.f, 0.f);
         if (tid < 8) myc = make_float4(p.mean[plane0 + tid], p.rstd[plane0 + tid], p.gamma ? p.gamma[8 * g + tid] : 1.f, p.beta ? p.beta[8 * g + tid] : 0.f);
         float xh[8][PPT], gy[8][PPT];
-        // the head's gradient at this thread's pixels (0 without a head, and outside the slab): requested FIRST, with the tensor loads behind it
-        // in one batch -- loaded where it is used (below, behind the conversions of dy) it was a second full memory round trip per item
-        float hv[PPT];
-#pragma unroll
-        for (int k = 0; k < PPT; ++k) hv[k] = 0.f;
-        if (p.r1) {
-            const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.r1 + (size_t)n * p.HW), 0, p.HW * 4, 0x00020000);
-#pragma unroll
-            for (int k = 0; k < PPT; ++k) {
-                const int px = tl + THREADS * k;
-                hv[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr, px < slab ? (member * slab + px) * 4 : 0x7ffffff0, 0, 0));
-            }
-        }
         // out-of-slab lanes: offsets past the buffer, the bounds check returns 0
         if constexpr (ZC8 != 0) {
             const __amdgpu_buffer_rsrc_t zr = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.z8 + ((size_t)n * p.G8 + g) * p.HW * 8), 0, p.HW * 16, 0x00020000);
@@ -395,10 +382,19 @@ __global__ __launch_bounds__(THREADS, THREADS >= 512 ? 4 : 2) void in_bwd_c8_ker
 #pragma unroll
                 for (int c = 0; c < 8; ++c) gy[c][k] = 0.f;
         }
+        float hv[PPT];          // the head's gradient at this thread's pixels (0 without a head, and outside the slab)
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) hv[k] = 0.f;
         if (p.r1) {
             // the input gradient of a ONE-output 1x1 conv head reading this activation is rank 1, w[c] * dyhead[n, pixel]: formed
-            // here from the head's 4-byte-per-pixel gradient (hv, requested above) instead of being written (4 B x C per pixel) by the head's
-            // dgrad and read back -- same products, added in the order the fan-in would have added them last
+            // here from the head's 4-byte-per-pixel gradient instead of being written (4 B x C per pixel) by the head's dgrad
+            // and read back -- same products, added in the order the fan-in would have added them last
+            const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.r1 + (size_t)n * p.HW), 0, p.HW * 4, 0x00020000);
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) {
+                const int px = tl + THREADS * k;
+                hv[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr, px < slab ? (member * slab + px) * 4 : 0x7ffffff0, 0, 0));
+            }
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
                 const float wc = p.r1w[8 * g + c];
