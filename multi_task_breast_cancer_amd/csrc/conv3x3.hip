@@ -2639,10 +2639,14 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_c8i_kernel(const WgC8P p) {
     for (int e = 0; e < 8; ++e) ones[e] = 1.0f;
 
     int stage = 0;
+    MTBC_WTS(p, 0);
     if (n_begin < n_end) issue(n_begin, 0);
+    MTBC_WTS(p, 1);
     for (int n = n_begin; n < n_end; ++n) {
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");      // image n has landed for everybody; everybody is done with image n - 1
+        if (n - n_begin < 3) MTBC_WTS(p, 2 + 3 * (n - n_begin));
         if (n + 1 < n_end) issue(n + 1, stage ^ 1);
+        if (n - n_begin < 3) MTBC_WTS(p, 3 + 3 * (n - n_begin));
         const unsigned short* sm = smemi + stage * SS;
         stage ^= 1;
         // the eight K-steps as one straight-line, software-pipelined body (see conv3x3_wgrad_c8w_kernel): pair slots this wave does not own
@@ -2712,7 +2716,9 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_c8i_kernel(const WgC8P p) {
         };
         using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
         if (COT == 2 && !pok[1]) body(I1{}); else body(I2{});
+        if (n - n_begin < 3) MTBC_WTS(p, 4 + 3 * (n - n_begin));
     }
+    MTBC_WTS(p, 11);
     float* prow_base = p.partial + (size_t)split * p.prow;
     if (do_bias && j == 0) {
 #pragma unroll
@@ -2737,6 +2743,7 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_c8i_kernel(const WgC8P p) {
                 dst[0] = acc[i][c][0][r]; dst[1] = acc[i][c][1][r]; dst[2] = acc[i][c][2][r];
             }
     }
+    MTBC_WTS(p, 12);
 }
 
 // fp32 planar (N,C,H,W) <-> 16-bit channel-blocked [N][C/8][H*W][8]; one thread = one 16-byte piece
@@ -3833,7 +3840,7 @@ int mtbc_conv3x3_wgrad(const mtbc_conv3x3_args* a, void* stream) {
         static unsigned long long* wdts = nullptr;
         const size_t wnb = (size_t)grid.x * grid.y;
         p.ts = nullptr;
-        if (wts_env && !w.c8i && wnb <= 4096) {
+        if (wts_env && wnb <= 4096) {
             if (!wdts) (void)hipMalloc(&wdts, 4096 * 16 * sizeof(unsigned long long));
             (void)hipMemsetAsync(wdts, 0, wnb * 16 * sizeof(unsigned long long), st);
             p.ts = wdts;
@@ -3901,8 +3908,12 @@ int mtbc_conv3x3_wgrad(const mtbc_conv3x3_args* a, void* stream) {
             for (size_t b = 0; b < wnb; ++b)
                 for (int k = 0; k < 13; ++k) if (hts[b * 16 + k]) { mean[k] += (double)(hts[b * 16 + k] - t0) * 0.01; ++cnt[k]; }
             for (int k = 0; k < 13; ++k) if (cnt[k]) mean[k] /= cnt[k];
-            fprintf(stderr, "wg_ts %s %d->%d @%dx%d blocks %zu | mean us since the first block's entry: entry %.2f", w.c8w ? "c8w" : "c8", p.Cin, p.Cout, p.H, p.W, wnb, mean[0]);
-            if (w.c8w) {
+            fprintf(stderr, "wg_ts %s %d->%d @%dx%d blocks %zu | mean us since the first block's entry: entry %.2f", w.c8i ? "c8i" : w.c8w ? "c8w" : "c8", p.Cin, p.Cout, p.H, p.W, wnb, mean[0]);
+            if (w.c8i) {
+                fprintf(stderr, " first image issued %.2f", mean[1]);
+                for (int k = 0; k < 3; ++k) fprintf(stderr, " | image %d: landed %.2f next issued %.2f mfma done %.2f", k, mean[2 + 3 * k], mean[3 + 3 * k], mean[4 + 3 * k]);
+                fprintf(stderr, " | loop done %.2f stored %.2f\n", mean[11], mean[12]);
+            } else if (w.c8w) {
                 fprintf(stderr, " first rows issued %.2f", mean[1]);
                 for (int k = 0; k < 3; ++k) fprintf(stderr, " | step %d: landed %.2f next issued %.2f mfma done %.2f", k + 2, mean[2 + 3 * k], mean[3 + 3 * k], mean[4 + 3 * k]);
                 fprintf(stderr, " | loop done %.2f stored %.2f\n", mean[11], mean[12]);
