@@ -189,16 +189,22 @@ def run_mode(args, dtype, dev, rank, world, dist, want_roofline):
     # HBM traffic per launch comes from PMC counters, which cannot be collected inside a timed run: the figure is read
     # from the committed summary of the separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same command
     # (tools/profile_round.sh); `traffic_source` names the file, and the field is null when no summary fits the build
-    traffic, traffic_source = None, None
-    for tag in ("r03", "r02c", "r02b", "r02", "r01"):
+    traffic, traffic_source, traffic_step = None, None, None
+    fam_prefix = {"f32": ("conv3x3_igemm_dma_kernel", "conv3x3_igemm_kernel"),
+                  "bf16": ("conv3x3_igemm_c8_kernel", "conv3x3_igemm_c8_ring_kernel"),
+                  "f16": ("conv3x3_igemm_c8_kernel", "conv3x3_igemm_c8_ring_kernel")}[dtype]
+    for tag in ("r04", "r03", "r02c", "r02b", "r02", "r01"):
         tpath = os.path.join(ROOT, "profiles", f"{tag}_hbm_traffic_{dtype}.json")
         if not os.path.exists(tpath):
             continue
         ks = json.load(open(tpath))["kernels"]
-        sel = [v for k, v in ks.items() if k.startswith(names[0])]
+        # the SAME launch set as the algorithmic bytes above: every template instance of every kernel of the family (the ring kernel of the
+        # deep levels included -- round 3 selected `startswith("conv3x3_igemm_c8_kernel")` only and compared it with bytes over all launches)
+        sel = [v for k, v in ks.items() if k.split("<")[0] in fam_prefix]
         if sel:
             w = sum(v["launches_in_trace"] for v in sel)
             traffic = round(sum(v["hbm_bytes_per_launch"] * v["launches_in_trace"] for v in sel) / w)
+            traffic_step = traffic * fam["igemm"][3]          # launch-weighted mean x this step's launches of the family
             traffic_source = f"profiles/{tag}_hbm_traffic_{dtype}.json (separate rocprofv3 --pmc passes, FETCH_SIZE x2 + WRITE_SIZE; not measured in this run)"
             break
     ig = fam["igemm"]
@@ -210,7 +216,11 @@ def run_mode(args, dtype, dev, rank, world, dist, want_roofline):
     else:
         roof.update({"achieved": round(ig[1] / ig[2] / 1e9, 1), "peak": PEAK_HBM_BYTES / 1e9, "unit": "GB/s",
                      "frac": round(ig[1] / ig[2] / PEAK_HBM_BYTES, 4)})
-    roof.update({"traffic": traffic, "traffic_source": traffic_source, "launches_per_step": ig[3], "avg_launch_ms": round(ig[2] / ig[3] * 1e3, 4),
+    roof.update({"traffic": traffic, "traffic_source": traffic_source,
+                 "traffic_GB_per_step": None if traffic_step is None else round(traffic_step / 1e9, 3),
+                 "algorithmic_GB_per_step": round(ig[1] / 1e9, 3),
+                 "traffic_over_algorithmic": None if traffic_step is None else round(traffic_step / ig[1], 3),
+                 "launches_per_step": ig[3], "avg_launch_ms": round(ig[2] / ig[3] * 1e3, 4),
                  "algorithmic_gflop_per_launch": round(ig[0] / ig[3] / 1e9, 3),
                  "algorithmic_MB_per_launch": round(ig[1] / ig[3] / 1e6, 1),
                  "tflops": round(ig[0] / ig[2] / 1e12, 2), "frac_of_mfma_peak": round(ig[0] / ig[2] / 1e12 / peak, 4),

@@ -19,6 +19,7 @@ from . import _lib as L
 
 from . import switches as _sw
 
+_sw.refuse_removed()        # a removed switch in the environment is an error here, for every consumer of the engine (bench, trainers, tools)
 # Plan switches (switches.py): each one selects between two step programs that a -m gpu test runs against the oracle / emulation
 _NO_COOP = _sw.flag("MTBC_NO_COOP")
 _NO_GATHER = _sw.flag("MTBC_NO_GATHER")

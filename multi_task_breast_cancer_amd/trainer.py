@@ -260,14 +260,22 @@ class FusedEvalStep:
     `process_segmentation_predicted` (:66-71: sigmoid(last head) > .5 against the mask, `dice_score_from_tensor`), and
     the confusion matrix of `processes_classification_predicted` (:34-63) accumulates on the device: multi-class =
     argmax of softmax vs argmax of the one-hot label (:41-51); binary head (n_classes == 2, ONE logit) = sigmoid > .5
-    vs the {0,1} label (:53-61), classification loss BCEWithLogits (experiment_init.py:242) by torch on the HIP
-    model's logit, as the reference does.  `result()` reads everything back once and returns the reference's 6-tuple
+    vs the {0,1} label (:53-61), classification loss BCEWithLogits (experiment_init.py:242) = the focal kernel's one-logit form
+    inside the same step program.  `cls_criterion` ("Focal" | "CE") is the criterion the run TRAINS with (the reference validates with
+    the training criterion, and `scheduler.step(val_loss)` runs on that value, training_multitask.py:234-237): with the same
+    (alpha, weighting, criterion) the evaluation step shares the training step's compiled plan at equal (N, H, W).  `result()` reads
+    everything back once and returns the reference's 6-tuple
     (avg_val_loss, avg_val_dice, val_acc, val_f1, avg_seg_val_loss, avg_cls_val_loss)."""
 
     def __init__(self, model, alpha: float, inversely_weighted: bool = True, n_classes: int = 3,
-                 focal_weight: Optional[torch.Tensor] = None):
+                 focal_weight: Optional[torch.Tensor] = None, cls_criterion: str = "Focal"):
         self.model, self.alpha, self.iw, self.n_classes = model, float(alpha), bool(inversely_weighted), n_classes
         self.binary = n_classes == 2
+        if cls_criterion not in ("Focal", "CE"):
+            raise ValueError(f"unknown classification criterion {cls_criterion!r} (Focal | CE; the binary head always evaluates BCEWithLogits)")
+        self.cls_gamma = 2.0 if cls_criterion == "Focal" else 0.0
+        if cls_criterion == "CE" and focal_weight is not None:       # same refusal as FusedTrainStep
+            raise NotImplementedError("class-weighted CrossEntropyLoss normalises by the weights' sum: use the drop-in loop for it")
         if n_classes > 3:       # the confusion matrix is the reference's 3 x 3 (f1_score(labels=[0, 1, 2]), training_multitask.py:155)
             raise NotImplementedError("FusedEvalStep covers the reference's label set {0, 1, 2} (n_classes <= 3)")
         if self.binary != (getattr(model, "n_classes", n_classes) == 1):
@@ -284,7 +292,7 @@ class FusedEvalStep:
     def __call__(self, image: torch.Tensor, mask: torch.Tensor, label: torch.Tensor) -> None:
         N, _, H, W = image.shape
         st = self.model.compiled(N, H, W, fused_loss={"alpha": self.alpha, "inversely_weighted": self.iw,
-                                                      "focal_weight": self.focal_weight, "binary": self.binary})
+                                                      "focal_weight": self.focal_weight, "binary": self.binary, "cls_gamma": self.cls_gamma})
         st.x.data.copy_(image, non_blocking=True)
         st.mask.copy_(mask, non_blocking=True)
         dev = st.plan.loss_out.device

@@ -54,3 +54,16 @@ def test_labels_follow_the_arguments():
 def test_mismatched_world_size_is_refused():
     r, lines = _run("--gpus", "2", "--cpu-stub", env_extra={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
     assert r.returncode != 0 and not lines and "nproc-per-node" in r.stderr
+
+
+@pytest.mark.timeout(900)
+def test_gpus_8_is_labelled_as_baseline_configs_3():
+    """The driver's scaling run: `python bench.py --gpus 8` (bare interpreter -> 8 ranks of torch.distributed.run; gloo + the stand-in step
+    here) must label its line BASELINE.json configs[3] -- U-Net++ global batch 256 = 32 per GPU x 8 -- and report the whole-job batch."""
+    r, lines = _run("--gpus", "8", "--steps", "2", "--warmup", "1", "--cpu-stub", env_extra={"OMP_NUM_THREADS": "1"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["config"]["baseline_config_index"] == 3
+    assert out["config"]["global_batch"] == 256 and out["config"]["parallelism"] == "dp8" and out["scaling"] == "weak"
+    assert "configs[3]" in out["config"]["workload"]

@@ -95,3 +95,54 @@ def test_two_rank_step_equals_single_rank_global_batch(G, cuts):
     assert rel < 1e-5, rel
     assert (p2 - p1).abs().max().item() < 2e-6
     assert l2[3].item() == 0.0 and abs(l1[0].item()) > 0
+
+
+def test_rccl_collectives_beside_the_cooperative_kernels_at_the_bench_plane_size(monkeypatch):
+    """SURVEY 8(e) readiness on one GPU: the data-parallel step of the BENCH model -- MTUNetPlusPlus, bf16, 256 x 256 planes, i.e. the cooperative
+    InstanceNorm backward in teams of 32 and the wide-block weight gradients -- with REAL RCCL all-reduce kernels on the communication stream
+    (world 1: the collectives still launch) beside the compute stream's cooperative launches, planned the way an 8-rank trainer plans it
+    (coop_reserve_cus = 64).  For 4 buckets (the default), ONE bucket (everything reduced after the last backward op) and 8 (more cuts than
+    the default: every boundary between parameter groups is exercised) the step must reproduce the local step planned with the same
+    reserve BIT FOR BIT, twice in a row, and the cooperative kernels' sticky error word must stay 0 (a member that was not resident would
+    set it).  No reference counterpart: the reference is single-device (experiment_init.py:339-347)."""
+    import torch.distributed as dist
+    from multi_task_breast_cancer_amd.miscellany import seed_everything
+    from multi_task_breast_cancer_amd.nets import MTUNetPlusPlus
+    from multi_task_breast_cancer_amd.optim import FusedAdam
+    from multi_task_breast_cancer_amd.trainer import FusedTrainStep
+    from oracle import torch_oracle as O
+    dev = torch.device("cuda:0")
+    monkeypatch.setenv("MTBC_COOP_RESERVE_CUS", "64")         # world 1 plans like world 8 (trainer.py: the reserve applies when world > 1 or the variable is set)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        batches = [O.synthetic_batch(2, 256, 256, seed=60 + s) for s in range(2)]
+
+        def run(distributed, n_buckets):
+            seed_everything(1993)
+            m = MTUNetPlusPlus(in_channels=1, out_channels=1, n_classes=3, deep_supervision=True).to(dev)
+            m.set_compute("bf16")
+            m.coop_reserve_cus = 64
+            step = FusedTrainStep(m, FusedAdam(m, lr=1e-4, eps=1e-4), alpha=0.5, distributed=distributed, n_buckets=n_buckets)
+            for img, mask, label in batches:
+                l = step(img.to(dev), mask.to(dev), label.to(dev))
+            torch.cuda.synchronize()
+            step.check_nan()                                   # raises MtbcError on a non-zero cooperative error word
+            assert m.coop_reserve_cus == 64
+            assert m.coop_error_word() is not None and int(m.coop_error_word().item()) == 0
+            kinds = {step._st.programs["bwd"].array[i].kind for i in range(step._st.programs["bwd"].n)}
+            return m.flat_p.clone(), m.flat_g.clone(), l.clone(), step
+
+        p0, g0, l0, _ = run(False, 4)
+        for nb in (4, 1, 8):
+            p1, g1, l1, step = run(True, nb)
+            bk = step._st.buckets
+            assert len(bk) == nb, (nb, len(bk))
+            assert [b.start for b in bk] == sorted((b.start for b in bk), reverse=True)
+            assert bk[-1].start == 0 and bk[0].end == step.model.flat_numel and all(a.start == b.end for a, b in zip(bk[:-1], bk[1:]))
+            assert torch.equal(l0, l1), nb
+            assert torch.equal(g0, g1), nb                      # world 1: the sum over ranks is the local gradient itself
+            assert torch.equal(p0, p1), nb
+    finally:
+        dist.destroy_process_group()

@@ -269,7 +269,9 @@ def test_distributed_step_single_rank_rccl_equals_local_step():
                                                  ("MTUNetPlusPlus", "bf16", 64, "z_bf16"),
                                                  # the BASELINE plane sizes: configs[1] (bf16, 256x256: cooperative InstanceNorm backward in teams of 32,
                                                  # wide-block weight gradients) and configs[4] (fp16, 512x512: teams of 128), whole model against the emulation
-                                                 ("MTUNetPlusPlus", "bf16", 256, ""), ("MTUNetPlusPlus", "f16", 512, "")])
+                                                 ("MTUNetPlusPlus", "bf16", 256, ""), ("MTUNetPlusPlus", "f16", 512, ""),
+                                                 # configs[2] in the arithmetic bench.py quotes it in (MTnnUNet, 256 x 256 planes, bf16)
+                                                 ("MTnnUNet", "bf16", 256, "")])
 def test_16bit_mfma_modes_match_their_emulation(arch, dtype, size, arm, monkeypatch):
     """Optional compute modes: conv3x3 MFMA operands rounded to bf16 / fp16 (fp32 storage + accumulation).  Not the
     reference-parity path (that is fp32); the oracle for it is oracle.lowp_conv3x3, which rounds the same operands

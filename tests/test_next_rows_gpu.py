@@ -285,3 +285,46 @@ def test_validation_epoch_with_the_binary_head_matches_oracle():
         assert abs(g_ - w_) < 1e-4, (got, want)
     with pytest.raises(NotImplementedError):
         FusedEvalStep(prod, alpha=0.35, n_classes=5)
+
+
+def test_validation_epoch_with_cross_entropy_matches_oracle_and_shares_the_training_plan():
+    """`classification_criterion: CE` (experiment_init.py:232-262): the reference validates with the criterion it trains with, and
+    `scheduler.step(val_loss)` runs on that value (training_multitask.py:119-159, 234-237).  FusedEvalStep(cls_criterion="CE") reports
+    CrossEntropy -- not Focal -- losses, and with the training step's (alpha, weighting, criterion) it runs on the SAME compiled plan at equal
+    (N, H, W): no second activation arena."""
+    seed_everything(19)
+    prod = MTUNetPlusPlus(in_channels=1, out_channels=1, n_classes=3, deep_supervision=True)
+    O.seed_everything(19)
+    ref = O.build_oracle_model("MTUNetPlusPlus", 1, 1, 3, True)
+    ref.load_state_dict(prod.state_dict())
+    prod = prod.to(DEV)
+    batches = []
+    for s in range(2):
+        img, mask, label = O.synthetic_batch(4, 64, 64, seed=90 + s)
+        batches.append({"image": img, "mask": mask, "label": label})
+    step = FusedEvalStep(prod, alpha=0.5, inversely_weighted=True, cls_criterion="CE")
+    got = validate_one_epoch(step, batches, DEV)
+    tot = seg_s = cls_s = 0.0
+    ref.train(False)
+    ce = torch.nn.CrossEntropyLoss()
+    with torch.no_grad():
+        for b in batches:
+            onehot = torch.nn.functional.one_hot(b["label"].flatten().long(), 3).float()
+            logits, outs = ref(b["image"])
+            seg = torch.sum(torch.stack([O.dice_loss_sigmoid_sq(s_, b["mask"]) / (j + 1) for j, s_ in enumerate(reversed(outs))]))
+            cls = torch.sum(torch.stack([ce(c_, onehot) for c_ in reversed(logits)]))
+            tot += (0.5 * seg + 0.5 * cls).item(); seg_s += seg.item(); cls_s += cls.item()
+    assert abs(got[0] - tot / 2) < 1e-4 and abs(got[4] - seg_s / 2) < 1e-4 and abs(got[5] - cls_s / 2) < 1e-4, (got, tot / 2, cls_s / 2)
+    # the Focal evaluation of the same batches reports another classification loss (gamma 2 down-weights easy samples)
+    focal = validate_one_epoch(FusedEvalStep(prod, alpha=0.5, inversely_weighted=True), batches, DEV)
+    assert focal[5] < got[5] - 1e-3
+    # one compiled plan for training and evaluation with the same criterion
+    n_before = len(prod._steps)
+    train = FusedTrainStep(prod, FusedAdam(prod, lr=1e-4, eps=1e-4), alpha=0.5, inversely_weighted=True, cls_criterion="CE")
+    b = batches[0]
+    train(b["image"].to(DEV), b["mask"].to(DEV), b["label"].to(DEV))
+    assert len(prod._steps) == n_before
+    with pytest.raises(NotImplementedError):
+        FusedEvalStep(prod, alpha=0.5, cls_criterion="CE", focal_weight=torch.ones(3, device=DEV))
+    with pytest.raises(ValueError):
+        FusedEvalStep(prod, alpha=0.5, cls_criterion="BCE")
