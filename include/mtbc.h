@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MTBC_VERSION 200            /* 0.2.0: the argument structs grew in round 2 (fields appended); a binding compiled against
+#define MTBC_VERSION 201            /* 0.2.1 (round 4: mtbc_conv3x3_args.wgrad_sync appended); 0.2.0: the argument structs grew in round 2 (fields appended); a binding compiled against
                                        another version must refuse the library (mtbc_version()) -- layouts are not negotiated */
 #define MTBC_MAX_SEGS 6
 
@@ -128,6 +128,15 @@ typedef struct {
     int32_t out_type;                /* fwd with out_layout C8: 0 = the type of `compute`; 2 with compute = 1 (bf16 operands): the
                                         output is stored as fp16 (saturated at +-65504) -- for conv outputs of O(1) that a norm
                                         follows: 11 significant bits in the same 2 bytes (mtbc_instnorm_args.z_type)              */
+    int32_t* wgrad_sync;             /* wgrad with operand_layout C8 (Cin >= 8), or NULL: mtbc_conv3x3_wgrad_sync_bytes(args) bytes of
+                                        ZEROED device memory (4-byte aligned) that stay the caller's between launches.  With it the
+                                        split-K partials are reduced INSIDE the weight-gradient launch -- the block that stores the last
+                                        partial of a group sums the group in row order (deterministic; no block waits for another, no
+                                        co-residency requirement), a tree of 1 - 3 levels whose top writes dw / dbias -- instead of by a
+                                        second launch.  Every counter is back at zero when the launch ends: one buffer serves all the
+                                        launches of a stream, in order.  Launches on DIFFERENT streams need different buffers.  (backward
+                                        of nn.Conv2d in MTUNetPlusPlus.py:47-81 / MTnnUNet.py:12-16, training_multitask.py:102)       */
+    size_t wgrad_sync_bytes;
 } mtbc_conv3x3_args;
 #define MTBC_LAYOUT_PLANAR 0
 #define MTBC_LAYOUT_C8 1
@@ -180,6 +189,8 @@ int mtbc_conv3x3_pack_many(const mtbc_pack_desc* descs, int32_t n, void* stream)
 /* pixel subsets per image of the forward launch these arguments select (0: the launch does not produce statistics) */
 int32_t mtbc_conv3x3_stats_slots(const mtbc_conv3x3_args* a);
 size_t mtbc_conv3x3_wgrad_workspace(const mtbc_conv3x3_args* a);
+/* bytes of zeroed counters mtbc_conv3x3_args.wgrad_sync needs for these arguments (0: this launch has no in-kernel reduction) */
+size_t mtbc_conv3x3_wgrad_sync_bytes(const mtbc_conv3x3_args* a);
 int mtbc_conv3x3_fwd(const mtbc_conv3x3_args* a, void* stream);
 int mtbc_conv3x3_dgrad(const mtbc_conv3x3_args* a, void* stream);
 int mtbc_conv3x3_wgrad(const mtbc_conv3x3_args* a, void* stream);

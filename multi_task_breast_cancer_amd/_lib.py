@@ -37,7 +37,7 @@ class Conv3x3Args(C.Structure):
                 ("compute", C.c_int32), ("operand_layout", C.c_int32), ("out_accumulate", C.c_int32), ("out_layout", C.c_int32),
                 ("stats_partial", C.c_void_p), ("out_partial", C.c_void_p), ("norm_z", C.c_void_p), ("norm_mean", C.c_void_p),
                 ("norm_rstd", C.c_void_p), ("norm_gamma", C.c_void_p), ("norm_beta", C.c_void_p), ("norm_slope", C.c_float),
-                ("out_type", C.c_int32)]
+                ("out_type", C.c_int32), ("wgrad_sync", C.c_void_p), ("wgrad_sync_bytes", C.c_size_t)]
 
 
 class InstNormArgs(C.Structure):
@@ -218,7 +218,7 @@ class WViewDesc(C.Structure):
 EXPORTS = [
     "mtbc_version", "mtbc_strerror", "mtbc_arch",
     "mtbc_conv3x3_packed_elems", "mtbc_conv3x3_packed_dgrad_elems", "mtbc_conv3x3_pack_fwd",
-    "mtbc_conv3x3_pack_dgrad", "mtbc_conv3x3_packed_lp_elems", "mtbc_conv3x3_pack_lp", "mtbc_conv3x3_pack_many", "mtbc_c8_pack", "mtbc_c8_unpack", "mtbc_c8_pack16", "mtbc_conv3x3_weight_view", "mtbc_conv3x3_weight_view_many", "mtbc_augment_flip_rotate", "mtbc_convT_head_combine", "mtbc_convT_head_expand", "mtbc_conv3x3_wgrad_workspace", "mtbc_conv3x3_stats_slots", "mtbc_conv3x3_fwd", "mtbc_conv3x3_dgrad",
+    "mtbc_conv3x3_pack_dgrad", "mtbc_conv3x3_packed_lp_elems", "mtbc_conv3x3_pack_lp", "mtbc_conv3x3_pack_many", "mtbc_c8_pack", "mtbc_c8_unpack", "mtbc_c8_pack16", "mtbc_conv3x3_weight_view", "mtbc_conv3x3_weight_view_many", "mtbc_augment_flip_rotate", "mtbc_convT_head_combine", "mtbc_convT_head_expand", "mtbc_conv3x3_wgrad_workspace", "mtbc_conv3x3_wgrad_sync_bytes", "mtbc_conv3x3_stats_slots", "mtbc_conv3x3_fwd", "mtbc_conv3x3_dgrad",
     "mtbc_conv3x3_wgrad", "mtbc_instnorm_fwd_workspace", "mtbc_instnorm_coop_state_bytes", "mtbc_instnorm_coop_error_offset", "mtbc_instnorm_c8_supported", "mtbc_instnorm_bwd_team", "mtbc_instnorm_dparam_many", "mtbc_instnorm_lrelu_fwd", "mtbc_instnorm_lrelu_bwd", "mtbc_maxpool2_fwd",
     "mtbc_maxpool2_bwd", "mtbc_convT_wgrad_workspace", "mtbc_convT_fwd_c8_supported", "mtbc_convT_fwd", "mtbc_convT_dgrad", "mtbc_convT_wgrad",
     "mtbc_conv1x1_wgrad_workspace", "mtbc_conv1x1_fwd", "mtbc_conv1x1_dgrad", "mtbc_conv1x1_wgrad",
@@ -227,7 +227,7 @@ EXPORTS = [
     "mtbc_program_run_ms", "mtbc_event_create", "mtbc_event_destroy",
 ]
 
-ABI_VERSION = 200          # MTBC_VERSION of include/mtbc.h these mirrors follow
+ABI_VERSION = 201          # MTBC_VERSION of include/mtbc.h these mirrors follow
 _lib: Optional[C.CDLL] = None
 
 
@@ -284,7 +284,7 @@ def load() -> C.CDLL:
     for name in ("mtbc_conv3x3_pack_fwd", "mtbc_conv3x3_pack_dgrad"):
         getattr(lib, name).restype = C.c_int
         getattr(lib, name).argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
-    for name, typ in (("mtbc_conv3x3_wgrad_workspace", Conv3x3Args), ("mtbc_convT_wgrad_workspace", ConvTArgs),
+    for name, typ in (("mtbc_conv3x3_wgrad_workspace", Conv3x3Args), ("mtbc_conv3x3_wgrad_sync_bytes", Conv3x3Args), ("mtbc_convT_wgrad_workspace", ConvTArgs),
                       ("mtbc_conv1x1_wgrad_workspace", Conv1x1Args)):
         getattr(lib, name).restype = C.c_size_t
         getattr(lib, name).argtypes = [C.POINTER(typ)]

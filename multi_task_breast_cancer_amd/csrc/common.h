@@ -28,6 +28,30 @@ static inline bool mtbc_probe_set(const char* name) { return getenv(name) != nul
 #define MTBC_DBG_BIT(p, bit) (0)
 #endif
 
+// Per-DEVICE facts (a kernel's opt-in to > 64 KB of dynamic LDS, the CU count, a kernel's resident-block capacity) are remembered per
+// device, not per process: one bit / one slot per device ordinal in an atomic owned by the call site.  A process that drives several
+// devices sets / queries each of them once; a race repeats an idempotent call.  (Round 3 kept them in `static bool` guards: right for one
+// process per GPU, wrong the day one process drives two.)
+#include <atomic>
+constexpr int MTBC_MAX_DEVICES = 64;
+struct DevOnce { std::atomic<unsigned long long> mask{0}; };
+static inline int mtbc_current_device() { int dev = 0; return hipGetDevice(&dev) == hipSuccess ? (dev & (MTBC_MAX_DEVICES - 1)) : 0; }
+template <typename K> static inline void mtbc_ensure_dyn_lds(DevOnce& once, K kernel, int bytes) {
+    const unsigned long long bit = 1ull << mtbc_current_device();
+    if (once.mask.load(std::memory_order_relaxed) & bit) return;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    once.mask.fetch_or(bit, std::memory_order_relaxed);
+}
+#define MTBC_ENSURE_DYN_LDS(kernel, bytes) do { static DevOnce once__; mtbc_ensure_dyn_lds(once__, (kernel), (bytes)); } while (0)
+struct DevInts { std::atomic<int> v[MTBC_MAX_DEVICES]; DevInts() { for (auto& x : v) x.store(-1, std::memory_order_relaxed); } };
+// value of `query()` on the current device, asked once per device (-1 = not asked yet; query() >= 0)
+template <typename F> static inline int mtbc_per_device(DevInts& cache, F&& query) {
+    std::atomic<int>& slot = cache.v[mtbc_current_device()];
+    int c = slot.load(std::memory_order_relaxed);
+    if (c < 0) { c = query(); if (c < 0) c = 0; slot.store(c, std::memory_order_relaxed); }
+    return c;
+}
+
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 

@@ -2054,6 +2054,111 @@ constexpr int C8W_ZG = 128 + 4;                  // 132 pieces per output-channe
 constexpr size_t C8W_LDS = (2 * 18 + 2) * 64 * sizeof(f32x4);      // the end-of-block reduction is the larger user (38 KB)
 static_assert((4 * C8WGeo<0>::HR * C8WGeo<0>::LW + 16 + 4 * C8W_ZG) * 16 <= (int)C8W_LDS, "stage buffer must fit the reduction area");
 static_assert((C8WGeo<0>::HR * C8WGeo<0>::LW * 16) % 256 == 192 && (C8WGeo<1>::HR * C8WGeo<1>::LW * 16) % 256 == 64, "group strides: 64/192 mod 256 B");
+// ------------------------------------------------------------------ split-K partials reduced by the LAST ARRIVER, inside the weight-gradient kernel (round 4)
+// Until round 3 every weight-gradient launch was followed by a reduction launch over its split-K partials (55 `splitk_reduce_k` launches,
+// 0.41 ms per step).  Now the block that stores the LAST partial of a group of rows sums that group -- no second launch, and the sums of the
+// groups that finish early run under the MFMAs of the blocks still working.  No block ever waits for another one: a block stores its partial
+// with AGENT-SCOPE stores (sc1: written through the XCD's L2 to memory), waits for them (vmcnt), bumps the group's counter with an agent-scope
+// atomic and EXITS unless the counter says it was the last of the group; the last one reads the group's rows with agent-scope loads and sums
+// them in ROW ORDER (not arrival order: bit-reproducible run to run) into the group's first row and arrives, the same way, at the next level.
+// (First version, measured: ordinary stores + __threadfence() = a write-back of the XCD's whole L2 per wave: +200 .. 250 us on EVERY launch,
+// 2.48 -> 9.98 ms over the step's 35 weight gradients, profiles/r04_wgrad_fixup_probe.txt.  The L2s of the 8 XCDs are not coherent with each
+// other for ordinary accesses; sc1 accesses are, at the price of going to the memory side every time.)  A tree of fan-in G and 1 - 3 levels (1024 splits: 11 x 11 x 9; a deep-level
+// tile with 6 splits: one level), so that no single block pulls more than G x (its tile of the gradient) through one CU; the top level writes
+// dw (+ bias gradient), adding to what is there when the module is shared.  No spin, no co-residency requirement (safe beside RCCL's resident
+// kernels and for grids larger than the chip).  Counters live in a small zeroed buffer of the caller's (mtbc_conv3x3_args.wgrad_sync): the
+// winner of a group resets its counter, so the buffer is all zeros again when the launch ends.
+// Leaf order: the kernels hand in a `leaf` index that puts the splits an XCD runs next to each other (workgroups go to the 8 XCDs round-robin by
+// linear id), so that a first-level group is mostly the work of ONE XCD: its rows are still in that XCD's L2 when the winner reads them.
+constexpr int SPLITK_MAXG = 16;
+template <bool AGENT> __device__ __forceinline__ void st_partial(float* p, float v) {
+    if constexpr (AGENT) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *p = v;
+}
+__device__ __forceinline__ float ld_agent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+struct SplitKFix {
+    int* ctr;                // nullptr: partials are left to a reduction launch
+    float* dw; float* dbias; // destination of the top level ([Cout][Cin][9], [Cout] or nullptr)
+    int accumulate;          // top level adds to dw / dbias
+    int G, levels, nsplit;   // fan-in, tree depth (G^levels >= nsplit), leaves per tile
+    int ctr_per_tile;        // counters of one (co block, ci block) tile: off[l] = first counter of level l
+    int off[3];
+};
+// counters a tile needs + the level offsets (host)
+static inline int splitk_fix_plan(int nsplit, SplitKFix* f) {
+    f->nsplit = nsplit;
+    f->levels = nsplit <= 8 ? 1 : nsplit <= 64 ? 2 : 3;
+    int G = 1;
+    for (;;) { long long c = 1; for (int l = 0; l < f->levels; ++l) c *= G; if (c >= nsplit) break; ++G; }
+    if (G > SPLITK_MAXG) { f->levels = 3; G = SPLITK_MAXG; }            // (nsplit <= 4096 = 16^3: every plan of plan_wgrad is <= 1024)
+    f->G = G < 2 ? 2 : G;
+    int n = nsplit, tot = 0;
+    for (int l = 0; l < 3; ++l) { f->off[l] = tot; if (l < f->levels) { n = (n + f->G - 1) / f->G; tot += n; } }
+    f->ctr_per_tile = tot;
+    return tot;
+}
+// splits with the same (split % 8) first: leaf index of `split` among `nsplit` (the classes keep their order of sizes: class x has
+// (nsplit - x + 7) / 8 members)
+__device__ __forceinline__ int splitk_leaf_mod8(int split, int nsplit) {
+    const int x = split & 7, q = nsplit >> 3, r = nsplit & 7;
+    return x * q + min(x, r) + (split >> 3);
+}
+// Called by EVERY thread of the block after the block's partial has been stored to row `leaf` (all stores issued; no thread may have
+// returned).  Tile region of a row: `nrun` runs of `runlen` floats at base + r * runstride (one run per output channel: its input channels
+// x 9 taps are contiguous), plus `nb` bias-gradient floats at boff (nb = 0: none).  `flag`: one int of LDS.
+template <int THREADS>
+__device__ __forceinline__ void splitk_fixup(const SplitKFix& f, float* __restrict__ partial, long long prow, int tile, int leaf,
+                                             size_t base, int nrun, int runlen, size_t runstride, size_t boff, int b0, int nb, int* flag) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    constexpr int NW = THREADS / 64;
+    int idx = leaf, n_here = f.nsplit;
+    long long stride = prow;                       // floats between consecutive members of a group at this level
+    for (int l = 0; l < f.levels; ++l) {
+        const int gid = idx / f.G, cnt = min(f.G, n_here - gid * f.G);
+        const bool top = l + 1 == f.levels;
+        if (cnt > 1) {
+            // this block's rows (its own partial, or the group sum it has just written: agent-scope stores) have reached memory before
+            // the counter moves: every wave waits for its stores, then the barrier
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) {
+                int* c = f.ctr + (size_t)tile * f.ctr_per_tile + f.off[l] + gid;
+                const int old = __hip_atomic_fetch_add(c, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int last = old == cnt - 1;
+                if (last) __hip_atomic_store(c, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // every member has arrived: the counter is free again
+                *flag = last;
+            }
+            __syncthreads();
+            const int last = *flag;
+            if (!last) return;
+        } else if (top) {
+            __syncthreads();                       // a single split: the row is this block's own partial
+        }
+        if (cnt > 1 || top) {
+            float* __restrict__ src = partial + (size_t)gid * f.G * stride;
+            for (int r = wv; r < nrun; r += NW) {
+                const size_t ro = base + (size_t)r * runstride;
+                for (int k = lane; k < runlen; k += 64) {
+                    float v[SPLITK_MAXG];
+#pragma unroll
+                    for (int m = 0; m < SPLITK_MAXG; ++m) v[m] = m < cnt ? ld_agent(src + (size_t)m * stride + ro + k) : 0.f;
+                    float sacc = v[0];
+#pragma unroll
+                    for (int m = 1; m < SPLITK_MAXG; ++m) sacc += v[m];            // row order; absent members add +0
+                    if (top) { float* d = f.dw + ro + k; *d = f.accumulate ? *d + sacc : sacc; }
+                    else st_partial<true>(src + ro + k, sacc);
+                }
+            }
+            if (tid < nb) {
+                float sacc = ld_agent(src + boff + b0 + tid);
+                for (int m = 1; m < cnt; ++m) sacc += ld_agent(src + (size_t)m * stride + boff + b0 + tid);
+                if (top) { float* d = f.dbias + b0 + tid; *d = f.accumulate ? *d + sacc : sacc; }
+                else st_partial<true>(src + boff + b0 + tid, sacc);
+            }
+        }
+        idx = gid; stride *= f.G; n_here = (n_here + f.G - 1) / f.G;
+    }
+}
+
 struct WgC8P {
     int N, H, W, Cin, Cout;
     SegTable in;                       // ptr = 16-bit base, bstride in 16-bit elements, channels % 8 == 0
@@ -2064,6 +2169,7 @@ struct WgC8P {
     int tiles_x, tiles_y, total_tiles, tiles_per_split, ciblocks;
     int hack;
     int coblocks, cit, segs, seg_tiles, depth;   // conv3x3_wgrad_c8w_kernel: input-channel tiles of 16 per block; row segments per strip, steps (4 rows) per segment
+    SplitKFix fix;                     // in-kernel reduction of the split-K partials (fix.ctr != nullptr), see splitk_fixup
 #ifdef MTBC_PROBES
     unsigned long long* ts;            // phase timestamps (MTBC_WG_TS=1): [block][16] ticks of the 100 MHz clock
 #endif
@@ -2209,29 +2315,40 @@ __global__ __launch_bounds__(256, 4) void conv3x3_wgrad_c8_kernel(const WgC8P p)
         if (do_bias) { red[(36 + 0) * 64 + lane] = accb[0]; red[(36 + 1) * 64 + lane] = accb[1]; }
     }
     __syncthreads();
-    if (kh == 1) return;
-    if (do_bias && j == 0) {
+    // the row this block's partial goes to: with the in-kernel reduction, the splits that ran on one XCD side by side (splitk_fixup)
+    const int prow_idx = p.fix.ctr ? splitk_leaf_mod8(split, (int)gridDim.x) : split;
+    auto store_partial = [&](auto agent_) {           // agent-scope stores when the partials are summed inside this launch (splitk_fixup)
+        constexpr bool AG = decltype(agent_)::value;
+        if (do_bias && j == 0) {
 #pragma unroll
-        for (int c = 0; c < 2; ++c)
+            for (int c = 0; c < 2; ++c)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int co = co0 + c * 16 + kg * 4 + r;
-                if (co < p.Cout) p.partial[(size_t)split * p.prow + (size_t)p.Cout * p.Cin * 9 + co] = accb[c][r] + red[(36 + c) * 64 + lane][r];
-            }
-    }
-    const int ci = ci0 + it * 16 + j;
-    if (ci >= p.Cin) return;
-#pragma unroll
-    for (int c = 0; c < 2; ++c)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int co = co0 + c * 16 + kg * 4 + r;
-            if (co >= p.Cout) continue;
-            float* dst = p.partial + (size_t)split * p.prow + ((size_t)co * p.Cin + ci) * 9;
-#pragma unroll
-            for (int tap = 0; tap < 9; ++tap) dst[tap] = acc[c][tap][r] + red[(it * 18 + c * 9 + tap) * 64 + lane][r];
+                for (int r = 0; r < 4; ++r) {
+                    const int co = co0 + c * 16 + kg * 4 + r;
+                    if (co < p.Cout) st_partial<AG>(p.partial + (size_t)prow_idx * p.prow + (size_t)p.Cout * p.Cin * 9 + co, accb[c][r] + red[(36 + c) * 64 + lane][r]);
+                }
         }
+        const int ci = ci0 + it * 16 + j;
+        if (ci < p.Cin) {
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int co = co0 + c * 16 + kg * 4 + r;
+                    if (co >= p.Cout) continue;
+                    float* dst = p.partial + (size_t)prow_idx * p.prow + ((size_t)co * p.Cin + ci) * 9;
+#pragma unroll
+                    for (int tap = 0; tap < 9; ++tap) st_partial<AG>(dst + tap, acc[c][tap][r] + red[(it * 18 + c * 9 + tap) * 64 + lane][r]);
+                }
+        }
+    };
+    if (kh == 0) { if (p.fix.ctr) store_partial(std::true_type{}); else store_partial(std::false_type{}); }
     MTBC_WTS(p, 12);
+    if (!p.fix.ctr) return;
+    int* fix_flag = reinterpret_cast<int*>(smemc8);      // (the LDS images are dead: splitk_fixup's first barrier is behind every wave's last read)
+    const int nco = min(32, p.Cout - co0), nci = min(32, p.Cin - ci0);
+    splitk_fixup<256>(p.fix, p.partial, p.prow, (int)blockIdx.y, prow_idx, ((size_t)co0 * p.Cin + ci0) * 9, nco, nci * 9, (size_t)p.Cin * 9,
+                      (size_t)p.Cout * p.Cin * 9, co0, (p.want_bias && cib == 0) ? nco : 0, fix_flag);
 }
 
 // ------------------------------------------------------------------ wgrad on channel-blocked operands, wide blocks + rolling rows ("c8w", round 3)
@@ -2518,31 +2635,45 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         MTBC_C8W_ADVANCE();
     }
     MTBC_WTS(p, 11);
-    float* prow_base = p.partial + (size_t)split * p.prow;
-    if (do_bias && j == 0) {
+    // the row of this block's partial: with the in-kernel reduction the images of one XCD (n % 8, see the block order above) are neighbours
+    const int per_img = p.tiles_x * p.segs;
+    const int prow_idx = (p.fix.ctr && p.N % 8 == 0) ? ((n & 7) * (p.N >> 3) + (n >> 3)) * per_img + tx * p.segs + seg : split;
+    float* prow_base = p.partial + (size_t)prow_idx * p.prow;
+    auto store_partial = [&](auto agent_) {           // agent-scope stores when the partials are summed inside this launch (splitk_fixup)
+        constexpr bool AG = decltype(agent_)::value;
+        if (do_bias && j == 0) {
 #pragma unroll
-        for (int c = 0; c < COT; ++c)
+            for (int c = 0; c < COT; ++c)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int co = co0 + c * 16 + kg * 4 + r;
-                if (co < p.Cout) prow_base[(size_t)p.Cout * p.Cin * 9 + co] = accb[c][r];
-            }
-    }
+                for (int r = 0; r < 4; ++r) {
+                    const int co = co0 + c * 16 + kg * 4 + r;
+                    if (co < p.Cout) st_partial<AG>(prow_base + (size_t)p.Cout * p.Cin * 9 + co, accb[c][r]);
+                }
+        }
 #pragma unroll
-    for (int i = 0; i < U; ++i) {
-        const int ci = ci0 + pcit[i] * 16 + j;
-        if (!pok[i] || ci >= p.Cin) continue;
+        for (int i = 0; i < U; ++i) {
+            const int ci = ci0 + pcit[i] * 16 + j;
+            if (!pok[i] || ci >= p.Cin) continue;
 #pragma unroll
-        for (int c = 0; c < COT; ++c)
+            for (int c = 0; c < COT; ++c)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int co = co0 + c * 16 + kg * 4 + r;
-                if (co >= p.Cout) continue;
-                float* dst = prow_base + ((size_t)co * p.Cin + ci) * 9 + 3 * prow[i];
-                dst[0] = acc[i][c][0][r]; dst[1] = acc[i][c][1][r]; dst[2] = acc[i][c][2][r];
-            }
-    }
+                for (int r = 0; r < 4; ++r) {
+                    const int co = co0 + c * 16 + kg * 4 + r;
+                    if (co >= p.Cout) continue;
+                    float* dst = prow_base + ((size_t)co * p.Cin + ci) * 9 + 3 * prow[i];
+                    st_partial<AG>(dst, acc[i][c][0][r]); st_partial<AG>(dst + 1, acc[i][c][1][r]); st_partial<AG>(dst + 2, acc[i][c][2][r]);
+                }
+        }
+    };
+    if (p.fix.ctr) store_partial(std::true_type{}); else store_partial(std::false_type{});
     MTBC_WTS(p, 12);
+    if (!p.fix.ctr) return;
+    {
+        int* fix_flag = reinterpret_cast<int*>(smemw);      // (a static LDS word would not fit beside 160 KB of dynamic LDS; the ring is dead by now)
+        const int nco = min(16 * COT, p.Cout - co0), nci = min(16 * ncit, p.Cin - ci0);
+        splitk_fixup<512>(p.fix, p.partial, p.prow, yb, prow_idx, ((size_t)co0 * p.Cin + ci0) * 9, nco, nci * 9, (size_t)p.Cin * 9,
+                          (size_t)p.Cout * p.Cin * 9, co0, (BIAS && cib == 0) ? nco : 0, fix_flag);
+    }
 }
 
 // ------------------------------------------------------------------ wgrad on channel-blocked operands, 16 x 16 maps ("c8i", round 3)
@@ -2719,31 +2850,44 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_c8i_kernel(const WgC8P p) {
         if (n - n_begin < 3) MTBC_WTS(p, 4 + 3 * (n - n_begin));
     }
     MTBC_WTS(p, 11);
-    float* prow_base = p.partial + (size_t)split * p.prow;
-    if (do_bias && j == 0) {
+    // (block id = split + segs * channel block: with segs % 8 == 0 the splits of one (split % 8) class run on one XCD)
+    const int prow_idx = (p.fix.ctr && p.segs % 8 == 0) ? splitk_leaf_mod8(split, p.segs) : split;
+    float* prow_base = p.partial + (size_t)prow_idx * p.prow;
+    auto store_partial = [&](auto agent_) {           // agent-scope stores when the partials are summed inside this launch (splitk_fixup)
+        constexpr bool AG = decltype(agent_)::value;
+        if (do_bias && j == 0) {
 #pragma unroll
-        for (int c = 0; c < COT; ++c)
+            for (int c = 0; c < COT; ++c)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int co = co0 + c * 16 + kg * 4 + r;
-                if (co < p.Cout) prow_base[(size_t)p.Cout * p.Cin * 9 + co] = accb[c][r];
-            }
-    }
+                for (int r = 0; r < 4; ++r) {
+                    const int co = co0 + c * 16 + kg * 4 + r;
+                    if (co < p.Cout) st_partial<AG>(prow_base + (size_t)p.Cout * p.Cin * 9 + co, accb[c][r]);
+                }
+        }
 #pragma unroll
-    for (int i = 0; i < U; ++i) {
-        const int ci = ci0 + pcit[i] * 16 + j;
-        if (!pok[i] || ci >= p.Cin) continue;
+        for (int i = 0; i < U; ++i) {
+            const int ci = ci0 + pcit[i] * 16 + j;
+            if (!pok[i] || ci >= p.Cin) continue;
 #pragma unroll
-        for (int c = 0; c < COT; ++c)
+            for (int c = 0; c < COT; ++c)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int co = co0 + c * 16 + kg * 4 + r;
-                if (co >= p.Cout) continue;
-                float* dst = prow_base + ((size_t)co * p.Cin + ci) * 9 + 3 * prow[i];
-                dst[0] = acc[i][c][0][r]; dst[1] = acc[i][c][1][r]; dst[2] = acc[i][c][2][r];
-            }
-    }
+                for (int r = 0; r < 4; ++r) {
+                    const int co = co0 + c * 16 + kg * 4 + r;
+                    if (co >= p.Cout) continue;
+                    float* dst = prow_base + ((size_t)co * p.Cin + ci) * 9 + 3 * prow[i];
+                    st_partial<AG>(dst, acc[i][c][0][r]); st_partial<AG>(dst + 1, acc[i][c][1][r]); st_partial<AG>(dst + 2, acc[i][c][2][r]);
+                }
+        }
+    };
+    if (p.fix.ctr) store_partial(std::true_type{}); else store_partial(std::false_type{});
     MTBC_WTS(p, 12);
+    if (!p.fix.ctr) return;
+    {
+        int* fix_flag = reinterpret_cast<int*>(smemi);
+        const int nco = min(16 * COT, p.Cout - co0), nci = min(16 * ncit, p.Cin - ci0);
+        splitk_fixup<512>(p.fix, p.partial, p.prow, yb, prow_idx, ((size_t)co0 * p.Cin + ci0) * 9, nco, nci * 9, (size_t)p.Cin * 9,
+                          (size_t)p.Cout * p.Cin * 9, co0, (BIAS && cib == 0) ? nco : 0, fix_flag);
+    }
 }
 
 // fp32 planar (N,C,H,W) <-> 16-bit channel-blocked [N][C/8][H*W][8]; one thread = one 16-byte piece
@@ -3175,14 +3319,8 @@ int launch_igemm(const ConvP& p, int mblocks, hipStream_t st) {
             static const int ring_env = mtbc_probe_int("MTBC_RING", 0);
             const int ring = ring_env ? ring_env : RING;
             const size_t lds = ((size_t)ring * (KC * G::PS + MT * KC * 144) + SEGL_FLOATS + MT * 16) * sizeof(float);
-            static bool attr_set = false;
-            if (!attr_set) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_igemm_dma_kernel<MT, GEO, 2>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_igemm_dma_kernel<MT, GEO, 3>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                attr_set = true;
-            }
+            MTBC_ENSURE_DYN_LDS((&conv3x3_igemm_dma_kernel<MT, GEO, 2>), 160 * 1024);      // > 64 KiB of dynamic LDS: opt-in per kernel and device
+            MTBC_ENSURE_DYN_LDS((&conv3x3_igemm_dma_kernel<MT, GEO, 3>), 160 * 1024);
             int gx = ((ring == 3 ? 512 : 768) / mblocks) / 8 * 8;          // <= 2 or 3 resident blocks per CU, one wave of blocks
             if (gx < 8) gx = 8;
             if (gx > p.ntiles) gx = p.ntiles;
@@ -3193,12 +3331,7 @@ int launch_igemm(const ConvP& p, int mblocks, hipStream_t st) {
         }
     }
     const size_t lds = (2ull * (KC * G::PS + MT * KC * 144) + SEGL_FLOATS) * sizeof(float);
-    static bool attr_set = false;   // >64 KiB dynamic LDS needs the opt-in once per kernel
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_igemm_kernel<MT, GEO>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
+    MTBC_ENSURE_DYN_LDS((&conv3x3_igemm_kernel<MT, GEO>), (int)lds);
     int gx = (768 / mblocks) / 8 * 8;
     if (gx < 8) gx = 8;
     if (gx > p.ntiles) gx = p.ntiles;
@@ -3220,12 +3353,8 @@ int launch_igemm_lp(const ConvP& p, int mblocks, bool f16, hipStream_t st) {
     using G = GeoLP<GEO>;
     constexpr int HP = G::IMG * (G::TH + 2) * (G::TW + 2);
     const size_t lds = ((size_t)HP * LPROW + (size_t)MT * 9 * 16 * WROW) * 2 + (SEGL_FLOATS + MT * 16) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_igemm_lp_kernel<MT, GEO, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_igemm_lp_kernel<MT, GEO, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
+    MTBC_ENSURE_DYN_LDS((&conv3x3_igemm_lp_kernel<MT, GEO, false>), 160 * 1024);
+    MTBC_ENSURE_DYN_LDS((&conv3x3_igemm_lp_kernel<MT, GEO, true>), 160 * 1024);
     // one wave of resident blocks: LDS allows 3 blocks per CU for MT <= 2 (51 KB) but only 2 for MT = 3 (62 KB); a grid
     // sized for 3 would run a second, two-thirds-empty round
     const int per_cu = lds * 3 <= 160 * 1024 ? 3 : 2;
@@ -3253,12 +3382,8 @@ int launch_igemm_c8(const ConvP& p, int mblocks, bool f16, hipStream_t st) {
     constexpr int TH = GEO == 0 ? 2 * NW : G::TH;
     constexpr int HP = G::IMG * (TH + 2) * (G::TW + 2), HPP = (HP + 15) / 16 * 16;
     const size_t lds = ((size_t)4 * HPP * 8 + (size_t)MT * 9 * 16 * WROW) * 2 + (SEGL_FLOATS + MT * 16) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_igemm_c8_kernel<MT, GEO, false, NW, O8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_igemm_c8_kernel<MT, GEO, true, NW, O8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
+    MTBC_ENSURE_DYN_LDS((&conv3x3_igemm_c8_kernel<MT, GEO, false, NW, O8>), 160 * 1024);
+    MTBC_ENSURE_DYN_LDS((&conv3x3_igemm_c8_kernel<MT, GEO, true, NW, O8>), 160 * 1024);
     static const int per_cu_env = mtbc_probe_int("MTBC_C8_BLOCKS_PER_CU", 0);      // A/B
     // one wave of resident blocks.  The 4-wave image fits 4 per CU (40.6 KB) and the kernel compiles to 128 VGPRs, but measured
     // (v9): 4 resident blocks are no faster than 3 (16.52 vs 16.49 ms per step; single launches 3-15 % slower) -> 3.
@@ -3313,12 +3438,8 @@ int launch_igemm_c8_ring(const ConvP& p, int mblocks, bool f16, hipStream_t st) 
     using RG = RingGeo<MT, GEO>;
     const size_t lds = (size_t)R * RG::SLOT * 2 + (SEGL_FLOATS + MT * 16) * sizeof(float) + 64 * 4 * sizeof(unsigned long long);      // + the (chunk, group) base table
     static_assert((size_t)R * RG::SLOT * 2 + (SEGL_FLOATS + MT * 16) * sizeof(float) + 2048 <= 160 * 1024, "ring slots + tables must fit a CU's LDS");
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_igemm_c8_ring_kernel<MT, GEO, false, O8, R>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_igemm_c8_ring_kernel<MT, GEO, true, O8, R>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
+    MTBC_ENSURE_DYN_LDS((&conv3x3_igemm_c8_ring_kernel<MT, GEO, false, O8, R>), 160 * 1024);
+    MTBC_ENSURE_DYN_LDS((&conv3x3_igemm_c8_ring_kernel<MT, GEO, true, O8, R>), 160 * 1024);
     int gx = 256 / mblocks;                  // one resident block per CU (147 KB of LDS), one wave of blocks
     if (gx < 1) gx = 1;
     if (gx > p.ntiles) gx = p.ntiles;
@@ -3798,6 +3919,13 @@ size_t mtbc_conv3x3_wgrad_workspace(const mtbc_conv3x3_args* a) {
     return (w.partial_elems + w.dbias_elems) * sizeof(float);
 }
 
+size_t mtbc_conv3x3_wgrad_sync_bytes(const mtbc_conv3x3_args* a) {
+    if (check_conv(a) || a->operand_layout != MTBC_LAYOUT_C8 || a->Cin == 1) return 0;      // (only the channel-blocked kernels reduce in-kernel)
+    const WgPlan w = plan_wgrad(a);
+    SplitKFix f{};
+    return (size_t)splitk_fix_plan(w.nsplit, &f) * w.coblocks * w.ciblocks * sizeof(int);
+}
+
 int mtbc_conv3x3_wgrad(const mtbc_conv3x3_args* a, void* stream) {
     int rc = check_conv(a); if (rc) return rc;
     if (!a->dout || !a->dw) return MTBC_E_BADARG;
@@ -3830,6 +3958,14 @@ int mtbc_conv3x3_wgrad(const mtbc_conv3x3_args* a, void* stream) {
         // blocks store straight into dw instead of into a 21 MB workspace that a reduction launch then copies (32 us)
         const bool direct = w.nsplit == 1 && !a->dbias && !a->accumulate_dw;
         if (direct) p.partial = a->dw;
+        // the split-K partials reduced inside this launch by the last arriver of each group (splitk_fixup) when the caller hands in the
+        // zeroed counter buffer; without it: one reduction launch behind the kernel
+        p.fix = SplitKFix{};
+        if (a->wgrad_sync && !direct) {
+            const size_t need = (size_t)splitk_fix_plan(w.nsplit, &p.fix) * w.coblocks * w.ciblocks * sizeof(int);
+            if (a->wgrad_sync_bytes < need || (reinterpret_cast<uintptr_t>(a->wgrad_sync) & 3)) return MTBC_E_WORKSPACE;
+            p.fix.ctr = a->wgrad_sync; p.fix.dw = a->dw; p.fix.dbias = a->dbias; p.fix.accumulate = a->accumulate_dw;
+        }
         p.tiles_x = w.tiles_x; p.tiles_y = w.tiles_y; p.total_tiles = w.total_tiles; p.tiles_per_split = w.tiles_per_split;
         p.ciblocks = w.ciblocks; p.coblocks = w.coblocks; p.cit = w.cit; p.segs = w.segs; p.seg_tiles = w.seg_tiles; p.depth = w.depth;
         { static const int hk = mtbc_probe_int("MTBC_C8W_HACK", 0); p.hack = hk; }
@@ -3851,9 +3987,7 @@ int mtbc_conv3x3_wgrad(const mtbc_conv3x3_args* a, void* stream) {
             const dim3 gridi(w.nsplit * w.coblocks * w.ciblocks);
 #define MTBC_C8I_LAUNCH(F16_, COT_, BIAS_)                                                                                             \
             do {                                                                                                                       \
-                static bool attr = false;                                                                                              \
-                if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wgrad_c8i_kernel<F16_, COT_, BIAS_>),    \
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }         \
+                MTBC_ENSURE_DYN_LDS((&conv3x3_wgrad_c8i_kernel<F16_, COT_, BIAS_>), 160 * 1024);                                      \
                 hipLaunchKernelGGL((conv3x3_wgrad_c8i_kernel<F16_, COT_, BIAS_>), gridi, dim3(512), lds, st, p);                      \
             } while (0)
             const int sel = (a->compute == 2 ? 4 : 0) + (w.cot == 3 ? 2 : 0) + (a->dbias ? 1 : 0);
@@ -3872,9 +4006,7 @@ int mtbc_conv3x3_wgrad(const mtbc_conv3x3_args* a, void* stream) {
             const size_t lds = c8w_lds_bytes(w.cit, w.cot, w.depth);
 #define MTBC_C8W_LAUNCH(F16_, COT_, BIAS_)                                                                                             \
             do {                                                                                                                       \
-                static bool attr = false;      /* up to 160 KB of dynamic LDS */                                                      \
-                if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wgrad_c8w_kernel<F16_, COT_, BIAS_>),    \
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }         \
+                MTBC_ENSURE_DYN_LDS((&conv3x3_wgrad_c8w_kernel<F16_, COT_, BIAS_>), 160 * 1024);      /* up to 160 KB of dynamic LDS */   \
                 hipLaunchKernelGGL((conv3x3_wgrad_c8w_kernel<F16_, COT_, BIAS_>), grid, dim3(512), lds, st, p);                       \
             } while (0)
             const int sel = (a->compute == 2 ? 4 : 0) + (w.cot == 3 ? 2 : 0) + (a->dbias ? 1 : 0);
@@ -3923,7 +4055,7 @@ int mtbc_conv3x3_wgrad(const mtbc_conv3x3_args* a, void* stream) {
             }
         }
 #endif
-        if (direct) return MTBC_OK;
+        if (direct || p.fix.ctr) return MTBC_OK;
         // one row per split = the weight-gradient partial followed by the bias-gradient partial: ONE reduction launch for both
         return mtbc_i_splitk_reduce2(partial, a->dw, a->dbias, w.nsplit, wel, a->dbias ? (size_t)a->Cout : 0, a->accumulate_dw, st);
     }
@@ -3952,12 +4084,8 @@ int mtbc_conv3x3_wgrad(const mtbc_conv3x3_args* a, void* stream) {
         } while (0)
         static const bool lp1 = mtbc_probe_set("MTBC_WGRAD_LP1");      // A/B: first-generation 16-bit wgrad
         if (w.geo == 0 && w.cot == 2 && lowp != 0 && !lp1) {
-            static bool attr2 = false;
-            if (!attr2) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wgrad_lp2_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wgrad_lp2_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-                attr2 = true;
-            }
+            MTBC_ENSURE_DYN_LDS((&conv3x3_wgrad_lp2_kernel<false>), 64 * 1024);
+            MTBC_ENSURE_DYN_LDS((&conv3x3_wgrad_lp2_kernel<true>), 64 * 1024);
             if (lowp == 2) hipLaunchKernelGGL((conv3x3_wgrad_lp2_kernel<true>), grid, dim3(256), W2_LDS, st, p);
             else hipLaunchKernelGGL((conv3x3_wgrad_lp2_kernel<false>), grid, dim3(256), W2_LDS, st, p);
         } else if (w.cot == 2) {

@@ -942,9 +942,7 @@ int mtbc_i_convT2_fwd(const mtbc_convT_args* a, hipStream_t st) {
     const int ki = cdiv(a->Cin, 4);
 #define MTBC_CT2F(KI_)                                                                                                     \
     do {                                                                                                                   \
-        static bool attr = false;                                                                                          \
-        if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&convT2_fwd_lds_kernel<KI_>),                 \
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); attr = true; }     \
+        MTBC_ENSURE_DYN_LDS((&convT2_fwd_lds_kernel<KI_>), 64 * 1024);                                                     \
         hipLaunchKernelGGL(convT2_fwd_lds_kernel<KI_>, dim3(blocks), dim3(256), lds, st, p, a->bias, a->y,                 \
                            (long long)a->y_batch_stride, wstride);                                                         \
     } while (0)
@@ -971,9 +969,7 @@ int mtbc_i_convT2_fwd_c8(const mtbc_convT_args* a, hipStream_t st) {
     unsigned short* y8 = reinterpret_cast<unsigned short*>(a->y);
 #define MTBC_CT2F8(KI_, F16_)                                                                                              \
     do {                                                                                                                   \
-        static bool attr = false;                                                                                          \
-        if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&convT2_fwd_c8_kernel<KI_, F16_>),            \
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); attr = true; }     \
+        MTBC_ENSURE_DYN_LDS((&convT2_fwd_c8_kernel<KI_, F16_>), 64 * 1024);                                                \
         hipLaunchKernelGGL((convT2_fwd_c8_kernel<KI_, F16_>), dim3(blocks), dim3(256), lds, st, p, a->bias, y8,            \
                            (long long)a->y_batch_stride, wstride, cp);                                                     \
     } while (0)
@@ -1012,9 +1008,7 @@ int mtbc_i_convT2_fwd_lp_c8(const mtbc_convT_args* a, hipStream_t st) {
     unsigned short* y8 = reinterpret_cast<unsigned short*>(a->y);
 #define MTBC_CT2LP(MTC_, F16_)                                                                                             \
     do {                                                                                                                   \
-        static bool attr = false;                                                                                          \
-        if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&convT2_fwd_lp_c8_kernel<MTC_, F16_>),        \
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); attr = true; }     \
+        MTBC_ENSURE_DYN_LDS((&convT2_fwd_lp_c8_kernel<MTC_, F16_>), 80 * 1024);                                            \
         hipLaunchKernelGGL((convT2_fwd_lp_c8_kernel<MTC_, F16_>), grid, dim3(256), lds, st, p, a->bias, x8,                \
                            (long long)a->x_batch_stride, y8, (long long)a->y_batch_stride, kpad, wrow);                    \
     } while (0)
@@ -1039,9 +1033,7 @@ int mtbc_i_convT2_dgrad(const mtbc_convT_args* a, int compute, hipStream_t st) {
         const dim3 grid(gx, p.mblocks);
 #define MTBC_CT2DG(LP_, D_)                                                                                              \
         do {                                                                                                             \
-            static bool attr = false;                                                                                    \
-            if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&convT2_dgrad_lds_kernel<LP_, D_>),     \
-                                                    hipFuncAttributeMaxDynamicSharedMemorySize, 104 * 1024); attr = true; } \
+            MTBC_ENSURE_DYN_LDS((&convT2_dgrad_lds_kernel<LP_, D_>), 104 * 1024);                                        \
             hipLaunchKernelGGL((convT2_dgrad_lds_kernel<LP_, D_>), grid, dim3(256), lds, st, p, wrow);                   \
         } while (0)
         if (compute == 1) MTBC_CT2DG(1, 4); else MTBC_CT2DG(2, 4);

@@ -751,10 +751,9 @@ template <typename K> int resident_blocks(K kernel) {
     if (per_cu > 3) per_cu = 3;
     return per_cu * prop.multiProcessorCount;
 }
-int device_cus() {
-    static int cus = -1;          // immutable after the first query (the device does not change under a process)
-    if (cus < 0) { int dev = 0; hipDeviceProp_t prop; cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 0; }
-    return cus;
+int device_cus() {           // of the CURRENT device, asked once per device (common.h: per-device caches, not per-process ones)
+    static DevInts cache;
+    return mtbc_per_device(cache, [] { int dev = 0; hipDeviceProp_t prop; return (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 0; });
 }
 // capacity with `reserve` of the device's CUs left to kernels of other streams (a per-call argument: no process state)
 int usable(int cap_all_cus, int reserve) {
@@ -811,8 +810,8 @@ int fill_coop(const mtbc_instnorm_args* a, CoP* p) {
 // One workgroup per (n, channel group): planes up to 64 x 64
 constexpr int SOLO_MAX_HW = 4096;
 // Resident capacity per kernel instantiation (the bf16 and fp16 variants have their own register counts): one occupancy
-// query each, cached in a function-local static (thread-safe initialisation, immutable afterwards).
-template <auto K> int cap_of() { static const int c = resident_blocks(K); return c; }
+// query each PER DEVICE, cached in a per-device slot (immutable once asked).
+template <auto K> int cap_of() { static DevInts cache; return mtbc_per_device(cache, [] { return resident_blocks(K); }); }
 // the variant a launch runs: (output type, z layout, dy layout)
 struct Var { bool f16; int zc8, dy8; };
 template <bool BWD, int THREADS, int PPT, bool COOP, bool F16, int ZC8, int DY8> constexpr auto kernel_of() {

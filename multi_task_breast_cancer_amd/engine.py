@@ -60,6 +60,10 @@ class Act:
     z16: bool = False                  # conv-cell output whose InstanceNorm runs on the channel-group kernels (16-bit z)
     r1: Optional[tuple] = None         # (dy of a one-output 1x1 head, its weight): rank-1 gradient term formed inside the InstanceNorm backward
     pool: Optional[tuple] = None       # (gradient of this tensor's 2 x 2 max-pool, argmax codes): routed inside the InstanceNorm backward
+    pooled: Optional["Act"] = None     # this tensor's 2 x 2 max-pool (planned once, however many modules pool it)
+    parent: Optional["Act"] = None     # this Act is images [view_index * N, (view_index + 1) * N) of `parent` (StepPlan.batch_pair / split_batch)
+    view_index: int = 0
+    views: list = field(default_factory=list)
     in_op: Optional[object] = None     # the InstanceNorm forward op that writes this activation (conv cells)
     pack_op: Optional[object] = None   # the op that fills `c8` from `data`
 
@@ -80,6 +84,7 @@ class _Cell:
     """What the forward half of a conv cell hands to its backward half (StepPlan.conv_cell / _conv_cell_backward)."""
     inputs: List["Act"]
     y: "Act"
+    N: int                                    # images of THIS cell (2 x the plan's batch for a module applied to two tensors at once)
     cin: int
     cout: int
     H: int
@@ -176,6 +181,8 @@ class StepPlan:
         self.ws_bytes = 0
         self.ws_users: List[Tuple[L.Op, str]] = []
         self._pending_dparams: List[Tuple[L.Op, tuple]] = []   # deferred InstanceNorm parameter-gradient reductions: (op, parameter names)
+        self._sync_users: List[L.Op] = []                  # weight gradients with the in-kernel split-K reduction: one zeroed counter buffer
+        self._sync_bytes = 0
         self._stat_users: List[Tuple[L.Op, str]] = []      # conv forward / InstanceNorm forward pairs sharing the epilogue-statistics scratch
         self._stat_bytes = 0
         self.arena_bytes = 0
@@ -193,10 +200,49 @@ class StepPlan:
         self.keep.append(t)
         return t
 
-    def new_act(self, name: str, C_: int, H: int, W: int, needs_grad: bool = True) -> Act:
-        a = Act(name, self.alloc(self.N, C_, H, W), needs_grad)
+    def new_act(self, name: str, C_: int, H: int, W: int, needs_grad: bool = True, N: Optional[int] = None) -> Act:
+        a = Act(name, self.alloc(self.N if N is None else N, C_, H, W), needs_grad)
         self.acts[name] = a
         return a
+
+    # ---- one module applied to TWO tensors with shared weights (U-Net++: process_level_3 on pool(x_3_0) and pool(x_3_1),
+    # MTUNetPlusPlus.py:79,128) runs ONCE over their batch concatenation: InstanceNorm is per sample, so the result is the two
+    # applications' results exactly, in half the launches and with ONE weight gradient instead of two accumulated ones.  The two
+    # halves of the 2N-image tensor are Acts of their own (views): producers write them, consumers read them, their gradients are
+    # the halves of the parent's gradient.
+    def _make_views(self, parent: Act) -> List[Act]:
+        n = parent.N // 2
+        parent.grad = self.grad_of(parent)
+        for i in range(2):
+            v = Act(f"{parent.name}[{i}]", parent.data[i * n:(i + 1) * n], parent.needs_grad)
+            v.grad = parent.grad[i * n:(i + 1) * n]
+            v.parent, v.view_index = parent, i
+            if parent.c8 is not None:
+                v.c8 = parent.c8[i * n:(i + 1) * n]
+            v.planar_valid = parent.planar_valid
+            parent.views.append(v)
+            self.acts[v.name] = v
+        return parent.views
+
+    def batch_pair(self, name: str, C_: int, H: int, W: int) -> Tuple[Act, List[Act]]:
+        """A 2N-image tensor whose halves are written by two producers (the returned views)."""
+        parent = self.new_act(name, C_, H, W, N=2 * self.N)
+        return parent, self._make_views(parent)
+
+    def split_batch(self, parent: Act) -> List[Act]:
+        """The two N-image halves of a 2N-image tensor as Acts for N-image consumers."""
+        assert parent.N == 2 * self.N and not parent.views
+        return self._make_views(parent)
+
+    def _view_c8(self, v: Act) -> torch.Tensor:
+        """channel-blocked storage of a view = its half of the parent's (allocated on first use)"""
+        par = v.parent
+        if par.c8 is None:
+            par.c8 = self.alloc(par.N, par.C // 8, par.H * par.W, 8, dtype=torch.int16)
+        for w in par.views:
+            n = par.N // 2
+            w.c8 = par.c8[w.view_index * n:(w.view_index + 1) * n]
+        return v.c8
 
     def grad_of(self, a: Act) -> torch.Tensor:
         if a.grad is None:
@@ -207,8 +253,18 @@ class StepPlan:
         """Where the next backward contribution to `a` goes: (buffer, accumulate flag).  The first writer overwrites the buffer, later
         writers read-modify-write it (the static plan knows who is first: no memsets).  (Private fan-in buffers summed by the
         InstanceNorm backward were built and measured in round 1: dgrad -0.6 ms, norm backward +1.25 ms; removed.)"""
+        if a.views:                 # a 2N-image tensor written as a whole: its halves are written with it
+            if a.grad_written != all(v.grad_written for v in a.views) or (not a.grad_written and any(v.grad_written for v in a.views)):
+                raise NotImplementedError(f"{a.name}: a batch-concatenated gradient written whole after one half was written alone")
+            acc = 1 if a.grad_written else 0
+            a.grad_written = True
+            for v in a.views:
+                v.grad_written = True
+            return self.grad_of(a), acc
         if not a.grad_written:
             a.grad_written = True
+            if a.parent is not None and all(v.grad_written for v in a.parent.views):
+                a.parent.grad_written = True
             return self.grad_of(a), 0
         return self.grad_of(a), 1
 
@@ -217,13 +273,15 @@ class StepPlan:
         if not a.planar_valid:
             raise NotImplementedError(f"{a.name} exists only in the channel-blocked 16-bit layout")
         a.planar_used = True
+        if a.parent is not None:
+            a.parent.planar_used = True
         return a.data.data_ptr()
 
-    def _c8_pack_op(self, src: torch.Tensor, dst: torch.Tensor, C_: int, HW: int) -> L.Op:
+    def _c8_pack_op(self, src: torch.Tensor, dst: torch.Tensor, C_: int, HW: int, N: Optional[int] = None) -> L.Op:
         op = _mk(L.OP_C8_PACK)
         a = op.u.c8pack
         a.src, a.src_batch_stride, a.dst = src.data_ptr(), C_ * HW, dst.data_ptr()
-        a.N, a.C, a.HW, a.compute = self.N, C_, HW, self.compute
+        a.N, a.C, a.HW, a.compute = (self.N if N is None else N), C_, HW, self.compute
         return op
 
     def c8_of(self, a: Act) -> torch.Tensor:
@@ -231,10 +289,17 @@ class StepPlan:
         behind the ops emitted so far, i.e. after its producer -- and then read by every 3x3 conv and weight gradient
         that consumes it (X0_0 of the U-Net++ feeds 4 convs and 4 wgrads): their staging becomes LDS-DMA."""
         a.c8_used = True
+        if a.parent is not None:
+            a.parent.c8_used = True
+            if a.c8 is None:
+                raise NotImplementedError(f"{a.name}: a view without channel-blocked storage (its producer writes fp32 planes)")
         if a.c8 is None:
-            a.c8 = self.alloc(self.N, a.C // 8, a.H * a.W, 8, dtype=torch.int16)
-            a.pack_op = self._c8_pack_op(a.data, a.c8, a.C, a.H * a.W)
+            a.c8 = self.alloc(a.N, a.C // 8, a.H * a.W, 8, dtype=torch.int16)
+            a.pack_op = self._c8_pack_op(a.data, a.c8, a.C, a.H * a.W, a.N)
             self.fwd_ops.append(a.pack_op)
+            if a.views:
+                for v in a.views:
+                    v.c8 = a.c8[v.view_index * (a.N // 2):(v.view_index + 1) * (a.N // 2)]
         return a.c8
 
     def _coop_state(self) -> int:
@@ -317,7 +382,8 @@ class StepPlan:
         inputs = list(inputs)
         for a_ in inputs:
             a_.readers += 1
-        N, H, W = self.N, inputs[0].H, inputs[0].W
+        N, H, W = inputs[0].N, inputs[0].H, inputs[0].W
+        assert all(a.N == N for a in inputs), [(a.name, a.N) for a in inputs]
         cin = sum(a.C for a in inputs)
         w = self.pv(wname)
         assert tuple(w.shape) == (cout, cin, 3, 3), (wname, tuple(w.shape), cout, cin)
@@ -338,10 +404,10 @@ class StepPlan:
                 op = _mk(L.OP_CONV3_PACK_DGRAD)
                 op.u.pack.w, op.u.pack.packed, op.u.pack.Cin, op.u.pack.Cout = w.data_ptr(), wp_d.data_ptr(), cin, cout
                 self.pack_ops.append(op)
-        y = self.new_act(out_name, cout, H, W)
+        y = self.new_act(out_name, cout, H, W, N=N)
         mean, rstd = self.alloc(N * cout), self.alloc(N * cout)
         self._tag += 1
-        cell = _Cell(inputs=inputs, y=y, cin=cin, cout=cout, H=H, W=W, tag=self._tag, w=w, wname=wname, bname=bname, gname=gname,
+        cell = _Cell(inputs=inputs, y=y, N=N, cin=cin, cout=cout, H=H, W=W, tag=self._tag, w=w, wname=wname, bname=bname, gname=gname,
                      betaname=betaname, slope=slope, mean=mean, rstd=rstd, use_packed=use_packed, wp_d=wp_d, wp_d_op=wp_d_op)
 
         # 16-bit modes: the MFMA operands are converted once per tensor into the channel-blocked 16-bit layout instead
@@ -444,7 +510,7 @@ class StepPlan:
     def _cell_conv_op(self, cell: "_Cell", kind: int) -> L.Op:
         op = _mk(kind, cell.tag)
         a = op.u.conv3
-        a.N, a.H, a.W, a.Cin, a.Cout, a.n_in = self.N, cell.H, cell.W, cell.cin, cell.cout, len(cell.inputs)
+        a.N, a.H, a.W, a.Cin, a.Cout, a.n_in = cell.N, cell.H, cell.W, cell.cin, cell.cout, len(cell.inputs)
         a.w = cell.w.data_ptr()
         a.force_direct = self.force_direct
         a.compute = self.compute if cell.use_packed else 0
@@ -453,7 +519,7 @@ class StepPlan:
     def _cell_norm_op(self, cell: "_Cell", kind: int) -> L.Op:
         op = _mk(kind, cell.tag)
         a = op.u.inorm
-        a.N, a.C, a.H, a.W, a.eps, a.slope = self.N, cell.cout, cell.H, cell.W, 1e-5, cell.slope
+        a.N, a.C, a.H, a.W, a.eps, a.slope = cell.N, cell.cout, cell.H, cell.W, 1e-5, cell.slope
         a.z = cell.z.data_ptr()
         a.z_layout = L.LAYOUT_C8 if cell.z16 else L.LAYOUT_PLANAR
         a.z_type = 2 if cell.zf16 else 0
@@ -467,7 +533,7 @@ class StepPlan:
         """The gradient of y with respect to ALL its 3x3 consumers in ONE forward-type launch over their channel-blocked dz (K = sum
         of their Cout), instead of one read-modify-write of y's fp32 gradient per consumer.  Weights: the consumers' slices for y's
         channels, transposed / tap-flipped, side by side (rebuilt each step: weight views, then the ordinary 16-bit image)."""
-        y, cout, N, H, W = cell.y, cell.cout, self.N, cell.H, cell.W
+        y, cout, N, H, W = cell.y, cell.cout, cell.N, cell.H, cell.W
         K = sum(pj[4] for pj in y.pending)
         wg = self.alloc(cout, K, 3, 3)
         koff = 0
@@ -497,7 +563,7 @@ class StepPlan:
     def _conv_cell_backward(self, cell: "_Cell") -> None:
         """Backward of a conv cell: [gathered dgrad of y] -> InstanceNorm + LeakyReLU backward (dz channel-blocked, or in place over dy)
         -> weight gradient -> input gradient (whole, or the suffix of the inputs whose gradient is not gathered by THEIR cell)."""
-        y, inputs, cout, N, H, W = cell.y, cell.inputs, cell.cout, self.N, cell.H, cell.W
+        y, inputs, cout, N, H, W = cell.y, cell.inputs, cell.cout, cell.N, cell.H, cell.W
         gname, betaname, bname, z16, c8_bwd = cell.gname, cell.betaname, cell.bname, cell.z16, cell.c8_bwd
         if not y.grad_written and not y.pending and y.r1 is None and y.pool is None:
             return
@@ -601,6 +667,13 @@ class StepPlan:
         # (batching the ~40 split-K reductions of a step into a few launches was built and measured: 15.20 vs 14.54 ms -- the
         #  partials then live in buffers of their own and travel to HBM and back instead of being reduced out of the cache)
         self._need_ws(op, "conv3", self.lib.mtbc_conv3x3_wgrad_workspace(C.byref(a)))
+        # channel-blocked weight gradients reduce their split-K partials inside the launch (last arriver per group, conv3x3.hip
+        # splitk_fixup): ONE zeroed counter buffer for the whole backward program -- the launches run in order on one stream and each
+        # leaves its counters at zero
+        nsync = int(self.lib.mtbc_conv3x3_wgrad_sync_bytes(C.byref(a)))
+        if nsync:
+            self._sync_users.append(op)
+            self._sync_bytes = max(self._sync_bytes, nsync)
         self.bwd_ops.append(op)
         # input gradient into every input that needs one
         need = [a_ for a_ in inputs if a_.needs_grad]
@@ -638,28 +711,46 @@ class StepPlan:
         """16-bit modes: may a small consumer (max-pool, 1x1 head) read the channel-blocked copy of x instead of fp32 planes?"""
         return bool(self.compute) and not self.force_direct and x.C % 8 == 0 and (x.H * x.W) % 4 == 0
 
-    def maxpool(self, x: Act, out_name: str) -> Act:
+    def maxpool(self, x: Act, out_name: str, out: Optional[Act] = None) -> Act:
+        """out: the pooled tensor is written into this (view) Act -- one half of a batch-concatenated tensor (batch_pair)."""
+        # A tensor pooled twice (U-Net++: x_3_0 feeds conv_4_0 AND the first application of process_level_3, MTUNetPlusPlus.py:75,128) is
+        # pooled ONCE: both consumers read the same pooled tensor and its gradient is their fan-in.  (Round 4: two pools of one tensor had
+        # each claimed the fold of their backward into the tensor's InstanceNorm backward -- ONE slot, the later emitter overwrote the
+        # earlier one and the 16-bit modes lost the classification head's gradient into x_3_0; found by comparing gradients with the
+        # emulation at a TRAINED state, tools/experiments/try_emul3.py.  fp32 mode was not affected: no fold there.)
+        if x.pooled is not None:
+            assert out is None or out is x.pooled
+            self.acts[out_name] = x.pooled
+            return x.pooled
         x.readers += 1
-        y = self.new_act(out_name, x.C, x.H // 2, x.W // 2)
+        if out is not None:
+            assert out.N == x.N and (out.C, out.H, out.W) == (x.C, x.H // 2, x.W // 2)
+            y = out
+            self.acts[out_name] = y
+        else:
+            y = self.new_act(out_name, x.C, x.H // 2, x.W // 2, N=x.N)
+        x.pooled = y
         # 16-bit modes: pool the channel-blocked 16-bit tensor into a channel-blocked 16-bit tensor (max commutes with the
         # rounding: bit-identical to the fp32 pool + pack) -- the pooled tensor feeds 3x3 convs only, and x then needs no
         # fp32 planes on the pool's account.  Only when those convs can take the layout (else they need planes of y).
         c8 = self._c8_small_ok(x) and (x.W // 2) % 4 == 0 and x.H // 2 >= 8 and x.W // 2 >= 8 and x.H % 2 == 0 and x.W % 2 == 0
         fold = False
         if c8:
-            y.c8 = self.alloc(self.N, x.C // 8, y.H * y.W, 8, dtype=torch.int16)
+            y.c8 = self._view_c8(y) if y.parent is not None else self.alloc(x.N, x.C // 8, y.H * y.W, 8, dtype=torch.int16)
             y.planar_valid = False
+            if y.parent is not None:
+                y.parent.planar_valid = False
             x8 = self.c8_of(x)
             # the pool's backward inside the InstanceNorm backward of x (mtbc_instnorm_args.dy_pool): the forward records where
             # each window's maximum sits (2 bits per channel), the pooled gradient is routed while the norm backward loads its
             # slab -- no 4x larger, three-quarters-zero fp32 tensor written, read-modify-written by the fan-in and read back
-            fold = x.z16 and x.needs_grad and x.pool is None
-        arg = self.alloc(self.N, x.C // 8, y.H * y.W, dtype=torch.int16) if fold else None
+            fold = x.z16 and x.needs_grad
+        arg = self.alloc(x.N, x.C // 8, y.H * y.W, dtype=torch.int16) if fold else None
 
         def base() -> L.Op:
             op = _mk(0)
             a = op.u.pool
-            a.N, a.C, a.H, a.W = self.N, x.C, x.H, x.W
+            a.N, a.C, a.H, a.W = x.N, x.C, x.H, x.W
             if c8:
                 a.layout, a.type16 = L.LAYOUT_C8, self.compute
                 a.x, a.x_batch_stride = x8.data_ptr(), x.bstride
@@ -685,6 +776,7 @@ class StepPlan:
             if not y.grad_written or not x.needs_grad:
                 return
             if fold:
+                assert x.pool is None, f"{x.name}: a second max-pool backward folded into one InstanceNorm backward"
                 x.pool = (self.grad_of(y), arg)
                 return
             op = base()
@@ -1075,6 +1167,12 @@ class StepPlan:
         for op, fieldname in self.ws_users:
             a = getattr(op.u, fieldname)
             a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+        if self._sync_bytes:
+            sync = torch.zeros((self._sync_bytes + 3) // 4, dtype=torch.int32, device=self.dev)
+            self.keep.append(sync)
+            self.arena_bytes += sync.numel() * 4
+            for op in self._sync_users:
+                op.u.conv3.wgrad_sync, op.u.conv3.wgrad_sync_bytes = sync.data_ptr(), sync.numel() * 4
         if self._stat_bytes:       # one scratch for all cells: a conv's partials are consumed by the InstanceNorm op right behind it
             sb = self.alloc((self._stat_bytes + 15) // 16 * 4)
             for op, fieldname in self._stat_users:

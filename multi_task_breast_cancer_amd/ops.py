@@ -269,8 +269,21 @@ def conv3x3_dgrad_c8(dz: "C8", w: torch.Tensor, dxs: Sequence[torch.Tensor], acc
     L.check(L.load().mtbc_conv3x3_dgrad(C.byref(a), _s()), "conv3x3_dgrad(c8)")
 
 
+_WGRAD_SYNC: dict = {}       # device -> zeroed int32 counters of the in-kernel split-K reduction (every launch leaves them at zero)
+
+
+def wgrad_sync_buffer(dev, nbytes: int) -> torch.Tensor:
+    buf = _WGRAD_SYNC.get(dev)
+    if buf is None or buf.numel() * 4 < nbytes:
+        buf = torch.zeros(max(4096, (nbytes + 3) // 4), dtype=torch.int32, device=dev)
+        _WGRAD_SYNC[dev] = buf
+    return buf
+
+
 def conv3x3_wgrad_c8(xs: Sequence["C8"], dz: "C8", w_shape, want_bias: bool = False, dw: Optional[torch.Tensor] = None,
-                     accumulate: bool = False):
+                     accumulate: bool = False, in_kernel_reduce: bool = True):
+    """in_kernel_reduce: the split-K partials are summed inside the launch by the last-arriving block of each group
+    (mtbc_conv3x3_args.wgrad_sync); False = the reduction launch behind the kernel (another, equally fixed, summation order)."""
     N, _, H, W = dz.shape
     dev = dz.data.device
     if dw is None:
@@ -287,6 +300,10 @@ def conv3x3_wgrad_c8(xs: Sequence["C8"], dz: "C8", w_shape, want_bias: bool = Fa
     nb = L.load().mtbc_conv3x3_wgrad_workspace(C.byref(a))
     ws = _ws(nb, dev)
     a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+    nsync = int(L.load().mtbc_conv3x3_wgrad_sync_bytes(C.byref(a))) if in_kernel_reduce else 0
+    if nsync:
+        sync = wgrad_sync_buffer(dev, nsync)
+        a.wgrad_sync, a.wgrad_sync_bytes = sync.data_ptr(), sync.numel() * 4
     L.check(L.load().mtbc_conv3x3_wgrad(C.byref(a), _s()), "conv3x3_wgrad(c8)")
     return dw, db
 

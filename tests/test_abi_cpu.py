@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol(lib):
     assert declared == set(L.EXPORTS), declared ^ set(L.EXPORTS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.mtbc_version() == 200
+    assert lib.mtbc_version() == 201
     # header, library and binding agree on the layout version (the binding refuses any other library at load time)
     assert int(re.search(r"#define\s+MTBC_VERSION\s+(\d+)", src).group(1)) == lib.mtbc_version() == L.ABI_VERSION
     assert lib.mtbc_arch() == b"gfx950"

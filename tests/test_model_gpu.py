@@ -263,16 +263,19 @@ def test_distributed_step_single_rank_rccl_equals_local_step():
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("arch,dtype,size,arm", [("MTUNetPlusPlus", "bf16", 64, ""), ("MTUNetPlusPlus", "f16", 64, ""), ("MTnnUNet", "bf16", 128, ""),
-                                                 ("MTUNetPlusPlus", "bf16", 128, ""), ("MTUNetPlusPlus", "bf16", 128, "no_gather"),
-                                                 ("MTUNetPlusPlus", "bf16", 64, "no_z16"), ("MTUNetPlusPlus", "bf16", 64, "no_da16"),
-                                                 ("MTUNetPlusPlus", "bf16", 64, "z_bf16"),
-                                                 # the BASELINE plane sizes: configs[1] (bf16, 256x256: cooperative InstanceNorm backward in teams of 32,
-                                                 # wide-block weight gradients) and configs[4] (fp16, 512x512: teams of 128), whole model against the emulation
-                                                 ("MTUNetPlusPlus", "bf16", 256, ""), ("MTUNetPlusPlus", "f16", 512, ""),
-                                                 # configs[2] in the arithmetic bench.py quotes it in (MTnnUNet, 256 x 256 planes, bf16)
-                                                 ("MTnnUNet", "bf16", 256, "")])
-def test_16bit_mfma_modes_match_their_emulation(arch, dtype, size, arm, monkeypatch):
+# (arch, dtype, size, arm, pre): pre = optimisation steps of the HIP fp32 mode (lr 1e-3, the parity-tested path) taken BEFORE the compared step
+@pytest.mark.parametrize("arch,dtype,size,arm,pre", [("MTUNetPlusPlus", "bf16", 64, "", 0), ("MTUNetPlusPlus", "f16", 64, "", 0), ("MTnnUNet", "bf16", 128, "", 0),
+                                                     ("MTUNetPlusPlus", "bf16", 128, "", 0), ("MTUNetPlusPlus", "bf16", 128, "no_gather", 0),
+                                                     ("MTUNetPlusPlus", "bf16", 64, "no_z16", 0), ("MTUNetPlusPlus", "bf16", 64, "no_da16", 0),
+                                                     ("MTUNetPlusPlus", "bf16", 64, "z_bf16", 0),
+                                                     # a TRAINED state at a small size too: every gradient path carries signal there (see below)
+                                                     ("MTUNetPlusPlus", "bf16", 64, "", 40), ("MTUNetPlusPlus", "f16", 128, "", 40),
+                                                     # the BASELINE plane sizes: configs[1] (bf16, 256x256: cooperative InstanceNorm backward in teams of 32,
+                                                     # wide-block weight gradients), configs[4] (fp16, 512x512: teams of 128) and configs[2] in the arithmetic
+                                                     # bench.py quotes it in (MTnnUNet, bf16, 256x256), whole model against the emulation
+                                                     ("MTUNetPlusPlus", "bf16", 256, "", 40), ("MTUNetPlusPlus", "f16", 512, "", 40),
+                                                     ("MTnnUNet", "bf16", 256, "", 40)])
+def test_16bit_mfma_modes_match_their_emulation(arch, dtype, size, arm, pre, monkeypatch):
     """Optional compute modes: conv3x3 MFMA operands rounded to bf16 / fp16 (fp32 storage + accumulation).  Not the
     reference-parity path (that is fp32); the oracle for it is oracle.lowp_conv3x3, which rounds the same operands
     at the same places on the CPU (fwd: x, w; dgrad: dy, w; wgrad: x, dy; RNE).  Rounding to 16 bits is itself
@@ -280,8 +283,18 @@ def test_16bit_mfma_modes_match_their_emulation(arch, dtype, size, arm, monkeypa
     another order moves by 2^-9, and the emulation run with fp32 accumulation already sits 6e-3 (forward) / 0.5
     (first-layer gradients, N=4 at 64x64) away from the same emulation with fp64 accumulation.  So the HIP path is
     judged like the fp32 test judges gradients: against the fp64-accumulating emulation, allowed 3x the distance the
-    fp32-accumulating CPU emulation has from it (and a small floor).  A wrong operand / rounding place shows up in
-    the forward as >= 3e-2.  fp16 runs with the static loss scale 4096 on both sides (unscaled, dz underflows fp16)."""
+    fp32-accumulating CPU emulation has from it (and a small floor) -- EVERY parameter tensor, no exception.  A wrong operand /
+    rounding place shows up in the forward as >= 3e-2.  fp16 runs with the static loss scale 4096 on both sides (unscaled, dz
+    underflows fp16).
+
+    `pre` > 0 (round 4): the compared step starts from weights that `pre` optimisation steps of the HIP fp32 mode have moved away from
+    the initialisation.  At initialisation and the BASELINE plane sizes the encoder gradients are cancellation residues: the fp32- and
+    fp64-accumulating emulations THEMSELVES differ by 25 - 38 % there (e_cpu), so "3 x e_cpu" allowed 75 - 100 % -- and round 3 added an
+    escape hatch (cosine > 0.6) on top.  Behind that slack a real defect survived two rounds: x_3_0 of the U-Net++ is max-pooled twice
+    (conv_4_0 and process_level_3, MTUNetPlusPlus.py:75,128) and only ONE of the two pools' folded backward reached its InstanceNorm
+    backward in the 16-bit modes (engine.maxpool) -- the classification head's gradient into the encoder was missing.  After 40 steps the
+    emulations agree to 2 - 13 % per tensor and that defect reads as e_hip = 0.45 - 0.53 on conv_3_0 / conv_2_0 (4 - 12 x e_cpu;
+    tools/experiments/try_emul3.py, profiles/r04_emulation_trained_state.txt).  The escape hatch is gone."""
     import copy
     from multi_task_breast_cancer_amd import engine
     # the plan switches (switches.py), each with the emulation told the same thing: fp32 instead of gathered 16-bit activation gradients
@@ -300,6 +313,13 @@ def test_16bit_mfma_modes_match_their_emulation(arch, dtype, size, arm, monkeypa
         monkeypatch.setattr(engine, "_Z_BF16", True)
     N = 4 if size == 64 else (1 if size == 512 else 2)          # >= 128x128: level 0 takes the cooperative InstanceNorm kernels
     prod, ref = _oracle_and_product(arch, 1993)
+    if pre:
+        warm = FusedTrainStep(prod, FusedAdam(prod, lr=1e-3, eps=1e-4), alpha=0.5)
+        for s_ in range(pre):
+            img, mask, label = O.synthetic_batch(4, size, size, seed=100 + s_)
+            warm(img.to(DEV), mask.to(DEV), label.to(DEV))
+        warm.check_nan()
+        ref.load_state_dict({k: v.detach().cpu().clone() for k, v in prod.state_dict().items()})
     prod.set_compute(dtype)
     ref64 = copy.deepcopy(ref).double()
     img, mask, label = O.synthetic_batch(N, size, size, seed=21)
@@ -317,22 +337,14 @@ def test_16bit_mfma_modes_match_their_emulation(arch, dtype, size, arm, monkeypa
     for got, w32, w64 in zip(st.segs, t32[4], t64[4]):
         assert rel(got.data, w64) < max(3 * rel(w32, w64), 2e-3)
     g32, g64 = dict(ref.named_parameters()), dict(ref64.named_parameters())
+    bad = []
     for name in prod._order:
         if name.endswith("conv.bias") or g64[name].grad.norm().item() == 0.0:
             continue
         e_hip, e_cpu = rel(prod._grad_view(name) / ls, g64[name].grad), rel(g32[name].grad, g64[name].grad)
-        if e_cpu <= 0.1 or e_hip < 3 * e_cpu:
-            assert e_hip < max(3 * e_cpu, 5e-2), (name, e_hip, e_cpu)
-        else:
-            # At the BASELINE plane sizes (256x256 / 512x512, N <= 2) the encoder's first cells have gradients that are cancellation
-            # residues at initialisation: the SAME roundings accumulated in fp32 instead of fp64 already move them by 13-18 % (e_cpu),
-            # and 16-bit rounding itself by 60-100 % (HIP bf16 against HIP fp32: 0.66-0.98; HIP fp16: 0.57-0.75, i.e. closer, as its
-            # 3 extra bits say it should be -- tools/experiments/try_emul2.py).  A 3 x e_cpu bar is meaningless there: such a tensor has
-            # to stay CORRELATED with the fp64 emulation (a wiring / rounding-place error gives >= 1.4 or a sign flip) and within
-            # 6 x the fp32-accumulating emulation's own distance.  Every kernel's backward is checked to 1e-5 in test_ops_gpu.py.
-            gh, gr = (prod._grad_view(name) / ls).double().cpu().flatten(), g64[name].grad.double().flatten()
-            cos = (gh @ gr / (gh.norm() * gr.norm())).item()
-            assert e_hip < min(1.0, 6 * e_cpu) and cos > 0.6, (name, e_hip, e_cpu, cos)
+        if not e_hip < max(3 * e_cpu, 5e-2):
+            bad.append((name, round(e_hip, 4), round(e_cpu, 4)))
+    assert not bad, bad
 
 
 def test_512_inputs_16bit_modes_track_the_fp32_step():

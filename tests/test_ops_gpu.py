@@ -538,6 +538,61 @@ def test_conv3x3_wgrad_c8_wide_blocks(N, segs, Cout, H, W, compute):
     assert torch.equal(again, dw1), "not deterministic"
 
 
+# the in-kernel split-K reduction across its tree shapes: (N, segs, Cout, H, W) -> splits per (co, ci) tile / levels
+FIXUP_CASES = [
+    (16, [24], 24, 256, 256),                  # 32 x 32 kernel, ONE tile, 1024 splits: three levels of fan-in 11
+    (8, [48], 48, 128, 128),                   # 4 tiles x 256 splits: three levels of 7
+    (4, [96], 96, 64, 64),                     # 9 tiles x 113 splits (not a multiple of 8: ragged (split % 8) classes)
+    (2, [192], 192, 32, 32),                   # 36 tiles x 28 splits: two levels of 6, ragged last group
+    (2, [384], 192, 32, 32),                   # 72 tiles x 14 splits
+    (8, [24, 24, 24], 24, 256, 256),           # wide-block kernel: 512 row-segment splits of image-major leaves (N % 8 == 0)
+    (3, [96, 48, 48], 48, 128, 128),           # wide-block kernel, N % 8 != 0: leaf = split
+    (32, [192], 384, 16, 16),                  # image-tile kernel: 24 channel blocks x 8 image ranges = one level
+    (6, [384], 384, 16, 16),                   # image-tile kernel: 6 ranges of one image
+    (1, [64], 48, 16, 16),                     # ONE split: with bias / accumulation the single row goes through the top level
+]
+
+
+@pytest.mark.parametrize("compute", [1, 2])
+@pytest.mark.parametrize("N,segs,Cout,H,W", FIXUP_CASES)
+def test_conv3x3_wgrad_c8_in_kernel_split_k_reduction(N, segs, Cout, H, W, compute):
+    """Round 4: the split-K partials of the channel-blocked weight gradients are summed INSIDE the launch by the last-arriving block of
+    each group of rows (mtbc_conv3x3_args.wgrad_sync; conv3x3.hip splitk_fixup) instead of by a reduction launch.  Against fp64 on the
+    rounded operands, like the reduction-launch path (which must agree with it to fp32 re-association); bit-identical from run to run
+    (sums are taken in row order, not arrival order); with bias, and accumulating into dw; the counter buffer is all zeros afterwards
+    (every group's winner resets its counter), so one buffer serves every launch of a stream.  Backward of nn.Conv2d,
+    MTUNetPlusPlus.py:47-81 / training_multitask.py:102."""
+    g = _g(N * 17 + Cout + H + compute)
+    Cin = sum(segs)
+    xs = [torch.randn(N, c, H, W, generator=g) for c in segs]
+    dz = torch.randn(N, Cout, H, W, generator=g)
+    x8 = [ops.C8.pack(x.to(DEV), compute) for x in xs]
+    dz8 = ops.C8.pack(dz.to(DEV), compute)
+    xr = _round16(torch.cat(xs, 1), compute).double()
+    dzr = _round16(dz, compute).double()
+    ref = torch.nn.grad.conv2d_weight(xr, (Cout, Cin, 3, 3), dzr, padding=1).float()
+    dbr = dzr.sum((0, 2, 3)).float()
+    scale = max(1.0, ref.abs().max().item())
+    shape = (Cout, Cin, 3, 3)
+    dw, db = ops.conv3x3_wgrad_c8(x8, dz8, shape, want_bias=True)
+    sync = ops.wgrad_sync_buffer(DEV, 4)
+    assert int(sync.abs().sum().item()) == 0, "counters not back at zero"
+    _close(dw, ref, 1e-5, 2e-5 * scale, "wgrad, in-kernel reduction")
+    _close(db, dbr, 1e-5, 2e-5 * max(1.0, dbr.abs().max().item()), "dbias, in-kernel reduction")
+    old, dbo = ops.conv3x3_wgrad_c8(x8, dz8, shape, want_bias=True, in_kernel_reduce=False)
+    _close(old, ref, 1e-5, 2e-5 * scale, "wgrad, reduction launch")
+    _close(dw, old.cpu(), 1e-5, 1e-5 * scale, "the two reductions agree")
+    _close(db, dbo.cpu(), 1e-5, 1e-5 * max(1.0, dbr.abs().max().item()), "the two bias reductions agree")
+    for _ in range(3):
+        again, dba = ops.conv3x3_wgrad_c8(x8, dz8, shape, want_bias=True)
+        assert torch.equal(again, dw) and torch.equal(dba, db), "not deterministic"
+    dw1, _ = ops.conv3x3_wgrad_c8(x8, dz8, shape, want_bias=False)
+    _close(dw1, ref, 1e-5, 2e-5 * scale, "no-bias instance")
+    dw2, _ = ops.conv3x3_wgrad_c8(x8, dz8, shape, want_bias=False, dw=dw1.clone(), accumulate=True)
+    _close(dw2, 2 * ref, 1e-5, 4e-5 * scale, "accumulate")
+    assert int(sync.abs().sum().item()) == 0, "counters not back at zero"
+
+
 @pytest.mark.parametrize("compute", [1, 2])
 @pytest.mark.parametrize("N,segs,Cout,H,W", C8_CASES + [(2, [24, 24, 24, 24, 24, 24], 24, 256, 256),   # 144->24 @256x256: the bench's widest level-0 node
                                                         (1, [384, 384, 384], 512, 16, 16),                 # K = 1152 x 9: the longest accumulation of the step

@@ -1,7 +1,7 @@
 """Scratch (round 4): the whole-model 16-bit-vs-emulation comparison of tests/test_model_gpu.py::test_16bit_mfma_modes_match_their_emulation at a state that
 is NOT the initialisation: K optimisation steps of the (parity-tested) HIP fp32 mode first, then ONE step of the 16-bit mode against the emulation from
 those weights.  Prints, per parameter tensor, e_hip / e_cpu / cosine -- are the level-0 encoder gradients still cancellation residues there?
-usage: try_emul3.py SIZE N DTYPE K LR"""
+usage: try_emul3.py SIZE N DTYPE K LR [ARM]      DTYPE f32 = the parity mode against the plain fp64 oracle; ARM in no_da16 | no_z16 | no_gather | z_bf16"""
 import sys, os, time, copy
 sys.path.insert(0, os.getcwd())
 import importlib.util
@@ -11,6 +11,14 @@ O, DEV = tm.O, tm.DEV
 from multi_task_breast_cancer_amd.trainer import FusedTrainStep
 from multi_task_breast_cancer_amd.optim import FusedAdam
 size, N, dtype, K, lr = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], int(sys.argv[4]), float(sys.argv[5])
+arm = sys.argv[6] if len(sys.argv) > 6 else ""
+import contextlib
+from multi_task_breast_cancer_amd import engine
+emu = {"": {"da16": True}, "no_da16": {"da16": False}, "no_gather": {"da16": False}, "no_z16": {"z16": False}, "z_bf16": {"z_fp16": False, "da16": True}}[arm]
+if arm == "no_gather": engine._NO_GATHER = True
+if arm == "no_z16": engine._NO_Z16 = True
+if arm == "no_da16": engine._DA16 = False
+if arm == "z_bf16": engine._Z_BF16 = True
 rel = lambda a, b: ((a.double().cpu() - b.double()).norm() / b.double().norm()).item()
 prod, ref = tm._oracle_and_product("MTUNetPlusPlus", 1993)
 if K:
@@ -28,10 +36,10 @@ st = step.load_batch(img.to(DEV), mask.to(DEV), label.to(DEV))
 losses = step.run(st).cpu()
 ls = prod.loss_scale
 t0 = time.time()
-with O.lowp_conv3x3(dtype, model=[ref, ref64], da16=True):
+with (contextlib.nullcontext() if dtype == 'f32' else O.lowp_conv3x3(dtype, model=[ref, ref64], **emu)):
     t32 = O.train_step(ref, O.make_adam(ref, 1e-4), img, mask, label, 0.5, True, 3, loss_scale=ls)
     t64 = O.train_step(ref64, O.make_adam(ref64, 1e-4), img.double(), mask.double(), label, 0.5, True, 3, loss_scale=ls)
-print(f"cpu emulation {time.time() - t0:.1f} s; loss hip {losses[0].item():.6f} cpu32 {t32[0].item():.6f} cpu64 {t64[0].item():.6f}", flush=True)
+print(f"[{dtype} {arm or 'default'} K={K} lr={lr}] cpu emulation {time.time() - t0:.1f} s; loss hip {losses[0].item():.6f} cpu32 {t32[0].item():.6f} cpu64 {t64[0].item():.6f}", flush=True)
 g32, g64 = dict(ref.named_parameters()), dict(ref64.named_parameters())
 rows = []
 for name in prod._order:

@@ -17,10 +17,13 @@ ap.add_argument("--arch", default="MTUNetPlusPlus"); ap.add_argument("--steps", 
 ap.add_argument("--batch", type=int, default=32); ap.add_argument("--size", type=int, default=256)
 ap.add_argument("--lr", type=float, default=5e-4); ap.add_argument("--eval-every", type=int, default=100)
 ap.add_argument("--eval-batches", type=int, default=8); ap.add_argument("--dtypes", default="f32,bf16")
-ap.add_argument("--seed", type=int, default=1993); ap.add_argument("--out", default=""); ap.add_argument("--cosine", action="store_true", help="CosineAnnealingLR(T_max=steps, eta_min=1e-6) as config.yaml scheduler: cosine")
+ap.add_argument("--seed", type=int, default=1993); ap.add_argument("--out", default=""); ap.add_argument("--hard", action="store_true", help="the task that can fail: synthetic.synthetic_batch(hard=True)"); ap.add_argument("--hard-contrast", default="", help="lo,span of the hard task's lesion contrast (calibration)"); ap.add_argument("--cosine", action="store_true", help="CosineAnnealingLR(T_max=steps, eta_min=1e-6) as config.yaml scheduler: cosine")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
-val = [synthetic_batch(args.batch, args.size, args.size, seed=10_000 + i, device=dev) for i in range(args.eval_batches)]
+if args.hard_contrast:
+    from multi_task_breast_cancer_amd import synthetic as _syn
+    _syn.HARD_CONTRAST = tuple(float(v) for v in args.hard_contrast.split(","))
+val = [synthetic_batch(args.batch, args.size, args.size, seed=10_000 + i, device=dev, hard=args.hard) for i in range(args.eval_batches)]
 
 def evaluate(model):
     tot = torch.zeros(3, dtype=torch.float64, device=dev); correct = 0; n = 0
@@ -41,7 +44,7 @@ for dtype in args.dtypes.split(","):
     sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=args.steps, eta_min=1e-6) if args.cosine else None
     curve = []; t0 = time.time(); run = 0.0
     for s in range(1, args.steps + 1):
-        batch = synthetic_batch(args.batch, args.size, args.size, seed=s, device=dev)
+        batch = synthetic_batch(args.batch, args.size, args.size, seed=s, device=dev, hard=args.hard)
         losses = step(*batch)
         if sched is not None:
             sched.step()

@@ -40,6 +40,7 @@ def operands(N, segs, Cout, S, seed):
     return xs, dz, [ops.C8.pack(x, compute) for x in xs], ops.C8.pack(dz, compute)
 
 
+IKR = os.environ.get('PROBE_REDUCE', 'kernel') != 'launch'      # PROBE_REDUCE=launch: the split-K partials summed by a second launch (the pre-round-4 path)
 ONLY = os.environ.get('PROBE_ONLY')          # e.g. PROBE_ONLY=144,24,256: one shape (Cin, Cout, size), for rocprofv3 --pmc runs
 if ONLY:
     ci_, co_, s_ = (int(v) for v in ONLY.split(','))
@@ -65,7 +66,7 @@ for segs, Cout, S, cnt in SHAPES:
     xs, dz, x8, dz8 = operands(NB, segs, Cout, S, 1)
     del xs, dz
     dw = torch.empty(shape, device=dev)
-    ms = timeit(lambda: ops.conv3x3_wgrad_c8(x8, dz8, shape, want_bias=BIAS, dw=dw))
+    ms = timeit(lambda: ops.conv3x3_wgrad_c8(x8, dz8, shape, want_bias=BIAS, dw=dw, in_kernel_reduce=IKR))
     by = 2.0 * NB * S * S * (Cin + Cout)
     fl = 2.0 * NB * S * S * Cin * Cout * 9
     tot += ms * cnt
