@@ -1498,6 +1498,9 @@ struct WgP {
     int tiles_x, tiles_y, total_tiles, tiles_per_split;
     int ciblocks;
     int dbg;      // timing probes (env MTBC_DBG): 1 = no global loads, 4 = no LDS commits
+#ifdef MTBC_PROBES
+    unsigned long long* ts;    // phase timestamps (MTBC_WG_TS=1): [block][16] ticks of the 100 MHz clock
+#endif
 };
 
 // COT = output-channel tiles per block (2 or 3): 128*COT threads, wave w = (co-tile w/2, half w%2 of the column tiles).  COT = 3 serves
@@ -1652,12 +1655,17 @@ __global__ __launch_bounds__(128 * COT, 3) void conv3x3_wgrad_mfma_kernel(const 
     for (int s = 0; s < XSLOTS; ++s) xr[s] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int s = 0; s < 4; ++s) zr[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+    MTBC_TS(p, 0);
     if (t_begin < t_end && !MTBC_DBG_BIT(p, 1)) prefetch(t_begin);
     for (int tile = t_begin; tile < t_end; ++tile) {
         __syncthreads();                       // everyone is done reading the previous tile
+        if (tile - t_begin < 3) MTBC_TS(p, 1 + 4 * (tile - t_begin));          // previous tile's MFMAs done by every wave
         if (!MTBC_DBG_BIT(p, 4)) commit();
+        if (tile - t_begin < 3) MTBC_TS(p, 2 + 4 * (tile - t_begin));          // this wave's loads have landed and are written to LDS
         __syncthreads();
+        if (tile - t_begin < 3) MTBC_TS(p, 3 + 4 * (tile - t_begin));          // ... everybody's
         if (tile + 1 < t_end && !MTBC_DBG_BIT(p, 1)) prefetch(tile + 1);   // in flight under the MFMAs below
+        if (tile - t_begin < 3) MTBC_TS(p, 4 + 4 * (tile - t_begin));          // next tile's loads issued
         // 32 k-steps of 4 pixels; fragments of step s+1 are read before the MFMAs of step s (bounded live ranges:
         // without the sched_barriers hipcc hoists all 320 LDS reads and needs >180 VGPRs, i.e. 2 waves/SIMD)
         float fa[2], fb[2][NTW];
@@ -1685,6 +1693,7 @@ __global__ __launch_bounds__(128 * COT, 3) void conv3x3_wgrad_mfma_kernel(const 
             __builtin_amdgcn_sched_barrier(0);
         }
     }
+    MTBC_TS(p, 13);
     // partial[split][co][ci][tap]; D row = co (kk*4+r), column = (tap, ci) of tile 2 i + (wv & 1)
 #pragma unroll
     for (int i = 0; i < NTW; ++i) {
@@ -1697,6 +1706,7 @@ __global__ __launch_bounds__(128 * COT, 3) void conv3x3_wgrad_mfma_kernel(const 
             if (co < p.Cout) p.partial[(((size_t)split * p.Cout + co) * p.Cin + ci) * 9 + tap] = acc[i][r];
         }
     }
+    MTBC_TS(p, 14);
 }
 
 // ------------------------------------------------------------------ wgrad on the 16-bit MFMA (optional compute mode)
@@ -4067,6 +4077,18 @@ int mtbc_conv3x3_wgrad(const mtbc_conv3x3_args* a, void* stream) {
         static const int dbgw = mtbc_probe_int("MTBC_DBG", 0);
         p.dbg = dbgw;
         dim3 grid(w.nsplit, w.coblocks * w.ciblocks);
+#ifdef MTBC_PROBES
+        // MTBC_WG_TS=1: phase timestamps of every block (thread 0) of the fp32 weight-gradient kernel, printed after the launch
+        static const int fts_env = mtbc_probe_int("MTBC_WG_TS", 0);
+        static unsigned long long* fdts = nullptr;
+        const size_t fnb = (size_t)grid.x * grid.y;
+        p.ts = nullptr;
+        if (fts_env && fnb <= 4096) {
+            if (!fdts) (void)hipMalloc(&fdts, 4096 * 16 * sizeof(unsigned long long));
+            (void)hipMemsetAsync(fdts, 0, fnb * 16 * sizeof(unsigned long long), st);
+            p.ts = fdts;
+        }
+#endif
         const int zch = 16 * w.cot;
         const dim3 blk(128 * w.cot);
         static const int lowp_env = mtbc_probe_int("MTBC_LOWP", -1);
@@ -4095,6 +4117,22 @@ int mtbc_conv3x3_wgrad(const mtbc_conv3x3_args* a, void* stream) {
         }
 #undef MTBC_WG_LAUNCH
         MTBC_CHECK_LAUNCH();
+#ifdef MTBC_PROBES
+        if (p.ts) {
+            (void)hipStreamSynchronize(st);
+            static unsigned long long fhts[4096 * 16];
+            (void)hipMemcpy(fhts, fdts, fnb * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+            unsigned long long t0 = ~0ull;
+            for (size_t b = 0; b < fnb; ++b) if (fhts[b * 16] && fhts[b * 16] < t0) t0 = fhts[b * 16];
+            double mean[15] = {0}; int cnt[15] = {0};
+            for (size_t b = 0; b < fnb; ++b)
+                for (int k = 0; k < 15; ++k) if (fhts[b * 16 + k]) { mean[k] += (double)(fhts[b * 16 + k] - t0) * 0.01; ++cnt[k]; }
+            for (int k = 0; k < 15; ++k) if (cnt[k]) mean[k] /= cnt[k];
+            fprintf(stderr, "wg_ts f32 %d->%d @%dx%d cot %d blocks %zu tiles/block %d | mean us since the first block's entry: entry %.2f", p.Cin, p.Cout, p.H, p.W, w.cot, fnb, w.tiles_per_split, mean[0]);
+            for (int k = 0; k < 3; ++k) fprintf(stderr, " | tile %d: all waves here %.2f own commit done %.2f published %.2f next loads issued %.2f", k, mean[1 + 4 * k], mean[2 + 4 * k], mean[3 + 4 * k], mean[4 + 4 * k]);
+            fprintf(stderr, " | loop done %.2f stored %.2f\n", mean[13], mean[14]);
+        }
+#endif
     } else {
         DirWgP p; p.N = a->N; p.H = a->H; p.W = a->W; p.Cin = a->Cin; p.Cout = a->Cout; p.nsplit = w.nsplit;
         p.in = in; p.dz = a->dout; p.partial = partial;

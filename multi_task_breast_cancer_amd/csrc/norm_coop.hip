@@ -291,6 +291,9 @@ __global__ __launch_bounds__(THREADS, THREADS >= 512 ? 4 : 2) void in_bwd_c8_ker
     CoopHdr* hdr = COOP ? reinterpret_cast<CoopHdr*>(p.state) : nullptr;
     unsigned epoch = 0;
     if constexpr (COOP) epoch = __hip_atomic_load(&hdr->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // (round 4: teams pinned to ONE XCD -- team t = the workgroups 8 (T (t / 8) + m) + t % 8 -- were built and measured: 11.33 / 11.34 / 11.37 ms
+    //  per step against 11.36 / 11.36 / 11.33, InstanceNorm backward 1.809 against 1.812 ms: nothing.  The mailbox words are agent-scope
+    //  atomics; they are served by the memory side wherever the members sit.  profiles/r04_ab.txt)
     const int team = COOP ? blockIdx.x / p.T : blockIdx.x, member = COOP ? blockIdx.x % p.T : 0;
     unsigned long long* mb = COOP ? reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(p.state) + CO_MAILBOX_OFF) + (size_t)team * CO_TEAM_WORDS : nullptr;
     const int slab = p.HW / p.T;

@@ -29,6 +29,7 @@ _DA16 = not _sw.flag("MTBC_NO_DA16")
 # measured crossovers of the cooperative (split-plane) InstanceNorm kernels on fp32 conv outputs (the MTBC_NO_Z16 arm): they win on
 # planes >= 128x128 forward / 256x256 backward; on small planes their barriers and 512-thread workgroups lose to one-plane kernels + pack
 _COOP_MIN_FWD, _COOP_MIN_BWD = 16384, 65536
+_IN_KERNEL_SPLITK = False   # see _conv_cell_backward: the in-kernel split-K reduction is slower than the reduction launches on this chip
 _DPARAM_BATCH = 12          # cells per batched InstanceNorm parameter-gradient reduction (36 launches of 5 us -> 3)
 
 
@@ -64,6 +65,7 @@ class Act:
     parent: Optional["Act"] = None     # this Act is images [view_index * N, (view_index + 1) * N) of `parent` (StepPlan.batch_pair / split_batch)
     view_index: int = 0
     views: list = field(default_factory=list)
+    c8_filled: bool = False            # (views) the channel-blocked half has a producer or a pack op already
     in_op: Optional[object] = None     # the InstanceNorm forward op that writes this activation (conv cells)
     pack_op: Optional[object] = None   # the op that fills `c8` from `data`
 
@@ -218,7 +220,7 @@ class StepPlan:
             v.grad = parent.grad[i * n:(i + 1) * n]
             v.parent, v.view_index = parent, i
             if parent.c8 is not None:
-                v.c8 = parent.c8[i * n:(i + 1) * n]
+                v.c8, v.c8_filled = parent.c8[i * n:(i + 1) * n], True
             v.planar_valid = parent.planar_valid
             parent.views.append(v)
             self.acts[v.name] = v
@@ -289,17 +291,27 @@ class StepPlan:
         behind the ops emitted so far, i.e. after its producer -- and then read by every 3x3 conv and weight gradient
         that consumes it (X0_0 of the U-Net++ feeds 4 convs and 4 wgrads): their staging becomes LDS-DMA."""
         a.c8_used = True
+
+        def pack_half(v: Act) -> None:      # a view whose producer wrote fp32 planes: re-block ITS images (the other half may not exist yet)
+            self._view_c8(v)
+            v.pack_op = self._c8_pack_op(v.data, v.c8, v.C, v.H * v.W, v.N)
+            self.fwd_ops.append(v.pack_op)
+            v.c8_filled = v.planar_used = v.parent.planar_used = True
+
         if a.parent is not None:
             a.parent.c8_used = True
-            if a.c8 is None:
-                raise NotImplementedError(f"{a.name}: a view without channel-blocked storage (its producer writes fp32 planes)")
+            if not a.c8_filled:
+                pack_half(a)
+            return a.c8
+        if a.views:
+            for v in a.views:
+                if not v.c8_filled:
+                    pack_half(v)
+            return a.c8
         if a.c8 is None:
             a.c8 = self.alloc(a.N, a.C // 8, a.H * a.W, 8, dtype=torch.int16)
             a.pack_op = self._c8_pack_op(a.data, a.c8, a.C, a.H * a.W, a.N)
             self.fwd_ops.append(a.pack_op)
-            if a.views:
-                for v in a.views:
-                    v.c8 = a.c8[v.view_index * (a.N // 2):(v.view_index + 1) * (a.N // 2)]
         return a.c8
 
     def _coop_state(self) -> int:
@@ -667,10 +679,12 @@ class StepPlan:
         # (batching the ~40 split-K reductions of a step into a few launches was built and measured: 15.20 vs 14.54 ms -- the
         #  partials then live in buffers of their own and travel to HBM and back instead of being reduced out of the cache)
         self._need_ws(op, "conv3", self.lib.mtbc_conv3x3_wgrad_workspace(C.byref(a)))
-        # channel-blocked weight gradients reduce their split-K partials inside the launch (last arriver per group, conv3x3.hip
-        # splitk_fixup): ONE zeroed counter buffer for the whole backward program -- the launches run in order on one stream and each
-        # leaves its counters at zero
-        nsync = int(self.lib.mtbc_conv3x3_wgrad_sync_bytes(C.byref(a)))
+        # (round 4: the library can reduce the split-K partials of a channel-blocked weight gradient INSIDE the launch -- last arriver per
+        #  group of rows, mtbc_conv3x3_args.wgrad_sync -- instead of by a reduction launch.  Built, tested, measured, NOT used: the 8 XCDs'
+        #  L2s are not coherent with each other, so the partials have to travel as agent-scope (write-through) accesses and the last
+        #  arriver of a tile pulls the whole tile's rows through ONE CU: every launch got 50 - 100 us slower, the step 11.2 -> 14.4 ms
+        #  (profiles/r04_wgrad_in_kernel_reduction.txt).  _IN_KERNEL_SPLITK stays False.)
+        nsync = int(self.lib.mtbc_conv3x3_wgrad_sync_bytes(C.byref(a))) if _IN_KERNEL_SPLITK else 0
         if nsync:
             self._sync_users.append(op)
             self._sync_bytes = max(self._sync_bytes, nsync)
@@ -737,6 +751,7 @@ class StepPlan:
         fold = False
         if c8:
             y.c8 = self._view_c8(y) if y.parent is not None else self.alloc(x.N, x.C // 8, y.H * y.W, 8, dtype=torch.int16)
+            y.c8_filled = True
             y.planar_valid = False
             if y.parent is not None:
                 y.parent.planar_valid = False

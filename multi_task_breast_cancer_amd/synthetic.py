@@ -5,7 +5,8 @@ oversampled class proportions 444:492:448 (benign : malignant : normal).  The ta
 normal = no lesion and an empty mask.  Deterministic in (seed, rank).
 
 `hard=True` (round 4): a task that can FAIL, shaped after what makes Curated-BUSI hard (the reference's published level is DSC 0.751 /
-ACC 0.802, README.md:77): low-contrast lesions (8 - 22 % instead of 38 - 50 %), multiplicative speckle with structure at lesion scale,
+ACC 0.802, README.md:77): lesions under multiplicative speckle with structure at lesion scale (excursions of +-25 %: a lesion of 30 - 50 %
+contrast is one dark region among several),
 dark distractor regions (acoustic shadows) that are NOT lesions in every class, an annotation that is not the lesion's exact outline
 (the mask is the lesion with its radii and centre jittered, as a second reader would draw it), benign / malignant told apart by
 boundary irregularity alone, and 12 % of the benign / malignant labels swapped.  No arithmetic reaches Dice 0.99 / accuracy 1.0 on it."""
@@ -63,7 +64,7 @@ def _blobs(n, h, w, g, device, cy, cx, ry, rx, amp, coef, phase):
     return (rad <= bound).float()
 
 
-HARD_CONTRAST = (0.08, 0.14)       # lesion contrast = lo + span * U(0, 1); tools/train_parity.py --hard-contrast calibrates it
+HARD_CONTRAST = (0.30, 0.20)       # lesion contrast = lo + span * U(0, 1); calibrated with tools/train_parity.py --hard-contrast (profiles/r04_quality_hard.md)
 
 
 def _hard_batch(n: int, h: int, w: int, seed: int, device, rank: int = 0):
@@ -96,8 +97,14 @@ def _hard_batch(n: int, h: int, w: int, seed: int, device, rank: int = 0):
         b = rndn(n, 1, h // scale + 2, w // scale + 2)
         return F.interpolate(b, size=(h, w), mode="bilinear", align_corners=True)
     low = field(32)
-    speckle = 0.55 * rndn(n, 1, h, w) + 0.35 * field(6) + 0.30 * field(20)
-    contrast = (HARD_CONTRAST[0] + HARD_CONTRAST[1] * rnd(n, 1, 1, 1))           # 8 - 22 %: inside the speckle's own excursions
+    # (the pixel-scale field comes from a generator ON the device: 2 M normals per batch from the CPU generator cost more than a training step)
+    if torch.device(dev).type == "cuda":
+        gd = torch.Generator(device=dev).manual_seed(seed * 104729 + rank + 23)
+        white = torch.randn(n, 1, h, w, generator=gd, device=dev)
+    else:
+        white = rndn(n, 1, h, w)
+    speckle = 0.55 * white + 0.35 * field(6) + 0.30 * field(20)
+    contrast = (HARD_CONTRAST[0] + HARD_CONTRAST[1] * rnd(n, 1, 1, 1))           # 30 - 50 % under speckle whose own excursions are +-25 %
     sc = (0.10 + 0.15 * rnd(n, 1, 1, 1))
     soft = lambda m: F.avg_pool2d(m.view(n, 1, h, w), 9, stride=1, padding=4)
     tissue = (118.0 + 40.0 * low) * (1.0 + 0.33 * speckle)
