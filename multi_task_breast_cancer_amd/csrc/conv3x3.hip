@@ -1557,23 +1557,31 @@ __global__ __launch_bounds__(128 * COT, 3) void conv3x3_wgrad_mfma_kernel(const 
         if (G::IMG == 1) {
             const bool interior = y0 >= 1 && y0 + G::TH + 1 <= p.H && x0 >= 4 && x0 + G::TW + 4 <= p.W && !MTBC_DBG_BIT(p, 1);   // uniform
             if (interior) {
-                const float* xt = xplane + ((size_t)n0 * xbs + y0 * p.W + x0);
-                const float* zt = zplane + ((size_t)n0 * p.Cout * HW + y0 * p.W + x0);
                 live = slots_ok;
                 // the slot offsets are recomputed per tile from an opaque copy of q: kept live across the MFMA loop they were spilled
                 // (the packed-column variant has 7 per-lane column offsets more), and every scratch reload between these loads waits
                 // for the loads already issued
                 int qq = q;
                 asm volatile("" : "+v"(qq));
+                // ONE base pointer per operand and an integer offset that is 0 for an absent slot.  (Round 4, found with the phase stamps + the ISA:
+                // written as `ok ? tile_pointer + offset : plane_pointer`, hipcc turned the pointer select into control flow -- a load from
+                // the plane for every lane, then, under an exec mask, the address computed INTO the first load's destination registers and
+                // a second load: two `s_waitcnt vmcnt(0)` in the middle of every prefetch, i.e. two exposed memory round trips per tile,
+                // 6.4 of a tile's 16.2 us at 24 -> 24 @256 x 256, profiles/r04_f32_wgrad_phase_stamps.txt.)
+                const long long xo = (long long)((size_t)n0 * xbs) + y0 * p.W + x0, zo = (long long)((size_t)n0 * p.Cout * HW) + y0 * p.W + x0;
 #pragma unroll
                 for (int s = 0; s < XSLOTS; ++s) {
                     const int f = qq + 8 * s, row = f / (G::LW / 4), c4 = f % (G::LW / 4);
-                    xr[s] = *reinterpret_cast<const float4*>(((slots_ok >> s) & 1u) ? xt + ((row - 1) * p.W + (c4 * 4 - 4)) : xplane);
+                    long long off = ((slots_ok >> s) & 1u) ? xo + ((row - 1) * p.W + (c4 * 4 - 4)) : 0;
+                    asm volatile("" : "+v"(off));          // opaque: the select stays a select (hipcc otherwise splits the LOAD over the two arms)
+                    xr[s] = *reinterpret_cast<const float4*>(xplane + off);
                 }
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
                     const int px = (qq + 8 * s) * 4;
-                    zr[s] = *reinterpret_cast<const float4*>(co_ok ? zt + ((px / G::TW) * p.W + px % G::TW) : zplane);
+                    long long off = co_ok ? zo + ((px / G::TW) * p.W + px % G::TW) : 0;
+                    asm volatile("" : "+v"(off));
+                    zr[s] = *reinterpret_cast<const float4*>(zplane + off);
                 }
                 return;
             }
@@ -1920,15 +1928,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_lp2_kernel(const WgP p) 
         const int tx = t % p.tiles_x; t /= p.tiles_x;
         const int ty = t % p.tiles_y; t /= p.tiles_y;
         const int n = t, x0 = tx * TW, y0 = ty * TH;
-        const float* xt = xplane + ((size_t)n * xbs + y0 * p.W + x0);
-        const float* zt = zplane + ((size_t)n * p.Cout * HW + y0 * p.W + x0);
+        // (one base pointer + an integer offset that is 0 for an absent slot: a SELECT OF POINTERS in front of a load becomes control flow with
+        //  two loads into the same registers and a vmcnt(0) between them -- see conv3x3_wgrad_mfma_kernel)
+        const long long xo = (long long)((size_t)n * xbs) + y0 * p.W + x0, zo = (long long)((size_t)n * p.Cout * HW) + y0 * p.W + x0;
         const bool interior = y0 >= 1 && y0 + TH + 1 <= p.H && x0 >= 4 && x0 + TW + 4 <= p.W && !MTBC_DBG_BIT(p, 1);   // uniform
         if (interior) {
             live = slots_ok;
 #pragma unroll
-            for (int s = 0; s < XSLOTS; ++s) xr[s] = *reinterpret_cast<const float4*>(((slots_ok >> s) & 1u) ? xt + xrel[s] : xplane);
+            for (int s = 0; s < XSLOTS; ++s) xr[s] = *reinterpret_cast<const float4*>(xplane + (((slots_ok >> s) & 1u) ? xo + xrel[s] : 0));
 #pragma unroll
-            for (int s = 0; s < 4; ++s) zr[s] = *reinterpret_cast<const float4*>(co_ok ? zt + zrel[s] : zplane);
+            for (int s = 0; s < 4; ++s) zr[s] = *reinterpret_cast<const float4*>(zplane + (co_ok ? zo + zrel[s] : 0));
             return;
         }
         live = 0;
@@ -1938,7 +1947,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_lp2_kernel(const WgP p) 
             const int row = f / (LW / 4), c4 = f % (LW / 4);
             const int y = y0 + row - 1, x = x0 - 4 + c4 * 4;
             const bool ok = f < XF4 && ci_ok && y >= 0 && y < p.H && x >= 0 && x < p.W && !MTBC_DBG_BIT(p, 1);
-            xr[s] = *reinterpret_cast<const float4*>(ok ? xt + xrel[s] : xplane);
+            xr[s] = *reinterpret_cast<const float4*>(xplane + (ok ? xo + xrel[s] : 0));
             live |= ok ? (1u << s) : 0u;
         }
 #pragma unroll
@@ -1946,7 +1955,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_lp2_kernel(const WgP p) 
             const int px = (q + 8 * s) * 4;
             const int y = y0 + px / TW, x = x0 + px % TW;
             const bool ok = co_ok && y < p.H && x < p.W && !MTBC_DBG_BIT(p, 1);
-            zr[s] = *reinterpret_cast<const float4*>(ok ? zt + zrel[s] : zplane);
+            zr[s] = *reinterpret_cast<const float4*>(zplane + (ok ? zo + zrel[s] : 0));
             live |= ok ? (1u << (XSLOTS + s)) : 0u;
         }
     };
@@ -3536,6 +3545,9 @@ IgemmPlan plan_igemm(int N, int H, int W, int rows, int compute, bool c8, bool a
         if (allow_nw8 && q.geo == 0 && q.MT == 2 && (nw_env ? nw_env == 8 : (long long)t16 * q.mblocks >= 2048)) {
             q.nw8 = true; q.tiles_y = cdiv(H, 16); q.ntiles = t16;
         }
+        // (round 4: the same 16 x 32 tiles for the 48-channel blocks (MT = 3) of the 128 x 128 maps -- 1024 tiles on 512 8-wave blocks = exactly two each, where
+        //  2048 tiles of 8 x 32 on 768 4-wave blocks are 2.67 -- were built and measured: 11.53 / 11.53 / 11.54 ms per step against 11.46 / 11.45 / 11.45.
+        //  Slower; removed.  profiles/r04_ab.txt)
     }
     return q;
 }
@@ -3714,10 +3726,12 @@ WgPlan plan_wgrad(const mtbc_conv3x3_args* a) {
         w.coblocks = cdiv(a->Cout, 16 * w.cot); w.ciblocks = cdiv(a->Cin, 32);
         // fp32 kernel: input-channel blocks of 24 where Cin is a multiple of 24 and not of 32 (every level-0 / level-1 conv of the U-Net++):
         // 13.5 (tap, ci) column tiles per block instead of 18 -- conv3x3_wgrad_mfma_kernel<.., PACK>
-        // MEASURED (round 3, profiles/r03_f32_wgrad_pack24.txt): no faster -- 24 -> 24 @256x256 0.298 ms with 28 MFMAs per K-step and block as
-        // with 36, i.e. the matrix pipe 64 % instead of 82 % busy: the level-0 / level-1 launches of this kernel are not bound by the number
-        // of MFMAs they issue.  Kept behind the probes build (MTBC_WGRAD_PACK24=1) for the next look at what does bound them.
-        static const int pack_probe = mtbc_probe_int("MTBC_WGRAD_PACK24", 0);
+        // Round 3 measured "no faster" on whole-step per-op times (profiles/r03_f32_wgrad_pack24.txt) and kept it behind the probes build.  Round 4,
+        // launch by launch (tools/experiments/f32_wgrad_one.py, profiles/r04_f32_wgrad.txt): 24 -> 24 @256 409 -> 346 us, 48 -> 48 @128 354 -> 292,
+        // 72 -> 24 1069 -> 932, 144 -> 24 1749 -> 1684 -- the phase stamps say why it has to: three resident blocks keep the matrix pipe busy ~95 % of
+        // a tile period, so the MFMAs a launch ISSUES (a third of them padding at Cin = 24) are its time.  On by default; MTBC_WGRAD_PACK24=0 in the
+        // probes build restores 32-channel blocks.
+        static const int pack_probe = mtbc_probe_int("MTBC_WGRAD_PACK24", 1);
         w.pack24 = pack_probe && a->compute == 0 && a->Cin % 24 == 0 && a->Cin % 32 != 0;
         if (w.pack24) w.ciblocks = a->Cin / 24;
         const int pairs = w.coblocks * w.ciblocks;

@@ -221,13 +221,8 @@ def _graph_unetpp(plan: StepPlan, x: Act):
     # process_level_3 (shared weights) is applied to pool(x_3_0) AND pool(x_3_1) (MTUNetPlusPlus.py:79,128): planned ONCE over their
     # batch concatenation (InstanceNorm is per sample: exact).  The two pooled tensors are the halves of one 2N-image tensor; conv_4_0
     # reads the first half (x_3_0 is pooled once, for both of its consumers)
-    import os as _os
-    _sep = bool(_os.environ.get("MTBC_X_PL3_SEPARATE"))      # TEMPORARY (A/B of the batched process_level_3): removed after the measurement
-    if _sep:
-        x40 = down(x30, f[4], "conv_4_0")
-    else:
-        pl3_in, (p30, p31) = plan.batch_pair("process_level_3.in", f[3], x30.H // 2, x30.W // 2)
-        x40 = two_conv([plan.maxpool(x30, "conv_4_0.pool", out=p30)], f[4], "conv_4_0.convs")
+    pl3_in, (p30, p31) = plan.batch_pair("process_level_3.in", f[3], x30.H // 2, x30.W // 2)
+    x40 = two_conv([plan.maxpool(x30, "conv_4_0.pool", out=p30)], f[4], "conv_4_0.convs")
     x31 = upcat(x40, [x30], f[3], "upcat_3_1")
     x22 = upcat(x31, [x20, x21], f[2], "upcat_2_2")
     x13 = upcat(x22, [x10, x11, x12], f[1], "upcat_1_3")
@@ -235,12 +230,8 @@ def _graph_unetpp(plan: StepPlan, x: Act):
     regions = plan.pv("final_conv_0_1.weight").shape[0]
     outs = [plan.conv1x1(t, regions, f"final_conv_0_{j}.weight", f"final_conv_0_{j}.bias", f"final_conv_0_{j}")
             for j, t in ((1, x01), (2, x02), (3, x03), (4, x04))]
-    if _sep:
-        pa = down(x30, f[4], "process_level_3", tag="a")
-        pb = down(x31, f[4], "process_level_3", tag="b")
-    else:
-        plan.maxpool(x31, "process_level_3.poolb", out=p31)
-        pa, pb = plan.split_batch(two_conv([pl3_in], f[4], "process_level_3.convs"))      # shared weights, both applications in one pass (F10)
+    plan.maxpool(x31, "process_level_3.poolb", out=p31)
+    pa, pb = plan.split_batch(two_conv([pl3_in], f[4], "process_level_3.convs"))      # shared weights, both applications in one pass (F10)
     feat = two_conv([pa, x40, pb], 512, "classifier.0")
     g = plan.gap(feat, "gap")
     h = plan.linear(g, 256, "classifier.3.weight", "classifier.3.bias", True, "fc1")

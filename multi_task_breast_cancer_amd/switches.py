@@ -16,7 +16,7 @@ from typing import Dict, List
 PLAN_SWITCHES: Dict[str, tuple] = {
     "MTBC_NO_COOP": ("0", "InstanceNorm by one-plane workgroups (fp32 conv outputs) + pack instead of the channel-group / cooperative kernels: "
                           "the fallback when their teams cannot be co-resident (the cooperative error message names it)",
-                     "tests/test_coop_safety_gpu.py::test_cooperative_step_beside_a_cu_hogging_kernel"),
+                     "tests/test_model_gpu.py::test_16bit_mfma_modes_match_their_emulation[...-no_coop-40]"),
     "MTBC_NO_GATHER": ("0", "every 3x3 conv back-propagates into all its inputs (fan-in by read-modify-write) instead of one gathered launch per dense-skip tensor",
                        "tests/test_model_gpu.py::test_16bit_mfma_modes_match_their_emulation[...-no_gather]"),
     "MTBC_NO_Z16": ("0", "16-bit modes keep the conv outputs z as fp32 planes (InstanceNorm reads 4 bytes per element in both directions): the storage arm of the quality sweeps",
@@ -46,7 +46,8 @@ REMOVED = ("MTBC_NO_C8", "MTBC_NO_CT_LP", "MTBC_COOP_MIN_FWD", "MTBC_COOP_MIN_BW
 # timings are not the product's when one of them takes effect
 RESULT_ALTERING = ("MTBC_DBG", "MTBC_NOACC", "MTBC_LOWP", "MTBC_LP_MT", "MTBC_RING", "MTBC_NODMA", "MTBC_C8_BLOCKS_PER_CU",
                    "MTBC_WGRAD_LP1", "MTBC_CT_WG_TASKS", "MTBC_IN_BWD_STREAM", "MTBC_CONVT_GENERIC", "MTBC_C8_NW", "MTBC_C8_RING",
-                   "MTBC_CT_DEPTH", "MTBC_CT_WG_CT", "MTBC_CT_DGRAD_DIRECT", "MTBC_WGRAD_C8W", "MTBC_C8W_BPC", "MTBC_C8W_DEPTH", "MTBC_C8W_HACK")
+                   "MTBC_CT_DEPTH", "MTBC_CT_WG_CT", "MTBC_CT_DGRAD_DIRECT", "MTBC_WGRAD_C8W", "MTBC_C8W_BPC", "MTBC_C8W_DEPTH", "MTBC_C8W_HACK",
+                   "MTBC_WGRAD_PACK24", "MTBC_WGRAD_C8I", "MTBC_WG_TS", "MTBC_C8_TS", "MTBC_RING_TS", "MTBC_INB_TS")
 
 
 def get(name: str) -> str:

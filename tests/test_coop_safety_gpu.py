@@ -88,7 +88,9 @@ def test_cooperative_step_beside_a_cu_hogging_kernel(dtype, N, size, monkeypatch
     monkeypatch.setattr(engine, "_NO_COOP", True)
     l_ref, p_ref, n_coop_ref, _ = _run_steps(_model(dtype, 0), batch, 2)
     assert n_coop_ref == 0
-    assert abs(l_ref[0].item() - l_idle[0].item()) < 2e-3 * abs(l_ref[0].item())
+    # (another arithmetic, not another order: this arm keeps the conv outputs in fp32 where the default plan stores them as fp16 -- the oracle check
+    #  of this arm is test_16bit_mfma_modes_match_their_emulation[...-no_coop-40]; here: the two plans train the same function)
+    assert abs(l_ref[0].item() - l_idle[0].item()) < 5e-3 * abs(l_ref[0].item())
     assert (p_ref - p_idle).abs().max().item() < 6.1e-4          # three Adam steps of lr 1e-4 move a weight by at most 3e-4 each way
 
 

@@ -270,6 +270,8 @@ def test_distributed_step_single_rank_rccl_equals_local_step():
                                                      ("MTUNetPlusPlus", "bf16", 64, "z_bf16", 0),
                                                      # a TRAINED state at a small size too: every gradient path carries signal there (see below)
                                                      ("MTUNetPlusPlus", "bf16", 64, "", 40), ("MTUNetPlusPlus", "f16", 128, "", 40),
+                                                     # the one-plane InstanceNorm kernels + pack (MTBC_NO_COOP: fp32 conv outputs), against the emulation told so
+                                                     ("MTUNetPlusPlus", "bf16", 128, "no_coop", 40),
                                                      # the BASELINE plane sizes: configs[1] (bf16, 256x256: cooperative InstanceNorm backward in teams of 32,
                                                      # wide-block weight gradients), configs[4] (fp16, 512x512: teams of 128) and configs[2] in the arithmetic
                                                      # bench.py quotes it in (MTnnUNet, bf16, 256x256), whole model against the emulation
@@ -301,8 +303,10 @@ def test_16bit_mfma_modes_match_their_emulation(arch, dtype, size, arm, pre, mon
     # (MTBC_NO_DA16), conv outputs kept in fp32 (MTBC_NO_Z16) or stored as bf16 instead of fp16 (MTBC_Z_BF16); per-consumer input
     # gradients with read-modify-write fan-in instead of the gathered launches (MTBC_NO_GATHER: same roundings, another fp32 order)
     # (default plan: the gathered activation gradients are stored in 16 bits -- da16; without gathered launches nothing is rounded there)
-    emu = {"": {"da16": True}, "no_da16": {"da16": False}, "no_gather": {"da16": False}, "no_z16": {"z16": False},
+    emu = {"": {"da16": True}, "no_da16": {"da16": False}, "no_gather": {"da16": False}, "no_z16": {"z16": False}, "no_coop": {"z16": False},
            "z_bf16": {"z_fp16": False, "da16": True}}[arm]
+    if arm == "no_coop":
+        monkeypatch.setattr(engine, "_NO_COOP", True)
     if arm == "no_gather":
         monkeypatch.setattr(engine, "_NO_GATHER", True)
     elif arm == "no_z16":
