@@ -3731,6 +3731,10 @@ WgPlan plan_wgrad(const mtbc_conv3x3_args* a) {
         // 72 -> 24 1069 -> 932, 144 -> 24 1749 -> 1684 -- the phase stamps say why it has to: three resident blocks keep the matrix pipe busy ~95 % of
         // a tile period, so the MFMAs a launch ISSUES (a third of them padding at Cin = 24) are its time.  On by default; MTBC_WGRAD_PACK24=0 in the
         // probes build restores 32-channel blocks.
+        // (Round 4, measured and NOT kept: the two tensors swapped for the level-0 multi-input convs -- rows = the 72 .. 144 input channels, whose 16-row
+        //  tiles are full, columns = (tap, the 24 output channels) packed: 13 - 25 % fewer MFMAs issued.  Launch by launch 72 -> 24 942 -> 907 us,
+        //  144 -> 24 1680 -> 1584, but 120 -> 24 1432 -> 1556, and the fp32 step 47.38 -> 47.46 ms: with 48-row blocks (6 waves, 2 blocks per CU) the
+        //  launches lose in phase overlap what they save in the matrix pipe.  profiles/r04_f32_wgrad.txt)
         static const int pack_probe = mtbc_probe_int("MTBC_WGRAD_PACK24", 1);
         w.pack24 = pack_probe && a->compute == 0 && a->Cin % 24 == 0 && a->Cin % 32 != 0;
         if (w.pack24) w.ciblocks = a->Cin / 24;

@@ -1,0 +1,62 @@
+"""Paired summary of the round-4 quality sweep on the task that can fail (tools/experiments/tp_r4_hard.sh): fp32 mode vs bf16 mode per seed, mean +- standard
+error of the paired differences.   usage: python tools/experiments/tp_r4_summary.py gpurun_out/r4q [gpurun_out/r4q6000] > profiles/r04_quality_hard.md"""
+import glob, json, math, os, re, sys
+d = sys.argv[1]
+rows = []
+for f in sorted(glob.glob(os.path.join(d, "tp_s*.json")), key=lambda s: int(re.search(r"tp_s(\d+)", s).group(1))):
+    r = json.load(open(f))
+    rows.append((r["config"]["seed"], r["runs"]["f32"], r["runs"]["bf16"], r["config"]))
+cfg = rows[0][3]
+print("# fp32 mode vs bf16 mode on a task that can fail: held-out Dice / accuracy over seeds (round 4)\n")
+print(f"`tools/experiments/tp_r4_hard.sh`: `python tools/train_parity.py --steps {cfg['steps']} --batch {cfg['batch']} --size {cfg['size']} --lr {cfg['lr']} --cosine "
+      f"--eval-every {cfg['eval_every']} --eval-batches {cfg['eval_batches']} --dtypes f32,bf16 --hard --seed S` -- U-Net++ MT (deep supervision, Dice + Focal, alpha 0.35, Adam eps 1e-4) on "
+      "`synthetic.synthetic_batch(hard=True)`: lesions of 30 - 50 % contrast under multiplicative speckle with structure at lesion scale, dark non-lesion regions in every "
+      "class, an annotation whose radii / centre are jittered against the lesion in the image, benign / malignant told apart by boundary irregularity alone, 12 % of those "
+      "labels swapped (accuracy ceiling ~0.92).  The same batch stream and initial weights in both modes of a seed; hard Dice (metrics.py:255-267) and 3-class accuracy on "
+      f"{cfg['eval_batches']} held-out batches ({cfg['eval_batches'] * cfg['batch']} images).  The reference publishes DSC 0.751 / ACC 0.802 on the real Curated BUSI (README.md:77, table 5): this task sits in "
+      "that regime -- no run of any arithmetic reaches 0.87 / 0.86 -- where round 3's task ended at 0.987 / 1.000 whatever was run.\n")
+print("| seed | fp32 mode: Dice mid-run | final | acc | bf16 mode: Dice mid-run | final | acc | bf16 - fp32 Dice (pt) | acc (pt) |")
+print("|---|---|---|---|---|---|---|---|---|")
+diffs, adiffs = [], []
+for seed, a, b, _ in rows:
+    da, db = a[-1]["val_dice"], b[-1]["val_dice"]
+    mid = len(a) // 2 - 1 if len(a) > 1 else 0
+    diffs.append(100 * (db - da)); adiffs.append(100 * (b[-1]["val_acc"] - a[-1]["val_acc"]))
+    print(f"| {seed} | {a[mid]['val_dice']:.4f} | {da:.4f} | {a[-1]['val_acc']:.4f} | {b[mid]['val_dice']:.4f} | {db:.4f} | {b[-1]['val_acc']:.4f} | {diffs[-1]:+.3f} | {adiffs[-1]:+.2f} |")
+n = len(diffs)
+if n >= 2:
+    m = sum(diffs) / n
+    se = math.sqrt(sum((x - m) ** 2 for x in diffs) / (n - 1) / n)
+    ma = sum(adiffs) / n
+    sea = math.sqrt(sum((x - ma) ** 2 for x in adiffs) / (n - 1) / n)
+    mf = sum(r[1][-1]["val_dice"] for r in rows) / n
+    mb = sum(r[2][-1]["val_dice"] for r in rows) / n
+    af = sum(r[1][-1]["val_acc"] for r in rows) / n
+    ab = sum(r[2][-1]["val_acc"] for r in rows) / n
+    inside = abs(m) + 2 * se < 0.2
+    print(f"\n**{n} paired seeds: mean Dice fp32 {mf:.4f}, bf16 {mb:.4f}; bf16 - fp32 = {m:+.3f} pt, standard error {se:.3f} pt (max |difference| {max(abs(x) for x in diffs):.3f} pt).  "
+          f"Accuracy fp32 {af:.4f}, bf16 {ab:.4f}: {ma:+.3f} +- {sea:.3f} pt (one image of {cfg['eval_batches'] * cfg['batch']} = {100.0 / (cfg['eval_batches'] * cfg['batch']):.2f} pt).**  "
+          f"north_star asks for +-0.2 pt: the paired Dice difference is {'inside' if inside else 'NOT shown to be inside'} that band at two standard errors"
+          + ("" if inside else f" (|mean| + 2 SE = {abs(m) + 2 * se:.3f} pt)") + f"; the accuracy difference is {'inside' if abs(ma) + 2 * sea < 0.2 else 'NOT resolved to'} +-0.2 pt "
+          f"(|mean| + 2 SE = {abs(ma) + 2 * sea:.2f} pt: the held-out set resolves {100.0 / (cfg['eval_batches'] * cfg['batch']):.2f} pt per image and 12 % of its labels are noise).")
+    # the jump from ~0.70 to ~0.85 mid-run: is one arithmetic systematically later?
+    md = [100 * (r[2][len(r[2]) // 2 - 1]["val_dice"] - r[1][len(r[1]) // 2 - 1]["val_dice"]) for r in rows]
+    mm_ = sum(md) / n
+    sem = math.sqrt(sum((x - mm_) ** 2 for x in md) / (n - 1) / n)
+    print(f"\nMid-run (step {rows[0][1][len(rows[0][1]) // 2 - 1]['step']}), where the runs are in the middle of their climb: bf16 - fp32 = {mm_:+.1f} +- {sem:.1f} pt "
+          f"({sum(1 for x in md if x < -1)} of {n} seeds with bf16 more than a point behind, {sum(1 for x in md if x > 1)} ahead) -- WHEN a run makes its jump varies by thousands of steps "
+          "with the seed; said plainly: on this evidence the bf16 mode may reach the plateau somewhat later, and it reaches the same plateau.")
+if len(sys.argv) > 2:
+    print("\n## The first protocol (6000 steps) had not converged\n")
+    print("The same command with `--steps 6000 --eval-every 2000`: the runs were still climbing (0.67 -> 0.70 -> 0.73 ...), and WHEN a run makes its jump from ~0.70 to ~0.85 depends on the seed, "
+          "not on the arithmetic -- paired differences of +-9 pt that say nothing about bf16.  (Round 3 had the same lesson at 3000 -> 6000 steps on the easy task.)\n")
+    print("| seed | fp32 Dice @2000 | @4000 | @6000 | bf16 @2000 | @4000 | @6000 | bf16 - fp32 @6000 (pt) |")
+    print("|---|---|---|---|---|---|---|---|")
+    for f in sorted(glob.glob(os.path.join(sys.argv[2], "tp_s*.log")), key=lambda s: int(re.search(r"tp_s(\d+)", s).group(1))):
+        v = {"f32": [], "bf16": []}
+        for line in open(f):
+            mm = re.match(r"\[(f32|bf16)\] step\s+\d+ loss [\d.]+ val dice ([\d.]+)", line)
+            if mm: v[mm.group(1)].append(float(mm.group(2)))
+        if len(v["f32"]) == 3 and len(v["bf16"]) == 3:
+            s_ = re.search(r"tp_s(\d+)", f).group(1)
+            print(f"| {s_} | " + " | ".join(f"{x:.4f}" for x in v["f32"] + v["bf16"]) + f" | {100 * (v['bf16'][2] - v['f32'][2]):+.2f} |")

@@ -5,9 +5,11 @@
 #     1. --kernel-trace --stats                                   -> TAG_{dt}_kernel_stats.csv
 #     2. --kernel-trace --pmc FETCH_SIZE ; 3. --pmc WRITE_SIZE    -> TAG_hbm_traffic_{dt}.json   (tools/pmc_traffic.py)
 #     4. --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE  -> TAG_mfma_busy_{dt}.txt
-#   plus the bench lines of BASELINE.json configs[2] (MTnnUNet B=64) and configs[4]'s per-GPU shape (512x512 fp16 B=16).
+#   plus the bench lines of BASELINE.json configs[2] (MTnnUNet B=64) and configs[4]'s per-GPU shape (512x512 fp16 B=16),
+#   the per-op HIP-event logs (tools/per_op.py, bf16 and f32), and the kernel stats of the EXACT driver command
+#   (python bench.py --gpus 1 --steps 20 --warmup 5: bf16 + fp32 parity mode + rooflines in one trace) beside its JSON line.
 set -e
-TAG=${1:-r03}
+TAG=${1:-r04}
 OUT=gpurun_out/prof_${TAG}
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -35,4 +37,10 @@ f=$(ls $OUT/c2_stats/*/*kernel_stats.csv | head -1); cp "$f" $OUT/${TAG}_config2
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c4_stats -- python3 bench.py --size 512 --dtype f16 --batch 16 --steps 5 --warmup 2 $COMMON > $OUT/c4_stats.log 2>&1
 f=$(ls $OUT/c4_stats/*/*kernel_stats.csv | head -1); cp "$f" $OUT/${TAG}_config4_512_f16_b16_kernel_stats.csv
 python3 tools/wgrad_probe.py 1 32 1 > $OUT/${TAG}_wgrad_probe.txt 2>&1 || true
+PEROP_MIN=0.02 python3 tools/per_op.py MTUNetPlusPlus 32 256 bf16 > $OUT/${TAG}_per_op_bf16.log 2>&1
+PEROP_MIN=0.05 python3 tools/per_op.py MTUNetPlusPlus 32 256 f32 > $OUT/${TAG}_per_op_f32.log 2>&1
+echo "per-op done"
+# the driver's own command, traced: the JSON line and the kernel stats of the SAME run
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/driver_stats -- python3 bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/${TAG}_bench_driver_command.json 2> $OUT/driver_stats.err
+f=$(ls $OUT/driver_stats/*/*kernel_stats.csv | head -1); cp "$f" $OUT/${TAG}_driver_command_kernel_stats.csv
 echo "all done"
