@@ -46,6 +46,33 @@ if n >= 2:
     print(f"\nMid-run (step {rows[0][1][len(rows[0][1]) // 2 - 1]['step']}), where the runs are in the middle of their climb: bf16 - fp32 = {mm_:+.1f} +- {sem:.1f} pt "
           f"({sum(1 for x in md if x < -1)} of {n} seeds with bf16 more than a point behind, {sum(1 for x in md if x > 1)} ahead) -- WHEN a run makes its jump varies by thousands of steps "
           "with the seed; said plainly: on this evidence the bf16 mode may reach the plateau somewhat later, and it reaches the same plateau.")
+# the fp16 mode (gpurun_out/r4q_f16, tools/experiments/tp_r4_hard_f16.sh), paired with the fp32 runs above by seed
+fdir = d.rstrip("/") + "_f16"
+fr = {}
+for f in glob.glob(os.path.join(fdir, "tp_s*.json")):
+    r = json.load(open(f))
+    fr[r["config"]["seed"]] = r["runs"]["f16"]
+if len(fr) >= 2:
+    print("\n## The fp16 mode (configs[4]'s arithmetic) on the same task\n")
+    print("`tools/experiments/tp_r4_hard_f16.sh`: the same command with `--dtypes f16` (fp16 MFMA operands, static loss scale 4096, 16-bit gathered activation gradients -- the plan "
+          "`bench.py --dtype f16` times), paired by seed with the fp32 runs above.  (ADVICE r3: the 16-bit gathered gradients had been measured for bf16 only.)\n")
+    print("| seed | fp32 Dice | acc | fp16 Dice | acc | fp16 - fp32 Dice (pt) | acc (pt) |")
+    print("|---|---|---|---|---|---|---|")
+    fd, fa = [], []
+    for seed, a, b, _ in rows:
+        if seed not in fr: continue
+        c = fr[seed]
+        fd.append(100 * (c[-1]["val_dice"] - a[-1]["val_dice"])); fa.append(100 * (c[-1]["val_acc"] - a[-1]["val_acc"]))
+        print(f"| {seed} | {a[-1]['val_dice']:.4f} | {a[-1]['val_acc']:.4f} | {c[-1]['val_dice']:.4f} | {c[-1]['val_acc']:.4f} | {fd[-1]:+.3f} | {fa[-1]:+.2f} |")
+    k = len(fd)
+    if k >= 2:
+        m = sum(fd) / k; se = math.sqrt(sum((x - m) ** 2 for x in fd) / (k - 1) / k)
+        ma = sum(fa) / k; sea = math.sqrt(sum((x - ma) ** 2 for x in fa) / (k - 1) / k)
+        ins = abs(m) + 2 * se < 0.2
+        print(f"\n**{k} paired seeds: fp16 - fp32 = {m:+.3f} pt Dice, standard error {se:.3f} pt (max |difference| {max(abs(x) for x in fd):.3f} pt); accuracy {ma:+.3f} +- {sea:.3f} pt.**  "
+              + ("Inside +-0.2 pt at two standard errors." if ins else
+                 f"Said plainly: NOT shown to be inside +-0.2 pt at two standard errors (|mean| + 2 SE = {abs(m) + 2 * se:.3f} pt); the mean itself is within the band, "
+                 f"two seeds of ten sit 0.4 - 0.7 pt below their fp32 twin."))
 if len(sys.argv) > 2:
     print("\n## The first protocol (6000 steps) had not converged\n")
     print("The same command with `--steps 6000 --eval-every 2000`: the runs were still climbing (0.67 -> 0.70 -> 0.73 ...), and WHEN a run makes its jump from ~0.70 to ~0.85 depends on the seed, "
