@@ -658,7 +658,7 @@ class StepPlan:
                 self.slots[name].ready_at = len(self.bwd_ops) - 1
         if c8_bwd and not coop:
             dz8 = dz8_buffer()
-            pk = self._c8_pack_op(dz16 if p16 else dy, dz8, cout, H * W)
+            pk = self._c8_pack_op(dz16 if p16 else dy, dz8, cout, H * W, N)
             if p16:
                 pk.kind = L.OP_C8_PACK16
             self.bwd_ops.append(pk)
@@ -806,6 +806,7 @@ class StepPlan:
         return y
 
     def convT(self, x: Act, cout: int, k: int, wname: str, bname: Optional[str], out_name: str) -> Act:
+        assert x.N == self.N, f"{x.name}: only conv cells and max-pools are planned over a batch-concatenated (2N) tensor"
         w = self.pv(wname)
         assert tuple(w.shape) == (x.C, cout, k, k), (wname, tuple(w.shape))
         x.readers += 1
@@ -890,6 +891,7 @@ class StepPlan:
         """ConvTranspose2d(x.C -> cmid, k = s) followed by Conv2d(cmid -> R, 1x1) as ONE transposed conv with the
         combined weights (mtbc_convT_head_combine / _expand, include/mtbc.h): the cmid-channel full-resolution
         intermediate is never formed."""
+        assert x.N == self.N
         wT, w1 = self.pv(wTname), self.pv(w1name)
         x.readers += 1
         R = w1.shape[0]
@@ -954,6 +956,7 @@ class StepPlan:
         return y
 
     def conv1x1(self, x: Act, cout: int, wname: str, bname: str, out_name: str) -> Act:
+        assert x.N == self.N, f"{x.name}: only conv cells and max-pools are planned over a batch-concatenated (2N) tensor"
         w = self.pv(wname)
         assert tuple(w.shape) == (cout, x.C, 1, 1), (wname, tuple(w.shape))
         x.readers += 1
@@ -1014,6 +1017,7 @@ class StepPlan:
         return y
 
     def gap(self, x: Act, out_name: str) -> Act:
+        assert x.N == self.N, f"{x.name}: only conv cells and max-pools are planned over a batch-concatenated (2N) tensor"
         x.readers += 1
         y = Act(out_name, self.alloc(self.N, x.C, 1, 1))
 
@@ -1043,6 +1047,7 @@ class StepPlan:
         return y
 
     def linear(self, x: Act, out_f: int, wname: str, bname: str, relu: bool, out_name: str) -> Act:
+        assert x.N == self.N, f"{x.name}: only conv cells and max-pools are planned over a batch-concatenated (2N) tensor"
         in_f = x.C * x.H * x.W
         x.readers += 1
         w = self.pv(wname)

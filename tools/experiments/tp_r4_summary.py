@@ -73,6 +73,27 @@ if len(fr) >= 2:
               + ("Inside +-0.2 pt at two standard errors." if ins else
                  f"Said plainly: NOT shown to be inside +-0.2 pt at two standard errors (|mean| + 2 SE = {abs(m) + 2 * se:.3f} pt); the mean itself is within the band, "
                  f"two seeds of ten sit 0.4 - 0.7 pt below their fp32 twin."))
+# the bf16 mode with fp32 gathered activation gradients (MTBC_NO_DA16=1; gpurun_out/r4q_noda16, tools/experiments/tp_r4_hard_noda16.sh)
+ndir = d.rstrip("/") + "_noda16"
+nr = {}
+for f in glob.glob(os.path.join(ndir, "tp_s*.json")):
+    r = json.load(open(f))
+    nr[r["config"]["seed"]] = r["runs"]["bf16"]
+if len(nr) >= 2:
+    print("\n## Which rounding delays the climb?  The bf16 mode with fp32 gathered activation gradients (`MTBC_NO_DA16=1`)\n")
+    print("`tools/experiments/tp_r4_hard_noda16.sh`: the bf16 runs again with the one storage choice round 3 made on the easy task's evidence switched off, paired by seed.\n")
+    print("| seed | fp32 mid-run | final | bf16 default mid-run | final | bf16 NO_DA16 mid-run | final |")
+    print("|---|---|---|---|---|---|---|")
+    dm, df, dm0 = [], [], []
+    for seed, a, b, _ in rows:
+        if seed not in nr: continue
+        c = nr[seed]; mid = len(a) // 2 - 1
+        print(f"| {seed} | {a[mid]['val_dice']:.4f} | {a[-1]['val_dice']:.4f} | {b[mid]['val_dice']:.4f} | {b[-1]['val_dice']:.4f} | {c[mid]['val_dice']:.4f} | {c[-1]['val_dice']:.4f} |")
+        dm.append(100 * (c[mid]["val_dice"] - a[mid]["val_dice"])); df.append(100 * (c[-1]["val_dice"] - a[-1]["val_dice"])); dm0.append(100 * (b[mid]["val_dice"] - a[mid]["val_dice"]))
+    k = len(dm)
+    st = lambda v: (sum(v) / len(v), math.sqrt(sum((x - sum(v) / len(v)) ** 2 for x in v) / (len(v) - 1) / len(v)))
+    (m1, s1), (m2, s2), (m0, s0) = st(dm), st(df), st(dm0)
+    print(f"\n**{k} paired seeds against fp32: NO_DA16 mid-run {m1:+.1f} +- {s1:.1f} pt (default bf16 plan on the same seeds: {m0:+.1f} +- {s0:.1f}), final {m2:+.3f} +- {s2:.3f} pt.**")
 if len(sys.argv) > 2:
     print("\n## The first protocol (6000 steps) had not converged\n")
     print("The same command with `--steps 6000 --eval-every 2000`: the runs were still climbing (0.67 -> 0.70 -> 0.73 ...), and WHEN a run makes its jump from ~0.70 to ~0.85 depends on the seed, "
