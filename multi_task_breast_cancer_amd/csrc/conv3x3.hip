@@ -79,16 +79,17 @@ constexpr int KC = 8;           // input channels per LDS chunk
 struct SegL { float* ptr; long long bs; int cb; int acc; };
 constexpr int SEGL_FLOATS = 2 * MTBC_MAX_SEGS * (int)(sizeof(SegL) / sizeof(float));
 __device__ __forceinline__ void segl_fill(SegL* dst, const SegTable& t) {
-    if (threadIdx.x < MTBC_MAX_SEGS) {
-        const int i = threadIdx.x;
-        SegL e;
-        // entries past t.n get cb = INT_MAX so that the scan below never selects them
-        e.ptr = t.ptr[0]; e.bs = t.bstride[0]; e.cb = 0; e.acc = t.accumulate[0];
+    // thread k writes entry k, one exec-masked store per entry with COMPILE-TIME indices into the by-value table.  (Round 4: written as "e = entry 0; if (i == k) e =
+    // entry k; dst[i] = e", hipcc recognised a dynamic index, copied the whole kernel-argument table to SCRATCH and loaded entry i back: 36 scratch stores, 3 scratch
+    // loads and two vmcnt waits in the prologue of every block of every igemm kernel -- a memory round trip before the first DMA could be issued.)
 #pragma unroll
-        for (int k = 1; k < MTBC_MAX_SEGS; ++k)
-            if (i == k) { e.ptr = t.ptr[k]; e.bs = t.bstride[k]; e.cb = k < t.n ? t.cbegin[k] : 0x7fffffff; e.acc = t.accumulate[k]; }
-        dst[i] = e;
-    }
+    for (int k = 0; k < MTBC_MAX_SEGS; ++k)
+        if (threadIdx.x == k) {
+            SegL e;
+            // entries past t.n get cb = INT_MAX so that the scan never selects them
+            e.ptr = t.ptr[k]; e.bs = t.bstride[k]; e.cb = (k == 0) ? 0 : (k < t.n ? t.cbegin[k] : 0x7fffffff); e.acc = t.accumulate[k];
+            dst[k] = e;
+        }
 }
 __device__ __forceinline__ SegL segl_ref(const SegL* t, int c) {
     SegL r = t[0];
@@ -1127,10 +1128,12 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 4) void conv3x3_igemm_c8_ker
     const int wvu = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int HW = p.H * p.W;
     const int mt0 = blockIdx.y * MT;
+    // the bias is REQUESTED now and lands in LDS right in front of the tile loop: its memory round trip runs under the block's set-up arithmetic
+    // instead of in front of it (round 4; with the scratch-free segl_fill no other memory access is left in the prologue)
+    float bias_v = 0.f;
+    if (tid < MT * 16) { const int co = mt0 * 16 + tid; if (p.bias && co < p.Cout) bias_v = p.bias[co]; }
     segl_fill(seg_in, p.in);
     segl_fill(seg_out, p.out);
-    if (tid < MT * 16) { const int co = mt0 * 16 + tid; bias_s[tid] = (p.bias && co < p.Cout) ? p.bias[co] : 0.f; }
-    __syncthreads();
 
     const int nchunks = (p.Cin + LPKC - 1) / LPKC;
     const int j = lane & 15, kg = lane >> 4;
@@ -1175,6 +1178,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 4) void conv3x3_igemm_c8_ker
     const int txs = (p.tiles_x & (p.tiles_x - 1)) == 0 ? __builtin_ctz(p.tiles_x) : -1;
     const int tys = (p.tiles_y & (p.tiles_y - 1)) == 0 ? __builtin_ctz(p.tiles_y) : -1;
     int tsk = 0;      // (probes: tile counter of the phase stamps)
+    if (tid < MT * 16) bias_s[tid] = bias_v;
+    __syncthreads();                     // segment tables + bias are in LDS
     for (; tile < tend; tile += tstep) {
         int t = tile, tx, ty;
         if (txs >= 0 && tys >= 0) { tx = t & (p.tiles_x - 1); t >>= txs; ty = t & (p.tiles_y - 1); t >>= tys; }
