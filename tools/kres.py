@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Per-kernel register / LDS / spill table of a HIP source (hipcc -Rpass-analysis=kernel-resource-usage).
+"""Per-kernel register / LDS / spill / SCRATCH table of a HIP source (a non-zero scratch size costs per LAUNCH, whatever put it there: DESIGN.md section 3, round 4) (hipcc -Rpass-analysis=kernel-resource-usage).
 usage: tools/kres.py multi_task_breast_cancer_amd/csrc/conv3x3.hip [name filter]"""
 import re, subprocess, sys
 src = sys.argv[1]
@@ -21,4 +21,4 @@ for line in out.splitlines():
 for r in rows:
     if flt in r["name"]:
         n = re.sub(r"\(anonymous namespace\)::", "", r["name"]).split("(")[0].replace("void ", "")
-        print(f"{n[:70]:70s} VGPR {r.get('VGPRs','?'):>4s} AGPR {r.get('AGPRs','?'):>3s} spillV {r.get('VGPRs Spill','?'):>3s} spillS {r.get('SGPRs Spill','?'):>3s} occ {r.get('Occupancy [waves/SIMD]','?')} LDS {r.get('LDS Size [bytes/block]','?')}")
+        print(f"{n[:70]:70s} VGPR {r.get('VGPRs','?'):>4s} AGPR {r.get('AGPRs','?'):>3s} spillV {r.get('VGPRs Spill','?'):>3s} spillS {r.get('SGPRs Spill','?'):>3s} scratch {r.get('ScratchSize [bytes/lane]','?'):>4s} occ {r.get('Occupancy [waves/SIMD]','?')} LDS {r.get('LDS Size [bytes/block]','?')}")
