@@ -25,7 +25,7 @@ _NO_COOP = _sw.flag("MTBC_NO_COOP")
 _NO_GATHER = _sw.flag("MTBC_NO_GATHER")
 _NO_Z16 = _sw.flag("MTBC_NO_Z16")
 _Z_BF16 = _sw.flag("MTBC_Z_BF16")
-_DA16 = not _sw.flag("MTBC_NO_DA16")
+_DA16 = _sw.flag("MTBC_DA16")            # 16-bit gathered activation gradients: opt-in again since round 4 (switches.py)
 # measured crossovers of the cooperative (split-plane) InstanceNorm kernels on fp32 conv outputs (the MTBC_NO_Z16 arm): they win on
 # planes >= 128x128 forward / 256x256 backward; on small planes their barriers and 512-thread workgroups lose to one-plane kernels + pack
 _COOP_MIN_FWD, _COOP_MIN_BWD = 16384, 65536
@@ -554,7 +554,7 @@ class StepPlan:
             koff += coutj
         wpg, _ = self._pack_lp(wg, K, cout, 0)
         if y.dy8_ok:
-            # (default; MTBC_NO_DA16 = off) ... written ONCE as a 16-bit channel-blocked tensor (fp32 sum over all consumers in the MFMA accumulators,
+            # (MTBC_DA16=1) ... written ONCE as a 16-bit channel-blocked tensor (fp32 sum over all consumers in the MFMA accumulators,
             # one RNE); what the tensor's other readers (pool / ConvT / 1x1 backward) wrote stays an fp32 planar partial that the
             # InstanceNorm backward adds while loading
             y.grad8 = self.alloc(N, cout // 8, H * W, 8, dtype=torch.int16)

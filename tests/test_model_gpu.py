@@ -266,7 +266,7 @@ def test_distributed_step_single_rank_rccl_equals_local_step():
 # (arch, dtype, size, arm, pre): pre = optimisation steps of the HIP fp32 mode (lr 1e-3, the parity-tested path) taken BEFORE the compared step
 @pytest.mark.parametrize("arch,dtype,size,arm,pre", [("MTUNetPlusPlus", "bf16", 64, "", 0), ("MTUNetPlusPlus", "f16", 64, "", 0), ("MTnnUNet", "bf16", 128, "", 0),
                                                      ("MTUNetPlusPlus", "bf16", 128, "", 0), ("MTUNetPlusPlus", "bf16", 128, "no_gather", 0),
-                                                     ("MTUNetPlusPlus", "bf16", 64, "no_z16", 0), ("MTUNetPlusPlus", "bf16", 64, "no_da16", 0),
+                                                     ("MTUNetPlusPlus", "bf16", 64, "no_z16", 0), ("MTUNetPlusPlus", "bf16", 64, "da16", 0),
                                                      ("MTUNetPlusPlus", "bf16", 64, "z_bf16", 0),
                                                      # a TRAINED state at a small size too: every gradient path carries signal there (see below)
                                                      ("MTUNetPlusPlus", "bf16", 64, "", 40), ("MTUNetPlusPlus", "f16", 128, "", 40),
@@ -276,6 +276,7 @@ def test_distributed_step_single_rank_rccl_equals_local_step():
                                                      # wide-block weight gradients), configs[4] (fp16, 512x512: teams of 128) and configs[2] in the arithmetic
                                                      # bench.py quotes it in (MTnnUNet, bf16, 256x256), whole model against the emulation
                                                      ("MTUNetPlusPlus", "bf16", 256, "", 40), ("MTUNetPlusPlus", "f16", 512, "", 40),
+                                                     ("MTUNetPlusPlus", "bf16", 256, "da16", 40),      # the opt-in 16-bit gathered gradients at the bench plane size
                                                      ("MTnnUNet", "bf16", 256, "", 40)])
 def test_16bit_mfma_modes_match_their_emulation(arch, dtype, size, arm, pre, monkeypatch):
     """Optional compute modes: conv3x3 MFMA operands rounded to bf16 / fp16 (fp32 storage + accumulation).  Not the
@@ -300,19 +301,19 @@ def test_16bit_mfma_modes_match_their_emulation(arch, dtype, size, arm, pre, mon
     import copy
     from multi_task_breast_cancer_amd import engine
     # the plan switches (switches.py), each with the emulation told the same thing: fp32 instead of gathered 16-bit activation gradients
-    # (MTBC_NO_DA16), conv outputs kept in fp32 (MTBC_NO_Z16) or stored as bf16 instead of fp16 (MTBC_Z_BF16); per-consumer input
+    # (the default since round 4; MTBC_DA16=1 = the gathered 16-bit tensor), conv outputs kept in fp32 (MTBC_NO_Z16) or stored as bf16 instead of fp16 (MTBC_Z_BF16); per-consumer input
     # gradients with read-modify-write fan-in instead of the gathered launches (MTBC_NO_GATHER: same roundings, another fp32 order)
-    # (default plan: the gathered activation gradients are stored in 16 bits -- da16; without gathered launches nothing is rounded there)
-    emu = {"": {"da16": True}, "no_da16": {"da16": False}, "no_gather": {"da16": False}, "no_z16": {"z16": False}, "no_coop": {"z16": False},
-           "z_bf16": {"z_fp16": False, "da16": True}}[arm]
+    # (default plan: fp32 activation gradients; "da16" = the gathered 16-bit tensor; without gathered launches nothing is rounded there)
+    emu = {"": {"da16": False}, "da16": {"da16": True}, "no_gather": {"da16": False}, "no_z16": {"z16": False}, "no_coop": {"z16": False},
+           "z_bf16": {"z_fp16": False, "da16": False}}[arm]
     if arm == "no_coop":
         monkeypatch.setattr(engine, "_NO_COOP", True)
     if arm == "no_gather":
         monkeypatch.setattr(engine, "_NO_GATHER", True)
     elif arm == "no_z16":
         monkeypatch.setattr(engine, "_NO_Z16", True)
-    elif arm == "no_da16":
-        monkeypatch.setattr(engine, "_DA16", False)
+    elif arm == "da16":
+        monkeypatch.setattr(engine, "_DA16", True)
     elif arm == "z_bf16":
         monkeypatch.setattr(engine, "_Z_BF16", True)
     N = 4 if size == 64 else (1 if size == 512 else 2)          # >= 128x128: level 0 takes the cooperative InstanceNorm kernels

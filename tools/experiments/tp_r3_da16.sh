@@ -1,4 +1,5 @@
 #!/bin/bash
+# HISTORICAL (rounds 2 - 3): MTBC_NO_DA16 / the defaults of that time; since round 4 the 16-bit gathered gradients are the opt-in MTBC_DA16=1 and MTBC_NO_DA16 is refused.
 # Round 3: the 16-bit gathered activation gradients under the 6000-step protocol of tp_r3.sh, bf16 mode only, paired by seed.  When this ran, the 16-bit
 # gradients were the opt-in arm (MTBC_DA16=1, paired with the then-default fp32-gradient runs of gpurun_out/r3q).  The default was flipped on its result:
 # the switch is now MTBC_NO_DA16 (MTBC_DA16 is refused, switches.REMOVED), so the pairing today is MTBC_NO_DA16=1 (fp32 gradients) vs the default plan.

@@ -1,4 +1,5 @@
 # held-out Dice after 3000 steps, bf16, 6 seeds x {default, MTBC_NO_DA16, MTBC_NO_Z16}: is the 16-bit storage of conv outputs / gathered gradients visible in quality?
+# HISTORICAL (rounds 2 - 3): MTBC_NO_DA16 / the defaults of that time; since round 4 the 16-bit gathered gradients are the opt-in MTBC_DA16=1 and MTBC_NO_DA16 is refused.
 mkdir -p gpurun_out/r02z
 C="--steps 3000 --batch 32 --size 256 --lr 3e-4 --cosine --eval-every 3000 --eval-batches 32 --dtypes bf16"
 for seed in 1 2 3 4 5 6; do

@@ -1,7 +1,7 @@
 """Scratch (round 4): the whole-model 16-bit-vs-emulation comparison of tests/test_model_gpu.py::test_16bit_mfma_modes_match_their_emulation at a state that
 is NOT the initialisation: K optimisation steps of the (parity-tested) HIP fp32 mode first, then ONE step of the 16-bit mode against the emulation from
 those weights.  Prints, per parameter tensor, e_hip / e_cpu / cosine -- are the level-0 encoder gradients still cancellation residues there?
-usage: try_emul3.py SIZE N DTYPE K LR [ARM]      DTYPE f32 = the parity mode against the plain fp64 oracle; ARM in no_da16 | no_z16 | no_gather | z_bf16"""
+usage: try_emul3.py SIZE N DTYPE K LR [ARM]      DTYPE f32 = the parity mode against the plain fp64 oracle; ARM in da16 | no_z16 | no_gather | z_bf16 (round 4's runs used the names of the time: the default plan had da16 on, 'no_da16' switched it off)"""
 import sys, os, time, copy
 sys.path.insert(0, os.getcwd())
 import importlib.util
@@ -14,10 +14,10 @@ size, N, dtype, K, lr = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], int(sys
 arm = sys.argv[6] if len(sys.argv) > 6 else ""
 import contextlib
 from multi_task_breast_cancer_amd import engine
-emu = {"": {"da16": True}, "no_da16": {"da16": False}, "no_gather": {"da16": False}, "no_z16": {"z16": False}, "z_bf16": {"z_fp16": False, "da16": True}}[arm]
+emu = {"": {"da16": False}, "da16": {"da16": True}, "no_gather": {"da16": False}, "no_z16": {"z16": False}, "z_bf16": {"z_fp16": False, "da16": False}}[arm]
 if arm == "no_gather": engine._NO_GATHER = True
 if arm == "no_z16": engine._NO_Z16 = True
-if arm == "no_da16": engine._DA16 = False
+if arm == "da16": engine._DA16 = True
 if arm == "z_bf16": engine._Z_BF16 = True
 rel = lambda a, b: ((a.double().cpu() - b.double()).norm() / b.double().norm()).item()
 prod, ref = tm._oracle_and_product("MTUNetPlusPlus", 1993)
