@@ -103,6 +103,26 @@ if len(nr) >= 2:
           f"({'inside' if ins else 'NOT shown inside'} +-0.2 pt at two standard errors).**  In the seeds where the 16-bit-gradient run is late (4, 5, 8, 10: 0.60 - 0.74 at mid-run) the fp32-gradient run "
           "sits within a few thousandths of the fp32 MODE's value: it follows the fp32 trajectory, the 16-bit gradients leave it.  Cost of the fp32 gradients: +0.2 ms per step (2 %); a plan that "
           "reaches the plateau thousands of steps later is not 2 % faster.")
+# the shipped fp16 plan (fp32 gathered gradients): gpurun_out/r4q_f16_shipped
+sdir = d.rstrip("/") + "_f16_shipped"
+sr = {}
+for f in glob.glob(os.path.join(sdir, "tp_s*.json")):
+    r = json.load(open(f))
+    sr[r["config"]["seed"]] = r["runs"]["f16"]
+if len(sr) >= 2:
+    print("\n### The shipped fp16 plan (fp32 gathered activation gradients), `tools/experiments/tp_r4_hard_f16_shipped.sh`\n")
+    print("| seed | fp32 mid-run | final | fp16 shipped mid-run | final | fp16 - fp32 final (pt) |")
+    print("|---|---|---|---|---|---|")
+    fm, ff = [], []
+    for seed, a, b, _ in rows:
+        if seed not in sr: continue
+        c = sr[seed]; mid = len(a) // 2 - 1
+        fm.append(100 * (c[mid]["val_dice"] - a[mid]["val_dice"])); ff.append(100 * (c[-1]["val_dice"] - a[-1]["val_dice"]))
+        print(f"| {seed} | {a[mid]['val_dice']:.4f} | {a[-1]['val_dice']:.4f} | {c[mid]['val_dice']:.4f} | {c[-1]['val_dice']:.4f} | {ff[-1]:+.3f} |")
+    k = len(ff)
+    st2 = lambda v: (sum(v) / len(v), math.sqrt(sum((x - sum(v) / len(v)) ** 2 for x in v) / (len(v) - 1) / len(v)))
+    (a1, b1), (a2, b2) = st2(fm), st2(ff)
+    print(f"\n**{k} paired seeds: shipped fp16 plan - fp32: final {a2:+.3f} +- {b2:.3f} pt ({'inside' if abs(a2) + 2 * b2 < 0.2 else 'NOT shown inside'} +-0.2 pt at two standard errors), mid-run {a1:+.1f} +- {b1:.1f} pt.**")
 if len(sys.argv) > 2:
     print("\n## 4. The first protocol (6000 steps) had not converged\n")
     print("The same command with `--steps 6000 --eval-every 2000`: the runs were still climbing (0.67 -> 0.70 -> 0.73 ...), and WHEN a run makes its jump from ~0.70 to ~0.85 depends on the seed, "
