@@ -2218,7 +2218,10 @@ __global__ __launch_bounds__(256, 4) void conv3x3_wgrad_c8_kernel(const WgC8P p)
     const int cib = blockIdx.y % p.ciblocks;
     const int co0 = (blockIdx.y / p.ciblocks) * 32, ci0 = cib * 32;
     const int split = blockIdx.x;
-    const int t_begin = split * p.tiles_per_split, t_end = min(p.total_tiles, t_begin + p.tiles_per_split);
+    // tiles dealt evenly over the splits (tiles_per_split < 0: split s owns [s T / S, (s + 1) T / S)), so that the plan can ask for ANY number of splits
+    // -- a multiple of 8, see plan_wgrad -- without a short last split
+    const int t_begin = p.tiles_per_split < 0 ? (int)((long long)split * p.total_tiles / (int)gridDim.x) : split * p.tiles_per_split;
+    const int t_end = p.tiles_per_split < 0 ? (int)((long long)(split + 1) * p.total_tiles / (int)gridDim.x) : min(p.total_tiles, t_begin + p.tiles_per_split);
 
     // DMA: wave w brings input-channel group w (4 instructions) and output-channel group w (2 instructions) of the block
     const int cx = ci0 + 8 * wv, cz = co0 + 8 * wv;
@@ -3708,8 +3711,22 @@ WgPlan plan_wgrad(const mtbc_conv3x3_args* a) {
         int ns = 1024 / (w.coblocks * w.ciblocks);
         if (ns > w.total_tiles) ns = w.total_tiles;
         if (ns < 1) ns = 1;
-        w.tiles_per_split = cdiv(w.total_tiles, ns);
-        w.nsplit = cdiv(w.total_tiles, w.tiles_per_split);
+        // The (co, ci) blocks of one split read the SAME pixels -- X once per output-channel block, dz once per input-channel block -- and all of a
+        // launch's blocks are resident at once (one wave of <= 1024), walking their tiles side by side.  Block (split, pair) is workgroup
+        // pair * nsplit + split, and workgroups go to the 8 XCDs round-robin: with nsplit a multiple of 8 every block of a split sits on XCD split % 8
+        // and the re-reads are hits in THAT XCD's L2; with the split counts the plain division gives (103, 54, 37, 52, 26 on the 64 x 64 / 32 x 32 levels)
+        // they are spread over all eight and every one of them is a miss (round 4: this kernel moved 4.2 GB per step for 1.95 algorithmic,
+        // profiles/r04_hbm_traffic_bf16.json).  So: a multiple of 8 splits, tiles dealt evenly (tiles_per_split < 0 in the kernel).
+        // Launch by launch (profiles/r04_wgrad_xcd_splits.txt): 96 -> 96 @64x64 46.7 -> 43.1 us, 192 -> 96 68.8 -> 66.1, 288 -> 96 97.8 -> 90.4; on 32 x 32 maps
+        // (256 tiles: the rounding costs blocks) 1 - 2 us SLOWER, so only from 1024 tiles up.  The step: -0.03 ms.
+        static const int ns8_probe = mtbc_probe_int("MTBC_WG_NS8", 16);      // probes build, A/B: smallest split count that is rounded (0 = never)
+        if (ns8_probe > 0 && ns >= ns8_probe && ns >= 8 && w.total_tiles >= 1024) {
+            w.nsplit = ns & ~7;
+            w.tiles_per_split = -1;
+        } else {
+            w.tiles_per_split = cdiv(w.total_tiles, ns);
+            w.nsplit = cdiv(w.total_tiles, w.tiles_per_split);
+        }
         w.partial_elems = (size_t)w.nsplit * a->Cout * a->Cin * 9;
         w.dbias_elems = a->dbias ? (size_t)w.nsplit * a->Cout : 0;
         return w;

@@ -84,6 +84,7 @@ struct Ct2P {
     int ctiles;                        // wgrad: tiles of 8 output channels
     int steps_per_split, nsplit;       // wgrad: 32-pixel steps per split (over the flattened (n, step) list)
     long long ntasks;
+    int xcd_tasks;                     // convT2_wgrad16_kernel: wave tasks per XCD (> 0: all tasks of a split run on XCD split % 8), 0 = plain task order
 };
 
 struct S0 { static constexpr int value = 0; };
@@ -366,14 +367,27 @@ __global__ __launch_bounds__(256) void convT2_wgrad16_kernel(const Ct2P p) {
     static_assert(LP != 0, "16-bit operands");
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 15, kg = lane >> 4;
-    const long long task = (long long)blockIdx.x * 4 + wv;
-    if (task >= p.ntasks) return;
     const int HW = p.H * p.W, oW = 2 * p.W;
     const int steps_per_img = HW / 32;
     const int ctw = (p.ctiles + CT - 1) / CT;                 // wave tiles along the output channels
-    const int ct = (int)(task % ctw);
-    const long long t = task / ctw;
-    const int mb = (int)(t % p.mblocks), split = (int)(t / p.mblocks);
+    // The (channel-tile, input-block) tasks of one split read the same pixels: x once per output-channel tile, dy once per block of 48 input
+    // channels.  Workgroups go to the XCDs round-robin, so with xcd_tasks the tasks of split s are consecutive waves of XCD s % 8 and the
+    // re-reads hit that XCD's L2 (in plain task order a split's tasks straddle neighbouring workgroups = different XCDs).
+    int ct, mb, split;
+    if (p.xcd_tasks > 0) {
+        const int k = (int)(blockIdx.x >> 3) * 4 + wv, pst = ctw * p.mblocks;
+        if (k >= p.xcd_tasks) return;
+        split = 8 * (k / pst) + (int)(blockIdx.x & 7);
+        if (split >= p.nsplit) return;
+        const int within = k % pst;
+        ct = within % ctw; mb = within / ctw;
+    } else {
+        const long long task = (long long)blockIdx.x * 4 + wv;
+        if (task >= p.ntasks) return;
+        ct = (int)(task % ctw);
+        const long long t = task / ctw;
+        mb = (int)(t % p.mblocks); split = (int)(t / p.mblocks);
+    }
     const int total_steps = p.N * steps_per_img;
     const int g0 = split * p.steps_per_split, g1 = min(total_steps, g0 + p.steps_per_split);
     bool rok[MT];
@@ -891,7 +905,7 @@ void fill(const mtbc_convT_args* a, Ct2P* p) {
     p->N = a->N; p->H = a->H; p->W = a->W; p->Cin = a->Cin; p->Cout = a->Cout;
     p->x = a->x; p->xbs = a->x_batch_stride; p->w = a->w; p->dy = a->dy; p->dybs = a->dy_batch_stride;
     p->dx = a->dx; p->dxbs = a->dx_batch_stride; p->acc_dx = a->accumulate_dx; p->partial = nullptr; p->dbias_part = nullptr;
-    p->mblocks = cdiv(a->Cin, 48); p->ctiles = cdiv(a->Cout, 8); p->steps_per_split = 1; p->nsplit = 1; p->ntasks = 0;
+    p->mblocks = cdiv(a->Cin, 48); p->ctiles = cdiv(a->Cout, 8); p->steps_per_split = 1; p->nsplit = 1; p->ntasks = 0; p->xcd_tasks = 0;
 }
 
 }  // namespace
@@ -1062,9 +1076,14 @@ int mtbc_i_convT2_wgrad(const mtbc_convT_args* a, int compute, float* partial, f
         if (!a->dy_type16 || a->x_type16 != compute) return MTBC_E_UNSUPPORTED;
         static const int ct_env = mtbc_probe_int("MTBC_CT_WG_CT", 0);      // A/B: tiles of 8 output channels per wave (1 | 2), 0 = by shape
         const int ctn = ct_env ? ct_env : (p.ctiles % 2 == 0 ? 2 : 1);
+        static const int xcd_env = mtbc_probe_int("MTBC_CT_WG_XCD", 1);      // A/B: a split's tasks on one XCD (1) | plain task order (0)
+        const long long pst = (long long)p.mblocks * cdiv(p.ctiles, ctn);
+        const long long per_xcd = (long long)cdiv(nsplit, 8) * pst;
+        unsigned xblocks = 0;
+        if (xcd_env && nsplit >= 8 && per_xcd < (1ll << 30)) { p.xcd_tasks = (int)per_xcd; xblocks = 8u * (unsigned)cdiv64(per_xcd, 4); }
         if (ctn == 2) {
             p.ntasks = (long long)p.mblocks * ((p.ctiles + 1) / 2) * nsplit;
-            const unsigned b2 = (unsigned)cdiv64(p.ntasks, 4);
+            const unsigned b2 = xblocks ? xblocks : (unsigned)cdiv64(p.ntasks, 4);
             static const int depth_env = mtbc_probe_int("MTBC_CT_DEPTH", 2);      // A/B: register sets (2 | 4); measured 0.59 vs 0.62 ms per step
             if (depth_env == 2) {
                 if (compute == 1) hipLaunchKernelGGL((convT2_wgrad16_kernel<1, 2, 2>), dim3(b2), dim3(256), 0, st, p);
@@ -1072,8 +1091,9 @@ int mtbc_i_convT2_wgrad(const mtbc_convT_args* a, int compute, float* partial, f
             } else if (compute == 1) hipLaunchKernelGGL((convT2_wgrad16_kernel<1, 2, 4>), dim3(b2), dim3(256), 0, st, p);
             else hipLaunchKernelGGL((convT2_wgrad16_kernel<2, 2, 4>), dim3(b2), dim3(256), 0, st, p);
         } else {
-            if (compute == 1) hipLaunchKernelGGL((convT2_wgrad16_kernel<1, 1, 4>), dim3(blocks), dim3(256), 0, st, p);
-            else hipLaunchKernelGGL((convT2_wgrad16_kernel<2, 1, 4>), dim3(blocks), dim3(256), 0, st, p);
+            const unsigned b1 = xblocks ? xblocks : blocks;
+            if (compute == 1) hipLaunchKernelGGL((convT2_wgrad16_kernel<1, 1, 4>), dim3(b1), dim3(256), 0, st, p);
+            else hipLaunchKernelGGL((convT2_wgrad16_kernel<2, 1, 4>), dim3(b1), dim3(256), 0, st, p);
         }
     } else if (a->dy_type16) {
         if (compute == 1) hipLaunchKernelGGL((convT2_wgrad_kernel<1, true>), dim3(blocks), dim3(256), 0, st, p);

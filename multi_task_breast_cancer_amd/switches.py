@@ -47,8 +47,8 @@ REMOVED = ("MTBC_NO_C8", "MTBC_NO_CT_LP", "MTBC_COOP_MIN_FWD", "MTBC_COOP_MIN_BW
 # timings are not the product's when one of them takes effect
 RESULT_ALTERING = ("MTBC_DBG", "MTBC_NOACC", "MTBC_LOWP", "MTBC_LP_MT", "MTBC_RING", "MTBC_NODMA", "MTBC_C8_BLOCKS_PER_CU",
                    "MTBC_WGRAD_LP1", "MTBC_CT_WG_TASKS", "MTBC_IN_BWD_STREAM", "MTBC_CONVT_GENERIC", "MTBC_C8_NW", "MTBC_C8_RING",
-                   "MTBC_CT_DEPTH", "MTBC_CT_WG_CT", "MTBC_CT_DGRAD_DIRECT", "MTBC_WGRAD_C8W", "MTBC_C8W_BPC", "MTBC_C8W_DEPTH", "MTBC_C8W_HACK",
-                   "MTBC_WGRAD_PACK24", "MTBC_WGRAD_C8I", "MTBC_WG_TS", "MTBC_C8_TS", "MTBC_RING_TS", "MTBC_INB_TS")
+                   "MTBC_CT_DEPTH", "MTBC_CT_WG_CT", "MTBC_CT_WG_XCD", "MTBC_CT_DGRAD_DIRECT", "MTBC_WGRAD_C8W", "MTBC_C8W_BPC", "MTBC_C8W_DEPTH", "MTBC_C8W_HACK",
+                   "MTBC_WGRAD_PACK24", "MTBC_WGRAD_C8I", "MTBC_WG_NS8", "MTBC_WG_TS", "MTBC_C8_TS", "MTBC_RING_TS", "MTBC_INB_TS")
 
 
 def get(name: str) -> str:

@@ -543,6 +543,7 @@ FIXUP_CASES = [
     (16, [24], 24, 256, 256),                  # 32 x 32 kernel, ONE tile, 1024 splits: three levels of fan-in 11
     (8, [48], 48, 128, 128),                   # 4 tiles x 256 splits: three levels of 7
     (4, [96], 96, 64, 64),                     # 9 tiles x 113 splits (not a multiple of 8: ragged (split % 8) classes)
+    (8, [96], 96, 128, 128),                   # 1024 pixel tiles, 9 channel blocks: 112 splits (a multiple of 8: one XCD per split) of 9 or 10 tiles each
     (2, [192], 192, 32, 32),                   # 36 tiles x 28 splits: two levels of 6, ragged last group
     (2, [384], 192, 32, 32),                   # 72 tiles x 14 splits
     (8, [24, 24, 24], 24, 256, 256),           # wide-block kernel: 512 row-segment splits of image-major leaves (N % 8 == 0)

@@ -17,7 +17,7 @@ ap.add_argument("--arch", default="MTUNetPlusPlus"); ap.add_argument("--steps", 
 ap.add_argument("--batch", type=int, default=32); ap.add_argument("--size", type=int, default=256)
 ap.add_argument("--lr", type=float, default=5e-4); ap.add_argument("--eval-every", type=int, default=100)
 ap.add_argument("--eval-batches", type=int, default=8); ap.add_argument("--dtypes", default="f32,bf16")
-ap.add_argument("--seed", type=int, default=1993); ap.add_argument("--out", default=""); ap.add_argument("--hard", action="store_true", help="the task that can fail: synthetic.synthetic_batch(hard=True)"); ap.add_argument("--hard-contrast", default="", help="lo,span of the hard task's lesion contrast (calibration)"); ap.add_argument("--cosine", action="store_true", help="CosineAnnealingLR(T_max=steps, eta_min=1e-6) as config.yaml scheduler: cosine")
+ap.add_argument("--seed", type=int, default=1993); ap.add_argument("--out", default=""); ap.add_argument("--hard", action="store_true", help="the task that can fail: synthetic.synthetic_batch(hard=True)"); ap.add_argument("--hard-contrast", default="", help="lo,span of the hard task's lesion contrast (calibration)"); ap.add_argument("--loss-scale", type=float, default=0.0, help="fp16 mode: static loss scale instead of the library default (nets.HipMultiTaskNet.set_compute)"); ap.add_argument("--cosine", action="store_true", help="CosineAnnealingLR(T_max=steps, eta_min=1e-6) as config.yaml scheduler: cosine")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 if args.hard_contrast:
@@ -39,6 +39,8 @@ for dtype in args.dtypes.split(","):
     seed_everything(args.seed)
     model = init_multitask_model(args.arch, 1, 1, 3, deep_supervision=True).to(dev)
     model.set_compute(dtype)
+    if args.loss_scale and dtype in ("f16", "fp16"):
+        model.loss_scale = float(args.loss_scale)
     opt = init_optimizer(model, "Adam", args.lr)
     step = FusedTrainStep(model, opt, alpha=0.35, inversely_weighted=True)
     sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=args.steps, eta_min=1e-6) if args.cosine else None
