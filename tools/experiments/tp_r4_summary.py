@@ -103,6 +103,7 @@ if len(nr) >= 2:
           f"({'inside' if ins else 'NOT shown inside'} +-0.2 pt at two standard errors).**  In the seeds where the 16-bit-gradient run is late (4, 5, 8, 10: 0.60 - 0.74 at mid-run) the fp32-gradient run "
           "sits within a few thousandths of the fp32 MODE's value: it follows the fp32 trajectory, the 16-bit gradients leave it.  Cost of the fp32 gradients: +0.2 ms per step (2 %); a plan that "
           "reaches the plateau thousands of steps later is not 2 % faster.")
+st2 = lambda v: (sum(v) / len(v), math.sqrt(sum((x - sum(v) / len(v)) ** 2 for x in v) / (len(v) - 1) / len(v)))
 # the shipped fp16 plan (fp32 gathered gradients): gpurun_out/r4q_f16_shipped
 sdir = d.rstrip("/") + "_f16_shipped"
 sr = {}
@@ -120,9 +121,39 @@ if len(sr) >= 2:
         fm.append(100 * (c[mid]["val_dice"] - a[mid]["val_dice"])); ff.append(100 * (c[-1]["val_dice"] - a[-1]["val_dice"]))
         print(f"| {seed} | {a[mid]['val_dice']:.4f} | {a[-1]['val_dice']:.4f} | {c[mid]['val_dice']:.4f} | {c[-1]['val_dice']:.4f} | {ff[-1]:+.3f} |")
     k = len(ff)
-    st2 = lambda v: (sum(v) / len(v), math.sqrt(sum((x - sum(v) / len(v)) ** 2 for x in v) / (len(v) - 1) / len(v)))
     (a1, b1), (a2, b2) = st2(fm), st2(ff)
     print(f"\n**{k} paired seeds: shipped fp16 plan - fp32: final {a2:+.3f} +- {b2:.3f} pt ({'inside' if abs(a2) + 2 * b2 < 0.2 else 'NOT shown inside'} +-0.2 pt at two standard errors), mid-run {a1:+.1f} +- {b1:.1f} pt.**")
+    reached = [x for x in ff if x > -2.0]
+    if len(reached) < k and len(reached) > 2:
+        (a3, b3) = st2(reached)
+        print(f"\nSaid plainly: {k - len(reached)} of {k} fp16 runs had NOT made the jump to the plateau when the cosine schedule ended (the fp32 run of the same seed made it between step 6000 and 9000; so did the fp16 run "
+              f"with 16-bit gradients of section 2); the other {len(reached)} end at {a3:+.3f} +- {b3:.3f} pt of their fp32 twin.  The +-0.2 pt claim does NOT hold for the fp16 mode on this evidence, and the fp32 gathered "
+              "gradients do not explain it (mid-run deficit with them and without them: the same within the noise).")
+# the fp16 plan at another static loss scale: gpurun_out/r4q_f16_ls<LS>
+for ldir in sorted(glob.glob(d.rstrip("/") + "_f16_ls*")):
+    ls = ldir.rsplit("_f16_ls", 1)[1]
+    lr_ = {}
+    for f in glob.glob(os.path.join(ldir, "tp_s*.json")):
+        r = json.load(open(f))
+        lr_[r["config"]["seed"]] = r["runs"]["f16"]
+    if len(lr_) < 2:
+        continue
+    print(f"\n### The fp16 plan with a static loss scale of {ls} instead of 4096, `LS={ls} tools/experiments/tp_r4_hard_f16_ls.sh`\n")
+    print(f"| seed | fp32 mid-run | final | fp16, scale 4096 mid-run | final | fp16, scale {ls} mid-run | final | scale {ls} - fp32 final (pt) |")
+    print("|---|---|---|---|---|---|---|---|")
+    gm, gf, hm, hf = [], [], [], []
+    for seed, a, b, _ in rows:
+        if seed not in lr_ or seed not in sr: continue
+        c = lr_[seed]; o = sr[seed]; mid = len(a) // 2 - 1
+        gm.append(100 * (c[mid]["val_dice"] - a[mid]["val_dice"])); gf.append(100 * (c[-1]["val_dice"] - a[-1]["val_dice"]))
+        hm.append(100 * (o[mid]["val_dice"] - a[mid]["val_dice"])); hf.append(100 * (o[-1]["val_dice"] - a[-1]["val_dice"]))
+        print(f"| {seed} | {a[mid]['val_dice']:.4f} | {a[-1]['val_dice']:.4f} | {o[mid]['val_dice']:.4f} | {o[-1]['val_dice']:.4f} | {c[mid]['val_dice']:.4f} | {c[-1]['val_dice']:.4f} | {gf[-1]:+.3f} |")
+    (a1, b1), (a2, b2), (c1, e1), (c2, e2) = st2(gm), st2(gf), st2(hm), st2(hf)
+    print(f"\n**{len(gf)} paired seeds: scale {ls} - fp32: final {a2:+.3f} +- {b2:.3f} pt ({'inside' if abs(a2) + 2 * b2 < 0.2 else 'NOT shown inside'} +-0.2 pt at two standard errors), mid-run {a1:+.1f} +- {b1:.1f} pt; "
+          f"scale 4096 on the same seeds: final {c2:+.3f} +- {e2:.3f}, mid-run {c1:+.1f} +- {e1:.1f}.**")
+    print("\nThese seeds were CHOSEN as the four with the largest mid-run deficit at scale 4096 (selection: they are the marginal ones, so 'worse' cannot be read off this table); what it does show: "
+          "a 16 x larger scale does not move the trajectories (mid-run values within 0.6 pt of the scale-4096 run on three of four seeds), i.e. the deficit is not fp16 underflow of the back-propagated dz.  "
+          "Open (next round): which fp16-only code path or storage choice is behind it -- bisect by switching the fp16 mode's tensors to the bf16 mode's types one at a time.")
 if len(sys.argv) > 2:
     print("\n## 4. The first protocol (6000 steps) had not converged\n")
     print("The same command with `--steps 6000 --eval-every 2000`: the runs were still climbing (0.67 -> 0.70 -> 0.73 ...), and WHEN a run makes its jump from ~0.70 to ~0.85 depends on the seed, "
