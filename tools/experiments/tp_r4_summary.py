@@ -154,6 +154,22 @@ for ldir in sorted(glob.glob(d.rstrip("/") + "_f16_ls*")):
     print("\nThese seeds were CHOSEN as the four with the largest mid-run deficit at scale 4096 (selection: they are the marginal ones, so 'worse' cannot be read off this table); what it does show: "
           "a 16 x larger scale does not move the trajectories (mid-run values within 0.6 pt of the scale-4096 run on three of four seeds), i.e. the deficit is not fp16 underflow of the back-propagated dz.  "
           "Open (next round): which fp16-only code path or storage choice is behind it -- bisect by switching the fp16 mode's tensors to the bf16 mode's types one at a time.")
+# fp16 at the shipped scale on a longer schedule: gpurun_out/r4q_f16_18000
+ldir = d.rstrip("/") + "_f16_18000"
+l18 = {}
+for f in glob.glob(os.path.join(ldir, "tp_s*.json")):
+    r = json.load(open(f))
+    l18[r["config"]["seed"]] = r["runs"]["f16"]
+if l18:
+    print("\n### The two seeds with an fp16 run that missed the plateau, 18000 steps (cosine over 18000), `OUT=gpurun_out/r4q_f16_18000 LS=4096 STEPS=18000 tools/experiments/tp_r4_hard_f16_ls.sh 3 7`\n")
+    print("| seed | " + " | ".join(f"Dice @{e['step']}" for e in next(iter(l18.values()))) + " |")
+    print("|---|" + "---|" * len(next(iter(l18.values()))))
+    for seed in sorted(l18):
+        print(f"| {seed} | " + " | ".join(f"{e['val_dice']:.4f}" for e in l18[seed]) + " |")
+    print("\nSeed 3 does not jump late, it does not jump: a slow climb (0.675 -> 0.768 over 18000 steps) where the fp32 run of the seed goes 0.718 -> 0.768 -> 0.856 by step 9000.  Over everything this "
+          "file holds: 4 of 26 fp16 runs (seed 3: three of four, seed 7: one of four) end in that slow mode, 0 of 30 fp32 / bf16 runs (Fisher exact p = 0.04).  The fp16 mode has a defect of convergence "
+          "on this task that its loss scale and its 16-bit gradients do not explain; the per-tensor parity of its gradients with the fp16 emulation at a trained state "
+          "(`test_16bit_mfma_modes_match_their_emulation[...f16-512-40]`) says the kernels compute what the mode is designed to compute.  Unresolved; first item of the next round's list.")
 if len(sys.argv) > 2:
     print("\n## 4. The first protocol (6000 steps) had not converged\n")
     print("The same command with `--steps 6000 --eval-every 2000`: the runs were still climbing (0.67 -> 0.70 -> 0.73 ...), and WHEN a run makes its jump from ~0.70 to ~0.85 depends on the seed, "
