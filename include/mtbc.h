@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MTBC_VERSION 201            /* 0.2.1 (round 4: mtbc_conv3x3_args.wgrad_sync appended); 0.2.0: the argument structs grew in round 2 (fields appended); a binding compiled against
+#define MTBC_VERSION 202            /* 0.2.2 (round 4: mtbc_adam_args.dynamic appended + mtbc_adam_dynamic); 0.2.1: mtbc_conv3x3_args.wgrad_sync appended; 0.2.0: the argument structs grew in round 2 (fields appended); a binding compiled against
                                        another version must refuse the library (mtbc_version()) -- layouts are not negotiated */
 #define MTBC_MAX_SEGS 6
 
@@ -499,8 +499,15 @@ typedef struct {
     float lr, beta1, beta2, eps, grad_scale;
     int32_t step;                    /* t >= 1 */
     int32_t zero_grad;               /* 1 = also clear g (optimizer.zero_grad) */
+    const float* dynamic;            /* optional, DEVICE memory, 3 floats {grad_scale, lr / (1-b1^t), 1 / sqrt(1-b2^t)} as mtbc_adam_dynamic writes them: the kernel
+                                        reads the three per-step scalars from here instead of taking them from lr / step / grad_scale as launch arguments --
+                                        a step captured into a hipGraph is then replayed with the learning rate and step count of the DAY (the caller
+                                        refreshes the 12 bytes in stream order before every replay).  NULL: the launch arguments.  Same arithmetic, same bits. */
 } mtbc_adam_args;
 int mtbc_adam_step(const mtbc_adam_args* a, void* stream);
+/* host only, no GPU call: the three per-step scalars of `a` (lr, betas, step, grad_scale) exactly as mtbc_adam_step computes them -- bias corrections in double,
+ * as torch.optim.Adam's scalar path -- for the caller to place in `dynamic`. */
+int mtbc_adam_dynamic(const mtbc_adam_args* a, float out3[3]);
 
 /* Whole-batch TP/FP/FN of (sigmoid(x) > .5) vs target, the train-loop Dice metric of
  * metrics.py:255-267 (training_multitask.py:66-71).  out3 = {tp, fp, fn} as float64.        */

@@ -121,7 +121,7 @@ class FocalArgs(C.Structure):
 class AdamArgs(C.Structure):
     _fields_ = [("n", C.c_int64), ("p", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p),
                 ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
-                ("grad_scale", C.c_float), ("step", C.c_int32), ("zero_grad", C.c_int32)]
+                ("grad_scale", C.c_float), ("step", C.c_int32), ("zero_grad", C.c_int32), ("dynamic", C.c_void_p)]
 
 
 class _PackArgs(C.Structure):
@@ -223,11 +223,11 @@ EXPORTS = [
     "mtbc_maxpool2_bwd", "mtbc_convT_wgrad_workspace", "mtbc_convT_fwd_c8_supported", "mtbc_convT_fwd", "mtbc_convT_dgrad", "mtbc_convT_wgrad",
     "mtbc_conv1x1_wgrad_workspace", "mtbc_conv1x1_fwd", "mtbc_conv1x1_dgrad", "mtbc_conv1x1_wgrad",
     "mtbc_gap_fwd", "mtbc_gap_bwd", "mtbc_linear_fwd", "mtbc_linear_bwd", "mtbc_dice_fwd", "mtbc_dice_bwd",
-    "mtbc_focal_fwd_bwd", "mtbc_loss_mix", "mtbc_adam_step", "mtbc_dice_counts", "mtbc_program_run",
+    "mtbc_focal_fwd_bwd", "mtbc_loss_mix", "mtbc_adam_step", "mtbc_adam_dynamic", "mtbc_dice_counts", "mtbc_program_run",
     "mtbc_program_run_ms", "mtbc_event_create", "mtbc_event_destroy",
 ]
 
-ABI_VERSION = 201          # MTBC_VERSION of include/mtbc.h these mirrors follow
+ABI_VERSION = 202          # MTBC_VERSION of include/mtbc.h these mirrors follow
 _lib: Optional[C.CDLL] = None
 
 
@@ -316,6 +316,8 @@ def load() -> C.CDLL:
     lib.mtbc_loss_mix.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]
     lib.mtbc_dice_counts.restype = C.c_int
     lib.mtbc_dice_counts.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+    lib.mtbc_adam_dynamic.restype = C.c_int
+    lib.mtbc_adam_dynamic.argtypes = [C.POINTER(AdamArgs), C.POINTER(C.c_float * 3)]
     lib.mtbc_program_run.restype = C.c_int
     lib.mtbc_program_run.argtypes = [C.POINTER(Op), C.c_int32, C.c_int32, C.c_void_p, C.POINTER(C.c_int32)]
     lib.mtbc_program_run_ms.restype = C.c_int

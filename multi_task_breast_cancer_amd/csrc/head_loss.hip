@@ -255,7 +255,7 @@ __global__ void loss_mix_kernel(const float* seg, const float* cls, float alpha,
 }
 
 // ------------------------------------------------------------------ Adam
-struct AdamP { long long n; float* p; float* g; float* m; float* v; float gs, b1, b2, eps, step_size, inv_bc2_sqrt; int zero; };
+struct AdamP { long long n; float* p; float* g; float* m; float* v; float gs, b1, b2, eps, step_size, inv_bc2_sqrt; int zero; const float* dyn; };
 __device__ __forceinline__ void adam1(float& p, float g, float& m, float& v, const AdamP& a) {
     g *= a.gs;
     m = m + (g - m) * (1.0f - a.b1);                     // lerp, as torch
@@ -263,7 +263,8 @@ __device__ __forceinline__ void adam1(float& p, float g, float& m, float& v, con
     const float denom = sqrtf(v) * a.inv_bc2_sqrt + a.eps;
     p = p - a.step_size * (m / denom);
 }
-__global__ void adam_kernel(const AdamP a) {
+__global__ void adam_kernel(AdamP a) {
+    if (a.dyn) { a.gs = a.dyn[0]; a.step_size = a.dyn[1]; a.inv_bc2_sqrt = a.dyn[2]; }      // the per-step scalars from memory (graph replay), uniform loads
     const long long n4 = a.n >> 2;
     const long long stride = (long long)gridDim.x * blockDim.x;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
@@ -399,21 +400,35 @@ int mtbc_loss_mix(const float* seg, const float* cls, float alpha, float* out4, 
     return MTBC_OK;
 }
 
+// bias corrections in double on the host, exactly as torch.optim.Adam's scalar path
+static void adam_scalars(const mtbc_adam_args* a, float out3[3]) {
+    const double bc1 = 1.0 - pow((double)a->beta1, (double)a->step);
+    const double bc2 = 1.0 - pow((double)a->beta2, (double)a->step);
+    out3[0] = a->grad_scale;
+    out3[1] = (float)((double)a->lr / bc1);
+    out3[2] = (float)(1.0 / sqrt(bc2));
+}
+int mtbc_adam_dynamic(const mtbc_adam_args* a, float out3[3]) {
+    if (!a || !out3 || a->step < 1) return MTBC_E_BADARG;
+    adam_scalars(a, out3);
+    return MTBC_OK;
+}
 int mtbc_adam_step(const mtbc_adam_args* a, void* stream) {
     if (!a || a->n <= 0 || a->step < 1) return MTBC_E_BADSHAPE;
     if (!a->p || !a->g || !a->m || !a->v) return MTBC_E_BADARG;
     if ((reinterpret_cast<uintptr_t>(a->p) | reinterpret_cast<uintptr_t>(a->g) | reinterpret_cast<uintptr_t>(a->m) |
          reinterpret_cast<uintptr_t>(a->v)) & 15)
         return MTBC_E_UNSUPPORTED;
-    // bias corrections in double on the host, exactly as torch.optim.Adam's scalar path
-    const double bc1 = 1.0 - pow((double)a->beta1, (double)a->step);
-    const double bc2 = 1.0 - pow((double)a->beta2, (double)a->step);
+    if (a->dynamic && (reinterpret_cast<uintptr_t>(a->dynamic) & 3)) return MTBC_E_BADARG;
+    float dyn[3];
+    adam_scalars(a, dyn);
     AdamP p;
-    p.n = a->n; p.p = a->p; p.g = const_cast<float*>(a->g); p.m = a->m; p.v = a->v; p.gs = a->grad_scale;
+    p.n = a->n; p.p = a->p; p.g = const_cast<float*>(a->g); p.m = a->m; p.v = a->v; p.gs = dyn[0];
     p.b1 = a->beta1; p.b2 = a->beta2; p.eps = a->eps;
-    p.step_size = (float)((double)a->lr / bc1);
-    p.inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
+    p.step_size = dyn[1];
+    p.inv_bc2_sqrt = dyn[2];
     p.zero = a->zero_grad;
+    p.dyn = a->dynamic;
     long long blocks = cdiv64(a->n / 4 + 1, 256);
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);

@@ -47,15 +47,47 @@ class FusedAdam(torch.optim.Optimizer):
                     slot.zero_()
                 elif p.grad.data_ptr() != slot.data_ptr():
                     slot.copy_(p.grad)
-        g = self.param_groups[0]
         self.step_count += 1
+        a = self._args()
+        L.check(L.load().mtbc_adam_step(C.byref(a), C.c_void_p(torch.cuda.current_stream().cuda_stream)), "adam")
+        return loss
+
+    def _args(self) -> "L.AdamArgs":
+        m, g = self.model, self.param_groups[0]
         a = L.AdamArgs()
         a.n, a.p, a.g = m.flat_numel, m.flat_p.data_ptr(), m.flat_g.data_ptr()
         a.m, a.v = self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr()
         a.lr, (a.beta1, a.beta2), a.eps = float(g["lr"]), g["betas"], float(g["eps"])
         a.grad_scale, a.step, a.zero_grad = float(self.grad_scale), self.step_count, 0
+        return a
+
+    # ---- the step as two halves, for a training step replayed as a hipGraph (trainer.FusedTrainStep(graph=True)): the three scalars that change from
+    #      step to step (grad_scale, lr / (1 - b1^t), 1 / sqrt(1 - b2^t)) travel through 12 bytes of device memory instead of the launch arguments
+    @torch.no_grad()
+    def advance_dynamic(self) -> None:
+        """Count the step and put its scalars where `launch_dynamic`'s kernel reads them -- three fills in stream order (values in the launch arguments of
+        torch's fill kernel: no host buffer that a later step could overwrite while a copy is in flight).  NOT captured."""
+        self._ensure_state()
+        if getattr(self, "_dyn", None) is None or self._dyn.device != self.model.flat_p.device:
+            self._dyn = torch.zeros(4, device=self.model.flat_p.device)
+        self.step_count += 1
+        out = (C.c_float * 3)()
+        L.check(L.load().mtbc_adam_dynamic(C.byref(self._args()), C.byref(out)), "adam scalars")
+        for i in range(3):
+            self._dyn[i:i + 1].fill_(float(out[i]))           # a float32 value passed as a double: exact
+
+    @torch.no_grad()
+    def launch_dynamic(self) -> None:
+        """The Adam launch itself, reading the scalars `advance_dynamic` left: the same kernel, the same bits as `step`.  Capturable."""
+        a = self._args()
+        a.step = max(1, a.step)
+        a.dynamic = self._dyn.data_ptr()
         L.check(L.load().mtbc_adam_step(C.byref(a), C.c_void_p(torch.cuda.current_stream().cuda_stream)), "adam")
-        return loss
+
+    def graph_key(self):
+        """What a captured launch_dynamic holds by address."""
+        return (self.model.flat_p.data_ptr(), self.model.flat_g.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), self._dyn.data_ptr(),
+                self.param_groups[0]["betas"], float(self.param_groups[0]["eps"]))
 
     # ---- checkpoint interchange (training_multitask.py:243-249 saves `optimizer.state_dict()`): the layout is the one
     #      torch.optim.Adam writes -- per-parameter {'step', 'exp_avg', 'exp_avg_sq'} keyed by parameter index -- so a

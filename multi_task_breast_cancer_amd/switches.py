@@ -24,12 +24,16 @@ PLAN_SWITCHES: Dict[str, tuple] = {
     "MTBC_Z_BF16": ("0", "bf16 mode stores the conv outputs as bf16 instead of fp16 (same bytes, 8 instead of 11 significant bits)",
                     "tests/test_model_gpu.py::test_16bit_mfma_modes_match_their_emulation[...-z_bf16]"),
     "MTBC_DA16": ("0", "the gradient a conv-cell activation gets from its 3x3 consumers is written by ONE gathered launch as a 16-bit channel-blocked tensor (fp32 sum in the MFMA "
-                       "accumulators, one RNE) instead of fp32 planar fan-in: -0.2 ms per step.  Default in round 3 on the easy task's evidence (-0.010 +- 0.025 pt); OFF again since "
+                       "accumulators, one RNE) instead of fp32 planar fan-in: -0.36 ms per step.  Default in round 3 on the easy task's evidence (-0.010 +- 0.025 pt); OFF again since "
                        "round 4: on the task that can fail it ends at the same Dice (-0.012 +- 0.042 pt against fp32, 10 paired seeds) but reaches the plateau LATER -- mid-run "
                        "-5.6 +- 2.9 pt against fp32 where the fp32-gradient plan is at -0.5 +- 1.4 and tracks the fp32 runs seed by seed (profiles/r04_quality_hard.md)",
                   "tests/test_model_gpu.py::test_16bit_mfma_modes_match_their_emulation[...-da16]"),
     "MTBC_NOFUSE_HEADS": ("0", "MTnnUNet deep-supervision heads as ConvT + 1x1 (the reference's two layers) instead of one combined ConvT",
                           "tests/test_model_gpu.py::test_mtnnunet_two_layer_heads_match_the_fused_heads_and_the_oracle"),
+    "MTBC_GRAPH": ("0", "trainer.FusedTrainStep (single process) captures each compiled step -- weight images, forward, losses, backward, Adam -- into ONE hipGraph at its third call "
+                        "and replays it from then on: the host issues a step in 0.1 ms instead of 8.4 (profiles/r04_graph_replay.txt); the GPU time is the same, the results are the same bits "
+                        "(Adam's per-step scalars travel through device memory, mtbc_adam_args.dynamic)",
+                   "tests/test_model_gpu.py::test_graph_replayed_steps_are_the_eager_steps"),
     "MTBC_COOP_RESERVE_CUS": ("64", "CUs kept out of the cooperative InstanceNorm grids under data parallel",
                               "tests/test_coop_safety_gpu.py::test_cooperative_step_beside_a_cu_hogging_kernel"),
 }

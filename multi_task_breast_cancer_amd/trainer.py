@@ -99,7 +99,13 @@ class FusedTrainStep:
 
     def __init__(self, model, optimizer, alpha: float, inversely_weighted: bool = True, n_classes: int = 3,
                  distributed: bool = False, n_buckets: int = 4, focal_weight: Optional[torch.Tensor] = None,
-                 cls_criterion: str = "Focal"):
+                 cls_criterion: str = "Focal", graph: Optional[bool] = None):
+        # graph: replay each compiled step as ONE hipGraph from its third call on (None: the MTBC_GRAPH switch).  The step is a static list of ~380
+        # launches with every pointer resolved at plan time -- exactly what a graph holds; what changes from step to step (the batch, the learning
+        # rate, Adam's bias corrections, the shard weight) lives in device buffers written BEFORE the replay.  Not under data parallel (the bucket
+        # all-reduces are issued between program ranges by the host).
+        self.graph = _sw.flag("MTBC_GRAPH") if graph is None else bool(graph)
+        self._graphs = {}
         self.binary = n_classes == 2
         if self.binary != (getattr(model, "n_classes", n_classes) == 1):
             raise ValueError("n_classes does not match the model's classification head (n_classes == 2 <=> ONE logit)")
@@ -169,8 +175,47 @@ class FusedTrainStep:
         allreduce_buckets(self.model.flat_g, self._st.buckets if self._st is not None and self._st.buckets else
                           plan_buckets([(0, self.model.flat_numel, 0)], self.model.flat_numel, 1))
 
+    def _run_graph(self, st) -> torch.Tensor:
+        """The step as a hipGraph replay: eager for the first two calls of a compiled step (lazily created buffers, kernel attributes), captured at the
+        third, replayed afterwards.  A graph holds addresses: it is keyed by the compiled step and by the optimizer's buffers and dropped when they move."""
+        opt = self.opt
+        opt.grad_scale = (1.0 / self.world) / getattr(st, "loss_scale", 1.0)
+        opt.advance_dynamic()                     # step count, lr, bias corrections -> 12 bytes of device memory, in stream order, outside the graph
+
+        def body():
+            P = st.programs
+            P["pack"].run(); P["fwd"].run(); P["loss"].run(); P["bwd"].run()
+            opt.launch_dynamic()
+
+        # the entry lives ON the compiled step (a dropped step takes its graph along; no address or id() can be reused under a stale graph)
+        ents = st.__dict__.setdefault("_graph_ents", {})
+        key = (id(self), opt.graph_key())
+        ent = ents.get(id(self))
+        if ent is None or ent[0] != key:
+            ents[id(self)] = ent = [key, 0, None]
+        self._graphs[id(st)] = ent                # (introspection: tests, tools)
+        if ent[2] is None and ent[1] >= 2:
+            cur = torch.cuda.current_stream()
+            side = torch.cuda.Stream()
+            side.wait_stream(cur)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=side):
+                body()
+            cur.wait_stream(side)
+            ent[2] = g
+        if ent[2] is not None:
+            ent[2].replay()
+        else:
+            ent[1] += 1
+            body()
+        self.losses = st.plan.loss_out
+        self._coop_err = self.model.coop_error_word()
+        return self.losses
+
     def run(self, st) -> torch.Tensor:
         """One optimisation step on the batch already resident in the plan's buffers."""
+        if self.graph and not self.distributed:
+            return self._run_graph(st)
         P = st.programs
         P["pack"].run()
         P["fwd"].run()

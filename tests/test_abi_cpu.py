@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol(lib):
     assert declared == set(L.EXPORTS), declared ^ set(L.EXPORTS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.mtbc_version() == 201
+    assert lib.mtbc_version() == 202
     # header, library and binding agree on the layout version (the binding refuses any other library at load time)
     assert int(re.search(r"#define\s+MTBC_VERSION\s+(\d+)", src).group(1)) == lib.mtbc_version() == L.ABI_VERSION
     assert lib.mtbc_arch() == b"gfx950"
@@ -52,7 +52,7 @@ def test_ctypes_layout_matches_header(tmp_path):
             ("mtbc_conv3x3_args", "out_accumulate", L.Conv3x3Args.out_accumulate.offset),
             ("mtbc_pack_desc", "kind", L.PackDesc.kind.offset),
             ("mtbc_dice_args", "gscale_dev", L.DiceArgs.gscale_dev.offset),
-            ("mtbc_adam_args", "zero_grad", L.AdamArgs.zero_grad.offset),
+            ("mtbc_adam_args", "zero_grad", L.AdamArgs.zero_grad.offset), ("mtbc_adam_args", "dynamic", L.AdamArgs.dynamic.offset),
             ("mtbc_op", "u", L.Op.u.offset)]
     lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{HEADER}"', "int main(void){"]
     for name in structs:

@@ -226,6 +226,37 @@ def test_step_is_deterministic_at_bench_shape(dtype):
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
 
 
+@pytest.mark.parametrize("arch,dtype,N,size", [("MTUNetPlusPlus", "bf16", 4, 256), ("MTUNetPlusPlus", "f32", 2, 64), ("MTnnUNet", "f16", 2, 128)])
+def test_graph_replayed_steps_are_the_eager_steps(arch, dtype, N, size):
+    """FusedTrainStep(graph=True) (the MTBC_GRAPH switch): the step is captured into ONE hipGraph at its third call and replayed afterwards.  Seven steps
+    over changing batches, with the learning rate changed in between (a scheduler) and a second batch size appearing mid-way (its own graph), must leave
+    the parameters, Adam's moments and the losses bit-identical to the eager, stream-ordered steps: what differs from step to step reaches the replayed
+    kernels through device memory only (mtbc_adam_args.dynamic; the plan's static input buffers).  training_multitask.py:87-103."""
+    res = []
+    for graph in (False, True):
+        seed_everything(1993)
+        cls = MTUNetPlusPlus if arch == "MTUNetPlusPlus" else MTnnUNet
+        m = (cls(in_channels=1, out_channels=1, n_classes=3, deep_supervision=True) if arch == "MTUNetPlusPlus" else cls(1, 1, 3)).to(DEV)
+        m.set_compute(dtype)
+        opt = FusedAdam(m, lr=1e-3, eps=1e-4)
+        step = FusedTrainStep(m, opt, alpha=0.35, graph=graph)
+        losses = []
+        for s in range(7):
+            n = N if s != 4 else max(1, N // 2)                    # another compiled step in the middle: eager there (its first call)
+            img, mask, label = O.synthetic_batch(n, size, size, seed=10 + s)
+            if s == 5:
+                opt.param_groups[0]["lr"] = 2.5e-4                   # what a scheduler does between steps
+            losses.append(step(img.to(DEV), mask.to(DEV), label.to(DEV)).clone())
+        torch.cuda.synchronize()
+        step.check_nan()
+        if graph:
+            assert any(e[2] is not None for e in step._graphs.values()), "no step was captured"
+        res.append((m.flat_p.clone(), opt.exp_avg.clone(), opt.exp_avg_sq.clone(), torch.stack(losses), opt.step_count))
+    assert res[0][4] == res[1][4] == 7
+    for a, b, what in zip(res[0][:4], res[1][:4], ("parameters", "exp_avg", "exp_avg_sq", "losses")):
+        assert torch.equal(a, b), f"graph replay changed the {what}: max |diff| {(a - b).abs().max().item():.3e}"
+
+
 def test_nan_guard_exits():
     seed_everything(1)
     m = MTnnUNet(1, 1, 3).to(DEV)
