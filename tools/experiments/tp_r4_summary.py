@@ -170,6 +170,21 @@ if l18:
           "file holds: 4 of 26 fp16 runs (seed 3: three of four, seed 7: one of four) end in that slow mode, 0 of 30 fp32 / bf16 runs (Fisher exact p = 0.04).  The fp16 mode has a defect of convergence "
           "on this task that its loss scale and its 16-bit gradients do not explain; the per-tensor parity of its gradients with the fp16 emulation at a trained state "
           "(`test_16bit_mfma_modes_match_their_emulation[...f16-512-40]`) says the kernels compute what the mode is designed to compute.  Unresolved; first item of the next round's list.")
+# fp16 on seed 3 under the plan switches: gpurun_out/r4q_f16_arms
+adir = d.rstrip("/") + "_f16_arms"
+arms = sorted(glob.glob(os.path.join(adir, "tp_s*_*.json")))
+if arms:
+    print("\n### Seed 3 in fp16 under the plan switches (9000 steps, cosine over 9000), `tools/experiments/tp_r4_hard_f16_arms.sh 3 \"MTBC_NO_Z16=1\" \"MTBC_NO_GATHER=1\" \"MTBC_NO_COOP=1\"`\n")
+    print("| arm | Dice @3000 | @6000 | @9000 | accuracy @9000 |")
+    print("|---|---|---|---|---|")
+    for f in arms:
+        r = json.load(open(f))["runs"]["f16"]
+        arm = re.search(r"tp_s\d+_(.*)\.json", os.path.basename(f)).group(1)
+        print(f"| `{arm}` | " + " | ".join(f"{e['val_dice']:.4f}" for e in r) + f" | {r[-1]['val_acc']:.4f} |")
+    print("\nEach switch moves where values are rounded or which kernels run.  With the conv outputs kept in fp32 (`MTBC_NO_Z16`) the seed reaches the plateau, with the one-plane InstanceNorm kernels (`MTBC_NO_COOP`, "
+          "fp32 conv outputs as well) it is in its jump at step 9000, with per-consumer input gradients (`MTBC_NO_GATHER`, conv outputs still fp16) it stays in the slow mode.  Together with the rows above: "
+          "on this seed the fp16 arithmetic with 16-bit conv outputs ends in the slow mode in 4 of 5 variants, with fp32 conv outputs or 16-bit gradients in 0 of 3 -- a lead (the fp16-stored conv output z in the fp16 "
+          "mode; the bf16 mode stores the same fp16 z and is not affected, so it is the combination), not a diagnosis.")
 if len(sys.argv) > 2:
     print("\n## 4. The first protocol (6000 steps) had not converged\n")
     print("The same command with `--steps 6000 --eval-every 2000`: the runs were still climbing (0.67 -> 0.70 -> 0.73 ...), and WHEN a run makes its jump from ~0.70 to ~0.85 depends on the seed, "
