@@ -112,3 +112,23 @@ def test_library_is_loaded_after_torch():
             "assert 'torch' in sys.modules\n")
     r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
+
+
+def test_adam_dynamic_scalars_are_torch_adams_scalar_path(lib):
+    """mtbc_adam_dynamic is host arithmetic only (no GPU call): the three per-step scalars a replayed (hipGraph) Adam launch reads from device
+    memory -- grad_scale, lr / (1 - b1^t), 1 / sqrt(1 - b2^t) -- with the bias corrections in double as torch.optim.Adam's scalar path computes them
+    (torch/optim/adam.py: bias_correction1 = 1 - beta1 ** step; step_size = lr / bias_correction1; bias_correction2_sqrt = sqrt(1 - beta2 ** step)),
+    the float32 betas / lr of the argument struct widened first.  experiment_init.py:186-187 (Adam, eps 1e-4), training_multitask.py:103."""
+    import math
+    import numpy as np
+    for lr, b1, b2, t, gs in [(1e-4, 0.9, 0.999, 1, 1.0), (3e-4, 0.9, 0.999, 7, 1.0 / 4096.0), (5e-4, 0.8, 0.99, 12345, 0.125), (1e-6, 0.9, 0.999, 2_000_000, 1.0)]:
+        a = L.AdamArgs()
+        a.lr, a.beta1, a.beta2, a.eps, a.grad_scale, a.step = lr, b1, b2, 1e-4, gs, t
+        out = (C.c_float * 3)()
+        assert lib.mtbc_adam_dynamic(C.byref(a), C.byref(out)) == 0
+        lr32, b132, b232 = (float(np.float32(v)) for v in (lr, b1, b2))
+        want = (np.float32(gs), np.float32(lr32 / (1.0 - math.pow(b132, t))), np.float32(1.0 / math.sqrt(1.0 - math.pow(b232, t))))
+        assert tuple(np.float32(v) for v in out) == want, (lr, b1, b2, t, list(out), want)
+    bad = L.AdamArgs()
+    bad.step = 0
+    assert lib.mtbc_adam_dynamic(C.byref(bad), C.byref((C.c_float * 3)())) != 0        # t >= 1, as mtbc_adam_step
