@@ -318,7 +318,7 @@ def test_16bit_mfma_modes_match_their_emulation(arch, dtype, size, arm, pre, mon
     (first-layer gradients, N=4 at 64x64) away from the same emulation with fp64 accumulation.  So the HIP path is
     judged like the fp32 test judges gradients: against the fp64-accumulating emulation, allowed 3x the distance the
     fp32-accumulating CPU emulation has from it (and a small floor) -- EVERY parameter tensor, no exception.  A wrong operand /
-    rounding place shows up in the forward as >= 3e-2.  fp16 runs with the static loss scale 4096 on both sides (unscaled, dz
+    rounding place shows up in the forward as >= 3e-2.  fp16 runs with the model's static loss scale (65536) on both sides (unscaled, dz
     underflows fp16).
 
     `pre` > 0 (round 4): the compared step starts from weights that `pre` optimisation steps of the HIP fp32 mode have moved away from
@@ -362,7 +362,7 @@ def test_16bit_mfma_modes_match_their_emulation(arch, dtype, size, arm, pre, mon
     step = FusedTrainStep(prod, FusedAdam(prod, lr=1e-4, eps=1e-4), alpha=0.5)
     st = step.load_batch(img.to(DEV), mask.to(DEV), label.to(DEV))
     losses = step.run(st).cpu()
-    ls = prod.loss_scale                      # 4096 in fp16 mode (dz would underflow fp16 otherwise), 1 in bf16
+    ls = prod.loss_scale                      # 65536 in fp16 mode (dz would underflow fp16 otherwise), 1 in bf16
     with O.lowp_conv3x3(dtype, model=[ref, ref64], **emu):
         t32 = O.train_step(ref, O.make_adam(ref, 1e-4), img, mask, label, 0.5, True, 3, loss_scale=ls)
         t64 = O.train_step(ref64, O.make_adam(ref64, 1e-4), img.double(), mask.double(), label, 0.5, True, 3, loss_scale=ls)
