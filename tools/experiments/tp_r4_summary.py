@@ -152,7 +152,8 @@ for ldir in sorted(glob.glob(d.rstrip("/") + "_f16_ls*")):
     print(f"\n**{len(gf)} paired seeds: scale {ls} - fp32: final {a2:+.3f} +- {b2:.3f} pt ({'inside' if abs(a2) + 2 * b2 < 0.2 else 'NOT shown inside'} +-0.2 pt at two standard errors), mid-run {a1:+.1f} +- {b1:.1f} pt; "
           f"scale 4096 on the same seeds: final {c2:+.3f} +- {e2:.3f}, mid-run {c1:+.1f} +- {e1:.1f}.**")
     print("\nThese seeds were CHOSEN as the four with the largest mid-run deficit at scale 4096 (selection: they are the marginal ones, so 'worse' cannot be read off this table); what it does show: "
-          "a 16 x larger scale does not move the trajectories (mid-run values within 0.6 pt of the scale-4096 run on three of four seeds), i.e. the deficit is not fp16 underflow of the back-propagated dz.  "
+          "a 16 x larger scale does not move the trajectories (mid-run values within 0.6 pt of the scale-4096 run on three of four seeds), i.e. fp16 underflow of the back-propagated dz is not what separates these runs from their fp32 twins.  "
+          "(The underflow exists and grows with training -- design error against the exact gradient, `profiles/r04_fp16_design_error.txt`: 13 - 23 % in conv_4_0 after 1500 steps at scale 4096, 0.7 - 2.3 % at 65536 -- and 65536 is the library default since; every ten-seed fp16 sweep of this file ran at 4096.)  "
           "Open (next round): which fp16-only code path or storage choice is behind it -- bisect by switching the fp16 mode's tensors to the bf16 mode's types one at a time.")
 # fp16 at the shipped scale on a longer schedule: gpurun_out/r4q_f16_18000
 ldir = d.rstrip("/") + "_f16_18000"
