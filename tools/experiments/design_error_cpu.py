@@ -45,6 +45,8 @@ designs = {
     "f16, z fp16, loss scale 65536": (lambda m: O.lowp_conv3x3("f16", model=[m], da16=False), 65536.0),
     "f16, z fp16, loss scale 2^20": (lambda m: O.lowp_conv3x3("f16", model=[m], da16=False), 1048576.0),
     "f16, z fp16, loss scale 1": (lambda m: O.lowp_conv3x3("f16", model=[m], da16=False), 1.0),
+    "bf16 + 16-bit gradients (MTBC_DA16)": (lambda m: O.lowp_conv3x3("bf16", model=[m], da16=True), 1.0),
+    "f16, loss scale 65536 + 16-bit gradients": (lambda m: O.lowp_conv3x3("f16", model=[m], da16=True), 65536.0),
 }
 res = {}
 for name, (ctx, ls) in designs.items():
@@ -53,7 +55,7 @@ for name, (ctx, ls) in designs.items():
     res[name] = {n: ((g[n] - exact[n]).norm() / exact[n].norm()).item() for n in exact if exact[n].norm().item() > 0 and not n.endswith("conv.bias")}
     print(f"{name}: {time.time() - t0:.0f} s", flush=True)
 names = list(res)
-keys = sorted(res[names[0]], key=lambda n: -res[names[1]][n])
+keys = sorted(res[names[0]], key=lambda n: -res[names[int(os.environ.get('SORT_BY', '1'))]][n])
 print(f"\nrelative gradient error of each design against the exact (fp64) gradient, the 30 tensors where the shipped fp16 design is worst; U-Net++ {size} x {size}, N = {N}, after {K} steps")
 print(f"{'tensor':50s} " + " ".join(f"{i}" .rjust(8) for i in range(len(names))))
 for n in keys[:30]:
