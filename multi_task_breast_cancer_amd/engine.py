@@ -731,7 +731,7 @@ class StepPlan:
         # pooled ONCE: both consumers read the same pooled tensor and its gradient is their fan-in.  (Round 4: two pools of one tensor had
         # each claimed the fold of their backward into the tensor's InstanceNorm backward -- ONE slot, the later emitter overwrote the
         # earlier one and the 16-bit modes lost the classification head's gradient into x_3_0; found by comparing gradients with the
-        # emulation at a TRAINED state, tools/experiments/try_emul3.py.  fp32 mode was not affected: no fold there.)
+        # emulation at a TRAINED state, tests/studies/try_emul3.py.  fp32 mode was not affected: no fold there.)
         if x.pooled is not None:
             assert out is None or out is x.pooled
             self.acts[out_name] = x.pooled

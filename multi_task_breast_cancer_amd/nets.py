@@ -329,7 +329,7 @@ class HipMultiTaskNet(nn.Module):
         self.compute = table[dtype]
         # fp16 operands: a static loss scale keeps the back-propagated dz out of fp16's subnormals when the MFMA operands are rounded (storage of the
         # sums and accumulation are fp32).  2^16 since round 4 (2^12 before): the design's gradient error against the exact gradient, tensor by tensor
-        # (tools/experiments/design_error_cpu.py, profiles/r04_fp16_design_error.txt): at initialisation the scale does not matter, but dz shrinks as
+        # (tests/studies/design_error_cpu.py, profiles/r04_fp16_design_error.txt): at initialisation the scale does not matter, but dz shrinks as
         # training goes on -- after 1500 steps 2^12 leaves 13 - 23 % error in the gradients of conv_4_0 (bf16 mode: 1.5 - 3.4 %) and a median of 0.65 %
         # over all tensors, 2^16 leaves 0.7 - 2.3 % and 0.07 % (2^20: 0.3 - 2.0 %, 0.07 %: nothing left to gain, and 16 x less room below 65504).
         # No overflow in 4 x 12000 training steps on the hard task at 2^16 (an inf would reach the NaN guard).  The real fix is a dynamic scale

@@ -2,7 +2,7 @@
 fp64 accumulation) against the plain fp64 oracle, per parameter tensor, at weights that K fp32 oracle steps have moved away from the initialisation.
 Asks whether the fp16 mode's arithmetic (fp16 operands AND fp16-stored conv outputs) carries a larger gradient error somewhere than the bf16 mode's
 (profiles/r04_quality_hard.md: a slow mode of convergence that only fp16 runs with 16-bit conv outputs end in).
-usage: python tools/experiments/design_error_cpu.py [SIZE=128] [N=2] [K=30] [LR=1e-3] [hard=1]"""
+usage: python tests/studies/design_error_cpu.py [SIZE=128] [N=2] [K=30] [LR=1e-3] [hard=1]"""
 import copy
 import os
 import sys

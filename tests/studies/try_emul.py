@@ -1,6 +1,6 @@
 """Scratch (round 3): the fp16 mode's whole-model gradient error against the fp64-accumulating emulation as a function of the static
 loss scale and the plane size (tests/test_model_gpu.py::test_16bit_mfma_modes_match_their_emulation's body with the scale overridden).
-usage: python tools/experiments/try_emul.py"""
+usage: python tests/studies/try_emul.py"""
 import sys, os, copy
 sys.path.insert(0, os.getcwd())
 import importlib.util

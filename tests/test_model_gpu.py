@@ -328,7 +328,7 @@ def test_16bit_mfma_modes_match_their_emulation(arch, dtype, size, arm, pre, mon
     (conv_4_0 and process_level_3, MTUNetPlusPlus.py:75,128) and only ONE of the two pools' folded backward reached its InstanceNorm
     backward in the 16-bit modes (engine.maxpool) -- the classification head's gradient into the encoder was missing.  After 40 steps the
     emulations agree to 2 - 13 % per tensor and that defect reads as e_hip = 0.45 - 0.53 on conv_3_0 / conv_2_0 (4 - 12 x e_cpu;
-    tools/experiments/try_emul3.py, profiles/r04_emulation_trained_state.txt).  The escape hatch is gone."""
+    tests/studies/try_emul3.py, profiles/r04_emulation_trained_state.txt).  The escape hatch is gone."""
     import copy
     from multi_task_breast_cancer_amd import engine
     # the plan switches (switches.py), each with the emulation told the same thing: fp32 instead of gathered 16-bit activation gradients
